@@ -1,0 +1,617 @@
+/*
+ * dvbs2_oracle.c -- CPU ORACLE for the DVB-S2 RX inner path.  TEST INFRASTRUCTURE ONLY
+ * (see dvbs2_oracle.h for the rules and the parity-pinning status: a1-a4 "parity
+ * unpinned", the reference's arithmetic lives in the absent lib/aff3ct).
+ *
+ * Plain C restatement, scalar, fp32 where the reference is fp32 (R = Q = float, B = int).
+ * Compiled with -ffp-contract=off so the fp32 results do not depend on FMA fusion.
+ * All path:line citations are relative to /root/reference.
+ */
+#include "dvbs2_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ======================================================================== LDPC */
+struct orc_ldpc {
+    int N, K, M, q, n_rows, E;
+    int *row_ptr, *addr;         /* ETSI address table */
+    int *chk_ptr, *chk_var;      /* H by check, natural order; per check: info vars in
+                                    (table row, position) order, then p_c, then p_{c-1} */
+    int *chk_lvl;                /* per edge: QC-schedule conflict level (0 = primary) */
+    int max_deg;
+};
+
+static inline int f_signbit(float x) { uint32_t u; memcpy(&u, &x, 4); return (int)(u >> 31); }
+
+orc_ldpc *orc_ldpc_create(int N, int K, int n_rows, const int *row_ptr, const int *addr)
+{
+    orc_ldpc *c = (orc_ldpc *)calloc(1, sizeof *c);
+    c->N = N; c->K = K; c->M = N - K; c->q = c->M / 360; c->n_rows = n_rows;
+    if (c->M % 360 || K % 360 || n_rows != K / 360) { free(c); return NULL; }
+    c->row_ptr = (int *)malloc(sizeof(int) * (n_rows + 1));
+    memcpy(c->row_ptr, row_ptr, sizeof(int) * (n_rows + 1));
+    int na = row_ptr[n_rows];
+    c->addr = (int *)malloc(sizeof(int) * na);
+    memcpy(c->addr, addr, sizeof(int) * na);
+    const int M = c->M, q = c->q;
+    /* check degrees */
+    int *deg = (int *)calloc(M, sizeof(int));
+    for (int g = 0; g < n_rows; g++)
+        for (int p = row_ptr[g]; p < row_ptr[g + 1]; p++)
+            for (int m = 0; m < 360; m++) deg[(addr[p] + m * q) % M]++;
+    for (int k = 0; k < M; k++) deg[k] += (k == 0) ? 1 : 2;
+    c->chk_ptr = (int *)malloc(sizeof(int) * (M + 1));
+    c->chk_ptr[0] = 0;
+    for (int k = 0; k < M; k++) {
+        c->chk_ptr[k + 1] = c->chk_ptr[k] + deg[k];
+        if (deg[k] > c->max_deg) c->max_deg = deg[k];
+    }
+    c->E = c->chk_ptr[M];
+    c->chk_var = (int *)malloc(sizeof(int) * c->E);
+    c->chk_lvl = (int *)calloc(c->E, sizeof(int));
+    int *fill = (int *)calloc(M, sizeof(int));
+    /* ETSI EN 302 307 5.3.2: info bit i = 360 g + m accumulates into parity address
+     * (x + m q) mod (N-K) for every x in table row g */
+    for (int g = 0; g < n_rows; g++)
+        for (int p = row_ptr[g]; p < row_ptr[g + 1]; p++)
+            for (int m = 0; m < 360; m++) {
+                int k = (addr[p] + m * q) % M;
+                c->chk_var[c->chk_ptr[k] + fill[k]++] = g * 360 + m;
+            }
+    /* p_k = p_k xor p_{k-1}: check k holds parity bits k and k-1 */
+    for (int k = 0; k < M; k++) {
+        c->chk_var[c->chk_ptr[k] + fill[k]++] = K + k;
+        if (k > 0) c->chk_var[c->chk_ptr[k] + fill[k]++] = K + k - 1;
+    }
+    /* conflict levels for the QC schedule: within one check, an info edge whose bit-GROUP
+     * already appeared earlier in the same check's slot list is a "later" edge */
+    for (int k = 0; k < M; k++) {
+        int b = c->chk_ptr[k], e = c->chk_ptr[k + 1];
+        for (int i = b; i < e; i++) {
+            int v = c->chk_var[i];
+            if (v >= K) continue;
+            int lvl = 0;
+            for (int j = b; j < i; j++)
+                if (c->chk_var[j] < K && c->chk_var[j] / 360 == v / 360) lvl++;
+            c->chk_lvl[i] = lvl;
+        }
+    }
+    free(fill); free(deg);
+    return c;
+}
+
+void orc_ldpc_destroy(orc_ldpc *c)
+{
+    if (!c) return;
+    free(c->row_ptr); free(c->addr); free(c->chk_ptr); free(c->chk_var); free(c->chk_lvl); free(c);
+}
+int orc_ldpc_n_edges(const orc_ldpc *c) { return c->E; }
+int orc_ldpc_q(const orc_ldpc *c) { return c->q; }
+void orc_ldpc_csr(const orc_ldpc *c, const int **chk_ptr, const int **chk_var)
+{ *chk_ptr = c->chk_ptr; *chk_var = c->chk_var; }
+
+void orc_ldpc_encode(const orc_ldpc *c, const int32_t *info, int32_t *cw)
+{
+    const int K = c->K, M = c->M, q = c->q;
+    memcpy(cw, info, sizeof(int32_t) * K);
+    int32_t *p = cw + K;
+    memset(p, 0, sizeof(int32_t) * M);
+    for (int g = 0; g < c->n_rows; g++)
+        for (int m = 0; m < 360; m++) {
+            if (!(info[g * 360 + m] & 1)) continue;
+            for (int a = c->row_ptr[g]; a < c->row_ptr[g + 1]; a++)
+                p[(c->addr[a] + m * q) % M] ^= 1;
+        }
+    for (int k = 1; k < M; k++) p[k] ^= p[k - 1];
+}
+
+int orc_ldpc_syndrome_weight(const orc_ldpc *c, const int32_t *cw)
+{
+    int w = 0;
+    for (int k = 0; k < c->M; k++) {
+        int s = 0;
+        for (int i = c->chk_ptr[k]; i < c->chk_ptr[k + 1]; i++) s ^= cw[c->chk_var[i]] & 1;
+        w += s;
+    }
+    return w;
+}
+
+static int soft_syndrome_ok(const orc_ldpc *c, const float *L)
+{
+    for (int k = 0; k < c->M; k++) {
+        int s = 0;
+        for (int i = c->chk_ptr[k]; i < c->chk_ptr[k + 1]; i++) s ^= (L[c->chk_var[i]] < 0.0f);
+        if (s) return 0;
+    }
+    return 1;
+}
+
+/* one check-node update.  v2c[] in, c2v_new[] out. */
+static void chk_update_nms(const float *v2c, int d, float alpha, float *out)
+{
+    float min1 = FLT_MAX, min2 = FLT_MAX;
+    int sign = 0;
+    for (int j = 0; j < d; j++) {
+        float a = fabsf(v2c[j]);
+        sign ^= f_signbit(v2c[j]);
+        float t = a > min1 ? a : min1;           /* max(a, min1) */
+        min2 = min2 < t ? min2 : t;
+        min1 = min1 < a ? min1 : a;
+    }
+    float cst1 = min2 * alpha, cst2 = min1 * alpha;
+    for (int j = 0; j < d; j++) {
+        float a = fabsf(v2c[j]);
+        float mag = (a == min1) ? cst1 : cst2;
+        int s = sign ^ f_signbit(v2c[j]);
+        out[j] = s ? -mag : mag;
+    }
+}
+
+static void chk_update_spa(const float *v2c, int d, float *out)
+{
+    /* exact sum-product in the tanh domain with forward/backward products (double) */
+    double fw[64], bw[64], th[64];
+    for (int j = 0; j < d; j++) {
+        double x = tanh(0.5 * (double)v2c[j]);
+        if (x > 0.999999999999) x = 0.999999999999;
+        if (x < -0.999999999999) x = -0.999999999999;
+        th[j] = x;
+    }
+    fw[0] = 1.0; for (int j = 1; j < d; j++) fw[j] = fw[j - 1] * th[j - 1];
+    bw[d - 1] = 1.0; for (int j = d - 2; j >= 0; j--) bw[j] = bw[j + 1] * th[j + 1];
+    for (int j = 0; j < d; j++) out[j] = (float)(2.0 * atanh(fw[j] * bw[j]));
+}
+
+int orc_ldpc_decode(const orc_ldpc *c, const float *llr, int implem, int sched, int n_ite,
+                    float alpha, int early_stop, int32_t *bits_K, float *post, int8_t *cwd)
+{
+    const int N = c->N, M = c->M, q = c->q;
+    float *L = (float *)malloc(sizeof(float) * N);
+    float *msg = (float *)calloc(c->E, sizeof(float));      /* c->v, zero-initialised */
+    float *v2c = (float *)malloc(sizeof(float) * 360 * c->max_deg);
+    float *nw  = (float *)malloc(sizeof(float) * 360 * c->max_deg);
+    memcpy(L, llr, sizeof(float) * N);
+    int ite = 0;
+    int max_lvl = 0;
+    for (int i = 0; i < c->E; i++) if (c->chk_lvl[i] > max_lvl) max_lvl = c->chk_lvl[i];
+    for (; ite < n_ite; ) {
+        if (sched == ORC_SCHED_NATURAL) {
+            for (int k = 0; k < M; k++) {
+                int b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
+                for (int j = 0; j < d; j++) v2c[j] = L[c->chk_var[b + j]] - msg[b + j];
+                if (implem == ORC_NMS) chk_update_nms(v2c, d, alpha, nw); else chk_update_spa(v2c, d, nw);
+                for (int j = 0; j < d; j++) { msg[b + j] = nw[j]; L[c->chk_var[b + j]] = v2c[j] + nw[j]; }
+            }
+        } else {
+            /* QC-layer schedule: layer r = checks {q t + r, t = 0..359}; all 360 checks of a
+             * layer read their posteriors before any of them writes (phase 1); primary
+             * edges write v2c + new (phase 2); level-k duplicate edges then add
+             * (new - old) in level order (phase 3). */
+            const int D = c->max_deg;
+            for (int r = 0; r < q; r++) {
+                for (int t = 0; t < 360; t++) {
+                    int k = q * t + r, b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
+                    for (int j = 0; j < d; j++) v2c[t * D + j] = L[c->chk_var[b + j]] - msg[b + j];
+                    if (implem == ORC_NMS) chk_update_nms(v2c + t * D, d, alpha, nw + t * D);
+                    else chk_update_spa(v2c + t * D, d, nw + t * D);
+                }
+                for (int t = 0; t < 360; t++) {
+                    int k = q * t + r, b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
+                    for (int j = 0; j < d; j++)
+                        if (c->chk_lvl[b + j] == 0) L[c->chk_var[b + j]] = v2c[t * D + j] + nw[t * D + j];
+                }
+                for (int lvl = 1; lvl <= max_lvl; lvl++)
+                    for (int t = 0; t < 360; t++) {
+                        int k = q * t + r, b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
+                        for (int j = 0; j < d; j++)
+                            if (c->chk_lvl[b + j] == lvl) {
+                                float delta = nw[t * D + j] - msg[b + j];
+                                L[c->chk_var[b + j]] = L[c->chk_var[b + j]] + delta;
+                            }
+                    }
+                for (int t = 0; t < 360; t++) {
+                    int k = q * t + r, b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
+                    for (int j = 0; j < d; j++) msg[b + j] = nw[t * D + j];
+                }
+            }
+        }
+        ite++;
+        if (early_stop && soft_syndrome_ok(c, L)) break;
+    }
+    if (cwd) *cwd = (int8_t)soft_syndrome_ok(c, L);
+    if (bits_K) for (int i = 0; i < c->K; i++) bits_K[i] = L[i] < 0.0f;
+    if (post) memcpy(post, L, sizeof(float) * N);
+    free(L); free(msg); free(v2c); free(nw);
+    return ite;
+}
+
+double orc_ldpc_decode_batch(const orc_ldpc *c, const float *llr, int F, int sched, int n_ite,
+                             float alpha, int32_t *bits, int threads)
+{
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+#endif
+    for (int f = 0; f < F; f++)
+        orc_ldpc_decode(c, llr + (size_t)f * c->N, ORC_NMS, sched, n_ite, alpha, 0,
+                        bits ? bits + (size_t)f * c->K : NULL, NULL, NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    (void)threads;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* ======================================================================== BCH */
+struct orc_bch {
+    int m, n, t, N, K, gdeg;
+    int *exp_, *log_;   /* alpha_to / index_of */
+    int *g;             /* generator, g[i] = coeff of x^i */
+};
+
+static int gf_mul(const orc_bch *b, int x, int y)
+{ return (x && y) ? b->exp_[(b->log_[x] + b->log_[y]) % b->n] : 0; }
+static int gf_div(const orc_bch *b, int x, int y)
+{ return x ? b->exp_[(b->log_[x] - b->log_[y] + b->n) % b->n] : 0; }
+
+orc_bch *orc_bch_create(int m, const int *prim, int t, int N, int K)
+{
+    orc_bch *b = (orc_bch *)calloc(1, sizeof *b);
+    b->m = m; b->n = (1 << m) - 1; b->t = t; b->N = N; b->K = K;
+    b->exp_ = (int *)malloc(sizeof(int) * (b->n + 1));
+    b->log_ = (int *)malloc(sizeof(int) * (b->n + 1));
+    int pm = 0; for (int i = 0; i <= m; i++) if (prim[i]) pm |= 1 << i;
+    int x = 1;
+    for (int i = 0; i < b->n; i++) {
+        b->exp_[i] = x; b->log_[x] = i;
+        x <<= 1; if (x >> m) x ^= pm;
+    }
+    b->exp_[b->n] = 1; b->log_[0] = -1;
+    /* generator = lcm of the minimal polynomials of alpha^1..alpha^2t (cyclotomic cosets) */
+    char *seen = (char *)calloc(b->n, 1);
+    int *g = (int *)calloc(m * t + 2, sizeof(int));     /* GF(2) coefficients */
+    int gdeg = 0; g[0] = 1;
+    for (int j = 1; j <= 2 * t; j++) {
+        if (seen[j % b->n]) continue;
+        /* minimal polynomial of alpha^j over GF(2^m) coefficients, product of (x + alpha^e) */
+        int mp[64]; int md = 0; mp[0] = 1;
+        int e = j % b->n;
+        do {
+            seen[e] = 1;
+            /* mp *= (x + alpha^e) */
+            mp[md + 1] = 0;
+            for (int i = md + 1; i >= 1; i--) mp[i] = mp[i - 1] ^ gf_mul(b, mp[i], b->exp_[e]);
+            mp[0] = gf_mul(b, mp[0], b->exp_[e]);
+            md++;
+            e = (e * 2) % b->n;
+        } while (e != j % b->n);
+        /* g *= mp (mp has 0/1 coefficients) */
+        int *ng = (int *)calloc(gdeg + md + 1, sizeof(int));
+        for (int a = 0; a <= gdeg; a++) if (g[a])
+            for (int c2 = 0; c2 <= md; c2++) if (mp[c2]) ng[a + c2] ^= 1;
+        memcpy(g, ng, sizeof(int) * (gdeg + md + 1));
+        gdeg += md; free(ng);
+    }
+    free(seen);
+    b->g = g; b->gdeg = gdeg;
+    if (gdeg != N - K) { /* caller checks orc_bch_gen_degree */ }
+    return b;
+}
+void orc_bch_destroy(orc_bch *b) { if (!b) return; free(b->exp_); free(b->log_); free(b->g); free(b); }
+int orc_bch_gen_degree(const orc_bch *b) { return b->gdeg; }
+const int *orc_bch_gen(const orc_bch *b) { return b->g; }
+
+void orc_bch_encode(const orc_bch *b, const int32_t *info, int32_t *cw)
+{
+    /* systematic: parity(x) = x^(n-k) u(x) mod g(x); DVB-S2 order: cw[i] = coeff of x^(N-1-i)
+     * (Encoder_BCH_DVBS2.cpp:28-43 reverses in/out around the LSB-first aff3ct encoder) */
+    const int r = b->gdeg, K = b->K;
+    int *bb = (int *)calloc(r, sizeof(int));
+    for (int i = 0; i < K; i++) {            /* first info bit = highest degree */
+        int fb = (info[i] & 1) ^ bb[r - 1];
+        for (int j = r - 1; j > 0; j--) bb[j] = bb[j - 1] ^ (b->g[j] & fb);
+        bb[0] = b->g[0] & fb;
+    }
+    for (int i = 0; i < K; i++) cw[i] = info[i] & 1;
+    for (int j = 0; j < r; j++) cw[K + j] = bb[r - 1 - j];
+    free(bb);
+}
+
+int orc_bch_decode(const orc_bch *b, const int32_t *in, int32_t *out, int8_t *cwd)
+{
+    const int t = b->t, N = b->N, K = b->K, n = b->n;
+    int S[64]; int any = 0;
+    /* S_j = r(alpha^j), r(x) = sum_i in[i] x^(N-1-i) */
+    for (int j = 1; j <= 2 * t; j++) {
+        int s = 0;
+        for (int i = 0; i < N; i++)
+            if (in[i] & 1) s ^= b->exp_[(int)(((long long)j * (N - 1 - i)) % n)];
+        S[j] = s; any |= s;
+    }
+    int nflip = 0, flip[64];
+    int status = 0;
+    if (any) {
+        /* Berlekamp-Massey */
+        int C[64] = {0}, B[64] = {0}, T[64];
+        C[0] = 1; B[0] = 1;
+        int L = 0, mm = 1, bb = 1;
+        for (int k = 0; k < 2 * t; k++) {
+            int d = S[k + 1];
+            for (int i = 1; i <= L; i++) d ^= gf_mul(b, C[i], S[k + 1 - i]);
+            if (d == 0) { mm++; }
+            else {
+                int coef = gf_div(b, d, bb);
+                if (2 * L <= k) {
+                    memcpy(T, C, sizeof C);
+                    for (int i = 0; i + mm < 64; i++) C[i + mm] ^= gf_mul(b, coef, B[i]);
+                    L = k + 1 - L; memcpy(B, T, sizeof B); bb = d; mm = 1;
+                } else {
+                    for (int i = 0; i + mm < 64; i++) C[i + mm] ^= gf_mul(b, coef, B[i]);
+                    mm++;
+                }
+            }
+        }
+        if (L > t) status = 1;
+        else {
+            /* Chien search over the whole field: root alpha^(-d) <=> error at degree d */
+            int count = 0;
+            for (int d = 0; d < n && count <= L; d++) {
+                int v = 0;
+                for (int i = 0; i <= L; i++)
+                    if (C[i]) v ^= b->exp_[(b->log_[C[i]] + (int)(((long long)i * (n - d)) % n)) % n];
+                if (v == 0) { if (count < 64) flip[count] = d; count++; }
+            }
+            if (count == L) nflip = L; else status = 1;
+        }
+    }
+    for (int i = 0; i < K; i++) out[i] = in[i] & 1;
+    for (int f = 0; f < nflip; f++) {
+        int pos = N - 1 - flip[f];            /* degree -> DVB-S2 position */
+        if (pos >= 0 && pos < K) out[pos] ^= 1;   /* degrees >= N (shortened zeros) ignored */
+    }
+    if (cwd) *cwd = (int8_t)!status;
+    return status;
+}
+
+/* ======================================================================== modem */
+void orc_cstl_normalise(const float *in, int n_pts, float *out)
+{
+    float es = 0.f;
+    for (int i = 0; i < n_pts; i++) es += in[2 * i] * in[2 * i] + in[2 * i + 1] * in[2 * i + 1];
+    float s = sqrtf(es / (float)n_pts);
+    for (int i = 0; i < 2 * n_pts; i++) out[i] = in[i] / s;
+}
+
+void orc_modulate(const float *cstl, int bps, const int32_t *bits, int n_bits, float *sym)
+{
+    int ns = n_bits / bps;
+    for (int k = 0; k < ns; k++) {
+        int idx = 0;
+        for (int j = 0; j < bps; j++) idx += (1 << j) * (bits[k * bps + j] & 1);
+        sym[2 * k] = cstl[2 * idx]; sym[2 * k + 1] = cstl[2 * idx + 1];
+    }
+}
+
+static inline float max_star(float a, float b)
+{
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    float mx = a > b ? a : b;
+    return mx + log1pf(expf(-fabsf(a - b)));
+}
+
+void orc_demodulate(const float *cstl, int bps, float sigma, const float *sym, int n_sym, float *llr)
+{
+    const int P = 1 << bps;
+    const float inv = 1.0f / (2.0f * sigma * sigma);
+    for (int k = 0; k < n_sym; k++) {
+        float met[64];
+        for (int s = 0; s < P; s++) {
+            float dr = sym[2 * k] - cstl[2 * s], di = sym[2 * k + 1] - cstl[2 * s + 1];
+            met[s] = -(dr * dr + di * di) * inv;
+        }
+        for (int b = 0; b < bps; b++) {
+            float L0 = -INFINITY, L1 = -INFINITY;
+            for (int s = 0; s < P; s++)
+                if (((s >> b) & 1) == 0) L0 = max_star(L0, met[s]); else L1 = max_star(L1, met[s]);
+            llr[k * bps + b] = L0 - L1;
+        }
+    }
+}
+
+void orc_itl_lut(int N, int n_cols, int order, uint32_t *lut)
+{
+    if (n_cols <= 1) { for (int i = 0; i < N; i++) lut[i] = (uint32_t)i; return; }
+    int n_rows = N / n_cols;
+    for (int i = 0; i < n_rows; i++)
+        for (int j = 0; j < n_cols; j++)
+            lut[i * n_cols + j] = (uint32_t)((order == 0 ? j : (n_cols - 1 - j)) * n_rows + i);
+}
+
+/* ======================================================================== glue */
+void orc_pl_rand_seq(int n, uint8_t *seq)
+{
+    /* ETSI EN 302 307 5.5.4: x(i+18)=x(i+7)+x(i), y(i+18)=y(i+10)+y(i+7)+y(i+5)+y(i);
+     * z_n(i) = x((i+n) mod (2^18-1)) + y(i); R_n(i) = 2 z_n((i+131072) mod (2^18-1)) + z_n(i) */
+    const int P = (1 << 18) - 1;
+    uint8_t *x = (uint8_t *)malloc(P), *y = (uint8_t *)malloc(P);
+    for (int i = 0; i < 18; i++) { x[i] = (i == 0); y[i] = 1; }
+    for (int i = 0; i + 18 < P; i++) {
+        x[i + 18] = x[i + 7] ^ x[i];
+        y[i + 18] = y[i + 10] ^ y[i + 7] ^ y[i + 5] ^ y[i];
+    }
+    for (int i = 0; i < 66420; i++) {
+        int z0 = x[(i + n) % P] ^ y[i];
+        int i2 = (i + 131072) % P;
+        int z1 = x[(i2 + n) % P] ^ y[i2];
+        seq[i] = (uint8_t)(2 * z1 + z0);
+    }
+    free(x); free(y);
+}
+
+void orc_pl_scramble(const float *in, float *out, int n_sym, int start_ix, int scramble)
+{
+    static uint8_t *seq = NULL;
+    if (!seq) { seq = (uint8_t *)malloc(66420); orc_pl_rand_seq(0, seq); }
+    for (int i = 0; i < 2 * start_ix; i++) out[i] = in[i];
+    for (int i = start_ix; i < n_sym; i++) {
+        int R = seq[i - start_ix];
+        int lsb = R % 2, msb = R / 2;
+        int rr = (1 - lsb) * (-2 * msb + 1);
+        int ri = lsb * (-2 * msb + 1);
+        ri = (2 * (scramble ? 1 : 0) - 1) * ri;
+        float dr = in[2 * i], di = in[2 * i + 1];
+        out[2 * i]     = rr * dr - ri * di;
+        out[2 * i + 1] = ri * dr + rr * di;
+    }
+}
+
+void orc_bb_scramble(const int32_t *in, int32_t *out, int n)
+{
+    /* 1 + x^14 + x^15, init 100101010000000, restarted every frame */
+    int lfsr[15] = {1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        int fb = (lfsr[14] + lfsr[13]) % 2;
+        for (int j = 14; j > 0; j--) lfsr[j] = lfsr[j - 1];
+        lfsr[0] = fb;
+        out[i] = (in[i] + fb) % 2;
+    }
+}
+
+void orc_plheader(const int *mod_cod, float *plh)
+{
+    static const int G[7][32] = {
+        {1,0,0,1,0,0,0,0,1,0,1,0,1,1,0,0,0,0,1,0,1,1,0,1,1,1,0,1,1,1,0,1},
+        {0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1},
+        {0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1},
+        {0,0,0,0,1,1,1,1,0,0,0,0,1,1,1,1,0,0,0,0,1,1,1,1,0,0,0,0,1,1,1,1},
+        {0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1},
+        {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1},
+        {1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1}};
+    static const int PLS_SCR[64] = {0,1,1,1,0,0,0,1,1,0,0,1,1,1,0,1,1,0,0,0,0,0,1,1,1,1,0,0,1,0,0,1,
+                                    0,1,0,1,0,0,1,1,0,1,0,0,0,0,1,0,0,0,1,0,1,1,0,1,1,1,1,1,1,0,1,0};
+    static const int SOF[26] = {0,1,1,0,0,0,1,1,0,1,0,0,1,0,1,1,1,0,1,0,0,0,0,0,1,0};
+    const float a = (float)(1 / sqrt(2.0));
+    for (int i = 0; i < 13; i++) {
+        int e = 1 - 2 * SOF[2 * i], o = 1 - 2 * SOF[2 * i + 1];
+        plh[4 * i] = a * e; plh[4 * i + 1] = a * e; plh[4 * i + 2] = -1 * a * o; plh[4 * i + 3] = a * o;
+    }
+    int coded[32], fin[64];
+    for (int c = 0; c < 32; c++) { int s = 0; for (int r = 0; r < 7; r++) s = (s + mod_cod[r] * G[r][c]) % 2; coded[c] = s; }
+    for (int i = 0; i < 32; i++) {
+        fin[2 * i]     = (coded[i] + PLS_SCR[2 * i]) % 2;
+        fin[2 * i + 1] = ((coded[i] == 0 ? 1 : 0) + PLS_SCR[2 * i + 1]) % 2;
+    }
+    float *p = plh + 52;
+    for (int i = 0; i < 32; i++) {
+        int e = 1 - 2 * fin[2 * i], o = 1 - 2 * fin[2 * i + 1];
+        if (mod_cod[0] == 0) { p[4*i] = a*e; p[4*i+1] = a*e; p[4*i+2] = -1*a*o; p[4*i+3] = a*o; }
+        else                 { p[4*i] = -1*a*e; p[4*i+1] = a*e; p[4*i+2] = -1*a*o; p[4*i+3] = -1*a*o; }
+    }
+}
+
+int orc_pl_frame_size(int n_xfec_sym)
+{
+    const int M = 90, P = 36;
+    int S = n_xfec_sym / M, np = n_xfec_sym / (16 * M);
+    return M * (S + 1) + np * P;                       /* DVBS2.cpp:351-355 */
+}
+
+void orc_framer_generate(const float *xfec, int n_xfec_sym, const float *plh, float *plf)
+{
+    const int M = 90, P = 36; int np = n_xfec_sym / (16 * M);
+    const float a = (float)(1 / sqrt(2.0));
+    int o = 0;
+    for (int i = 0; i < 180; i++) plf[o++] = plh[i];
+    int d = 0;
+    for (int b = 0; b < np; b++) {
+        for (int i = 0; i < 2 * 16 * M; i++) plf[o++] = xfec[d++];
+        for (int i = 0; i < P; i++) { plf[o++] = a; plf[o++] = a; }
+    }
+    while (d < 2 * n_xfec_sym) plf[o++] = xfec[d++];
+}
+
+void orc_framer_remove_plh(const float *plf, int n_xfec_sym, float *xfec)
+{
+    const int M = 90, P = 36; int np = n_xfec_sym / (16 * M);
+    int s = 2 * M, d = 0;
+    for (int b = 0; b < np; b++) {
+        for (int i = 0; i < 2 * 16 * M; i++) xfec[d++] = plf[s++];
+        s += 2 * P;
+    }
+    while (d < 2 * n_xfec_sym) xfec[d++] = plf[s++];
+}
+
+void orc_estimate(const float *x, int n_sym, float code_rate, int bps, float *out3)
+{
+    float m2 = 0, m4 = 0;
+    for (int i = 0; i < n_sym; i++) {
+        float tmp = x[2 * i] * x[2 * i] + x[2 * i + 1] * x[2 * i + 1];
+        m2 += tmp; m4 += tmp * tmp;
+    }
+    m2 /= n_sym; m4 /= n_sym;
+    float Se = sqrtf(fabsf(2 * m2 * m2 - m4));
+    float Ne = fabsf(m2 - Se);
+    float esn0 = 10 * log10f(Se / Ne);
+    if (isinf(esn0)) esn0 = 100.f;
+    /* tools::esn0_to_sigma (upsample 1) and esn0_to_ebn0 */
+    float sigma = sqrtf(1.0f / (2.0f * powf(10.0f, esn0 / 10.0f)));
+    float ebn0 = esn0 - 10.0f * log10f(code_rate * (float)bps);
+    out3[0] = sigma; out3[1] = ebn0; out3[2] = esn0;
+}
+
+void orc_rrc_taps(float rolloff, int osf, int grp, float *taps)
+{
+    const float PI = (float)3.1415926535897932384626433832795;
+    int c = grp * osf, T = 2 * c + 1;
+    float eps = FLT_EPSILON;
+    taps[c] = 1.0f - rolloff + 4.0f * rolloff / PI;
+    float en = taps[c] * taps[c];
+    for (int i = 1; i <= c; i++) {
+        float t = (float)i / (float)osf, v;
+        if (fabsf(4.0f * rolloff * t - 1.0f) <= eps || fabsf(4.0f * rolloff * t + 1.0f) <= eps)
+            v = rolloff / sqrtf(2.0f) * ((1.0f + 2.0f / PI) * sinf(PI / (4.0f * rolloff)) +
+                                         (1.0f - 2.0f / PI) * cosf(PI / (4.0f * rolloff)));
+        else {
+            float den = PI * t * (1.0f - 16.0f * rolloff * rolloff * t * t);
+            float num = sinf(PI * t * (1.0f - rolloff)) + 4.0f * rolloff * t * cosf(PI * t * (1.0f + rolloff));
+            v = num / den;
+        }
+        taps[c + i] = v; taps[c - i] = v;
+        en += v * v + v * v;
+    }
+    for (int i = 0; i < T; i++) taps[i] /= sqrtf(en);
+}
+
+void orc_fir(const float *taps, int T, float *hist, const float *x, float *y, int n)
+{
+    /* y[i] = sum_k brev[k] x[i-(T-1)+k], brev[k] = taps[T-1-k] (Filter_FIR_ccr.cpp:26-27);
+     * x[<0] = tail of the previous frame */
+    const int H = T - 1;
+    float *ext = (float *)malloc(sizeof(float) * 2 * (n + H));
+    memcpy(ext, hist, sizeof(float) * 2 * H);
+    memcpy(ext + 2 * H, x, sizeof(float) * 2 * n);
+    for (int i = 0; i < n; i++) {
+        float ar = ext[2 * i] * taps[T - 1], ai = ext[2 * i + 1] * taps[T - 1];
+        for (int k = 1; k < T; k++) {
+            ar += ext[2 * (i + k)] * taps[T - 1 - k];
+            ai += ext[2 * (i + k) + 1] * taps[T - 1 - k];
+        }
+        y[2 * i] = ar; y[2 * i + 1] = ai;
+    }
+    memcpy(hist, ext + 2 * n, sizeof(float) * 2 * H);
+    free(ext);
+}
+
+void orc_upfir(const float *taps, int T, int osf, float *hist, const float *x, float *y, int n_in)
+{
+    float *up = (float *)calloc((size_t)2 * n_in * osf, sizeof(float));
+    for (int i = 0; i < n_in; i++) { up[2 * i * osf] = x[2 * i]; up[2 * i * osf + 1] = x[2 * i + 1]; }
+    orc_fir(taps, T, hist, up, y, n_in * osf);
+    free(up);
+}

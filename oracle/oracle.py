@@ -1,0 +1,321 @@
+"""ctypes front-end of the CPU ORACLE (oracle/libdvbs2_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+May be imported from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never
+from the dvbs2_amd package (tests/test_no_oracle_in_product.py enforces that).
+Parity status: see oracle/dvbs2_oracle.h ("parity unpinned" for a1-a4).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libdvbs2_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "dvbs2_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.orc_ldpc_create.restype = vp
+        L.orc_ldpc_create.argtypes = [ci, ci, ci, vp, vp]
+        L.orc_ldpc_destroy.argtypes = [vp]
+        L.orc_ldpc_n_edges.argtypes = [vp]
+        L.orc_ldpc_q.argtypes = [vp]
+        L.orc_ldpc_csr.argtypes = [vp, vp, vp]
+        L.orc_ldpc_encode.argtypes = [vp, vp, vp]
+        L.orc_ldpc_syndrome_weight.argtypes = [vp, vp]
+        L.orc_ldpc_decode.argtypes = [vp, vp, ci, ci, ci, cf, ci, vp, vp, vp]
+        L.orc_ldpc_decode_batch.restype = C.c_double
+        L.orc_ldpc_decode_batch.argtypes = [vp, vp, ci, ci, ci, cf, vp, ci]
+        L.orc_bch_create.restype = vp
+        L.orc_bch_create.argtypes = [ci, vp, ci, ci, ci]
+        L.orc_bch_destroy.argtypes = [vp]
+        L.orc_bch_gen_degree.argtypes = [vp]
+        L.orc_bch_gen.restype = vp
+        L.orc_bch_gen.argtypes = [vp]
+        L.orc_bch_encode.argtypes = [vp, vp, vp]
+        L.orc_bch_decode.argtypes = [vp, vp, vp, vp]
+        L.orc_cstl_normalise.argtypes = [vp, ci, vp]
+        L.orc_modulate.argtypes = [vp, ci, vp, ci, vp]
+        L.orc_demodulate.argtypes = [vp, ci, cf, vp, ci, vp]
+        L.orc_itl_lut.argtypes = [ci, ci, ci, vp]
+        L.orc_pl_rand_seq.argtypes = [ci, vp]
+        L.orc_pl_scramble.argtypes = [vp, vp, ci, ci, ci]
+        L.orc_bb_scramble.argtypes = [vp, vp, ci]
+        L.orc_plheader.argtypes = [vp, vp]
+        L.orc_framer_generate.argtypes = [vp, ci, vp, vp]
+        L.orc_framer_remove_plh.argtypes = [vp, ci, vp]
+        L.orc_pl_frame_size.argtypes = [ci]
+        L.orc_estimate.argtypes = [vp, ci, cf, ci, vp]
+        L.orc_rrc_taps.argtypes = [cf, ci, ci, vp]
+        L.orc_fir.argtypes = [vp, ci, vp, vp, vp, ci]
+        L.orc_upfir.argtypes = [vp, ci, ci, vp, vp, vp, ci]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+NMS, SPA = 0, 1
+NATURAL, QC = 0, 1
+
+
+class Ldpc:
+    def __init__(self, N, K, row_ptr, addr):
+        self.N, self.K = N, K
+        self._rp, self._ad = _i32(row_ptr), _i32(addr)
+        self.h = lib().orc_ldpc_create(N, K, len(self._rp) - 1, _p(self._rp), _p(self._ad))
+        if not self.h:
+            raise ValueError("bad LDPC table")
+        self.q = lib().orc_ldpc_q(self.h)
+        self.E = lib().orc_ldpc_n_edges(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_ldpc_destroy(self.h)
+            self.h = None
+
+    def csr(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        lib().orc_ldpc_csr(self.h, C.byref(a), C.byref(b))
+        M = self.N - self.K
+        ptr = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_int)), (M + 1,)).copy()
+        var = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_int)), (self.E,)).copy()
+        return ptr, var
+
+    def encode(self, info):
+        info = _i32(info).reshape(-1, self.K)
+        cw = np.empty((info.shape[0], self.N), dtype=np.int32)
+        for f in range(info.shape[0]):
+            lib().orc_ldpc_encode(self.h, _p(info[f]), _p(cw[f]))
+        return cw
+
+    def syndrome_weight(self, cw):
+        cw = _i32(cw)
+        return lib().orc_ldpc_syndrome_weight(self.h, _p(cw))
+
+    def decode(self, llr, n_ite=10, alpha=1.0, implem=NMS, sched=QC, early_stop=False):
+        """-> bits[F,K] int32, post[F,N] f32, cwd[F] int8, n_ite_done[F]"""
+        llr = _f32(llr).reshape(-1, self.N)
+        F = llr.shape[0]
+        bits = np.empty((F, self.K), dtype=np.int32)
+        post = np.empty((F, self.N), dtype=np.float32)
+        cwd = np.zeros(F, dtype=np.int8)
+        ites = np.zeros(F, dtype=np.int32)
+        for f in range(F):
+            ites[f] = lib().orc_ldpc_decode(self.h, _p(llr[f]), implem, sched, n_ite, alpha,
+                                            int(early_stop), _p(bits[f]), _p(post[f]),
+                                            C.c_void_p(cwd.ctypes.data + f))
+        return bits, post, cwd, ites
+
+    def decode_batch_timed(self, llr, n_ite=10, alpha=1.0, sched=NATURAL, threads=1):
+        llr = _f32(llr).reshape(-1, self.N)
+        bits = np.empty((llr.shape[0], self.K), dtype=np.int32)
+        sec = lib().orc_ldpc_decode_batch(self.h, _p(llr), llr.shape[0], sched, n_ite, alpha,
+                                          _p(bits), threads)
+        return bits, sec
+
+
+class Bch:
+    def __init__(self, m, prim, t, N, K):
+        self.m, self.t, self.N, self.K = m, t, N, K
+        self._prim = _i32(prim)
+        self.h = lib().orc_bch_create(m, _p(self._prim), t, N, K)
+        self.gdeg = lib().orc_bch_gen_degree(self.h)
+        if self.gdeg != N - K:
+            raise ValueError("generator degree %d != N-K %d" % (self.gdeg, N - K))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_bch_destroy(self.h)
+            self.h = None
+
+    def gen(self):
+        p = lib().orc_bch_gen(self.h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int)), (self.gdeg + 1,)).copy()
+
+    def encode(self, info):
+        info = _i32(info).reshape(-1, self.K)
+        cw = np.empty((info.shape[0], self.N), dtype=np.int32)
+        for f in range(info.shape[0]):
+            lib().orc_bch_encode(self.h, _p(info[f]), _p(cw[f]))
+        return cw
+
+    def decode(self, cw):
+        cw = _i32(cw).reshape(-1, self.N)
+        out = np.empty((cw.shape[0], self.K), dtype=np.int32)
+        cwd = np.zeros(cw.shape[0], dtype=np.int8)
+        for f in range(cw.shape[0]):
+            lib().orc_bch_decode(self.h, _p(cw[f]), _p(out[f]), C.c_void_p(cwd.ctypes.data + f))
+        return out, cwd
+
+
+def cstl_normalise(pts):
+    pts = _f32(pts).reshape(-1, 2)
+    out = np.empty_like(pts)
+    lib().orc_cstl_normalise(_p(pts), pts.shape[0], _p(out))
+    return out
+
+
+def modulate(cstl, bps, bits):
+    cstl, bits = _f32(cstl), _i32(bits).ravel()
+    sym = np.empty(2 * (bits.size // bps), dtype=np.float32)
+    lib().orc_modulate(_p(cstl), bps, _p(bits), bits.size, _p(sym))
+    return sym
+
+
+def demodulate(cstl, bps, sigma, sym):
+    cstl, sym = _f32(cstl), _f32(sym).ravel()
+    n_sym = sym.size // 2
+    llr = np.empty(n_sym * bps, dtype=np.float32)
+    lib().orc_demodulate(_p(cstl), bps, float(sigma), _p(sym), n_sym, _p(llr))
+    return llr
+
+
+def itl_lut(N, n_cols, order):
+    lut = np.empty(N, dtype=np.uint32)
+    lib().orc_itl_lut(N, n_cols, order, _p(lut))
+    return lut
+
+
+def pl_rand_seq(n=0):
+    seq = np.empty(66420, dtype=np.uint8)
+    lib().orc_pl_rand_seq(n, _p(seq))
+    return seq
+
+
+def pl_scramble(x, start_ix=90, scramble=True):
+    x = _f32(x).ravel()
+    y = np.empty_like(x)
+    lib().orc_pl_scramble(_p(x), _p(y), x.size // 2, start_ix, int(scramble))
+    return y
+
+
+def bb_scramble(bits):
+    bits = _i32(bits).ravel()
+    out = np.empty_like(bits)
+    lib().orc_bb_scramble(_p(bits), _p(out), bits.size)
+    return out
+
+
+def plheader(mod_cod7):
+    mc = _i32(mod_cod7)
+    plh = np.empty(180, dtype=np.float32)
+    lib().orc_plheader(_p(mc), _p(plh))
+    return plh
+
+
+def pl_frame_size(n_xfec_sym):
+    return lib().orc_pl_frame_size(n_xfec_sym)
+
+
+def framer_generate(xfec, plh):
+    xfec, plh = _f32(xfec).ravel(), _f32(plh)
+    n = xfec.size // 2
+    out = np.empty(2 * pl_frame_size(n), dtype=np.float32)
+    lib().orc_framer_generate(_p(xfec), n, _p(plh), _p(out))
+    return out
+
+
+def framer_remove_plh(plf, n_xfec_sym):
+    plf = _f32(plf).ravel()
+    out = np.empty(2 * n_xfec_sym, dtype=np.float32)
+    lib().orc_framer_remove_plh(_p(plf), n_xfec_sym, _p(out))
+    return out
+
+
+def estimate(xfec, code_rate, bps):
+    xfec = _f32(xfec).ravel()
+    out = np.empty(3, dtype=np.float32)
+    lib().orc_estimate(_p(xfec), xfec.size // 2, float(code_rate), bps, _p(out))
+    return out   # sigma, ebn0, esn0
+
+
+def rrc_taps(rolloff=0.2, osf=2, grp_delay=20):
+    t = np.empty(2 * grp_delay * osf + 1, dtype=np.float32)
+    lib().orc_rrc_taps(float(rolloff), osf, grp_delay, _p(t))
+    return t
+
+
+def fir(taps, hist, x):
+    """hist: float32[2*(T-1)] updated in place.  x: interleaved complex."""
+    taps, x = _f32(taps), _f32(x).ravel()
+    y = np.empty_like(x)
+    assert hist.dtype == np.float32 and hist.size == 2 * (taps.size - 1)
+    lib().orc_fir(_p(taps), taps.size, _p(hist), _p(x), _p(y), x.size // 2)
+    return y
+
+
+def upfir(taps, osf, hist, x):
+    taps, x = _f32(taps), _f32(x).ravel()
+    y = np.empty(x.size * osf, dtype=np.float32)
+    lib().orc_upfir(_p(taps), taps.size, osf, _p(hist), _p(x), _p(y), x.size // 2)
+    return y
+
+
+# ---------------------------------------------------------------- convenience: full TX / RX chains
+class Chain:
+    """Oracle TX and RX baseband chains with the socket graph of
+    /root/reference src/mains/TX_RX_BB/main.cpp:75-94."""
+
+    def __init__(self, mc):
+        from dvbs2_amd import params as P   # data tables only (no product code paths)
+        self.mc = mc
+        rp, ad = P.load_ldpc_table(mc.ldpc_table)
+        self.ldpc = Ldpc(mc.N_ldpc, mc.K_ldpc, rp, ad)
+        self.bch = Bch(mc.bch_m, mc.bch_prim, mc.bch_t, mc.N_bch, mc.K_bch)
+        self.cstl = cstl_normalise(P.load_constellation(mc.cstl_file))
+        self.lut = itl_lut(mc.N_ldpc, mc.itl_cols, mc.itl_order)
+        self.plh = plheader(mc.pls)
+
+    def tx(self, info_bits):
+        """info_bits int32[K_bch] -> (pl_frame f32[2*pl_frame] scrambled, ldpc codeword)"""
+        mc = self.mc
+        scr = bb_scramble(info_bits)
+        bch = self.bch.encode(scr)[0]
+        cw = self.ldpc.encode(bch)[0]
+        itl = cw[self.lut]
+        sym = modulate(self.cstl, mc.bps, itl)
+        plf = framer_generate(sym, self.plh)
+        return pl_scramble(plf, 90, True), cw
+
+    def rx(self, pl_frame, sigma=None, n_ite=10, alpha=1.0, implem=NMS, sched=QC, early_stop=False):
+        mc = self.mc
+        d = pl_scramble(pl_frame, 90, False)
+        xfec = framer_remove_plh(d, mc.N_xfec)
+        est = estimate(xfec, mc.code_rate, mc.bps)
+        s = float(est[0]) if sigma is None else float(sigma)
+        llr_i = demodulate(self.cstl, mc.bps, s, xfec)
+        llr = np.empty_like(llr_i)
+        llr[self.lut] = llr_i
+        bits, post, cwd, ites = self.ldpc.decode(llr, n_ite, alpha, implem, sched, early_stop)
+        out, cwd2 = self.bch.decode(bits[0])
+        info = bb_scramble(out[0])
+        return dict(info=info, llr=llr, post=post[0], ldpc_bits=bits[0], ldpc_cwd=cwd[0],
+                    bch_cwd=cwd2[0], sigma=s, est=est, ites=ites[0], xfec=xfec)
