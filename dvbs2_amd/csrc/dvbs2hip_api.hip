@@ -1,0 +1,697 @@
+// C ABI of libdvbs2hip.so (include/dvbs2hip.h): handle, tables, workspaces, stream plumbing.
+// The arithmetic is in k_ldpc.hip / k_bch.hip / k_front.hip / k_fir.hip.  No CPU fallback.
+#include "dvbs2hip_internal.h"
+#include "dvbs2_tables_gen.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <utility>
+
+using namespace dvbs2;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct dvbs2hip_handle {
+    // configuration
+    int N_ldpc = 0, K_ldpc = 0, K_bch = 0, bps = 0, itl_cols = 1, itl_order = 0;
+    int n_sym = 0, pl_frame = 0, max_frames = 1, device = 0;
+    int n_ite = 50, early_stop = 1, implem = 0;
+    float alpha = 1.f, code_rate = 0.f;
+    int fir_T = 0, fir_osf = 1;
+    // device state
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cus = 256;
+    LdpcPlan ldpc;
+    BchPlan bch;
+    float *d_cstl = nullptr;
+    uint8_t *d_pl_seq = nullptr;
+    float *d_taps_rev = nullptr;
+    float *d_hist[2] = {nullptr, nullptr};
+    int hist_cur = 0;
+    unsigned long long *d_ctr = nullptr;
+    float *d_gwork = nullptr;
+    std::map<int, DevBuf> bufs;        // lazily grown staging / intermediate buffers
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[DVBS2HIP_K_COUNT];
+    std::string err;
+};
+
+namespace {
+
+int fail(dvbs2hip_t *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                       \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return fail(h, DVBS2HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+enum BufId { B_IN = 0, B_OUT, B_AUX0, B_AUX1, B_AUX2, B_AUX3, B_LLR, B_PACKED, B_EST, B_CWD0, B_CWD1, B_INFO, B_SIG };
+
+int ensure(dvbs2hip_t *h, int id, size_t bytes, void **out)
+{
+    DevBuf &b = h->bufs[id];
+    if (b.bytes < bytes) {
+        if (b.p) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+        hipError_t e = hipMalloc(&b.p, bytes);
+        if (e != hipSuccess) return fail(h, DVBS2HIP_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
+        b.bytes = bytes;
+    }
+    *out = b.p;
+    return 0;
+}
+
+int check_frames(dvbs2hip_t *h, int n_frames)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    if (n_frames < 1 || n_frames > h->max_frames)
+        return fail(h, DVBS2HIP_EINVAL, "'n_frames' has to be in [1, max_frames] ('n_frames' = " + std::to_string(n_frames) +
+                                            ", 'max_frames' = " + std::to_string(h->max_frames) + ").");
+    return 0;
+}
+
+struct Timer {      // RAII: events around one kernel launch when timing is on
+    dvbs2hip_t *h; int k; hipEvent_t a = nullptr, b = nullptr;
+    Timer(dvbs2hip_t *h_, int k_) : h(h_), k(k_)
+    {
+        if (!h->timing) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, h->stream);
+    }
+    ~Timer()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, h->stream);
+        h->ev[k].push_back({a, b});
+    }
+};
+
+void pl_sequence(std::vector<uint8_t> &seq)
+{
+    // ETSI EN 302 307 5.5.4, n = 0; equals PL_RAND_SEQ (Scrambler_PL.hpp:54-4207)
+    const int P = (1 << 18) - 1;
+    std::vector<uint8_t> x(P), y(P);
+    for (int i = 0; i < 18; i++) { x[i] = i == 0; y[i] = 1; }
+    for (int i = 0; i + 18 < P; i++) { x[i + 18] = x[i + 7] ^ x[i]; y[i + 18] = y[i + 10] ^ y[i + 7] ^ y[i + 5] ^ y[i]; }
+    seq.resize(66420);
+    for (int i = 0; i < 66420; i++) {
+        const int i2 = (i + 131072) % P;
+        seq[i] = (uint8_t)(2 * (x[i2] ^ y[i2]) + (x[i] ^ y[i]));
+    }
+}
+
+void bb_prbs(int K, std::vector<uint32_t> &out)
+{
+    // Scrambler_BB.hpp:28 init, Scrambler_BB.hxx:56-64 step
+    int l[15] = {1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0};
+    out.assign((K + 31) / 32, 0u);
+    for (int i = 0; i < K; i++) {
+        const int fb = l[14] ^ l[13];
+        for (int j = 14; j > 0; j--) l[j] = l[j - 1];
+        l[0] = fb;
+        if (fb) out[i >> 5] |= 1u << (i & 31);
+    }
+}
+
+template <typename T>
+int upload(dvbs2hip_t *h, T **dst, const T *src, size_t n)
+{
+    HIPCHK(h, hipMalloc((void **)dst, n * sizeof(T)));
+    HIPCHK(h, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvbs2hip_cfg_from_modcod(const char *modcod, dvbs2hip_cfg *cfg)
+{
+    if (!cfg) return DVBS2HIP_EINVAL;
+    std::string name = modcod ? modcod : "";
+    if (name.empty()) name = "QPSK-S_8/9";
+    for (int i = 0; i < DVBS2_N_MODCODS; i++) {
+        const dvbs2_modcod_row &r = dvbs2_modcod_rows[i];
+        if (name != r.name) continue;
+        memset(cfg, 0, sizeof *cfg);
+        cfg->N_ldpc = r.N_ldpc; cfg->K_ldpc = r.K_ldpc; cfg->K_bch = r.K_bch;
+        cfg->ldpc_n_rows = r.ldpc_n_rows; cfg->ldpc_row_ptr = r.rp; cfg->ldpc_addr = r.ad;
+        cfg->ldpc_n_ite = 50; cfg->ldpc_implem = DVBS2HIP_IMPLEM_NMS; cfg->ldpc_alpha = 1.0f; cfg->ldpc_early_stop = 1;
+        cfg->bch_m = r.bch_m; cfg->bch_t = r.bch_t; cfg->bch_prim = r.prim;
+        cfg->bps = r.bps; cfg->cstl = r.cstl;
+        cfg->itl_cols = r.itl_cols; cfg->itl_order = r.itl_order;
+        cfg->fir_n_taps = 81; cfg->fir_taps = rrc_taps_81; cfg->fir_osf = 2;
+        cfg->max_frames = 1; cfg->device = 0; cfg->stream = nullptr; cfg->ldpc_lds_groups = -1;
+        return DVBS2HIP_OK;
+    }
+    g_create_error = name + " mod-cod scheme not supported.";
+    return DVBS2HIP_EINVAL;
+}
+
+int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
+{
+    if (!cfg || !out) return fail(nullptr, DVBS2HIP_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->max_frames < 1) return fail(nullptr, DVBS2HIP_EINVAL, "'max_frames' has to be greater than 0");
+    if (cfg->bps < 1 || cfg->bps > 5 || !cfg->cstl) return fail(nullptr, DVBS2HIP_EINVAL, "'bps' has to be in [1,5] with a constellation");
+    if (cfg->N_ldpc <= 0 || cfg->N_ldpc % cfg->bps) return fail(nullptr, DVBS2HIP_EINVAL, "'N_ldpc' has to be a positive multiple of 'bps'");
+    if (cfg->itl_cols > 1 && cfg->N_ldpc % cfg->itl_cols) return fail(nullptr, DVBS2HIP_EINVAL, "'N_ldpc' has to be a multiple of 'itl_cols'");
+    if (cfg->ldpc_implem != DVBS2HIP_IMPLEM_NMS && cfg->ldpc_implem != DVBS2HIP_IMPLEM_MS)
+        return fail(nullptr, DVBS2HIP_EUNSUPPORTED, "LDPC implem not supported (NMS and MS only)");
+    if (!cfg->ldpc_row_ptr || !cfg->ldpc_addr || !cfg->bch_prim) return fail(nullptr, DVBS2HIP_EINVAL, "missing code tables");
+    if (cfg->ldpc_n_ite < 1) return fail(nullptr, DVBS2HIP_EINVAL, "'ldpc_n_ite' has to be greater than 0");
+    if (cfg->fir_n_taps < 0 || cfg->fir_n_taps > 257 || (cfg->fir_n_taps > 0 && !cfg->fir_taps))
+        return fail(nullptr, DVBS2HIP_EINVAL, "'fir_n_taps' has to be in [0,257] with taps");
+
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1)
+        return fail(nullptr, DVBS2HIP_ENODEVICE, "no HIP device available (libdvbs2hip has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= n_dev) return fail(nullptr, DVBS2HIP_EINVAL, "'device' out of range");
+
+    dvbs2hip_t *h = new (std::nothrow) dvbs2hip_handle;
+    if (!h) return fail(nullptr, DVBS2HIP_ENOMEM, "out of host memory");
+#define CREATE_FAIL(code, msg) do { std::string m__ = (msg); dvbs2hip_destroy(h); return fail(nullptr, code, m__); } while (0)
+#define CREATE_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) CREATE_FAIL(DVBS2HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
+    h->device = cfg->device;
+    CREATE_HIP(hipSetDevice(h->device));
+    hipDeviceProp_t prop;
+    CREATE_HIP(hipGetDeviceProperties(&prop, h->device));
+    h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
+    else { CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+
+    h->N_ldpc = cfg->N_ldpc; h->K_ldpc = cfg->K_ldpc; h->K_bch = cfg->K_bch; h->bps = cfg->bps;
+    h->itl_cols = cfg->itl_cols; h->itl_order = cfg->itl_order; h->max_frames = cfg->max_frames;
+    h->n_sym = cfg->N_ldpc / cfg->bps;
+    h->pl_frame = 90 * (h->n_sym / 90 + 1) + (h->n_sym / (16 * 90)) * 36;      // DVBS2.cpp:351-355
+    h->n_ite = cfg->ldpc_n_ite; h->early_stop = cfg->ldpc_early_stop ? 1 : 0; h->implem = cfg->ldpc_implem;
+    h->alpha = cfg->ldpc_implem == DVBS2HIP_IMPLEM_MS ? 1.0f : cfg->ldpc_alpha;
+    h->code_rate = (float)cfg->K_bch / (float)cfg->N_ldpc;                      // TX_RX_BB/main.cpp:142
+    if (h->n_sym % 90) CREATE_FAIL(DVBS2HIP_EINVAL, "'N_ldpc / bps' has to be a multiple of the 90-symbol slot");
+
+    // ---- LDPC
+    // gfx950: a workgroup may own the CU's whole 160 KiB LDS (MI355X_MICROARCH "LDS")
+    size_t lds_limit = strstr(prop.gcnArchName, "gfx950") ? 160 * 1024 : prop.sharedMemPerBlock;
+    if (const char *ev = getenv("DVBS2HIP_LDS_LIMIT")) lds_limit = (size_t)atol(ev);
+    if (lds_limit < 32 * 1024) lds_limit = 32 * 1024;
+    lds_limit -= 512;                                    // static LDS of the kernel + slack
+    std::string e = ldpc_build_plan(h->ldpc, cfg->N_ldpc, cfg->K_ldpc, cfg->ldpc_n_rows, cfg->ldpc_row_ptr, cfg->ldpc_addr,
+                                    cfg->ldpc_lds_groups, lds_limit);
+    if (!e.empty()) CREATE_FAIL(DVBS2HIP_EINVAL, e);
+    LdpcPlan &lp = h->ldpc;
+    if (upload(h, &lp.d_entries, lp.entries.data(), lp.entries.size()) ||
+        upload(h, &lp.d_layer_deg, lp.layer_deg.data(), lp.layer_deg.size()) ||
+        upload(h, &lp.d_layer_lvl, lp.layer_lvl.data(), lp.layer_lvl.size()) ||
+        upload(h, &lp.d_groups, lp.groups.data(), lp.groups.size()))
+        CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+    lp.grid_max = ldpc_blocks_per_cu(lp) * h->n_cus;
+    if (lp.gwork_words > 0) CREATE_HIP(hipMalloc((void **)&h->d_gwork, (size_t)lp.grid_max * lp.gwork_words * sizeof(float)));
+
+    // ---- BCH
+    e = bch_build_plan(h->bch, cfg->bch_m, cfg->bch_prim, cfg->bch_t, cfg->K_ldpc, cfg->K_bch);
+    if (!e.empty()) CREATE_FAIL(DVBS2HIP_EINVAL, e);
+    if (upload(h, &h->bch.d_exp, h->bch.exp_.data(), h->bch.exp_.size()) ||
+        upload(h, &h->bch.d_log, h->bch.log_.data(), h->bch.log_.size()))
+        CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+    std::vector<uint32_t> prbs;
+    bb_prbs(cfg->K_bch, prbs);
+    if (upload(h, &h->bch.d_prbs, prbs.data(), prbs.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+
+    // ---- modem: normalise to unit mean energy in fp32 (tools::Constellation_user)
+    const int P = 1 << cfg->bps;
+    std::vector<float> cs(2 * P);
+    float es = 0.f;
+    for (int i = 0; i < P; i++) es += cfg->cstl[2 * i] * cfg->cstl[2 * i] + cfg->cstl[2 * i + 1] * cfg->cstl[2 * i + 1];
+    const float sc = sqrtf(es / (float)P);
+    if (!(sc > 0.f)) CREATE_FAIL(DVBS2HIP_EINVAL, "constellation has zero energy");
+    for (int i = 0; i < 2 * P; i++) cs[i] = cfg->cstl[i] / sc;
+    if (upload(h, &h->d_cstl, cs.data(), cs.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+    std::vector<uint8_t> seq;
+    pl_sequence(seq);
+    if (h->pl_frame - 90 > (int)seq.size()) CREATE_FAIL(DVBS2HIP_EINVAL, "PL frame longer than the scrambling sequence");
+    if (upload(h, &h->d_pl_seq, seq.data(), seq.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+
+    // ---- matched filter: taps stored reversed (Filter_FIR_ccr.cpp:26-27)
+    h->fir_T = cfg->fir_n_taps; h->fir_osf = cfg->fir_osf > 0 ? cfg->fir_osf : 1;
+    if (h->fir_T > 0) {
+        std::vector<float> rev(h->fir_T);
+        for (int i = 0; i < h->fir_T; i++) rev[i] = cfg->fir_taps[h->fir_T - 1 - i];
+        if (upload(h, &h->d_taps_rev, rev.data(), rev.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+        const size_t hb = sizeof(float) * 2 * (size_t)(h->fir_T > 1 ? h->fir_T - 1 : 1);
+        for (int i = 0; i < 2; i++) { CREATE_HIP(hipMalloc((void **)&h->d_hist[i], hb)); CREATE_HIP(hipMemset(h->d_hist[i], 0, hb)); }
+    }
+    CREATE_HIP(hipMalloc((void **)&h->d_ctr, 3 * sizeof(unsigned long long)));
+    CREATE_HIP(hipMemset(h->d_ctr, 0, 3 * sizeof(unsigned long long)));
+    CREATE_HIP(hipDeviceSynchronize());
+#undef CREATE_FAIL
+#undef CREATE_HIP
+    *out = h;
+    return DVBS2HIP_OK;
+}
+
+void dvbs2hip_destroy(dvbs2hip_t *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &kv : h->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
+        for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    void *ptrs[] = {h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->bch.d_exp, h->bch.d_log,
+                    h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char *dvbs2hip_last_error(const dvbs2hip_t *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dvbs2hip_reset(dvbs2hip_t *h)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    int r = dvbs2hip_filter_reset(h);
+    if (r) return r;
+    return dvbs2hip_monitor_reset(h);
+}
+
+int dvbs2hip_set_ldpc_params(dvbs2hip_t *h, int32_t n_ite, float alpha, int32_t early_stop)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    if (n_ite < 1) return fail(h, DVBS2HIP_EINVAL, "'n_ite' has to be greater than 0");
+    if (!(alpha > 0.f)) return fail(h, DVBS2HIP_EINVAL, "'alpha' has to be greater than 0");
+    h->n_ite = n_ite; h->alpha = alpha; h->early_stop = early_stop ? 1 : 0;
+    return 0;
+}
+
+void *dvbs2hip_get_stream(dvbs2hip_t *h) { return h ? (void *)h->stream : nullptr; }
+
+int dvbs2hip_synchronize(dvbs2hip_t *h)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int dvbs2hip_get_sizes(const dvbs2hip_t *h, dvbs2hip_sizes *o)
+{
+    if (!h || !o) return DVBS2HIP_EINVAL;
+    o->N_ldpc = h->N_ldpc; o->K_ldpc = h->K_ldpc; o->K_bch = h->K_bch; o->bps = h->bps;
+    o->N_xfec_sym = h->n_sym; o->pl_frame_sym = h->pl_frame; o->ldpc_edges = h->ldpc.E; o->ldpc_q = h->ldpc.q;
+    return 0;
+}
+
+// ------------------------------------------------------------------ a1
+static int ldpc_dev(dvbs2hip_t *h, const float *Y, int8_t *CWD, int32_t *V, uint32_t *packed, float *post, int32_t *ites, int F)
+{
+    LdpcKParams p;
+    memset(&p, 0, sizeof p);
+    p.llr = Y; p.bits = V; p.packed = packed; p.cwd = CWD; p.post = post; p.ites = ites; p.gwork = h->d_gwork;
+    p.n_frames = F; p.n_ite = h->n_ite; p.early_stop = h->early_stop; p.alpha = h->alpha;
+    Timer tm(h, DVBS2HIP_K_LDPC);
+    HIPCHK(h, ldpc_launch(h->ldpc, p, h->stream));
+    return 0;
+}
+
+int dvbs2hip_ldpc_decode_siho_dev(dvbs2hip_t *h, const float *Y_N, int8_t *CWD, int32_t *V_K, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!Y_N || !V_K) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    return ldpc_dev(h, Y_N, CWD, V_K, nullptr, nullptr, nullptr, F);
+}
+
+int dvbs2hip_ldpc_decode_siho_post(dvbs2hip_t *h, const float *Y_N, int8_t *CWD, int32_t *V_K, float *post, int32_t *ites, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!Y_N || !V_K) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const size_t nin = (size_t)F * h->N_ldpc * 4, nout = (size_t)F * h->K_ldpc * 4;
+    void *din, *dout, *dcwd, *dpost = nullptr, *dit = nullptr;
+    if ((r = ensure(h, B_IN, nin, &din)) || (r = ensure(h, B_OUT, nout, &dout)) || (r = ensure(h, B_CWD0, F, &dcwd))) return r;
+    if (post && (r = ensure(h, B_AUX0, nin, &dpost))) return r;
+    if (ites && (r = ensure(h, B_AUX1, (size_t)F * 4, &dit))) return r;
+    HIPCHK(h, hipMemcpyAsync(din, Y_N, nin, hipMemcpyHostToDevice, h->stream));
+    if ((r = ldpc_dev(h, (const float *)din, (int8_t *)dcwd, (int32_t *)dout, nullptr, (float *)dpost, (int32_t *)dit, F))) return r;
+    HIPCHK(h, hipMemcpyAsync(V_K, dout, nout, hipMemcpyDeviceToHost, h->stream));
+    if (CWD) HIPCHK(h, hipMemcpyAsync(CWD, dcwd, F, hipMemcpyDeviceToHost, h->stream));
+    if (post) HIPCHK(h, hipMemcpyAsync(post, dpost, nin, hipMemcpyDeviceToHost, h->stream));
+    if (ites) HIPCHK(h, hipMemcpyAsync(ites, dit, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int dvbs2hip_ldpc_decode_siho(dvbs2hip_t *h, const float *Y_N, int8_t *CWD, int32_t *V_K, int32_t F)
+{
+    return dvbs2hip_ldpc_decode_siho_post(h, Y_N, CWD, V_K, nullptr, nullptr, F);
+}
+
+// ------------------------------------------------------------------ a2
+static int bch_dev(dvbs2hip_t *h, const int32_t *Y, const uint32_t *packed, int8_t *CWD, int32_t *V, bool descramble, int F)
+{
+    BchKParams p;
+    memset(&p, 0, sizeof p);
+    p.in_bits = Y; p.in_packed = packed; p.out_bits = V; p.cwd = CWD; p.n_frames = F;
+    p.prbs = descramble ? h->bch.d_prbs : nullptr;
+    Timer tm(h, DVBS2HIP_K_BCH);
+    HIPCHK(h, bch_launch(h->bch, p, h->stream));
+    return 0;
+}
+
+int dvbs2hip_bch_decode_hiho_dev(dvbs2hip_t *h, const int32_t *Y_N, int8_t *CWD, int32_t *V_K, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!Y_N || !V_K) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    return bch_dev(h, Y_N, nullptr, CWD, V_K, false, F);
+}
+
+int dvbs2hip_bch_decode_hiho(dvbs2hip_t *h, const int32_t *Y_N, int8_t *CWD, int32_t *V_K, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!Y_N || !V_K) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const size_t nin = (size_t)F * h->K_ldpc * 4, nout = (size_t)F * h->K_bch * 4;
+    void *din, *dout, *dcwd;
+    if ((r = ensure(h, B_IN, nin, &din)) || (r = ensure(h, B_OUT, nout, &dout)) || (r = ensure(h, B_CWD0, F, &dcwd))) return r;
+    HIPCHK(h, hipMemcpyAsync(din, Y_N, nin, hipMemcpyHostToDevice, h->stream));
+    if ((r = bch_dev(h, (const int32_t *)din, nullptr, (int8_t *)dcwd, (int32_t *)dout, false, F))) return r;
+    HIPCHK(h, hipMemcpyAsync(V_K, dout, nout, hipMemcpyDeviceToHost, h->stream));
+    if (CWD) HIPCHK(h, hipMemcpyAsync(CWD, dcwd, F, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ a3 / a4
+static FrontKParams front_params(dvbs2hip_t *h, const float *in, const float *sigma, float *llr, float *est, int F)
+{
+    FrontKParams p;
+    memset(&p, 0, sizeof p);
+    p.in = in; p.sigma_in = sigma; p.llr = llr; p.est = est; p.cstl = h->d_cstl; p.pl_seq = h->d_pl_seq;
+    p.n_sym = h->n_sym; p.pl_frame = h->pl_frame; p.bps = h->bps; p.itl_cols = h->itl_cols; p.itl_order = h->itl_order;
+    p.n_frames = F; p.code_rate = h->code_rate;
+    return p;
+}
+
+static int demod_any_dev(dvbs2hip_t *h, const float *CP, const float *Y1, float *Y2, bool deitl, int F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!CP || !Y1 || !Y2) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    Timer tm(h, DVBS2HIP_K_DEMAP);
+    HIPCHK(h, demod_launch(front_params(h, Y1, CP, Y2, nullptr, F), deitl, h->stream));
+    return 0;
+}
+
+static int demod_any_host(dvbs2hip_t *h, const float *CP, const float *Y1, float *Y2, bool deitl, int F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!CP || !Y1 || !Y2) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const size_t nin = (size_t)F * 2 * h->n_sym * 4, nout = (size_t)F * h->N_ldpc * 4;
+    void *din, *dout, *dsig;
+    if ((r = ensure(h, B_IN, nin, &din)) || (r = ensure(h, B_OUT, nout, &dout)) || (r = ensure(h, B_SIG, (size_t)F * 4, &dsig))) return r;
+    HIPCHK(h, hipMemcpyAsync(din, Y1, nin, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dsig, CP, (size_t)F * 4, hipMemcpyHostToDevice, h->stream));
+    if ((r = demod_any_dev(h, (const float *)dsig, (const float *)din, (float *)dout, deitl, F))) return r;
+    HIPCHK(h, hipMemcpyAsync(Y2, dout, nout, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int dvbs2hip_demodulate_dev(dvbs2hip_t *h, const float *CP, const float *Y1, float *Y2, int32_t F) { return demod_any_dev(h, CP, Y1, Y2, false, F); }
+int dvbs2hip_demodulate(dvbs2hip_t *h, const float *CP, const float *Y1, float *Y2, int32_t F) { return demod_any_host(h, CP, Y1, Y2, false, F); }
+int dvbs2hip_demodulate_deinterleave_dev(dvbs2hip_t *h, const float *CP, const float *Y1, float *nat, int32_t F) { return demod_any_dev(h, CP, Y1, nat, true, F); }
+int dvbs2hip_demodulate_deinterleave(dvbs2hip_t *h, const float *CP, const float *Y1, float *nat, int32_t F) { return demod_any_host(h, CP, Y1, nat, true, F); }
+
+int dvbs2hip_deinterleave_dev(dvbs2hip_t *h, const float *itl, float *nat, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!itl || !nat) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    Timer tm(h, DVBS2HIP_K_MISC);
+    HIPCHK(h, deinterleave_launch(itl, nat, h->N_ldpc, h->itl_cols, h->itl_order, F, h->stream));
+    return 0;
+}
+
+}  // extern "C"
+
+// generic "same-size or two-size elementwise" host wrapper
+template <typename Tin, typename Tout, typename Fn>
+static int host_wrap(dvbs2hip_t *h, const Tin *in, size_t nin_el, Tout *out, size_t nout_el, int F, Fn dev_call)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!in || !out) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const size_t nin = (size_t)F * nin_el * sizeof(Tin), nout = (size_t)F * nout_el * sizeof(Tout);
+    void *din, *dout;
+    if ((r = ensure(h, B_IN, nin, &din)) || (r = ensure(h, B_OUT, nout, &dout))) return r;
+    HIPCHK(h, hipMemcpyAsync(din, in, nin, hipMemcpyHostToDevice, h->stream));
+    if ((r = dev_call((const Tin *)din, (Tout *)dout))) return r;
+    HIPCHK(h, hipMemcpyAsync(out, dout, nout, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" {
+
+int dvbs2hip_deinterleave(dvbs2hip_t *h, const float *itl, float *nat, int32_t F)
+{
+    return host_wrap(h, itl, h ? h->N_ldpc : 0, nat, h ? h->N_ldpc : 0, F,
+                     [&](const float *a, float *b) { return dvbs2hip_deinterleave_dev(h, a, b, F); });
+}
+
+// ------------------------------------------------------------------ a5
+int dvbs2hip_filter_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X || !Y) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    if (h->fir_T <= 0) return fail(h, DVBS2HIP_EUNSUPPORTED, "handle was created without filter taps");
+    if (n_cplx < 1) return fail(h, DVBS2HIP_EINVAL, "'n_cplx' has to be greater than 0");
+    Timer tm(h, DVBS2HIP_K_FIR);
+    HIPCHK(h, fir_launch(X, Y, h->d_hist[h->hist_cur], h->d_hist[h->hist_cur ^ 1], h->d_taps_rev, h->fir_T,
+                         (long long)n_cplx * F, h->stream));
+    h->hist_cur ^= 1;
+    return 0;
+}
+
+int dvbs2hip_filter(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx, int32_t F)
+{
+    return host_wrap(h, X, (size_t)2 * (n_cplx > 0 ? n_cplx : 0), Y, (size_t)2 * (n_cplx > 0 ? n_cplx : 0), F,
+                     [&](const float *a, float *b) { return dvbs2hip_filter_dev(h, a, b, n_cplx, F); });
+}
+
+int dvbs2hip_filter_reset(dvbs2hip_t *h)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    if (h->fir_T > 1)
+        for (int i = 0; i < 2; i++) HIPCHK(h, hipMemsetAsync(h->d_hist[i], 0, sizeof(float) * 2 * (h->fir_T - 1), h->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ a6
+int dvbs2hip_estimate_dev(dvbs2hip_t *h, const float *X, float *SIG, float *EB, float *ES, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X || !SIG || !EB || !ES) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    Timer tm(h, DVBS2HIP_K_MISC);
+    HIPCHK(h, estimate_launch(X, SIG, EB, ES, h->n_sym, h->code_rate, h->bps, F, h->stream));
+    return 0;
+}
+
+int dvbs2hip_estimate(dvbs2hip_t *h, const float *X, float *SIG, float *EB, float *ES, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X || !SIG || !EB || !ES) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const size_t nin = (size_t)F * 2 * h->n_sym * 4;
+    void *din, *dout;
+    if ((r = ensure(h, B_IN, nin, &din)) || (r = ensure(h, B_OUT, (size_t)F * 12, &dout))) return r;
+    float *o = (float *)dout;
+    HIPCHK(h, hipMemcpyAsync(din, X, nin, hipMemcpyHostToDevice, h->stream));
+    if ((r = dvbs2hip_estimate_dev(h, (const float *)din, o, o + F, o + 2 * F, F))) return r;
+    HIPCHK(h, hipMemcpyAsync(SIG, o, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(EB, o + F, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ES, o + 2 * F, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ a7
+int dvbs2hip_pl_descramble_dev(dvbs2hip_t *h, const float *a, float *b, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!a || !b) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    Timer tm(h, DVBS2HIP_K_MISC);
+    HIPCHK(h, pl_descramble_launch(a, b, h->d_pl_seq, h->pl_frame, F, h->stream));
+    return 0;
+}
+int dvbs2hip_pl_descramble(dvbs2hip_t *h, const float *a, float *b, int32_t F)
+{
+    const size_t n = h ? (size_t)2 * h->pl_frame : 0;
+    return host_wrap(h, a, n, b, n, F, [&](const float *x, float *y) { return dvbs2hip_pl_descramble_dev(h, x, y, F); });
+}
+int dvbs2hip_remove_plh_dev(dvbs2hip_t *h, const float *a, float *b, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!a || !b) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    Timer tm(h, DVBS2HIP_K_MISC);
+    HIPCHK(h, remove_plh_launch(a, b, h->n_sym, h->pl_frame, F, h->stream));
+    return 0;
+}
+int dvbs2hip_remove_plh(dvbs2hip_t *h, const float *a, float *b, int32_t F)
+{
+    return host_wrap(h, a, h ? (size_t)2 * h->pl_frame : 0, b, h ? (size_t)2 * h->n_sym : 0, F,
+                     [&](const float *x, float *y) { return dvbs2hip_remove_plh_dev(h, x, y, F); });
+}
+
+// ------------------------------------------------------------------ a8
+int dvbs2hip_bb_descramble_dev(dvbs2hip_t *h, const int32_t *a, int32_t *b, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!a || !b) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    Timer tm(h, DVBS2HIP_K_MISC);
+    HIPCHK(h, bb_descramble_launch(a, b, h->bch.d_prbs, h->K_bch, F, h->stream));
+    return 0;
+}
+int dvbs2hip_bb_descramble(dvbs2hip_t *h, const int32_t *a, int32_t *b, int32_t F)
+{
+    const size_t n = h ? (size_t)h->K_bch : 0;
+    return host_wrap(h, a, n, b, n, F, [&](const int32_t *x, int32_t *y) { return dvbs2hip_bb_descramble_dev(h, x, y, F); });
+}
+
+// ------------------------------------------------------------------ a9
+int dvbs2hip_monitor_check_errors_dev(dvbs2hip_t *h, const int32_t *U, const int32_t *V, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!U || !V) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    Timer tm(h, DVBS2HIP_K_MISC);
+    HIPCHK(h, monitor_launch(U, V, h->d_ctr, h->K_bch, F, h->stream));
+    return 0;
+}
+int dvbs2hip_monitor_check_errors(dvbs2hip_t *h, const int32_t *U, const int32_t *V, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!U || !V) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const size_t n = (size_t)F * h->K_bch * 4;
+    void *du, *dv;
+    if ((r = ensure(h, B_IN, n, &du)) || (r = ensure(h, B_OUT, n, &dv))) return r;
+    HIPCHK(h, hipMemcpyAsync(du, U, n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dv, V, n, hipMemcpyHostToDevice, h->stream));
+    if ((r = dvbs2hip_monitor_check_errors_dev(h, (const int32_t *)du, (const int32_t *)dv, F))) return r;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+int dvbs2hip_monitor_get(dvbs2hip_t *h, uint64_t out[3])
+{
+    if (!h || !out) return DVBS2HIP_EINVAL;
+    unsigned long long tmp[3];
+    HIPCHK(h, hipMemcpyAsync(tmp, h->d_ctr, sizeof tmp, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 3; i++) out[i] = tmp[i];
+    return 0;
+}
+int dvbs2hip_monitor_reset(dvbs2hip_t *h)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    HIPCHK(h, hipMemsetAsync(h->d_ctr, 0, 3 * sizeof(unsigned long long), h->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ fused RX baseband chain
+int dvbs2hip_rx_bb_dev(dvbs2hip_t *h, const float *pl, const float *sigma, int32_t *info, int8_t *cwd_l, int8_t *cwd_b, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!pl || !info) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    void *dllr, *dpk, *dest;
+    const size_t nwords = (size_t)(h->K_ldpc + 31) / 32;
+    if ((r = ensure(h, B_LLR, (size_t)F * h->N_ldpc * 4, &dllr)) || (r = ensure(h, B_PACKED, (size_t)F * nwords * 4, &dpk)) ||
+        (r = ensure(h, B_EST, (size_t)F * 12, &dest)))
+        return r;
+    {
+        Timer tm(h, DVBS2HIP_K_FRONT);
+        HIPCHK(h, front_rx_launch(front_params(h, pl, sigma, (float *)dllr, (float *)dest, F), h->stream));
+    }
+    if ((r = ldpc_dev(h, (const float *)dllr, cwd_l, nullptr, (uint32_t *)dpk, nullptr, nullptr, F))) return r;
+    return bch_dev(h, nullptr, (const uint32_t *)dpk, cwd_b, info, true, F);
+}
+
+int dvbs2hip_rx_bb(dvbs2hip_t *h, const float *pl, const float *sigma, int32_t *info, int8_t *cwd_l, int8_t *cwd_b, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!pl || !info) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const size_t nin = (size_t)F * 2 * h->pl_frame * 4, nout = (size_t)F * h->K_bch * 4;
+    void *din, *dout, *dc0, *dc1, *dsig = nullptr;
+    if ((r = ensure(h, B_IN, nin, &din)) || (r = ensure(h, B_INFO, nout, &dout)) || (r = ensure(h, B_CWD0, F, &dc0)) ||
+        (r = ensure(h, B_CWD1, F, &dc1)))
+        return r;
+    if (sigma) {
+        if ((r = ensure(h, B_SIG, (size_t)F * 4, &dsig))) return r;
+        HIPCHK(h, hipMemcpyAsync(dsig, sigma, (size_t)F * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipMemcpyAsync(din, pl, nin, hipMemcpyHostToDevice, h->stream));
+    if ((r = dvbs2hip_rx_bb_dev(h, (const float *)din, (const float *)dsig, (int32_t *)dout, (int8_t *)dc0, (int8_t *)dc1, F))) return r;
+    HIPCHK(h, hipMemcpyAsync(info, dout, nout, hipMemcpyDeviceToHost, h->stream));
+    if (cwd_l) HIPCHK(h, hipMemcpyAsync(cwd_l, dc0, F, hipMemcpyDeviceToHost, h->stream));
+    if (cwd_b) HIPCHK(h, hipMemcpyAsync(cwd_b, dc1, F, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ measurement + memory helpers
+int dvbs2hip_timing_enable(dvbs2hip_t *h, int32_t on) { if (!h) return DVBS2HIP_EINVAL; h->timing = on != 0; return 0; }
+int dvbs2hip_timing_reset(dvbs2hip_t *h)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < DVBS2HIP_K_COUNT; k++) {
+        for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        h->ev[k].clear();
+    }
+    return 0;
+}
+int dvbs2hip_timing_get(dvbs2hip_t *h, int32_t k, double *total_ms, int64_t *n)
+{
+    if (!h || k < 0 || k >= DVBS2HIP_K_COUNT || !total_ms || !n) return DVBS2HIP_EINVAL;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double tot = 0.0;
+    for (auto &p : h->ev[k]) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, p.first, p.second));
+        tot += ms;
+    }
+    *total_ms = tot; *n = (int64_t)h->ev[k].size();
+    return 0;
+}
+int dvbs2hip_malloc(dvbs2hip_t *h, void **d, size_t bytes)
+{
+    if (!h || !d) return DVBS2HIP_EINVAL;
+    if (hipMalloc(d, bytes) != hipSuccess) return fail(h, DVBS2HIP_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
+    return 0;
+}
+int dvbs2hip_free(dvbs2hip_t *h, void *d) { if (!h) return DVBS2HIP_EINVAL; HIPCHK(h, hipFree(d)); return 0; }
+int dvbs2hip_memcpy_h2d(dvbs2hip_t *h, void *dst, const void *src, size_t bytes)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+int dvbs2hip_memcpy_d2h(dvbs2hip_t *h, void *dst, const void *src, size_t bytes)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// Internal declarations shared by the HIP translation units of libdvbs2hip.so.
+// Nothing here is part of the ABI (include/dvbs2hip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/dvbs2hip.h"
+
+namespace dvbs2 {
+
+// ---------------------------------------------------------------- LDPC (a1)
+// One slot of a QC layer = one circulant: variable = group element (t - t0) mod 360.
+struct LdpcEntry {
+    uint32_t base;    // word offset of the bit-group in its store (LDS or per-frame global)
+    uint16_t t0;      // circulant shift
+    uint16_t flags;   // bit0: store is LDS, bit1: edge absent for t == 0, bits 2..3: level
+};
+enum { LE_LDS = 1, LE_MASK0 = 2, LE_LVL_SHIFT = 2 };
+
+struct LdpcGroup {    // where the 360 posteriors of one bit-group live
+    uint32_t base;
+    uint32_t lds;     // 1 = LDS, 0 = per-frame global workspace
+};
+
+constexpr int LDPC_Z = 360;          // DVB-S2 parallelism factor
+constexpr int LDPC_THREADS = 384;    // 6 wavefronts, 360 active lanes
+constexpr int LDPC_MAX_SLOTS = 27;   // 27 sign bits + 5 index bits = one packed dword
+
+struct LdpcKParams {
+    const float *llr;        // [F][N]
+    int32_t *bits;           // [F][K]            (may be null)
+    uint32_t *packed;        // [F][K/32 words]   (may be null) packed hard decisions, bit i of word w = info bit 32 w + i
+    int8_t *cwd;             // [F]               (may be null)
+    float *post;             // [F][N] natural    (may be null)
+    int32_t *ites;           // [F]               (may be null)
+    float *gwork;            // [grid][gwork_words] per-workgroup global workspace
+    const LdpcEntry *entries;  // [q][deg_max_padded]
+    const int32_t *layer_deg;  // [q]
+    const int32_t *layer_lvl;  // [q] max conflict level in the layer
+    const LdpcGroup *groups;   // [n_groups] info groups then parity groups
+    int32_t N, K, M, q, n_info, n_groups;
+    int32_t ent_stride;      // entries per layer in `entries`
+    int32_t lds_post_words;  // LDS words used by posteriors
+    int32_t glb_post_words;  // global words per frame used by posteriors
+    int32_t gwork_words;     // global words per frame in total (posteriors + c2v state)
+    int32_t n_frames, n_ite, early_stop;
+    float alpha;
+};
+
+struct LdpcPlan {             // host-side description, built once per handle
+    int N = 0, K = 0, M = 0, q = 0, n_info = 0, n_groups = 0, E = 0;
+    int deg_max = 0, ent_stride = 0;
+    int lds_groups = 0;
+    bool c2v_lds = false, hybrid = false;
+    int lds_post_words = 0, glb_post_words = 0, gwork_words = 0;
+    size_t lds_bytes = 0;
+    int grid_max = 1;         // persistent grid: resident workgroups on the device
+    std::vector<LdpcEntry> entries;
+    std::vector<int32_t> layer_deg, layer_lvl;
+    std::vector<LdpcGroup> groups;
+    // device copies
+    LdpcEntry *d_entries = nullptr;
+    int32_t *d_layer_deg = nullptr, *d_layer_lvl = nullptr;
+    LdpcGroup *d_groups = nullptr;
+};
+
+// builds the layer tables; returns empty string on success, else the error text
+std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,
+                            const int32_t *addr, int lds_groups_req, size_t lds_limit_bytes);
+hipError_t ldpc_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
+int ldpc_blocks_per_cu(const LdpcPlan &pl);
+
+// ---------------------------------------------------------------- BCH (a2)
+struct BchPlan {
+    int m = 0, n = 0, t = 0, N = 0, K = 0;
+    std::vector<uint16_t> exp_, log_;
+    uint16_t *d_exp = nullptr, *d_log = nullptr;   // exp has 2n entries (no modulo on sums)
+    uint32_t *d_prbs = nullptr;                    // BB scrambler sequence, packed, K bits
+};
+struct BchKParams {
+    const int32_t *in_bits;     // [F][N] or null
+    const uint32_t *in_packed;  // [F][ceil(N/32)] or null
+    int32_t *out_bits;          // [F][K]
+    int8_t *cwd;                // [F] or null
+    const uint16_t *exp_, *log_;
+    const uint32_t *prbs;       // packed K-bit BB descrambling sequence or null (no descramble)
+    int32_t N, K, m, n, t, n_frames;
+};
+std::string bch_build_plan(BchPlan &pl, int m, const int32_t *prim, int t, int N, int K);
+hipError_t bch_launch(const BchPlan &pl, BchKParams p, hipStream_t s);
+
+// ---------------------------------------------------------------- front end (a3, a4, a6, a7)
+struct FrontKParams {
+    const float *in;        // pl frames [F][2*pl_frame] or xfec frames [F][2*n_sym]
+    const float *sigma_in;  // [F] or null
+    float *llr;             // [F][N_ldpc]
+    float *est;             // [F][3] sigma, ebn0, esn0 (may be null)
+    const float *cstl;      // normalised constellation, 2^bps points
+    const uint8_t *pl_seq;  // PL scrambling sequence R(i), 66420 entries
+    int32_t n_sym, pl_frame, bps, itl_cols, itl_order, n_frames;
+    float code_rate;
+};
+hipError_t front_rx_launch(FrontKParams p, hipStream_t s);                     // a7+a6+a3+a4 fused, in = pl frames
+hipError_t demod_launch(FrontKParams p, bool deinterleave, hipStream_t s);     // a3 (+a4), in = xfec frames, sigma_in required
+hipError_t deinterleave_launch(const float *itl, float *nat, int N, int cols, int order, int F, hipStream_t s);
+hipError_t estimate_launch(const float *x, float *sig, float *ebn0, float *esn0, int n_sym, float code_rate,
+                           int bps, int F, hipStream_t s);
+hipError_t pl_descramble_launch(const float *in, float *out, const uint8_t *seq, int pl_frame, int F, hipStream_t s);
+hipError_t remove_plh_launch(const float *in, float *out, int n_sym, int pl_frame, int F, hipStream_t s);
+hipError_t bb_descramble_launch(const int32_t *in, int32_t *out, const uint32_t *prbs, int K, int F, hipStream_t s);
+hipError_t monitor_launch(const int32_t *U, const int32_t *V, unsigned long long *ctr, int K, int F, hipStream_t s);
+
+// ---------------------------------------------------------------- FIR (a5)
+hipError_t fir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps_rev,
+                      int T, long long n_total, hipStream_t s);
+
+}  // namespace dvbs2

@@ -1,0 +1,199 @@
+// a2 -- DVB-S2 BCH hard-decision decoder (syndromes -> Berlekamp-Massey -> Chien) for gfx950,
+// with the BB descrambler (a8) optionally fused into the output store.
+//
+// Replaces Decoder_BCH_DVBS2<B,R>::_decode_hiho
+// (/root/reference src/common/Module/Decoder_BCH_DVBS2/Decoder_BCH_DVBS2.cpp:28-40) and the
+// aff3ct Decoder_BCH_std::_decode it wraps; the two reverse_copy calls of the reference
+// disappear because the syndromes are evaluated directly in DVB-S2 bit order (position i of
+// the frame is the coefficient of x^(N-1-i)).
+//
+// One frame per 256-thread workgroup.  The frame is packed to a bit image in LDS (N/32 words);
+// the odd syndromes are accumulated per set bit from the alpha^k table (L1/L2 resident,
+// 2^(m+1) bytes), even ones are squares.  Almost every frame leaving the LDPC decoder has a
+// zero syndrome and stops there (H5); otherwise lane 0 runs Berlekamp-Massey (<= 2t steps) and
+// all lanes share the Chien search over the 2^m-1 field positions.
+// Integer work: results are bit-exact against oracle/dvbs2_oracle.c (orc_bch_decode).
+#include "dvbs2hip_internal.h"
+
+namespace dvbs2 {
+
+std::string bch_build_plan(BchPlan &pl, int m, const int32_t *prim, int t, int N, int K)
+{
+    if (m < 3 || m > 16) return "BCH: need 3 <= m <= 16";
+    if (t < 1 || t > 12) return "BCH: need 1 <= t <= 12";
+    const int n = (1 << m) - 1;
+    if (N > n || K >= N || K <= 0) return "BCH: need 0 < K < N <= 2^m-1";
+    if (N - K != m * t) return "BCH: N-K must equal m*t for the DVB-S2 codes";
+    pl.m = m; pl.n = n; pl.t = t; pl.N = N; pl.K = K;
+    int pm = 0;
+    for (int i = 0; i <= m; i++) if (prim[i]) pm |= 1 << i;
+    if (!(pm >> m) || !(pm & 1)) return "BCH: primitive polynomial must have degree m and constant term";
+    pl.exp_.assign(2 * (size_t)n + 2, 0);
+    pl.log_.assign((size_t)n + 1, 0);
+    int x = 1;
+    for (int i = 0; i < n; i++) {
+        if (i > 0 && x == 1) return "BCH: polynomial is not primitive";
+        pl.exp_[i] = (uint16_t)x; pl.exp_[i + n] = (uint16_t)x; pl.log_[x] = (uint16_t)i;
+        x <<= 1; if (x >> m) x ^= pm;
+    }
+    pl.exp_[2 * (size_t)n] = 1;
+    return "";
+}
+
+__device__ __forceinline__ uint32_t mod_n(uint32_t x, int m, uint32_t n)
+{
+    x = (x & n) + (x >> m);
+    x = (x & n) + (x >> m);
+    return x >= n ? x - n : x;
+}
+
+constexpr int BCH_THREADS = 256;
+constexpr int BCH_TMAX = 12;
+
+__global__ void __launch_bounds__(BCH_THREADS)
+bch_decode_kernel(const BchKParams p)
+{
+    extern __shared__ uint32_t words[];             // ceil(N/32) packed received bits
+    __shared__ uint32_t S[2 * BCH_TMAX + 2];        // S[1..2t]
+    __shared__ int Cs[2 * BCH_TMAX + 4], Bs[2 * BCH_TMAX + 4], Ts[2 * BCH_TMAX + 4];
+    __shared__ int s_L, s_status, s_nroots, s_any;
+    __shared__ int roots[BCH_TMAX + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int N = p.N, K = p.K, t = p.t, m = p.m;
+    const uint32_t n = (uint32_t)p.n;
+    const int nw = (N + 31) / 32;
+
+    for (int f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
+        // ---- 1. bit image
+        if (p.in_packed) {
+            const uint32_t *src = p.in_packed + (size_t)f * nw;
+            for (int w = tid; w < nw; w += BCH_THREADS) words[w] = src[w];
+        } else {
+            const int32_t *src = p.in_bits + (size_t)f * N;
+            for (int base = 0; base < nw * 32; base += BCH_THREADS) {
+                const int i = base + tid;
+                const int bit = (i < N) ? (src[i] & 1) : 0;
+                const unsigned long long mask = __ballot(bit);
+                if (lane == 0 && (i >> 5) < nw) words[i >> 5] = (uint32_t)mask;
+                if (lane == 32 && (i >> 5) < nw) words[i >> 5] = (uint32_t)(mask >> 32);
+            }
+        }
+        if (tid < 2 * BCH_TMAX + 2) S[tid] = 0u;
+        if (tid == 0) { s_L = 0; s_status = 0; s_nroots = 0; s_any = 0; }
+        __syncthreads();
+
+        // ---- 2. odd syndromes S_j = sum_i r_i alpha^(j (N-1-i))
+        uint32_t acc[BCH_TMAX];
+#pragma unroll
+        for (int k = 0; k < BCH_TMAX; k++) acc[k] = 0u;
+        for (int w = tid; w < nw; w += BCH_THREADS) {
+            uint32_t x = words[w];
+            while (x) {
+                const int b = __ffs(x) - 1;
+                x &= x - 1;
+                const uint32_t d = (uint32_t)(N - 1 - (32 * w + b));
+#pragma unroll
+                for (int k = 0; k < BCH_TMAX; k++)
+                    if (k < t) acc[k] ^= p.exp_[mod_n((uint32_t)(2 * k + 1) * d, m, n)];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BCH_TMAX; k++)
+            if (k < t) {
+                uint32_t a = acc[k];
+                for (int o = 32; o > 0; o >>= 1) a ^= __shfl_xor(a, o);
+                if (lane == 0 && a) atomicXor(&S[2 * k + 1], a);
+            }
+        __syncthreads();
+        if (tid == 0) {
+            int any = 0;
+            for (int j = 2; j <= 2 * t; j += 2) {          // S_2k = S_k^2
+                const uint32_t h = S[j / 2];
+                S[j] = h ? p.exp_[2u * p.log_[h]] : 0u;
+            }
+            for (int j = 1; j <= 2 * t; j++) any |= (int)S[j];
+            s_any = any;
+        }
+        __syncthreads();
+
+        if (s_any) {
+            // ---- 3. Berlekamp-Massey (serial, <= 2t steps; same recurrence as the oracle)
+            if (tid == 0) {
+                const uint16_t *ex = p.exp_, *lg = p.log_;
+                for (int i = 0; i < 2 * BCH_TMAX + 4; i++) { Cs[i] = 0; Bs[i] = 0; }
+                Cs[0] = 1; Bs[0] = 1;
+                int L = 0, mm = 1, bb = 1;
+                const int lim = 2 * BCH_TMAX + 4;
+                for (int k = 0; k < 2 * t; k++) {
+                    int d = (int)S[k + 1];
+                    for (int i = 1; i <= L; i++) {
+                        const int c = Cs[i], s = (int)S[k + 1 - i];
+                        if (c && s) d ^= ex[lg[c] + lg[s]];
+                    }
+                    if (d == 0) { mm++; continue; }
+                    const int lcoef = (int)lg[d] + (int)n - (int)lg[bb];       // log(d / b)
+                    if (2 * L <= k) {
+                        for (int i = 0; i < lim; i++) Ts[i] = Cs[i];
+                        for (int i = 0; i + mm < lim; i++) if (Bs[i]) Cs[i + mm] ^= ex[mod_n((uint32_t)(lcoef + lg[Bs[i]]), m, n)];
+                        L = k + 1 - L;
+                        for (int i = 0; i < lim; i++) Bs[i] = Ts[i];
+                        bb = d; mm = 1;
+                    } else {
+                        for (int i = 0; i + mm < lim; i++) if (Bs[i]) Cs[i + mm] ^= ex[mod_n((uint32_t)(lcoef + lg[Bs[i]]), m, n)];
+                        mm++;
+                    }
+                }
+                s_L = L;
+                if (L > t) s_status = 1;
+            }
+            __syncthreads();
+            const int L = s_L;
+            if (!s_status) {
+                // ---- 4. Chien search over the whole field: sigma(alpha^-d) == 0 <=> error at degree d
+                uint32_t lc[BCH_TMAX + 1];
+#pragma unroll
+                for (int i = 0; i <= BCH_TMAX; i++) lc[i] = (i <= L && Cs[i]) ? (uint32_t)p.log_[Cs[i]] : 0xFFFFFFFFu;
+                for (uint32_t d = tid; d < n; d += BCH_THREADS) {
+                    uint32_t v = 0u;
+                    const uint32_t nd = n - d;        // 1..n
+#pragma unroll
+                    for (int i = 0; i <= BCH_TMAX; i++)
+                        if (lc[i] != 0xFFFFFFFFu) v ^= p.exp_[lc[i] + mod_n((uint32_t)i * nd, m, n)];
+                    if (v == 0u) {
+                        const int slot = atomicAdd(&s_nroots, 1);
+                        if (slot < BCH_TMAX + 4) roots[slot] = (int)d;
+                    }
+                }
+                __syncthreads();
+                if (s_nroots == L) {
+                    if (tid < L) {
+                        const int pos = N - 1 - roots[tid];
+                        if (pos >= 0 && pos < K) atomicXor(&words[pos >> 5], 1u << (pos & 31));
+                    }
+                } else if (tid == 0) s_status = 1;
+                __syncthreads();
+            }
+        }
+
+        // ---- 5. output the K systematic bits (optionally BB-descrambled, Scrambler_BB.hxx:51-72)
+        int32_t *out = p.out_bits + (size_t)f * K;
+        for (int k = tid; k < K; k += BCH_THREADS) {
+            uint32_t b = (words[k >> 5] >> (k & 31)) & 1u;
+            if (p.prbs) b ^= (p.prbs[k >> 5] >> (k & 31)) & 1u;
+            out[k] = (int32_t)b;
+        }
+        if (tid == 0 && p.cwd) p.cwd[f] = s_status ? 0 : 1;
+        __syncthreads();
+    }
+}
+
+hipError_t bch_launch(const BchPlan &pl, BchKParams p, hipStream_t s)
+{
+    p.exp_ = pl.d_exp; p.log_ = pl.d_log;
+    p.N = pl.N; p.K = pl.K; p.m = pl.m; p.n = pl.n; p.t = pl.t;
+    const size_t lds = (size_t)((pl.N + 31) / 32) * 4;
+    hipLaunchKernelGGL(bch_decode_kernel, dim3(p.n_frames), dim3(BCH_THREADS), lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace dvbs2

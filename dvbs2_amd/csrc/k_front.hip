@@ -1,0 +1,299 @@
+// a3 soft demapper, a4 LLR de-interleaver, a6 noise estimator, a7 PL descrambler + header /
+// pilot removal, a8 BB descrambler, a9 BER/FER monitor -- the streaming (HBM-bound) kernels of
+// the DVB-S2 RX inner path for gfx950.
+//
+// Reference interfaces replaced (/root/reference):
+//   a3  Modem_generic_fast::demodulate            src/common/Factory/DVBS2/DVBS2.cpp:478-488
+//   a4  Interleaver<float,uint32_t>::deinterleave src/common/Factory/DVBS2/DVBS2.cpp:451-476
+//   a6  Estimator_DVBS2::_estimate                src/common/Module/Estimator/Estimator_DVBS2.hxx:31-58
+//   a7  Scrambler_PL::__scramble(false)           src/common/Module/Scrambler/Scrambler_PL/Scrambler_PL.hxx:61-78
+//       Framer::_remove_plh                       src/common/Module/Framer/Framer.hxx:330-343
+//   a8  Scrambler_BB::_descramble                 src/common/Module/Scrambler/Scrambler_BB/Scrambler_BB.hxx:51-72
+//   a9  Monitor_BFER::check_errors                src/common/Factory/DVBS2/DVBS2.cpp:575-591
+//
+// front_rx_kernel fuses a7 -> a6 -> a3 -> a4: the PL frame is read from HBM once (the second
+// sweep hits L2), the index maps of remove_plh and of the column/row de-interleaver are pure
+// arithmetic folded into the load and the store, and the only HBM write is the LLR frame the
+// LDPC kernel consumes.
+#include "dvbs2hip_internal.h"
+
+namespace dvbs2 {
+
+constexpr int FRONT_THREADS = 256;
+constexpr int PL_M = 90, PL_P = 36, PL_SLOTS = 16;
+
+// xfec symbol k -> index of the same symbol inside the PL frame (Framer.hxx:330-343)
+__device__ __forceinline__ int pl_index(int k, int n_pilots)
+{
+    int b = k / (PL_SLOTS * PL_M);
+    b = b < n_pilots ? b : n_pilots;
+    return PL_M + k + PL_P * b;
+}
+
+// multiply by conj(exp(j pi/2 R)) (Scrambler_PL.hxx:66-76 with scr_flag = false)
+__device__ __forceinline__ float2 pl_derotate(float2 x, int R)
+{
+    switch (R & 3) {
+        case 0: return x;
+        case 1: return make_float2(x.y, -x.x);
+        case 2: return make_float2(-x.x, -x.y);
+        default: return make_float2(-x.y, x.x);
+    }
+}
+
+__device__ __forceinline__ float max_star(float a, float b)
+{
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    const float mx = fmaxf(a, b);
+    return mx + log1pf(expf(-fabsf(a - b)));
+}
+
+// position of interleaved LLR i = k*bps + b in the natural (code) order
+__device__ __forceinline__ int deitl_index(int k, int b, int bps, int cols, int order, int n_rows)
+{
+    if (cols <= 1) return k * bps + b;
+    const int i = k * bps + b, row = i / cols, j = i - row * cols;
+    return (order == DVBS2HIP_ITL_TOP_LEFT ? j : cols - 1 - j) * n_rows + row;
+}
+
+template <int BPS>
+__device__ __forceinline__ void demap_symbol(float2 y, float inv2s2, const float *cs, float *out)
+{
+    constexpr int P = 1 << BPS;
+    float met[P];
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+        const float dr = y.x - cs[2 * s], di = y.y - cs[2 * s + 1];
+        met[s] = -(dr * dr + di * di) * inv2s2;
+    }
+#pragma unroll
+    for (int b = 0; b < BPS; b++) {
+        float L0 = -INFINITY, L1 = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < P; s++) {
+            if (((s >> b) & 1) == 0) L0 = max_star(L0, met[s]); else L1 = max_star(L1, met[s]);
+        }
+        out[b] = L0 - L1;
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float *red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += red[i];
+    return s;
+}
+
+// Estimator_DVBS2.hxx:44-56 from the two moment sums
+__device__ __forceinline__ void m2m4_finish(float m2, float m4, int n_sym, float code_rate, int bps,
+                                            float &sigma, float &ebn0, float &esn0)
+{
+    m2 /= (float)n_sym; m4 /= (float)n_sym;
+    const float Se = sqrtf(fabsf(2 * m2 * m2 - m4));
+    const float Ne = fabsf(m2 - Se);
+    esn0 = 10 * log10f(Se / Ne);
+    if (isinf(esn0)) esn0 = 100.f;
+    sigma = sqrtf(1.0f / (2.0f * powf(10.0f, esn0 / 10.0f)));
+    ebn0 = esn0 - 10.0f * log10f(code_rate * (float)bps);
+}
+
+// FROM_PL = true : in = PL frames, a7 folded in, sigma estimated unless sigma_in given
+// FROM_PL = false: in = XFEC frames, sigma_in required
+template <int BPS, bool FROM_PL, bool DEITL>
+__global__ void __launch_bounds__(FRONT_THREADS)
+front_kernel(const FrontKParams p)
+{
+    __shared__ float cs[2 * (1 << BPS)];
+    __shared__ float red[FRONT_THREADS / 64];
+    __shared__ float s_sigma;
+    const int tid = threadIdx.x, f = blockIdx.x;
+    if (tid < 2 * (1 << BPS)) cs[tid] = p.cstl[tid];
+    const int n_sym = p.n_sym, n_pil = n_sym / (PL_SLOTS * PL_M);
+    const size_t in_stride = FROM_PL ? 2 * (size_t)p.pl_frame : 2 * (size_t)n_sym;
+    const float2 *in = reinterpret_cast<const float2 *>(p.in + (size_t)f * in_stride);
+    float sigma;
+    if (FROM_PL && p.sigma_in == nullptr) {
+        float m2 = 0.f, m4 = 0.f;
+        for (int k = tid; k < n_sym; k += FRONT_THREADS) {
+            const int pi = pl_index(k, n_pil);
+            const float2 y = in[pi];              // |y| is invariant under the PL derotation
+            const float e = y.x * y.x + y.y * y.y;
+            m2 += e; m4 += e * e;
+        }
+        m2 = block_sum(m2, red);
+        m4 = block_sum(m4, red);
+        float ebn0, esn0;
+        m2m4_finish(m2, m4, n_sym, p.code_rate, p.bps, sigma, ebn0, esn0);
+        if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = ebn0; p.est[3 * f + 2] = esn0; }
+    } else {
+        if (tid == 0) s_sigma = p.sigma_in[f];
+        __syncthreads();
+        sigma = s_sigma;
+        if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = 0.f; p.est[3 * f + 2] = 0.f; }
+    }
+    __syncthreads();
+    const float inv2s2 = 1.0f / (2.0f * sigma * sigma);
+    float *llr = p.llr + (size_t)f * n_sym * BPS;
+    const int n_rows = (n_sym * BPS) / (p.itl_cols > 1 ? p.itl_cols : 1);
+    for (int k = tid; k < n_sym; k += FRONT_THREADS) {
+        float2 y;
+        if (FROM_PL) {
+            const int pi = pl_index(k, n_pil);
+            y = pl_derotate(in[pi], p.pl_seq[pi - PL_M]);
+        } else y = in[k];
+        float out[BPS];
+        demap_symbol<BPS>(y, inv2s2, cs, out);
+#pragma unroll
+        for (int b = 0; b < BPS; b++) {
+            const int dst = DEITL ? deitl_index(k, b, BPS, p.itl_cols, p.itl_order, n_rows) : k * BPS + b;
+            llr[dst] = out[b];
+        }
+    }
+}
+
+template <bool FROM_PL, bool DEITL>
+static hipError_t front_dispatch(const FrontKParams &p, hipStream_t s)
+{
+    dim3 g(p.n_frames), b(FRONT_THREADS);
+    switch (p.bps) {
+        case 1: hipLaunchKernelGGL((front_kernel<1, FROM_PL, DEITL>), g, b, 0, s, p); break;
+        case 2: hipLaunchKernelGGL((front_kernel<2, FROM_PL, DEITL>), g, b, 0, s, p); break;
+        case 3: hipLaunchKernelGGL((front_kernel<3, FROM_PL, DEITL>), g, b, 0, s, p); break;
+        case 4: hipLaunchKernelGGL((front_kernel<4, FROM_PL, DEITL>), g, b, 0, s, p); break;
+        case 5: hipLaunchKernelGGL((front_kernel<5, FROM_PL, DEITL>), g, b, 0, s, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t front_rx_launch(FrontKParams p, hipStream_t s) { return front_dispatch<true, true>(p, s); }
+hipError_t demod_launch(FrontKParams p, bool deinterleave, hipStream_t s)
+{
+    return deinterleave ? front_dispatch<false, true>(p, s) : front_dispatch<false, false>(p, s);
+}
+
+// ---------------------------------------------------------------- a4 stand-alone
+__global__ void deinterleave_kernel(const float *itl, float *nat, int N, int cols, int order, int n_rows)
+{
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int dst = i;
+    if (cols > 1) {
+        const int row = i / cols, j = i - row * cols;
+        dst = (order == DVBS2HIP_ITL_TOP_LEFT ? j : cols - 1 - j) * n_rows + row;
+    }
+    nat[(size_t)f * N + dst] = itl[(size_t)f * N + i];
+}
+hipError_t deinterleave_launch(const float *itl, float *nat, int N, int cols, int order, int F, hipStream_t s)
+{
+    const int n_rows = N / (cols > 1 ? cols : 1);
+    hipLaunchKernelGGL(deinterleave_kernel, dim3((N + 255) / 256, F), dim3(256), 0, s, itl, nat, N, cols, order, n_rows);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- a6 stand-alone
+__global__ void __launch_bounds__(FRONT_THREADS)
+estimate_kernel(const float *x, float *sig, float *ebn0o, float *esn0o, int n_sym, float code_rate, int bps)
+{
+    __shared__ float red[FRONT_THREADS / 64];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const float2 *in = reinterpret_cast<const float2 *>(x + (size_t)f * 2 * n_sym);
+    float m2 = 0.f, m4 = 0.f;
+    for (int k = tid; k < n_sym; k += FRONT_THREADS) {
+        const float2 y = in[k];
+        const float e = y.x * y.x + y.y * y.y;
+        m2 += e; m4 += e * e;
+    }
+    m2 = block_sum(m2, red);
+    m4 = block_sum(m4, red);
+    float sigma, ebn0, esn0;
+    m2m4_finish(m2, m4, n_sym, code_rate, bps, sigma, ebn0, esn0);
+    if (tid == 0) { sig[f] = sigma; ebn0o[f] = ebn0; esn0o[f] = esn0; }
+}
+hipError_t estimate_launch(const float *x, float *sig, float *ebn0, float *esn0, int n_sym, float code_rate,
+                           int bps, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(estimate_kernel, dim3(F), dim3(FRONT_THREADS), 0, s, x, sig, ebn0, esn0, n_sym, code_rate, bps);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- a7 stand-alone
+__global__ void pl_descramble_kernel(const float *in, float *out, const uint8_t *seq, int pl_frame)
+{
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pl_frame) return;
+    const float2 *src = reinterpret_cast<const float2 *>(in + (size_t)f * 2 * pl_frame);
+    float2 *dst = reinterpret_cast<float2 *>(out + (size_t)f * 2 * pl_frame);
+    float2 y = src[i];
+    if (i >= PL_M) y = pl_derotate(y, seq[i - PL_M]);
+    dst[i] = y;
+}
+hipError_t pl_descramble_launch(const float *in, float *out, const uint8_t *seq, int pl_frame, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(pl_descramble_kernel, dim3((pl_frame + 255) / 256, F), dim3(256), 0, s, in, out, seq, pl_frame);
+    return hipGetLastError();
+}
+
+__global__ void remove_plh_kernel(const float *in, float *out, int n_sym, int pl_frame)
+{
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_sym) return;
+    const float2 *src = reinterpret_cast<const float2 *>(in + (size_t)f * 2 * pl_frame);
+    float2 *dst = reinterpret_cast<float2 *>(out + (size_t)f * 2 * n_sym);
+    dst[k] = src[pl_index(k, n_sym / (PL_SLOTS * PL_M))];
+}
+hipError_t remove_plh_launch(const float *in, float *out, int n_sym, int pl_frame, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(remove_plh_kernel, dim3((n_sym + 255) / 256, F), dim3(256), 0, s, in, out, n_sym, pl_frame);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- a8 stand-alone
+__global__ void bb_descramble_kernel(const int32_t *in, int32_t *out, const uint32_t *prbs, int K)
+{
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int32_t fb = (int32_t)((prbs[k >> 5] >> (k & 31)) & 1u);
+    out[(size_t)f * K + k] = (in[(size_t)f * K + k] + fb) % 2;        // Scrambler_BB.hxx:63
+}
+hipError_t bb_descramble_launch(const int32_t *in, int32_t *out, const uint32_t *prbs, int K, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(bb_descramble_kernel, dim3((K + 255) / 256, F), dim3(256), 0, s, in, out, prbs, K);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- a9
+__global__ void __launch_bounds__(FRONT_THREADS)
+monitor_kernel(const int32_t *U, const int32_t *V, unsigned long long *ctr, int K)
+{
+    __shared__ int red[FRONT_THREADS / 64];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    int be = 0;
+    for (int k = tid; k < K; k += FRONT_THREADS) be += (U[(size_t)f * K + k] != V[(size_t)f * K + k]) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) be += __shfl_xor(be, o);
+    if ((tid & 63) == 0) red[tid >> 6] = be;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int i = 0; i < FRONT_THREADS / 64; i++) tot += red[i];
+        atomicAdd(&ctr[0], 1ull);
+        if (tot) { atomicAdd(&ctr[1], (unsigned long long)tot); atomicAdd(&ctr[2], 1ull); }
+    }
+}
+hipError_t monitor_launch(const int32_t *U, const int32_t *V, unsigned long long *ctr, int K, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(monitor_kernel, dim3(F), dim3(FRONT_THREADS), 0, s, U, V, ctr, K);
+    return hipGetLastError();
+}
+
+}  // namespace dvbs2

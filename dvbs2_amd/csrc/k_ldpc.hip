@@ -1,0 +1,371 @@
+// a1 -- DVB-S2 LDPC decoder, horizontal-layered normalised min-sum, for gfx950.
+//
+// Replaces the decoder behind tools::Codec_LDPC<B,Q>::get_decoder_siho()
+// (/root/reference src/common/Factory/DVBS2/DVBS2.cpp:418-449, type "BP_HORIZONTAL_LAYERED",
+// implem "NMS").  Not a port of AFF3CT's SIMD decoder: that one sweeps the checks of one
+// frame serially (inter-frame SIMD only).  Here ONE FRAME = ONE WORKGROUP of 6 wavefronts and
+// the code's quasi-cyclic structure gives the intra-frame parallelism:
+//
+//   * the M = 360 q checks split into q LAYERS {c : c mod q = r}; inside a layer the 360
+//     checks (t = c div q) touch every bit-group through a circulant: check t reads element
+//     (t - t0) mod 360 of the group, so lane t's accesses are unit-stride across lanes
+//     (conflict-free LDS banks / fully coalesced global segments);
+//   * posteriors live on chip: as many 360-element bit-groups as fit are kept in LDS
+//     (all of them for N = 16200); for N = 64800 (259 KB fp32 > 160 KB LDS) the
+//     least-touched groups spill to a per-frame global workspace that stays L2/MALL hot;
+//   * check->variable messages are stored COMPRESSED per check: the two output
+//     magnitudes, 27 sign bits and the 5-bit position of the minimum = 12 bytes per check
+//     instead of 4 bytes per edge, and decompress bit-exactly to the fp32 messages.
+//
+// Schedule and arithmetic are restated in oracle/dvbs2_oracle.c (ORC_SCHED_QC) and the two
+// must agree bit for bit: tests/test_ldpc_gpu.py.
+#include "dvbs2hip_internal.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+namespace dvbs2 {
+
+// ------------------------------------------------------------------------------------------
+// host: layer tables
+// ------------------------------------------------------------------------------------------
+std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,
+                            const int32_t *addr, int lds_groups_req, size_t lds_limit)
+{
+    if (N <= 0 || K <= 0 || K >= N) return "LDPC: need 0 < K < N";
+    const int M = N - K;
+    if (M % LDPC_Z || K % LDPC_Z) return "LDPC: N-K and K must be multiples of 360";
+    if (n_rows != K / LDPC_Z) return "LDPC: address table must have K/360 rows";
+    const int q = M / LDPC_Z;
+    pl.N = N; pl.K = K; pl.M = M; pl.q = q; pl.n_info = n_rows; pl.n_groups = n_rows + q;
+    for (int i = 0; i < row_ptr[n_rows]; i++)
+        if (addr[i] < 0 || addr[i] >= M) return "LDPC: address out of range";
+
+    struct Slot { int group, t0, lvl, mask0; };
+    std::vector<std::vector<Slot>> layers(q);
+    for (int g = 0; g < n_rows; g++)
+        for (int p = row_ptr[g]; p < row_ptr[g + 1]; p++) {
+            const int r = addr[p] % q, t0 = addr[p] / q;
+            int lvl = 0;
+            for (const Slot &s : layers[r]) {
+                if (s.group == g) { lvl++; if (s.t0 == t0) return "LDPC: duplicate edge in address table"; }
+            }
+            if (lvl > 3) return "LDPC: more than 4 edges of one bit-group in one layer";
+            layers[r].push_back({g, t0, lvl, 0});
+        }
+    for (int r = 0; r < q; r++) {
+        layers[r].push_back({n_rows + r, 0, 0, 0});                 // p_c
+        if (r > 0) layers[r].push_back({n_rows + r - 1, 0, 0, 0});  // p_{c-1}, same t
+        else       layers[r].push_back({n_rows + q - 1, 1, 0, 1});  // p_{c-1} = group q-1, element t-1; absent for c = 0
+    }
+    pl.deg_max = 0; pl.E = -1;
+    pl.layer_deg.assign(q, 0); pl.layer_lvl.assign(q, 0);
+    for (int r = 0; r < q; r++) {
+        pl.layer_deg[r] = (int)layers[r].size();
+        pl.deg_max = std::max(pl.deg_max, pl.layer_deg[r]);
+        pl.E += LDPC_Z * pl.layer_deg[r];
+        for (const Slot &s : layers[r]) pl.layer_lvl[r] = std::max(pl.layer_lvl[r], s.lvl);
+    }
+    if (pl.deg_max > LDPC_MAX_SLOTS) return "LDPC: check degree > 27 not supported by the packed message format";
+
+    // ---- storage policy: which bit-groups live in LDS
+    std::vector<int> touches(pl.n_groups, 0);
+    for (int r = 0; r < q; r++) for (const Slot &s : layers[r]) touches[s.group]++;
+    std::vector<int> order(pl.n_groups);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return touches[a] > touches[b]; });
+
+    const size_t c2v_bytes = (size_t)M * 12, grp_bytes = (size_t)LDPC_Z * 4;
+    const char *env_c2v = getenv("DVBS2HIP_LDPC_C2V");
+    const char *env_grp = getenv("DVBS2HIP_LDPC_LDS_GROUPS");
+    if (env_grp) lds_groups_req = atoi(env_grp);
+    const size_t all_post = (size_t)pl.n_groups * grp_bytes;
+    bool c2v_lds;
+    if (env_c2v) c2v_lds = !strcmp(env_c2v, "lds");
+    else c2v_lds = (all_post + c2v_bytes <= lds_limit);     // everything on chip when it fits
+    if (c2v_lds && c2v_bytes + grp_bytes > lds_limit) c2v_lds = false;
+    const size_t avail = lds_limit - (c2v_lds ? c2v_bytes : 0);
+    int max_groups = (int)std::min<size_t>(pl.n_groups, avail / grp_bytes);
+    int n_lds = (lds_groups_req < 0) ? max_groups : std::min(lds_groups_req, max_groups);
+    pl.lds_groups = n_lds; pl.c2v_lds = c2v_lds; pl.hybrid = n_lds < pl.n_groups;
+
+    pl.groups.assign(pl.n_groups, {0, 0});
+    int nl = 0, ng = 0;
+    for (int i = 0; i < pl.n_groups; i++) {
+        const int g = order[i];
+        if (i < n_lds) pl.groups[g] = {(uint32_t)(nl++ * LDPC_Z), 1u};
+        else           pl.groups[g] = {(uint32_t)(ng++ * LDPC_Z), 0u};
+    }
+    pl.lds_post_words = nl * LDPC_Z;
+    pl.glb_post_words = ng * LDPC_Z;
+    pl.gwork_words = pl.glb_post_words + (c2v_lds ? 0 : 3 * M);
+    pl.lds_bytes = (size_t)pl.lds_post_words * 4 + (c2v_lds ? c2v_bytes : 0);
+
+    pl.ent_stride = pl.deg_max <= 13 ? 13 : LDPC_MAX_SLOTS;
+    pl.entries.assign((size_t)q * pl.ent_stride, {0, 0, 0});
+    for (int r = 0; r < q; r++)
+        for (size_t j = 0; j < layers[r].size(); j++) {
+            const Slot &s = layers[r][j];
+            LdpcEntry e;
+            e.base = pl.groups[s.group].base;
+            e.t0 = (uint16_t)s.t0;
+            e.flags = (uint16_t)((pl.groups[s.group].lds ? LE_LDS : 0) | (s.mask0 ? LE_MASK0 : 0) | (s.lvl << LE_LVL_SHIFT));
+            pl.entries[(size_t)r * pl.ent_stride + j] = e;
+        }
+    return "";
+}
+
+// ------------------------------------------------------------------------------------------
+// device
+// ------------------------------------------------------------------------------------------
+// LDS pointers carry their address space in the type, so the optimiser can never merge an
+// LDS access and a global access into one flat access through a selected generic pointer.
+typedef __attribute__((address_space(3))) float lds_float;
+
+template <bool HYBRID>
+__device__ __forceinline__ float post_ld(const LdpcEntry e, int m, const lds_float *lpost, const float *gpost)
+{
+    if (HYBRID && !(e.flags & LE_LDS)) return gpost[e.base + m];
+    return lpost[e.base + m];
+}
+template <bool HYBRID>
+__device__ __forceinline__ void post_st(const LdpcEntry e, int m, lds_float *lpost, float *gpost, float v)
+{
+    if (HYBRID && !(e.flags & LE_LDS)) gpost[e.base + m] = v;
+    else lpost[e.base + m] = v;
+}
+
+// fp32 message from the packed per-check state: magnitude c1 at the slot of the minimum, c2
+// elsewhere, sign bit j of pk
+__device__ __forceinline__ float c2v_unpack(float c1, float c2, uint32_t pk, int j)
+{
+    const float mag = ((pk >> 27) == (uint32_t)j) ? c1 : c2;
+    return __uint_as_float(__float_as_uint(mag) | ((pk << (31 - j)) & 0x80000000u));
+}
+
+template <int DEG, bool HYBRID, bool C2V_LDS>
+__global__ void __launch_bounds__(LDPC_THREADS)
+ldpc_layered_nms_kernel(const LdpcKParams p)
+{
+    extern __shared__ float smem[];
+    lds_float *lpost = (lds_float *)smem;
+    const int t = threadIdx.x;
+    const bool act = t < LDPC_Z;
+    const int M = p.M, q = p.q;
+
+    for (int f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
+        const float *Y = p.llr + (size_t)f * p.N;
+        float *gwork = p.gwork + (size_t)blockIdx.x * p.gwork_words;   // per-WORKGROUP slot: stays cache-hot across frames
+        float *gpost = gwork;
+        // packed c->v state [r][t]: two magnitudes + (5-bit min position | 27 sign bits).
+        // Kept as two separately typed pointers (never a generic LDS-or-global pointer).
+        lds_float *lc = lpost + p.lds_post_words;     // LDS image   (C2V_LDS)
+        float *gc = gwork + p.glb_post_words;         // global image (!C2V_LDS)
+#define C2V_LD(arr, i) (C2V_LDS ? lc[(arr) * M + (i)] : gc[(arr) * M + (i)])
+#define C2V_ST(arr, i, val) do { if (C2V_LDS) lc[(arr) * M + (i)] = (val); else gc[(arr) * M + (i)] = (val); } while (0)
+
+        // ---- load channel LLRs into the posterior stores (parity bits regrouped [r][t])
+        if (act)
+            for (int g = 0; g < p.n_groups; g++) {
+                const LdpcGroup gl = p.groups[g];
+                const int src = g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info);
+                const float v = Y[src];
+                if (HYBRID && !gl.lds) gpost[gl.base + t] = v; else lpost[gl.base + t] = v;
+            }
+        for (int i = t; i < 3 * M; i += LDPC_THREADS) C2V_ST(0, i, 0.f);
+        __syncthreads();
+
+        int it = 0;
+        bool ok = false;
+        while (it < p.n_ite) {
+            for (int r = 0; r < q; r++) {
+                const LdpcEntry *ent = p.entries + (size_t)r * p.ent_stride;
+                const int deg = p.layer_deg[r];
+                const int maxlvl = p.layer_lvl[r];
+                const int ci = r * LDPC_Z + t;
+                float v[DEG];
+                float c1o = 0.f, c2o = 0.f, cst1 = 0.f, cst2 = 0.f, mn1 = INFINITY, mn2 = INFINITY;
+                uint32_t pko = 0u, sacc = 0u;
+                if (act) {
+                    c1o = C2V_LD(0, ci); c2o = C2V_LD(1, ci); pko = __float_as_uint(C2V_LD(2, ci));
+                    // ---- pass 1: v->c = posterior - old c->v ; running min1/min2/sign
+#pragma unroll
+                    for (int j = 0; j < DEG; j++) {
+                        v[j] = INFINITY;
+                        if (j < deg) {
+                            const LdpcEntry e = ent[j];
+                            int m = t - (int)e.t0; m += (m < 0) ? LDPC_Z : 0;
+                            const float L = post_ld<HYBRID>(e, m, lpost, gpost);
+                            float x = L - c2v_unpack(c1o, c2o, pko, j);
+                            if ((e.flags & LE_MASK0) && t == 0) x = INFINITY;
+                            v[j] = x;
+                            const float a = fabsf(x);
+                            mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);
+                            mn1 = fminf(mn1, a);
+                            sacc ^= __float_as_uint(x);
+                        }
+                    }
+                    cst1 = mn2 * p.alpha;
+                    cst2 = mn1 * p.alpha;
+                }
+                if (maxlvl > 0) __syncthreads();      // every read of the layer precedes its writes
+                uint32_t pkn = 0u, idxn = 0u;
+                if (act) {
+                    // ---- pass 2: new c->v ; posterior = v->c + new c->v (primary edges)
+#pragma unroll
+                    for (int j = 0; j < DEG; j++) {
+                        if (j < deg) {
+                            const LdpcEntry e = ent[j];
+                            int m = t - (int)e.t0; m += (m < 0) ? LDPC_Z : 0;
+                            const float x = v[j];
+                            const bool ismin = fabsf(x) == mn1;
+                            const float mag = ismin ? cst1 : cst2;
+                            const uint32_t s = (sacc ^ __float_as_uint(x)) & 0x80000000u;
+                            const float nw = __uint_as_float(__float_as_uint(mag) | s);
+                            pkn |= s >> (31 - j);
+                            idxn = ismin ? (uint32_t)j : idxn;
+                            const bool valid = !((e.flags & LE_MASK0) && t == 0);
+                            if (valid && (e.flags >> LE_LVL_SHIFT) == 0) post_st<HYBRID>(e, m, lpost, gpost, x + nw);
+                        }
+                    }
+                    pkn |= idxn << 27;
+                }
+                // ---- duplicate edges of a bit-group inside this layer: ordered delta updates
+                for (int lvl = 1; lvl <= maxlvl; lvl++) {
+                    __syncthreads();
+                    if (act) {
+#pragma unroll
+                        for (int j = 0; j < DEG; j++) {
+                            if (j < deg) {
+                                const LdpcEntry e = ent[j];
+                                if ((int)(e.flags >> LE_LVL_SHIFT) == lvl) {
+                                    int m = t - (int)e.t0; m += (m < 0) ? LDPC_Z : 0;
+                                    const float nw = c2v_unpack(cst1, cst2, pkn, j);
+                                    const float od = c2v_unpack(c1o, c2o, pko, j);
+                                    const float L = post_ld<HYBRID>(e, m, lpost, gpost);
+                                    post_st<HYBRID>(e, m, lpost, gpost, L + (nw - od));
+                                }
+                            }
+                        }
+                    }
+                }
+                if (act) { C2V_ST(0, ci, cst1); C2V_ST(1, ci, cst2); C2V_ST(2, ci, __uint_as_float(pkn)); }
+                __syncthreads();
+            }
+            it++;
+            if (p.early_stop || it == p.n_ite) {
+                // ---- syndrome of the hard decisions (enable_syndrome, depth 1)
+                int bad = 0;
+                if (act)
+                    for (int r = 0; r < q; r++) {
+                        const LdpcEntry *ent = p.entries + (size_t)r * p.ent_stride;
+                        const int deg = p.layer_deg[r];
+                        uint32_t x = 0u;
+#pragma unroll
+                        for (int j = 0; j < DEG; j++)
+                            if (j < deg) {
+                                const LdpcEntry e = ent[j];
+                                int m = t - (int)e.t0; m += (m < 0) ? LDPC_Z : 0;
+                                const float L = post_ld<HYBRID>(e, m, lpost, gpost);
+                                const bool valid = !((e.flags & LE_MASK0) && t == 0);
+                                x ^= (valid && L < 0.f) ? 1u : 0u;
+                            }
+                        bad |= (int)x;
+                    }
+                ok = !__syncthreads_or(bad);
+                if (ok) break;
+            }
+        }
+
+        // ---- outputs
+        if (t == 0) {
+            if (p.cwd) p.cwd[f] = ok ? 1 : 0;
+            if (p.ites) p.ites[f] = it;
+        }
+        if (act) {
+            for (int g = 0; g < p.n_info; g++) {
+                const LdpcGroup gl = p.groups[g];
+                const float L = (HYBRID && !gl.lds) ? gpost[gl.base + t] : lpost[gl.base + t];
+                if (p.bits) p.bits[(size_t)f * p.K + g * LDPC_Z + t] = L < 0.f ? 1 : 0;
+                if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + t] = L;
+            }
+            if (p.post)
+                for (int g = p.n_info; g < p.n_groups; g++) {
+                    const LdpcGroup gl = p.groups[g];
+                    const float L = (HYBRID && !gl.lds) ? gpost[gl.base + t] : lpost[gl.base + t];
+                    p.post[(size_t)f * p.N + p.K + q * t + (g - p.n_info)] = L;
+                }
+        }
+        if (p.packed) {
+            // bit i of word w = info bit 32 w + i (tail bits zero); 360 = 11.25 words per group, so pack by word
+            const int n_words = (p.K + 31) / 32;
+            for (int w = t; w < n_words; w += LDPC_THREADS) {
+                uint32_t word = 0u;
+                for (int b = 0; b < 32; b++) {
+                    const int k = 32 * w + b;
+                    if (k >= p.K) break;
+                    const int g = k / LDPC_Z, m = k - g * LDPC_Z;
+                    const LdpcGroup gl = p.groups[g];
+                    const float L = (HYBRID && !gl.lds) ? gpost[gl.base + m] : lpost[gl.base + m];
+                    word |= (L < 0.f ? 1u : 0u) << b;
+                }
+                p.packed[(size_t)f * n_words + w] = word;
+            }
+        }
+        __syncthreads();     // LDS is reused by the next frame of this workgroup
+    }
+#undef C2V_LD
+#undef C2V_ST
+}
+
+template <int DEG, bool HYBRID, bool C2V_LDS>
+static hipError_t launch_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
+{
+    auto kern = ldpc_layered_nms_kernel<DEG, HYBRID, C2V_LDS>;
+    static size_t configured = 0;
+    if (pl.lds_bytes > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
+        if (e != hipSuccess) return e;
+        configured = pl.lds_bytes;
+    }
+    const int grid = p.n_frames < pl.grid_max ? p.n_frames : pl.grid_max;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_THREADS), pl.lds_bytes, s, p);
+    return hipGetLastError();
+}
+
+// resident workgroups per CU for the instantiation the plan selects (persistent grid size)
+template <int DEG, bool HYBRID, bool C2V_LDS>
+static int occ_inst(const LdpcPlan &pl)
+{
+    auto kern = ldpc_layered_nms_kernel<DEG, HYBRID, C2V_LDS>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, LDPC_THREADS, pl.lds_bytes) != hipSuccess) nb = 1;
+    return nb < 1 ? 1 : nb;
+}
+int ldpc_blocks_per_cu(const LdpcPlan &pl)
+{
+    const bool small = pl.ent_stride == 13;
+#define OCC(H, C) (small ? occ_inst<13, H, C>(pl) : occ_inst<LDPC_MAX_SLOTS, H, C>(pl))
+    if (pl.hybrid) return pl.c2v_lds ? OCC(true, true) : OCC(true, false);
+    return pl.c2v_lds ? OCC(false, true) : OCC(false, false);
+#undef OCC
+}
+
+hipError_t ldpc_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
+{
+    p.entries = pl.d_entries; p.layer_deg = pl.d_layer_deg; p.layer_lvl = pl.d_layer_lvl; p.groups = pl.d_groups;
+    p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
+    p.ent_stride = pl.ent_stride; p.lds_post_words = pl.lds_post_words; p.glb_post_words = pl.glb_post_words;
+    p.gwork_words = pl.gwork_words;
+    const bool small = pl.ent_stride == 13;
+#define DISPATCH(H, C)                                                      \
+    (small ? launch_inst<13, H, C>(pl, p, s) : launch_inst<LDPC_MAX_SLOTS, H, C>(pl, p, s))
+    if (pl.hybrid) return pl.c2v_lds ? DISPATCH(true, true) : DISPATCH(true, false);
+    return pl.c2v_lds ? DISPATCH(false, true) : DISPATCH(false, false);
+#undef DISPATCH
+}
+
+}  // namespace dvbs2

@@ -1,0 +1,227 @@
+"""Python host side over the C ABI: one `Dvbs2Hip` object = one dvbs2hip handle = one GPU.
+
+Method names and socket arguments mirror the reference's tasks (decode_siho, decode_hiho,
+demodulate, deinterleave, filter, estimate, descramble, remove_plh, check_errors:
+/root/reference src/mains/TX_RX_BB/main.cpp:83-94).  numpy arrays in/out (host sockets);
+the `*_dev` methods take raw device pointers (ints, e.g. torch.Tensor.data_ptr()) and only
+enqueue on the handle's stream.
+
+Product code: nothing here imports or calls the CPU oracle, and nothing computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib_binding as B
+from . import params as P
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Dvbs2Hip:
+    def __init__(self, modcod: str = "QPSK-S_8/9", max_frames: int = 1, n_ite: int = 50, alpha: float = 1.0,
+                 early_stop: bool = True, device: int = 0, stream: int | None = None, fir_taps=None,
+                 fir_osf: int = 2, lds_groups: int = -1):
+        self.L = B.load()
+        self.h = None
+        self.mc = P.get_modcod(modcod)            # raises ValueError like DVBS2.cpp:319
+        cfg = B.Cfg()
+        rc = self.L.dvbs2hip_cfg_from_modcod(self.mc.name.encode(), C.byref(cfg))
+        if rc:
+            raise B.Dvbs2HipError(rc, self.L.dvbs2hip_last_error(None).decode())
+        cfg.max_frames = int(max_frames)
+        cfg.ldpc_n_ite = int(n_ite)
+        cfg.ldpc_alpha = float(alpha)
+        cfg.ldpc_early_stop = 1 if early_stop else 0
+        cfg.device = int(device)
+        cfg.stream = stream
+        cfg.ldpc_lds_groups = int(lds_groups)
+        self._taps = None
+        if fir_taps is not None:
+            self._taps = np.ascontiguousarray(fir_taps, dtype=np.float32)
+            cfg.fir_n_taps = self._taps.size
+            cfg.fir_taps = self._taps.ctypes.data
+            cfg.fir_osf = int(fir_osf)
+        h = C.c_void_p()
+        rc = self.L.dvbs2hip_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise B.Dvbs2HipError(rc, self.L.dvbs2hip_last_error(None).decode())
+        self.h = h
+        self.max_frames = int(max_frames)
+        sz = B.Sizes()
+        self._chk(self.L.dvbs2hip_get_sizes(self.h, C.byref(sz)))
+        self.N_ldpc, self.K_ldpc, self.K_bch, self.bps = sz.N_ldpc, sz.K_ldpc, sz.K_bch, sz.bps
+        self.N_xfec, self.pl_frame, self.ldpc_edges, self.ldpc_q = sz.N_xfec_sym, sz.pl_frame_sym, sz.ldpc_edges, sz.ldpc_q
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, rc):
+        if rc:
+            raise B.Dvbs2HipError(rc, self.L.dvbs2hip_last_error(self.h).decode())
+
+    def close(self):
+        if self.h is not None:
+            self.L.dvbs2hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _frames(self, a, per_frame, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        if a.size % per_frame:
+            raise ValueError("socket size %d is not a multiple of the frame size %d" % (a.size, per_frame))
+        return a.reshape(-1, per_frame), a.size // per_frame
+
+    @property
+    def stream(self) -> int:
+        return int(self.L.dvbs2hip_get_stream(self.h) or 0)
+
+    def synchronize(self):
+        self._chk(self.L.dvbs2hip_synchronize(self.h))
+
+    def reset(self):
+        self._chk(self.L.dvbs2hip_reset(self.h))
+
+    def set_ldpc_params(self, n_ite, alpha=1.0, early_stop=True):
+        self._chk(self.L.dvbs2hip_set_ldpc_params(self.h, int(n_ite), float(alpha), 1 if early_stop else 0))
+
+    # ------------------------------------------------------------------ a1
+    def decode_siho(self, Y_N, with_post=False):
+        Y, F = self._frames(Y_N, self.N_ldpc, np.float32)
+        V = np.empty((F, self.K_ldpc), dtype=np.int32)
+        CWD = np.zeros(F, dtype=np.int8)
+        if not with_post:
+            self._chk(self.L.dvbs2hip_ldpc_decode_siho(self.h, _ptr(Y), _ptr(CWD), _ptr(V), F))
+            return V, CWD
+        post = np.empty((F, self.N_ldpc), dtype=np.float32)
+        ites = np.zeros(F, dtype=np.int32)
+        self._chk(self.L.dvbs2hip_ldpc_decode_siho_post(self.h, _ptr(Y), _ptr(CWD), _ptr(V), _ptr(post), _ptr(ites), F))
+        return V, CWD, post, ites
+
+    def decode_siho_dev(self, Y_N, CWD, V_K, n_frames):
+        self._chk(self.L.dvbs2hip_ldpc_decode_siho_dev(self.h, _ptr(Y_N), _ptr(CWD), _ptr(V_K), n_frames))
+
+    # ------------------------------------------------------------------ a2
+    def decode_hiho(self, Y_N):
+        Y, F = self._frames(Y_N, self.K_ldpc, np.int32)
+        V = np.empty((F, self.K_bch), dtype=np.int32)
+        CWD = np.zeros(F, dtype=np.int8)
+        self._chk(self.L.dvbs2hip_bch_decode_hiho(self.h, _ptr(Y), _ptr(CWD), _ptr(V), F))
+        return V, CWD
+
+    def decode_hiho_dev(self, Y_N, CWD, V_K, n_frames):
+        self._chk(self.L.dvbs2hip_bch_decode_hiho_dev(self.h, _ptr(Y_N), _ptr(CWD), _ptr(V_K), n_frames))
+
+    # ------------------------------------------------------------------ a3 / a4
+    def demodulate(self, CP, Y_N1, deinterleave=False):
+        Y, F = self._frames(Y_N1, 2 * self.N_xfec, np.float32)
+        cp = np.ascontiguousarray(np.broadcast_to(np.asarray(CP, dtype=np.float32).ravel(), (F,)))
+        out = np.empty((F, self.N_ldpc), dtype=np.float32)
+        fn = self.L.dvbs2hip_demodulate_deinterleave if deinterleave else self.L.dvbs2hip_demodulate
+        self._chk(fn(self.h, _ptr(cp), _ptr(Y), _ptr(out), F))
+        return out
+
+    def deinterleave(self, itl):
+        X, F = self._frames(itl, self.N_ldpc, np.float32)
+        out = np.empty_like(X)
+        self._chk(self.L.dvbs2hip_deinterleave(self.h, _ptr(X), _ptr(out), F))
+        return out
+
+    # ------------------------------------------------------------------ a5
+    def filter(self, X_N1, n_frames=1):
+        X = np.ascontiguousarray(X_N1, dtype=np.float32).ravel()
+        if X.size % (2 * n_frames):
+            raise ValueError("filter socket size must be a multiple of 2 * n_frames")
+        out = np.empty_like(X)
+        self._chk(self.L.dvbs2hip_filter(self.h, _ptr(X), _ptr(out), X.size // (2 * n_frames), n_frames))
+        return out
+
+    def filter_dev(self, X, Y, n_cplx, n_frames):
+        self._chk(self.L.dvbs2hip_filter_dev(self.h, _ptr(X), _ptr(Y), n_cplx, n_frames))
+
+    def filter_reset(self):
+        self._chk(self.L.dvbs2hip_filter_reset(self.h))
+
+    # ------------------------------------------------------------------ a6
+    def estimate(self, X_N):
+        X, F = self._frames(X_N, 2 * self.N_xfec, np.float32)
+        sig, eb, es = (np.empty(F, dtype=np.float32) for _ in range(3))
+        self._chk(self.L.dvbs2hip_estimate(self.h, _ptr(X), _ptr(sig), _ptr(eb), _ptr(es), F))
+        return sig, eb, es
+
+    # ------------------------------------------------------------------ a7
+    def pl_descramble(self, Y_N1):
+        X, F = self._frames(Y_N1, 2 * self.pl_frame, np.float32)
+        out = np.empty_like(X)
+        self._chk(self.L.dvbs2hip_pl_descramble(self.h, _ptr(X), _ptr(out), F))
+        return out
+
+    def remove_plh(self, Y_N1):
+        X, F = self._frames(Y_N1, 2 * self.pl_frame, np.float32)
+        out = np.empty((F, 2 * self.N_xfec), dtype=np.float32)
+        self._chk(self.L.dvbs2hip_remove_plh(self.h, _ptr(X), _ptr(out), F))
+        return out
+
+    # ------------------------------------------------------------------ a8
+    def bb_descramble(self, Y_N1):
+        X, F = self._frames(Y_N1, self.K_bch, np.int32)
+        out = np.empty_like(X)
+        self._chk(self.L.dvbs2hip_bb_descramble(self.h, _ptr(X), _ptr(out), F))
+        return out
+
+    # ------------------------------------------------------------------ a9
+    def check_errors(self, U, V):
+        Ua, F = self._frames(U, self.K_bch, np.int32)
+        Va, F2 = self._frames(V, self.K_bch, np.int32)
+        if F != F2:
+            raise ValueError("U and V hold a different number of frames")
+        self._chk(self.L.dvbs2hip_monitor_check_errors(self.h, _ptr(Ua), _ptr(Va), F))
+
+    def check_errors_dev(self, U, V, n_frames):
+        self._chk(self.L.dvbs2hip_monitor_check_errors_dev(self.h, _ptr(U), _ptr(V), n_frames))
+
+    def monitor_get(self):
+        out = np.zeros(3, dtype=np.uint64)
+        self._chk(self.L.dvbs2hip_monitor_get(self.h, _ptr(out)))
+        return int(out[0]), int(out[1]), int(out[2])     # FRA, BE, FE
+
+    def monitor_reset(self):
+        self._chk(self.L.dvbs2hip_monitor_reset(self.h))
+
+    # ------------------------------------------------------------------ fused chain
+    def rx_bb(self, pl_frames, sigma=None):
+        X, F = self._frames(pl_frames, 2 * self.pl_frame, np.float32)
+        info = np.empty((F, self.K_bch), dtype=np.int32)
+        c0, c1 = np.zeros(F, dtype=np.int8), np.zeros(F, dtype=np.int8)
+        sg = None
+        if sigma is not None:
+            sg = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, dtype=np.float32).ravel(), (F,)))
+        self._chk(self.L.dvbs2hip_rx_bb(self.h, _ptr(X), _ptr(sg), _ptr(info), _ptr(c0), _ptr(c1), F))
+        return info, c0, c1
+
+    def rx_bb_dev(self, pl_frames, sigma, info, cwd_ldpc, cwd_bch, n_frames):
+        self._chk(self.L.dvbs2hip_rx_bb_dev(self.h, _ptr(pl_frames), _ptr(sigma), _ptr(info), _ptr(cwd_ldpc),
+                                            _ptr(cwd_bch), n_frames))
+
+    # ------------------------------------------------------------------ measurement
+    def timing_enable(self, on=True):
+        self._chk(self.L.dvbs2hip_timing_enable(self.h, 1 if on else 0))
+
+    def timing_reset(self):
+        self._chk(self.L.dvbs2hip_timing_reset(self.h))
+
+    def timing_get(self, k):
+        ms, n = C.c_double(), C.c_int64()
+        self._chk(self.L.dvbs2hip_timing_get(self.h, k, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

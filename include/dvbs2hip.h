@@ -1,0 +1,234 @@
+/*
+ * dvbs2hip.h -- C ABI of libdvbs2hip.so: the DVB-S2 RX inner path on AMD MI355X (gfx950).
+ *
+ * Drop-in boundary: each entry point replaces the body of ONE task codelet
+ * of the reference (aff3ct/dvbs2).  The "replaces" lines cite the reference interface
+ * (path:line relative to /root/reference).  Sockets of the reference hold n_frames
+ * frames contiguously (frame f at offset f * n_elmts); so do all buffers here.
+ *
+ * Conventions
+ *   - plain C, opaque handle, no exceptions across the ABI
+ *   - return value: 0 = success, < 0 = dvbs2hip_status error (text: dvbs2hip_last_error)
+ *   - B = int32_t (one bit per int, 0/1), R = Q = float, as in the reference (H6)
+ *   - entry points WITHOUT suffix take HOST pointers (socket semantics): H2D copy,
+ *     kernels, D2H copy, stream synchronised on return
+ *   - entry points WITH `_dev` take DEVICE pointers, enqueue on the handle's stream and
+ *     return without synchronising (chained tasks avoid PCIe round trips)
+ *   - 1 <= n_frames <= cfg.max_frames; inter-frame batching (-F) maps to the grid width
+ *   - a handle is entered by one host thread at a time (a StreamPU module instance is
+ *     only ever entered by one thread: SURVEY.md 8b "Threading")
+ *   - there is NO CPU fallback: without a usable HIP device dvbs2hip_create fails
+ */
+#ifndef DVBS2HIP_H
+#define DVBS2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVBS2HIP_VERSION 100
+
+typedef enum {
+    DVBS2HIP_OK           = 0,
+    DVBS2HIP_EINVAL       = -1,  /* spu::tools::invalid_argument / length_error        */
+    DVBS2HIP_ENOMEM       = -2,  /* spu::tools::cannot_allocate                        */
+    DVBS2HIP_EHIP         = -3,  /* spu::tools::runtime_error (HIP runtime failure)    */
+    DVBS2HIP_EUNSUPPORTED = -4,  /* spu::tools::unimplemented_error                    */
+    DVBS2HIP_ENODEVICE    = -5   /* no HIP device: the product never falls back to CPU */
+} dvbs2hip_status;
+
+typedef struct dvbs2hip_handle dvbs2hip_t;
+
+/* LDPC check-node rule (--dec-implem, DVBS2.cpp:117-149).  SPA is not implemented yet. */
+enum { DVBS2HIP_IMPLEM_NMS = 0, DVBS2HIP_IMPLEM_MS = 1 };
+/* Interleaver read order (DVBS2.cpp:300-317) */
+enum { DVBS2HIP_ITL_TOP_LEFT = 0, DVBS2HIP_ITL_TOP_RIGHT = 1 };
+
+/*
+ * Configuration = the arguments the reference passes to its build_* functions
+ * (DVBS2.cpp:287-356 modcod_init, :406-495 builders).  Pointers are only read during
+ * dvbs2hip_create.  dvbs2hip_cfg_from_modcod fills everything for a named MODCOD.
+ */
+typedef struct dvbs2hip_cfg {
+    /* code sizes */
+    int32_t N_ldpc;            /* 16200 | 64800                                   */
+    int32_t K_ldpc;            /* = N_bch                                         */
+    int32_t K_bch;
+    /* LDPC: ETSI EN 302 307 Annex B/C address table, K_ldpc/360 rows              */
+    int32_t        ldpc_n_rows;
+    const int32_t *ldpc_row_ptr;   /* n_rows + 1                                  */
+    const int32_t *ldpc_addr;
+    int32_t ldpc_n_ite;        /* --dec-ite                                       */
+    int32_t ldpc_implem;       /* DVBS2HIP_IMPLEM_*                               */
+    float   ldpc_alpha;        /* NMS normalisation factor; 1.0 = AFF3CT default  */
+    int32_t ldpc_early_stop;   /* 1: stop on zero syndrome (enable_syndrome)      */
+    /* BCH: GF(2^m) primitive polynomial (coefficient of x^i at [i], m+1 entries), t */
+    int32_t        bch_m;
+    int32_t        bch_t;
+    const int32_t *bch_prim;
+    /* modem: raw constellation (2^bps points, re/im interleaved, conf/mod order);  */
+    /* normalised to unit mean energy inside, like tools::Constellation_user        */
+    int32_t      bps;
+    const float *cstl;
+    /* bit interleaver: itl_cols <= 1 means Interleaver_core_NO                     */
+    int32_t itl_cols;
+    int32_t itl_order;
+    /* matched filter: real taps (as Filter_RRC_ccr_naive::compute_rrc_coefs returns */
+    /* them); fir_n_taps = 0 disables the filter entry points                       */
+    int32_t      fir_n_taps;
+    const float *fir_taps;
+    int32_t      fir_osf;      /* samples per symbol of the filter input           */
+    /* runtime */
+    int32_t max_frames;        /* capacity of one call (the -F of the socket)      */
+    int32_t device;            /* HIP device ordinal                               */
+    void   *stream;            /* hipStream_t to enqueue on, or NULL: own stream   */
+    int32_t ldpc_lds_groups;   /* tuning: < 0 = automatic                          */
+    int32_t reserved[7];
+} dvbs2hip_cfg;
+
+/* ------------------------------------------------------------------ lifecycle */
+/* Names accepted: the reference's five ("QPSK-S_8/9", "QPSK-S_3/5", "8PSK-S_3/5",
+ * "8PSK-S_8/9", "16APSK-S_8/9"; "" = "QPSK-S_8/9": DVBS2.cpp:287-319) plus the extension
+ * rows "QPSK-N_8/9", "8PSK-N_8/9", "16APSK-N_8/9", "32APSK-S_3/4".  Unknown name:
+ * DVBS2HIP_EINVAL (the reference throws invalid_argument, DVBS2.cpp:319).  Fills code
+ * sizes, tables, constellation, interleaver and the 81-tap SRRC (Shaping_filter.hpp:24-28);
+ * n_ite = 50, alpha = 1, early_stop = 1, max_frames = 1 (the reference's defaults,
+ * DVBS2.cpp:135-142). */
+int dvbs2hip_cfg_from_modcod(const char *modcod, dvbs2hip_cfg *cfg);
+int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out);
+void dvbs2hip_destroy(dvbs2hip_t *h);
+/* text of the last error on this handle (or of the last failed create when h == NULL) */
+const char *dvbs2hip_last_error(const dvbs2hip_t *h);
+/* Interface_reset: clears the filter state and the monitor counters */
+int dvbs2hip_reset(dvbs2hip_t *h);
+/* change --dec-ite / alpha / early-stop without rebuilding tables */
+int dvbs2hip_set_ldpc_params(dvbs2hip_t *h, int32_t n_ite, float alpha, int32_t early_stop);
+void *dvbs2hip_get_stream(dvbs2hip_t *h);      /* hipStream_t */
+int dvbs2hip_synchronize(dvbs2hip_t *h);
+/* derived sizes (per frame), as DVBS2.cpp:351-355 */
+typedef struct dvbs2hip_sizes {
+    int32_t N_ldpc, K_ldpc, K_bch, bps, N_xfec_sym, pl_frame_sym, ldpc_edges, ldpc_q;
+} dvbs2hip_sizes;
+int dvbs2hip_get_sizes(const dvbs2hip_t *h, dvbs2hip_sizes *out);
+
+/* ------------------------------------------------------------------ a1  LDPC decoder
+ * replaces: module::Decoder_SIHO::decode_siho(Y_N, CWD, V_K) of the decoder returned by
+ * tools::Codec_LDPC<B,Q>::get_decoder_siho() -- built DVBS2.cpp:418-449, bound
+ * TX_RX_BB/main.cpp:65,90-91 (sockets dec::sck::decode_siho::{Y_N,CWD,V_K}).
+ *   Y_N : float  [n_frames * N_ldpc]  channel LLRs, LLR > 0 <=> bit 0
+ *   CWD : int8_t [n_frames]           1 = codeword detected (zero syndrome)
+ *   V_K : int32_t[n_frames * K_ldpc]  hard decisions of the systematic bits        */
+int dvbs2hip_ldpc_decode_siho(dvbs2hip_t *h, const float *Y_N, int8_t *CWD, int32_t *V_K, int32_t n_frames);
+int dvbs2hip_ldpc_decode_siho_dev(dvbs2hip_t *h, const float *Y_N, int8_t *CWD, int32_t *V_K, int32_t n_frames);
+/* test hook: also returns the N_ldpc posteriors (natural order) and the iteration count */
+int dvbs2hip_ldpc_decode_siho_post(dvbs2hip_t *h, const float *Y_N, int8_t *CWD, int32_t *V_K,
+                                   float *post_N, int32_t *n_ite_done, int32_t n_frames);
+
+/* ------------------------------------------------------------------ a2  BCH decoder
+ * replaces: Decoder_BCH_DVBS2<B,R>::_decode_hiho(const B *Y_N, int8_t *CWD, B *V_K, frame_id)
+ * -- src/common/Module/Decoder_BCH_DVBS2/Decoder_BCH_DVBS2.cpp:28-40 (bit reversal around
+ * Decoder_BCH_std::_decode), built DVBS2.cpp:406-416, bound TX_RX_BB/main.cpp:91-92.
+ *   Y_N : int32_t[n_frames * K_ldpc]   V_K : int32_t[n_frames * K_bch]   CWD = !status */
+int dvbs2hip_bch_decode_hiho(dvbs2hip_t *h, const int32_t *Y_N, int8_t *CWD, int32_t *V_K, int32_t n_frames);
+int dvbs2hip_bch_decode_hiho_dev(dvbs2hip_t *h, const int32_t *Y_N, int8_t *CWD, int32_t *V_K, int32_t n_frames);
+
+/* ------------------------------------------------------------------ a3  soft demapper
+ * replaces: module::Modem_generic_fast<B,R,Q,max_star>::demodulate(CP, Y_N1, Y_N2)
+ * -- built DVBS2.cpp:478-488, bound TX_RX_BB/main.cpp:87-88.
+ *   CP  : float[n_frames]              sigma (per real dimension), one per frame
+ *   Y_N1: float[n_frames * 2*N_xfec]   symbols, re/im interleaved
+ *   Y_N2: float[n_frames * N_ldpc]     LLRs in transmission (interleaved) order      */
+int dvbs2hip_demodulate(dvbs2hip_t *h, const float *CP, const float *Y_N1, float *Y_N2, int32_t n_frames);
+int dvbs2hip_demodulate_dev(dvbs2hip_t *h, const float *CP, const float *Y_N1, float *Y_N2, int32_t n_frames);
+
+/* ------------------------------------------------------------------ a4  LLR de-interleaver
+ * replaces: module::Interleaver<float,uint32_t>::deinterleave(itl, nat)
+ * -- DVBS2.cpp:451-476, bound TX_RX_BB/main.cpp:56,89.                              */
+int dvbs2hip_deinterleave(dvbs2hip_t *h, const float *itl, float *nat, int32_t n_frames);
+int dvbs2hip_deinterleave_dev(dvbs2hip_t *h, const float *itl, float *nat, int32_t n_frames);
+/* a3+a4 fused (one pass, permuted store) */
+int dvbs2hip_demodulate_deinterleave(dvbs2hip_t *h, const float *CP, const float *Y_N1, float *nat, int32_t n_frames);
+int dvbs2hip_demodulate_deinterleave_dev(dvbs2hip_t *h, const float *CP, const float *Y_N1, float *nat, int32_t n_frames);
+
+/* ------------------------------------------------------------------ a5  SRRC matched filter
+ * replaces: Filter<R>::filter(X_N1, Y_N2) -> Filter_FIR_ccr<R>::_filter
+ * -- src/common/Module/Filter/Filter_FIR/Filter_FIR_ccr.cpp:68-142 (+ step(),
+ * Filter_FIR_ccr.hpp:39-52), bound RX/main_sched.cpp:199-201.  The n_frames frames of
+ * one call are consecutive in time; the last (n_taps-1) complex samples are kept in the
+ * handle between calls (Filter_FIR_ccr.cpp:80-83); dvbs2hip_filter_reset zeroes them.
+ *   X_N1, Y_N2 : float[n_frames * 2 * n_cplx]                                        */
+int dvbs2hip_filter(dvbs2hip_t *h, const float *X_N1, float *Y_N2, int32_t n_cplx, int32_t n_frames);
+int dvbs2hip_filter_dev(dvbs2hip_t *h, const float *X_N1, float *Y_N2, int32_t n_cplx, int32_t n_frames);
+int dvbs2hip_filter_reset(dvbs2hip_t *h);
+
+/* ------------------------------------------------------------------ a6  noise estimator
+ * replaces: Estimator<R>::estimate(X_N, SIG, Eb_N0, Es_N0) -> Estimator_DVBS2<R>::_estimate
+ * -- src/common/Module/Estimator/Estimator_DVBS2.hxx:31-58, wrapper Estimator.hxx:103-118.
+ *   X_N : float[n_frames * 2*N_xfec]; SIG, Eb_N0, Es_N0 : float[n_frames]            */
+int dvbs2hip_estimate(dvbs2hip_t *h, const float *X_N, float *SIG, float *Eb_N0, float *Es_N0, int32_t n_frames);
+int dvbs2hip_estimate_dev(dvbs2hip_t *h, const float *X_N, float *SIG, float *Eb_N0, float *Es_N0, int32_t n_frames);
+
+/* ------------------------------------------------------------------ a7  PL descramble, header/pilot removal
+ * replaces: Scrambler_PL<D>::descramble -> __scramble(scr_flag = false)
+ * -- src/common/Module/Scrambler/Scrambler_PL/Scrambler_PL.hxx:61-78 (start_ix = 90)
+ *   Y_N1, Y_N2 : float[n_frames * 2*pl_frame]                                        */
+int dvbs2hip_pl_descramble(dvbs2hip_t *h, const float *Y_N1, float *Y_N2, int32_t n_frames);
+int dvbs2hip_pl_descramble_dev(dvbs2hip_t *h, const float *Y_N1, float *Y_N2, int32_t n_frames);
+/* replaces: Framer<B>::remove_plh -> _remove_plh -- src/common/Module/Framer/Framer.hxx:330-343
+ *   Y_N1 : float[n_frames * 2*pl_frame] -> Y_N2 : float[n_frames * 2*N_xfec]         */
+int dvbs2hip_remove_plh(dvbs2hip_t *h, const float *Y_N1, float *Y_N2, int32_t n_frames);
+int dvbs2hip_remove_plh_dev(dvbs2hip_t *h, const float *Y_N1, float *Y_N2, int32_t n_frames);
+
+/* ------------------------------------------------------------------ a8  BB descramble
+ * replaces: Scrambler_BB<D>::_descramble -- src/common/Module/Scrambler/Scrambler_BB/Scrambler_BB.hxx:51-72
+ *   Y_N1, Y_N2 : int32_t[n_frames * K_bch]                                           */
+int dvbs2hip_bb_descramble(dvbs2hip_t *h, const int32_t *Y_N1, int32_t *Y_N2, int32_t n_frames);
+int dvbs2hip_bb_descramble_dev(dvbs2hip_t *h, const int32_t *Y_N1, int32_t *Y_N2, int32_t n_frames);
+
+/* ------------------------------------------------------------------ a9  BER/FER monitor
+ * replaces: module::Monitor_BFER<B>::check_errors(U, V) -- built DVBS2.cpp:575-591, bound
+ * TX_RX_BB/main.cpp:93-94.  Counters {FRA, BE, FE} live on the device; get copies them out
+ * (what tools::Monitor_reduction sums across threads, main.cpp:123-125, is summed across
+ * GPUs by the host with one 24-byte all-reduce: DESIGN.md "multi-GPU").
+ *   U, V : int32_t[n_frames * K_bch]                                                 */
+int dvbs2hip_monitor_check_errors(dvbs2hip_t *h, const int32_t *U, const int32_t *V, int32_t n_frames);
+int dvbs2hip_monitor_check_errors_dev(dvbs2hip_t *h, const int32_t *U, const int32_t *V, int32_t n_frames);
+int dvbs2hip_monitor_get(dvbs2hip_t *h, uint64_t fra_be_fe[3]);
+int dvbs2hip_monitor_reset(dvbs2hip_t *h);
+
+/* ------------------------------------------------------------------ fused RX baseband chain (a7 -> a8)
+ * One call = the RX half of TX_RX_BB/main.cpp:83-92:
+ *   PL descramble -> remove_plh -> estimate -> demodulate -> deinterleave -> LDPC
+ *   decode_siho -> BCH decode_hiho -> BB descramble, all intermediates device-resident.
+ *   pl_frames: float  [n_frames * 2*pl_frame]
+ *   sigma_in : float  [n_frames] or NULL (NULL: Estimator_DVBS2; else Estimator_perfect)
+ *   info_bits: int32_t[n_frames * K_bch]
+ *   cwd_ldpc, cwd_bch: int8_t[n_frames] (either may be NULL)                         */
+int dvbs2hip_rx_bb(dvbs2hip_t *h, const float *pl_frames, const float *sigma_in, int32_t *info_bits,
+                   int8_t *cwd_ldpc, int8_t *cwd_bch, int32_t n_frames);
+int dvbs2hip_rx_bb_dev(dvbs2hip_t *h, const float *pl_frames, const float *sigma_in, int32_t *info_bits,
+                       int8_t *cwd_ldpc, int8_t *cwd_bch, int32_t n_frames);
+
+/* ------------------------------------------------------------------ measurement
+ * Per-kernel device time, measured with hipEvents recorded on the handle's stream around
+ * each launch while timing is enabled (the equivalent of `--sim-stats`,
+ * TX_RX_BB/main.cpp:110,170-178).                                                    */
+enum { DVBS2HIP_K_LDPC = 0, DVBS2HIP_K_BCH = 1, DVBS2HIP_K_DEMAP = 2, DVBS2HIP_K_FIR = 3,
+       DVBS2HIP_K_FRONT = 4, DVBS2HIP_K_MISC = 5, DVBS2HIP_K_COUNT = 6 };
+int dvbs2hip_timing_enable(dvbs2hip_t *h, int32_t on);
+int dvbs2hip_timing_reset(dvbs2hip_t *h);
+/* synchronises, then returns the summed device ms and the number of launches of kernel k */
+int dvbs2hip_timing_get(dvbs2hip_t *h, int32_t k, double *total_ms, int64_t *n_launches);
+/* device memory helpers so non-HIP hosts (ctypes, cgo, JNI) can own device buffers */
+int dvbs2hip_malloc(dvbs2hip_t *h, void **dptr, size_t bytes);
+int dvbs2hip_free(dvbs2hip_t *h, void *dptr);
+int dvbs2hip_memcpy_h2d(dvbs2hip_t *h, void *dst, const void *src, size_t bytes);
+int dvbs2hip_memcpy_d2h(dvbs2hip_t *h, void *dst, const void *src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVBS2HIP_H */

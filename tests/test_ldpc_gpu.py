@@ -1,0 +1,120 @@
+"""a1 parity: HIP layered-NMS LDPC decoder vs the CPU oracle running the same QC-layer
+schedule.  Bar (BASELINE.json north_star): hard decisions bit-exact, soft values within
+1e-4 (they are expected to be bit-identical: same fp32 operations in the same order)."""
+import numpy as np
+import pytest
+
+from helpers import chain, make_llrs
+
+pytestmark = pytest.mark.gpu
+
+LLR_TOL = 1e-4
+CASES = [  # modcod, Eb/N0 (dB) near / below the waterfall, frames
+    ("QPSK-S_8/9", 4.6, 6), ("QPSK-S_8/9", 3.0, 4),
+    ("QPSK-S_3/5", 2.4, 4), ("QPSK-S_3/5", 0.8, 3),
+    ("32APSK-S_3/4", 3.4, 4),
+    ("QPSK-N_8/9", 4.2, 3), ("QPSK-N_8/9", 3.0, 2),
+]
+
+
+@pytest.fixture(scope="module")
+def Rx():
+    from dvbs2_amd.receiver import Dvbs2Hip
+    return Dvbs2Hip
+
+
+@pytest.mark.parametrize("modcod,ebn0,F", CASES)
+@pytest.mark.parametrize("early", [False, True])
+def test_ldpc_matches_oracle(O, Rx, modcod, ebn0, F, early):
+    ch = chain(O, modcod)
+    _, llr, cw = make_llrs(O, modcod, F, ebn0, seed=11)
+    rx = Rx(modcod, max_frames=F, n_ite=10, alpha=0.875, early_stop=early)
+    V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+    Vo, posto, cwdo, iteso = ch.ldpc.decode(llr, n_ite=10, alpha=0.875, sched=O.QC, early_stop=early)
+    assert np.array_equal(V, Vo), "hard decisions differ: %d bits" % int((V != Vo).sum())
+    assert np.array_equal(CWD, cwdo)
+    assert np.array_equal(ites, iteso)
+    assert np.max(np.abs(post - posto)) <= LLR_TOL
+    assert np.array_equal(post, posto), "posteriors are expected to be bit-identical"
+    rx.close()
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.75])
+def test_ldpc_alpha_and_iterations(O, Rx, alpha):
+    modcod = "QPSK-S_8/9"
+    ch = chain(O, modcod)
+    _, llr, _ = make_llrs(O, modcod, 3, 3.8, seed=5)
+    rx = Rx(modcod, max_frames=3, n_ite=1, alpha=alpha, early_stop=False)
+    for n_ite in (1, 2, 7, 20):
+        rx.set_ldpc_params(n_ite, alpha, False)
+        V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+        Vo, posto, cwdo, _ = ch.ldpc.decode(llr, n_ite=n_ite, alpha=alpha, sched=O.QC, early_stop=False)
+        assert np.array_equal(V, Vo) and np.array_equal(post, posto) and np.array_equal(CWD, cwdo)
+        assert (ites == n_ite).all()
+    rx.close()
+
+
+def test_ldpc_hybrid_storage_policies_agree(O, Rx, monkeypatch):
+    """Where the posteriors live (LDS vs per-workgroup global workspace) and where the packed
+    c->v state lives must not change a single bit."""
+    modcod = "QPSK-S_8/9"
+    ch = chain(O, modcod)
+    _, llr, _ = make_llrs(O, modcod, 4, 4.0, seed=7)
+    Vo, posto, _, _ = ch.ldpc.decode(llr, n_ite=6, alpha=1.0, sched=O.QC, early_stop=False)
+    for c2v in ("lds", "global"):
+        for groups in (0, 7, 30, -1):
+            monkeypatch.setenv("DVBS2HIP_LDPC_C2V", c2v)
+            rx = Rx(modcod, max_frames=4, n_ite=6, alpha=1.0, early_stop=False, lds_groups=groups)
+            V, _, post, _ = rx.decode_siho(llr, with_post=True)
+            assert np.array_equal(V, Vo) and np.array_equal(post, posto), (c2v, groups)
+            rx.close()
+
+
+def test_ldpc_batch_larger_than_grid_and_roundtrip(O, Rx):
+    """More frames than resident workgroups (persistent grid loops), noiseless and noisy:
+    encode -> decode round trip is the identity; every frame of the batch is decoded."""
+    modcod = "QPSK-S_8/9"
+    ch = chain(O, modcod)
+    F = 1500
+    rng = np.random.default_rng(3)
+    info = rng.integers(0, 2, (8, ch.mc.K_ldpc)).astype(np.int32)
+    cw = ch.ldpc.encode(info)
+    idx = rng.integers(0, 8, F)
+    sigma = 0.28
+    y = (1.0 - 2.0 * cw[idx]) + sigma * rng.standard_normal((F, ch.mc.N_ldpc))
+    llr = (2 * y / sigma ** 2).astype(np.float32)
+    rx = Rx(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=True)
+    V, CWD = rx.decode_siho(llr)
+    assert np.array_equal(V, info[idx])
+    assert (CWD == 1).all()
+    rx.close()
+
+
+def test_ldpc_normal_frame_full_batch_properties(O, Rx):
+    """BASELINE config 2 shape (N=64800, 8/9): size-independent properties on a batch the
+    oracle could not finish: round trip at high SNR, all-zero codeword symmetry (decoding
+    llr with the codeword's signs flipped gives the all-zero word), determinism."""
+    modcod = "QPSK-N_8/9"
+    ch = chain(O, modcod)
+    mc = ch.mc
+    F = 512
+    rng = np.random.default_rng(9)
+    info = rng.integers(0, 2, (4, mc.K_ldpc)).astype(np.int32)
+    cw = ch.ldpc.encode(info)
+    idx = rng.integers(0, 4, F)
+    sigma = 0.30
+    noise = sigma * rng.standard_normal((F, mc.N_ldpc))
+    llr = (2 * ((1.0 - 2.0 * cw[idx]) + noise) / sigma ** 2).astype(np.float32)
+    rx = Rx(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=False)
+    V, CWD = rx.decode_siho(llr)
+    assert np.array_equal(V, info[idx]) and (CWD == 1).all()
+    V2, _ = rx.decode_siho(llr)
+    assert np.array_equal(V, V2)
+    # symmetry: flip LLR signs where the codeword bit is 1 -> the decoder must output zeros
+    llr0 = (llr * (1.0 - 2.0 * cw[idx])).astype(np.float32)
+    V0, C0 = rx.decode_siho(llr0)
+    assert not V0.any() and (C0 == 1).all()
+    # the first 3 frames agree with the oracle bit for bit
+    Vo, _, _, _ = ch.ldpc.decode(llr[:3], n_ite=10, alpha=1.0, sched=O.QC, early_stop=False)
+    assert np.array_equal(V[:3], Vo)
+    rx.close()
