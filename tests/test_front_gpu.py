@@ -31,12 +31,20 @@ def test_front_stages_match_oracle(O, Rx, modcod):
     x = rx.remove_plh(d)
     xo = np.stack([O.framer_remove_plh(do[f], mc.N_xfec) for f in range(F)])
     assert np.array_equal(x, xo)
-    # a6: fp32 reduction order differs from the reference's serial sum -> 1e-5 relative
+    # a6: the M2M4 estimator subtracts nearly equal moments (2 M2^2 - M4), so the fp32 summation
+    # ORDER shows up at ~1e-5 relative in sigma: the reference sums serially
+    # (Estimator_DVBS2.hxx:36-41), the GPU sums per lane then by tree.  Tolerance 1e-4 relative
+    # against the oracle, and the GPU must be at least as close to the fp64 value as the oracle.
     sig, eb, es = rx.estimate(x)
     for f in range(F):
         e = O.estimate(xo[f], mc.code_rate, mc.bps)
-        assert abs(sig[f] - e[0]) <= 1e-5 * abs(e[0])
-        assert abs(eb[f] - e[1]) <= 1e-4 and abs(es[f] - e[2]) <= 1e-4
+        assert abs(sig[f] - e[0]) <= 1e-4 * abs(e[0])
+        assert abs(eb[f] - e[1]) <= 2e-3 and abs(es[f] - e[2]) <= 2e-3      # dB
+        p = (xo[f].astype(np.float64).reshape(-1, 2) ** 2).sum(axis=1)
+        m2, m4 = p.mean(), (p * p).mean()
+        se = np.sqrt(abs(2 * m2 * m2 - m4))
+        s64 = np.sqrt(1.0 / (2.0 * se / abs(m2 - se)))
+        assert abs(sig[f] - s64) <= abs(e[0] - s64) + 2e-6 * s64
     # a3: |LLR error| <= 1e-4 * max(1, |LLR|)   (north_star: 1e-4 LLR tolerance)
     llr = rx.demodulate(np.full(F, sigma, np.float32), x)
     llro = np.stack([O.demodulate(ch.cstl, mc.bps, np.float32(sigma), xo[f]) for f in range(F)])
