@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: information-bits/s (+ FEC-frames/s) of the DVB-S2 LDPC
+layered-NMS decoder, N = 64800, rate 8/9, 10 iterations, on N MI355X.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (dvbs2hip_ldpc_decode_siho_dev) over one batch of
+synthetic channel LLRs already resident in HBM: BASELINE configs[1] = 4096 frames of
+N = 64800 / K = 57600 per GPU (weak scaling: every rank decodes its own 4096-frame batch,
+no data-path collective; RCCL only sums the BER counters and takes the max of the timings).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODCOD = "QPSK-N_8/9"
+FRAMES_PER_GPU = 4096
+N_ITE = 10
+EBN0_DB = 4.0            # waterfall, few errors
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def ldpc_encode_np(mc, rp, ad, info):
+    """IRA encoder (ETSI EN 302 307 5.3.2) in numpy -- input synthesis only."""
+    K, N = mc.K_ldpc, mc.N_ldpc
+    M = N - K
+    q = M // 360
+    F = info.shape[0]
+    par = np.zeros((F, M), dtype=np.uint8)
+    m = np.arange(360)
+    for g in range(K // 360):
+        blk = info[:, g * 360:(g + 1) * 360].astype(np.uint8)
+        for a in ad[rp[g]:rp[g + 1]]:
+            par[:, (a + m * q) % M] ^= blk
+    par = np.bitwise_xor.accumulate(par, axis=1)
+    return np.concatenate([info.astype(np.uint8), par], axis=1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libdvbs2hip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dvbs2_amd import params as P
+    from dvbs2_amd import lib_binding as B
+    from dvbs2_amd.receiver import Dvbs2Hip
+    from dvbs2_amd.parallel import reduce_counters, reduce_max
+
+    mc = P.get_modcod(MODCOD)
+    F = args.frames
+    rx = Dvbs2Hip(MODCOD, max_frames=F, n_ite=N_ITE, alpha=1.0, early_stop=False, device=local_rank)
+    N, K = rx.N_ldpc, rx.K_ldpc
+
+    # ---- synthetic input, resident in HBM: random codewords + AWGN at Eb/N0 = 4.0 dB
+    rp, ad = P.load_ldpc_table(mc.ldpc_table)
+    rng = np.random.default_rng(1 + rank)
+    n_cw = 16
+    info = rng.integers(0, 2, (n_cw, K)).astype(np.int32)
+    cw = torch.from_numpy(ldpc_encode_np(mc, rp, ad, info).astype(np.float32)).to(dev)
+    sel = torch.from_numpy(rng.integers(0, n_cw, F)).to(dev)
+    rate = mc.K_bch / mc.N_ldpc
+    sigma = float(np.sqrt(1.0 / (2.0 * rate * 10.0 ** (EBN0_DB / 10.0))))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2 + rank)
+    llr = torch.empty((F, N), dtype=torch.float32, device=dev)
+    chunk = 256
+    for s in range(0, F, chunk):
+        e = min(F, s + chunk)
+        y = (1.0 - 2.0 * cw[sel[s:e]]) + sigma * torch.randn((e - s, N), generator=gen, device=dev)
+        llr[s:e] = y * (2.0 / sigma ** 2)
+    bits = torch.empty((F, K), dtype=torch.int32, device=dev)
+    cwd = torch.empty((F,), dtype=torch.int8, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        rx.decode_siho_dev(llr.data_ptr(), cwd.data_ptr(), bits.data_ptr(), F)
+
+    for _ in range(args.warmup):
+        step()
+    rx.synchronize()
+    rx.timing_enable(True)
+    rx.timing_reset()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    rx.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = reduce_max(elapsed, dev) if world > 1 else elapsed
+    k_ms, k_n = rx.timing_get(B.K_LDPC)          # HIP events on the launch stream, per launch
+    rx.timing_enable(False)
+
+    # ---- correctness of what was timed (untimed): BER/FER of the decoded batch, summed over ranks
+    ref = torch.from_numpy(info).to(dev)[sel]
+    be_f = (bits != ref).sum(dim=1)
+    ctr = [int(F), int(be_f.sum().item()), int((be_f > 0).sum().item())]
+    ctr = reduce_counters(ctr, dev) if world > 1 else ctr
+    n_cwd = int(cwd.sum().item())
+
+    frames_total = world * F * args.steps
+    fps = frames_total / elapsed
+    bytes_per_frame = 16 * rx.ldpc_edges * N_ITE + 4 * N + 4 * K
+    avg_launch_s = (k_ms / max(k_n, 1)) * 1e-3
+    achieved = bytes_per_frame * F / avg_launch_s / 1e9 if k_n else 0.0
+
+    out = {
+        "metric": "info_bits_per_s (N=64800 LDPC NMS 10-ite)",
+        "value": fps * mc.K_bch,
+        "unit": "bit/s",
+        "fec_frames_per_s": fps,
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: LDPC-only layered NMS decode, N=64800 rate 8/9 (K_ldpc=57600, K_bch=57472), "
+                               "10 iterations fixed (early stop off), alpha=1.0, batch %d frames per GPU, Eb/N0=%.1f dB" % (F, EBN0_DB),
+                   "frames_per_gpu": F, "n_ite": N_ITE, "parallelism": "frames sharded, %d rank(s)" % world},
+        "ber": {"FRA": ctr[0], "BE": ctr[1], "FE": ctr[2], "cwd_rank0": n_cwd},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": _pmc_traffic(),
+                     "kernel": "ldpc_layered_nms_kernel", "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_n,
+                     "algorithmic_bytes_per_launch": bytes_per_frame * F},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(mc, llr, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    rx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or null."""
+    p = os.path.join(ROOT, "profiles", "ldpc_pmc_traffic.json")
+    try:
+        with open(p) as fh:
+            return json.load(fh).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(mc, llr, target_s):
+    """CPU leg: the oracle's AFF3CT-style decoder (natural row order, scalar fp32, NMS 10 ite)
+    timed on the host cores on a bounded sample of the same LLRs.  Checker code used as a
+    reported baseline only -- never on the product path."""
+    from oracle import oracle as O
+    from dvbs2_amd import params as P
+    rp, ad = P.load_ldpc_table(mc.ldpc_table)
+    code = O.Ldpc(mc.N_ldpc, mc.K_ldpc, rp, ad)
+    cores = os.cpu_count() or 1
+    probe = llr[:cores].cpu().numpy()
+    _, sec = code.decode_batch_timed(probe, n_ite=N_ITE, alpha=1.0, sched=O.NATURAL, threads=cores)
+    per_round = max(sec, 1e-3)
+    rounds = int(max(1, min(64, target_s / per_round)))
+    n = min(llr.shape[0], cores * rounds)
+    sample = llr[:n].cpu().numpy()
+    _, sec = code.decode_batch_timed(sample, n_ite=N_ITE, alpha=1.0, sched=O.NATURAL, threads=cores)
+    return {"value": n * mc.K_bch / sec, "unit": "bit/s", "fec_frames_per_s": n / sec, "cores": cores, "kind": "port",
+            "sample": "%d frames of the same batch, oracle layered NMS (natural row order, scalar fp32, 10 ite, "
+                      "frames sharded over %d threads), %.1f s" % (n, cores, sec)}
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,7 @@ int ensure(dvbs2hip_t *h, int id, size_t bytes, void **out)
 int check_frames(dvbs2hip_t *h, int n_frames)
 {
     if (!h) return DVBS2HIP_EINVAL;
+    if (hipSetDevice(h->device) != hipSuccess) return fail(h, DVBS2HIP_EHIP, "hipSetDevice failed");
     if (n_frames < 1 || n_frames > h->max_frames)
         return fail(h, DVBS2HIP_EINVAL, "'n_frames' has to be in [1, max_frames] ('n_frames' = " + std::to_string(n_frames) +
                                             ", 'max_frames' = " + std::to_string(h->max_frames) + ").");
@@ -223,6 +224,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         upload(h, &lp.d_layer_lvl, lp.layer_lvl.data(), lp.layer_lvl.size()) ||
         upload(h, &lp.d_groups, lp.groups.data(), lp.groups.size()))
         CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+    if (lp.fast && upload(h, &lp.d_fast_tab, lp.fast_tab.data(), lp.fast_tab.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
     lp.grid_max = ldpc_blocks_per_cu(lp) * h->n_cus;
     if (lp.gwork_words > 0) CREATE_HIP(hipMalloc((void **)&h->d_gwork, (size_t)lp.grid_max * lp.gwork_words * sizeof(float)));
 
@@ -276,7 +278,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     for (auto &kv : h->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
         for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->bch.d_exp, h->bch.d_log,
+    void *ptrs[] = {h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);

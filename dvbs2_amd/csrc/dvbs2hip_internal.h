@@ -11,12 +11,13 @@ namespace dvbs2 {
 
 // ---------------------------------------------------------------- LDPC (a1)
 // One slot of a QC layer = one circulant: variable = group element (t - t0) mod 360.
-struct LdpcEntry {
-    uint32_t base;    // word offset of the bit-group in its store (LDS or per-frame global)
-    uint16_t t0;      // circulant shift
-    uint16_t flags;   // bit0: store is LDS, bit1: edge absent for t == 0, bits 2..3: level
-};
-enum { LE_LDS = 1, LE_MASK0 = 2, LE_LVL_SHIFT = 2 };
+// Packed in ONE dword so a whole layer (<= 27 entries) is preloaded into SGPRs by a few wide
+// scalar loads:  bits 0..8 circulant shift t0 | bits 9..16 slot of the bit-group in its store
+// (word offset = 360 * slot) | bit 17 store is LDS | bit 18 edge absent for t == 0 |
+// bits 19..20 conflict level | bit 21 padding entry (no edge).
+typedef uint32_t LdpcEntry;
+enum { LE_T0_MASK = 0x1FF, LE_SLOT_SHIFT = 9, LE_SLOT_MASK = 0xFF, LE_LDS = 1u << 17, LE_MASK0 = 1u << 18,
+       LE_LVL_SHIFT = 19, LE_LVL_MASK = 3, LE_NULL = 1u << 21 };
 
 struct LdpcGroup {    // where the 360 posteriors of one bit-group live
     uint32_t base;
@@ -46,6 +47,7 @@ struct LdpcKParams {
     int32_t gwork_words;     // global words per frame in total (posteriors + c2v state)
     int32_t n_frames, n_ite, early_stop;
     float alpha;
+    const uint32_t *fast_tab;  // regular-code fast path: [q][LDPC_FAST_STRIDE] (see k_ldpc_fast.hip)
 };
 
 struct LdpcPlan {             // host-side description, built once per handle
@@ -63,7 +65,16 @@ struct LdpcPlan {             // host-side description, built once per handle
     LdpcEntry *d_entries = nullptr;
     int32_t *d_layer_deg = nullptr, *d_layer_lvl = nullptr;
     LdpcGroup *d_groups = nullptr;
+    // regular-code fast path (k_ldpc_fast.hip): every layer has exactly deg_max slots
+    bool fast = false;
+    int fast_mode = 0;            // 0: all posteriors in LDS, 1: all in the global workspace
+    std::vector<uint32_t> fast_tab;
+    uint32_t *d_fast_tab = nullptr;
 };
+constexpr int LDPC_FAST_STRIDE = 64;   // dwords per layer: 27 entries | prim mask | n_conf | 16 conf entries | 16 conf meta
+constexpr int LDPC_FAST_MAXC = 16;
+hipError_t ldpc_fast_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
+int ldpc_fast_blocks_per_cu(const LdpcPlan &pl);
 
 // builds the layer tables; returns empty string on success, else the error text
 std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,

@@ -102,16 +102,66 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
     pl.gwork_words = pl.glb_post_words + (c2v_lds ? 0 : 3 * M);
     pl.lds_bytes = (size_t)pl.lds_post_words * 4 + (c2v_lds ? c2v_bytes : 0);
 
+    // ---- regular-code fast path: uniform check degree (11 or 27), few same-layer duplicates
+    {
+        bool regular = (pl.deg_max == 11 || pl.deg_max == 27);
+        int maxc = 0;
+        for (int r = 0; r < q && regular; r++) {
+            if (pl.layer_deg[r] != pl.deg_max) regular = false;
+            int c = 0;
+            for (const Slot &s : layers[r]) c += s.lvl > 0;
+            maxc = std::max(maxc, c);
+        }
+        const char *env_path = getenv("DVBS2HIP_LDPC_PATH");
+        if (env_path && !strcmp(env_path, "generic")) regular = false;
+        if (regular && maxc <= LDPC_FAST_MAXC) {
+            pl.fast = true;
+            const char *env_mode = getenv("DVBS2HIP_LDPC_FAST_MODE");
+            // short frames: the whole posterior image (N fp32 + one dummy row) fits LDS twice per CU
+            pl.fast_mode = ((size_t)(pl.n_groups + 1) * grp_bytes * 2 <= lds_limit + 1024) ? 0 : 1;
+            if (env_mode) pl.fast_mode = !strcmp(env_mode, "lds") ? 0 : 1;
+            if (pl.fast_mode == 0 && (size_t)(pl.n_groups + 1) * grp_bytes > lds_limit) pl.fast_mode = 1;
+            pl.fast_tab.assign((size_t)q * LDPC_FAST_STRIDE, 0u);
+            for (int r = 0; r < q; r++) {
+                uint32_t *T = &pl.fast_tab[(size_t)r * LDPC_FAST_STRIDE];
+                uint32_t prim = 0; int nc = 0;
+                // conflict list sorted by level
+                for (int lvl = 1; lvl <= 3; lvl++)
+                    for (size_t j = 0; j < layers[r].size(); j++)
+                        if (layers[r][j].lvl == lvl) {
+                            const Slot &sl = layers[r][j];
+                            T[32 + nc] = (uint32_t)(sl.t0 * 4) | ((uint32_t)(sl.group * LDPC_Z * 4) << 11);
+                            T[48 + nc] = (uint32_t)j | ((uint32_t)lvl << 8);
+                            nc++;
+                        }
+                for (size_t j = 0; j < layers[r].size(); j++) {
+                    const Slot &sl = layers[r][j];
+                    // byte shift (11 bits) | byte offset of the bit-group, group g at word 360 g
+                    T[j] = (uint32_t)(sl.t0 * 4) | ((uint32_t)(sl.group * LDPC_Z * 4) << 11);
+                    if (sl.lvl == 0) prim |= 1u << j;
+                }
+                T[27] = prim; T[28] = (uint32_t)nc;
+            }
+            // workspace of one workgroup: [posteriors (global mode) | packed c->v state 3 M words]
+            pl.glb_post_words = pl.fast_mode == 1 ? pl.n_groups * LDPC_Z : 0;
+            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1) * LDPC_Z : 0;
+            pl.gwork_words = pl.glb_post_words + 3 * M;
+            pl.lds_bytes = (size_t)pl.lds_post_words * 4;
+            pl.hybrid = false; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : 0;
+        }
+    }
+    if (pl.n_groups > 255) return "LDPC: more than 255 bit-groups not supported by the packed entry format";
     pl.ent_stride = pl.deg_max <= 13 ? 13 : LDPC_MAX_SLOTS;
-    pl.entries.assign((size_t)q * pl.ent_stride, {0, 0, 0});
+    // padding entries read slot 0 of a store that exists and are ignored
+    const LdpcEntry null_entry = LE_NULL | (nl > 0 ? LE_LDS : 0u);
+    pl.entries.assign((size_t)q * pl.ent_stride, null_entry);
     for (int r = 0; r < q; r++)
         for (size_t j = 0; j < layers[r].size(); j++) {
             const Slot &s = layers[r][j];
-            LdpcEntry e;
-            e.base = pl.groups[s.group].base;
-            e.t0 = (uint16_t)s.t0;
-            e.flags = (uint16_t)((pl.groups[s.group].lds ? LE_LDS : 0) | (s.mask0 ? LE_MASK0 : 0) | (s.lvl << LE_LVL_SHIFT));
-            pl.entries[(size_t)r * pl.ent_stride + j] = e;
+            const LdpcGroup &gl = pl.groups[s.group];
+            pl.entries[(size_t)r * pl.ent_stride + j] =
+                (LdpcEntry)s.t0 | ((gl.base / LDPC_Z) << LE_SLOT_SHIFT) | (gl.lds ? LE_LDS : 0u) |
+                (s.mask0 ? LE_MASK0 : 0u) | ((uint32_t)s.lvl << LE_LVL_SHIFT);
         }
     return "";
 }
@@ -122,19 +172,45 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
 // LDS pointers carry their address space in the type, so the optimiser can never merge an
 // LDS access and a global access into one flat access through a selected generic pointer.
 typedef __attribute__((address_space(3))) float lds_float;
+// The layer tables are read-only for the whole launch.  Reading them through the CONSTANT
+// address space lets the compiler use scalar loads (SGPRs, scalar cache) for these
+// wave-uniform addresses; through a plain global pointer it must assume the kernel's own
+// stores may alias them and falls back to per-lane vector loads with a full memory round
+// trip in front of every edge.
+typedef const __attribute__((address_space(4))) uint32_t *const_u32;
+typedef const __attribute__((address_space(4))) int32_t *const_i32;
+typedef const __attribute__((address_space(4))) unsigned long long *const_u64;
+static_assert(sizeof(LdpcGroup) == 8, "group table is read as 64-bit scalars");
 
-template <bool HYBRID>
-__device__ __forceinline__ float post_ld(const LdpcEntry e, int m, const lds_float *lpost, const float *gpost)
+__device__ __forceinline__ LdpcGroup group_ld(const_u64 groups, int g)
 {
-    if (HYBRID && !(e.flags & LE_LDS)) return gpost[e.base + m];
-    return lpost[e.base + m];
+    const unsigned long long raw = groups[g];
+    LdpcGroup v;
+    v.base = (uint32_t)raw; v.lds = (uint32_t)(raw >> 32);
+    return v;
+}
+
+// element (t - t0) mod 360 of the entry's bit-group, as a word offset into its store
+__device__ __forceinline__ int ent_off(LdpcEntry e, int t)
+{
+    const int m = t - (int)(e & LE_T0_MASK);
+    return (int)(((e >> LE_SLOT_SHIFT) & LE_SLOT_MASK) * LDPC_Z) + (int)min((unsigned)m, (unsigned)(m + LDPC_Z));
 }
 template <bool HYBRID>
-__device__ __forceinline__ void post_st(const LdpcEntry e, int m, lds_float *lpost, float *gpost, float v)
+__device__ __forceinline__ float post_ld(LdpcEntry e, int off, const lds_float *lpost, const float *gpost)
 {
-    if (HYBRID && !(e.flags & LE_LDS)) gpost[e.base + m] = v;
-    else lpost[e.base + m] = v;
+    if (HYBRID && !(e & LE_LDS)) return gpost[off];
+    return lpost[off];
 }
+template <bool HYBRID>
+__device__ __forceinline__ void post_st(LdpcEntry e, int off, lds_float *lpost, float *gpost, float v)
+{
+    if (HYBRID && !(e & LE_LDS)) gpost[off] = v;
+    else lpost[off] = v;
+}
+// the edge does not exist for this lane (padding entry, or p_{c-1} of check 0)
+__device__ __forceinline__ bool ent_absent(LdpcEntry e, int t) { return (e & LE_NULL) || ((e & LE_MASK0) && t == 0); }
+__device__ __forceinline__ int ent_lvl(LdpcEntry e) { return (int)((e >> LE_LVL_SHIFT) & LE_LVL_MASK); }
 
 // fp32 message from the packed per-check state: magnitude c1 at the slot of the minimum, c2
 // elsewhere, sign bit j of pk
@@ -145,7 +221,7 @@ __device__ __forceinline__ float c2v_unpack(float c1, float c2, uint32_t pk, int
 }
 
 template <int DEG, bool HYBRID, bool C2V_LDS>
-__global__ void __launch_bounds__(LDPC_THREADS)
+__global__ void __launch_bounds__(LDPC_THREADS, 3)
 ldpc_layered_nms_kernel(const LdpcKParams p)
 {
     extern __shared__ float smem[];
@@ -153,6 +229,9 @@ ldpc_layered_nms_kernel(const LdpcKParams p)
     const int t = threadIdx.x;
     const bool act = t < LDPC_Z;
     const int M = p.M, q = p.q;
+    const const_u32 entries = (const_u32)p.entries;
+    const const_i32 layer_lvl = (const_i32)p.layer_lvl;
+    const const_u64 groups = (const_u64)p.groups;
 
     for (int f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
         const float *Y = p.llr + (size_t)f * p.N;
@@ -168,7 +247,7 @@ ldpc_layered_nms_kernel(const LdpcKParams p)
         // ---- load channel LLRs into the posterior stores (parity bits regrouped [r][t])
         if (act)
             for (int g = 0; g < p.n_groups; g++) {
-                const LdpcGroup gl = p.groups[g];
+                const LdpcGroup gl = group_ld(groups, g);
                 const int src = g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info);
                 const float v = Y[src];
                 if (HYBRID && !gl.lds) gpost[gl.base + t] = v; else lpost[gl.base + t] = v;
@@ -178,33 +257,41 @@ ldpc_layered_nms_kernel(const LdpcKParams p)
 
         int it = 0;
         bool ok = false;
+        // the packed state of check (r, t) is private to lane t: prefetch the next layer's
+        // while the current layer computes (global-memory latency off the critical path)
+        float nx1 = 0.f, nx2 = 0.f, nxk = 0.f;
+        if (act) { nx1 = C2V_LD(0, t); nx2 = C2V_LD(1, t); nxk = C2V_LD(2, t); }
         while (it < p.n_ite) {
             for (int r = 0; r < q; r++) {
-                const LdpcEntry *ent = p.entries + (size_t)r * p.ent_stride;
-                const int deg = p.layer_deg[r];
-                const int maxlvl = p.layer_lvl[r];
+                // the whole layer's table in SGPRs up front (unconditional, padded table)
+                LdpcEntry E[DEG];
+#pragma unroll
+                for (int j = 0; j < DEG; j++) E[j] = entries[r * p.ent_stride + j];
+                const int maxlvl = layer_lvl[r];
                 const int ci = r * LDPC_Z + t;
                 float v[DEG];
-                float c1o = 0.f, c2o = 0.f, cst1 = 0.f, cst2 = 0.f, mn1 = INFINITY, mn2 = INFINITY;
-                uint32_t pko = 0u, sacc = 0u;
+                float cst1 = 0.f, cst2 = 0.f, mn1 = INFINITY, mn2 = INFINITY;
+                const float c1o = nx1, c2o = nx2;
+                const uint32_t pko = __float_as_uint(nxk);
+                uint32_t sacc = 0u;
                 if (act) {
-                    c1o = C2V_LD(0, ci); c2o = C2V_LD(1, ci); pko = __float_as_uint(C2V_LD(2, ci));
-                    // ---- pass 1: v->c = posterior - old c->v ; running min1/min2/sign
+                    // ---- pass 1a: issue every posterior load of the check before using any
+#pragma unroll
+                    for (int j = 0; j < DEG; j++) v[j] = post_ld<HYBRID>(E[j], ent_off(E[j], t), lpost, gpost);
+                    {
+                        const int cn = (r + 1 < q ? ci + LDPC_Z : t);
+                        nx1 = C2V_LD(0, cn); nx2 = C2V_LD(1, cn); nxk = C2V_LD(2, cn);
+                    }
+                    // ---- pass 1b: v->c = posterior - old c->v ; running min1/min2/sign
 #pragma unroll
                     for (int j = 0; j < DEG; j++) {
-                        v[j] = INFINITY;
-                        if (j < deg) {
-                            const LdpcEntry e = ent[j];
-                            int m = t - (int)e.t0; m += (m < 0) ? LDPC_Z : 0;
-                            const float L = post_ld<HYBRID>(e, m, lpost, gpost);
-                            float x = L - c2v_unpack(c1o, c2o, pko, j);
-                            if ((e.flags & LE_MASK0) && t == 0) x = INFINITY;
-                            v[j] = x;
-                            const float a = fabsf(x);
-                            mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);
-                            mn1 = fminf(mn1, a);
-                            sacc ^= __float_as_uint(x);
-                        }
+                        float x = v[j] - c2v_unpack(c1o, c2o, pko, j);
+                        if (ent_absent(E[j], t)) x = INFINITY;
+                        v[j] = x;
+                        const float a = fabsf(x);
+                        mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);
+                        mn1 = fminf(mn1, a);
+                        sacc ^= __float_as_uint(x);
                     }
                     cst1 = mn2 * p.alpha;
                     cst2 = mn1 * p.alpha;
@@ -215,21 +302,19 @@ ldpc_layered_nms_kernel(const LdpcKParams p)
                     // ---- pass 2: new c->v ; posterior = v->c + new c->v (primary edges)
 #pragma unroll
                     for (int j = 0; j < DEG; j++) {
-                        if (j < deg) {
-                            const LdpcEntry e = ent[j];
-                            int m = t - (int)e.t0; m += (m < 0) ? LDPC_Z : 0;
-                            const float x = v[j];
-                            const bool ismin = fabsf(x) == mn1;
-                            const float mag = ismin ? cst1 : cst2;
-                            const uint32_t s = (sacc ^ __float_as_uint(x)) & 0x80000000u;
-                            const float nw = __uint_as_float(__float_as_uint(mag) | s);
-                            pkn |= s >> (31 - j);
-                            idxn = ismin ? (uint32_t)j : idxn;
-                            const bool valid = !((e.flags & LE_MASK0) && t == 0);
-                            if (valid && (e.flags >> LE_LVL_SHIFT) == 0) post_st<HYBRID>(e, m, lpost, gpost, x + nw);
-                        }
+                        const float x = v[j];
+                        const bool ismin = fabsf(x) == mn1;
+                        const float mag = ismin ? cst1 : cst2;
+                        const uint32_t s = (sacc ^ __float_as_uint(x)) & 0x80000000u;
+                        const float nw = __uint_as_float(__float_as_uint(mag) | s);
+                        pkn |= s >> (31 - j);
+                        idxn = ismin ? (uint32_t)j : idxn;
+                        if (!ent_absent(E[j], t) && ent_lvl(E[j]) == 0)
+                            post_st<HYBRID>(E[j], ent_off(E[j], t), lpost, gpost, x + nw);
                     }
                     pkn |= idxn << 27;
+                    C2V_ST(0, ci, cst1); C2V_ST(1, ci, cst2); C2V_ST(2, ci, __uint_as_float(pkn));
+                    if (q == 1) { nx1 = cst1; nx2 = cst2; nxk = __uint_as_float(pkn); }
                 }
                 // ---- duplicate edges of a bit-group inside this layer: ordered delta updates
                 for (int lvl = 1; lvl <= maxlvl; lvl++) {
@@ -237,20 +322,16 @@ ldpc_layered_nms_kernel(const LdpcKParams p)
                     if (act) {
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
-                            if (j < deg) {
-                                const LdpcEntry e = ent[j];
-                                if ((int)(e.flags >> LE_LVL_SHIFT) == lvl) {
-                                    int m = t - (int)e.t0; m += (m < 0) ? LDPC_Z : 0;
-                                    const float nw = c2v_unpack(cst1, cst2, pkn, j);
-                                    const float od = c2v_unpack(c1o, c2o, pko, j);
-                                    const float L = post_ld<HYBRID>(e, m, lpost, gpost);
-                                    post_st<HYBRID>(e, m, lpost, gpost, L + (nw - od));
-                                }
+                            if (ent_lvl(E[j]) == lvl && !(E[j] & LE_NULL)) {
+                                const int off = ent_off(E[j], t);
+                                const float nw = c2v_unpack(cst1, cst2, pkn, j);
+                                const float od = c2v_unpack(c1o, c2o, pko, j);
+                                const float L = post_ld<HYBRID>(E[j], off, lpost, gpost);
+                                post_st<HYBRID>(E[j], off, lpost, gpost, L + (nw - od));
                             }
                         }
                     }
                 }
-                if (act) { C2V_ST(0, ci, cst1); C2V_ST(1, ci, cst2); C2V_ST(2, ci, __uint_as_float(pkn)); }
                 __syncthreads();
             }
             it++;
@@ -259,18 +340,13 @@ ldpc_layered_nms_kernel(const LdpcKParams p)
                 int bad = 0;
                 if (act)
                     for (int r = 0; r < q; r++) {
-                        const LdpcEntry *ent = p.entries + (size_t)r * p.ent_stride;
-                        const int deg = p.layer_deg[r];
                         uint32_t x = 0u;
 #pragma unroll
-                        for (int j = 0; j < DEG; j++)
-                            if (j < deg) {
-                                const LdpcEntry e = ent[j];
-                                int m = t - (int)e.t0; m += (m < 0) ? LDPC_Z : 0;
-                                const float L = post_ld<HYBRID>(e, m, lpost, gpost);
-                                const bool valid = !((e.flags & LE_MASK0) && t == 0);
-                                x ^= (valid && L < 0.f) ? 1u : 0u;
-                            }
+                        for (int j = 0; j < DEG; j++) {
+                            const LdpcEntry e = entries[r * p.ent_stride + j];
+                            const float L = post_ld<HYBRID>(e, ent_off(e, t), lpost, gpost);
+                            x ^= (!ent_absent(e, t) && L < 0.f) ? 1u : 0u;
+                        }
                         bad |= (int)x;
                     }
                 ok = !__syncthreads_or(bad);
@@ -285,14 +361,14 @@ ldpc_layered_nms_kernel(const LdpcKParams p)
         }
         if (act) {
             for (int g = 0; g < p.n_info; g++) {
-                const LdpcGroup gl = p.groups[g];
+                const LdpcGroup gl = group_ld(groups, g);
                 const float L = (HYBRID && !gl.lds) ? gpost[gl.base + t] : lpost[gl.base + t];
                 if (p.bits) p.bits[(size_t)f * p.K + g * LDPC_Z + t] = L < 0.f ? 1 : 0;
                 if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + t] = L;
             }
             if (p.post)
                 for (int g = p.n_info; g < p.n_groups; g++) {
-                    const LdpcGroup gl = p.groups[g];
+                    const LdpcGroup gl = group_ld(groups, g);
                     const float L = (HYBRID && !gl.lds) ? gpost[gl.base + t] : lpost[gl.base + t];
                     p.post[(size_t)f * p.N + p.K + q * t + (g - p.n_info)] = L;
                 }
@@ -306,7 +382,7 @@ ldpc_layered_nms_kernel(const LdpcKParams p)
                     const int k = 32 * w + b;
                     if (k >= p.K) break;
                     const int g = k / LDPC_Z, m = k - g * LDPC_Z;
-                    const LdpcGroup gl = p.groups[g];
+                    const LdpcGroup gl = group_ld(groups, g);
                     const float L = (HYBRID && !gl.lds) ? gpost[gl.base + m] : lpost[gl.base + m];
                     word |= (L < 0.f ? 1u : 0u) << b;
                 }
@@ -347,6 +423,7 @@ static int occ_inst(const LdpcPlan &pl)
 }
 int ldpc_blocks_per_cu(const LdpcPlan &pl)
 {
+    if (pl.fast) return ldpc_fast_blocks_per_cu(pl);
     const bool small = pl.ent_stride == 13;
 #define OCC(H, C) (small ? occ_inst<13, H, C>(pl) : occ_inst<LDPC_MAX_SLOTS, H, C>(pl))
     if (pl.hybrid) return pl.c2v_lds ? OCC(true, true) : OCC(true, false);
@@ -356,6 +433,7 @@ int ldpc_blocks_per_cu(const LdpcPlan &pl)
 
 hipError_t ldpc_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
+    if (pl.fast) return ldpc_fast_launch(pl, p, s);
     p.entries = pl.d_entries; p.layer_deg = pl.d_layer_deg; p.layer_lvl = pl.d_layer_lvl; p.groups = pl.d_groups;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.ent_stride = pl.ent_stride; p.lds_post_words = pl.lds_post_words; p.glb_post_words = pl.glb_post_words;
