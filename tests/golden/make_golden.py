@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/.  Run in the BUILD container (it reads
+/root/reference, which does not exist on the GPU box; the fixtures travel instead).
+
+  pl_rand_seq_2bit.npy   PL scrambling sequence = the 66420 values of PL_RAND_SEQ in the reference
+                         header src/common/Module/Scrambler/Scrambler_PL/Scrambler_PL.hpp:54-4207,
+                         packed 4 values per byte (DATA: expected output of the Gold generator)
+  refs_tx_rx_bb.json     the result rows + size headers of refs/TX_RX_BB/*.txt (the reference's
+                         only regression oracle: BER/FER traces, SPA 50 ite)
+  src_K_14232.npy        conf/src/K_14232.src fixed payload (data file), packed bits
+  kat_*.npz              known-answer vectors produced by the CPU oracle (seeded), small frames
+"""
+import json, os, re, sys
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = "/root/reference"
+
+def pl_seq():
+    txt = open(os.path.join(REF, "src/common/Module/Scrambler/Scrambler_PL/Scrambler_PL.hpp")).read()
+    i0 = txt.index("PL_RAND_SEQ")
+    body = txt[txt.index("{", i0) + 1: txt.index("}", i0)]
+    v = np.array([int(x) for x in re.findall(r"\d+", body)], dtype=np.uint8)
+    assert v.size == 66420 and v.max() == 3
+    packed = (v[0::4] | (v[1::4] << 2) | (v[2::4] << 4) | (v[3::4] << 6)).astype(np.uint8)
+    np.save(os.path.join(HERE, "pl_rand_seq_2bit.npy"), packed)
+
+def refs():
+    out = {}
+    for name in sorted(os.listdir(os.path.join(REF, "refs/TX_RX_BB"))):
+        txt = open(os.path.join(REF, "refs/TX_RX_BB", name)).read()
+        cmd = re.search(r"command=(.*)", txt).group(1).strip()
+        rows = []
+        for line in txt.splitlines():
+            if line.startswith("#") or "|" not in line:
+                continue
+            f = [x.strip() for x in line.replace("||", "|").split("|")]
+            rows.append(dict(esn0=float(f[0]), ebn0=float(f[1]), fra=int(f[2]), be=int(f[3]), fe=int(f[4]),
+                             ber=float(f[5]), fer=float(f[6]), thr_mbps=float(f[7])))
+        hdr = {}
+        for key, pat in (("modcod", r"Modulation and coding = (\S+)"), ("n_cw", r"N\. cw\s+\(N\)\s+= (\d+)"),
+                         ("implem", r"LDPC implem\s+= (\S+)"), ("n_ite", r"LDPC n iterations\s+= (\d+)")):
+            m = re.search(pat, txt)
+            hdr[key] = m.group(1) if m else None
+        out[name] = dict(command=cmd, header=hdr, rows=rows)
+    json.dump(out, open(os.path.join(HERE, "refs_tx_rx_bb.json"), "w"), indent=1)
+
+def src():
+    t = open(os.path.join(REF, "conf/src/K_14232.src")).read().split()
+    assert t[0] == "1" and t[1] == "14232"
+    bits = np.array([int(x) for x in t[2:2 + 14232]], dtype=np.uint8)
+    np.save(os.path.join(HERE, "src_K_14232.npy"), np.packbits(bits))
+
+def kats():
+    from oracle import oracle as O
+    from helpers import chain, make_llrs, make_pl_frames
+    # LDPC, short 8/9: both schedules
+    ch = chain(O, "QPSK-S_8/9")
+    _, llr, cw = make_llrs(O, "QPSK-S_8/9", 2, 3.9, seed=101)
+    bq, pq, cq, iq = ch.ldpc.decode(llr, 10, 0.875, sched=O.QC, early_stop=False)
+    bn, pn, cn, i_n = ch.ldpc.decode(llr, 10, 0.875, sched=O.NATURAL, early_stop=False)
+    np.savez_compressed(os.path.join(HERE, "kat_ldpc_short_8_9.npz"), llr=llr, cw=np.packbits(cw.astype(np.uint8), axis=1),
+                        bits_qc=np.packbits(bq.astype(np.uint8), axis=1), post_qc=pq, cwd_qc=cq,
+                        bits_nat=np.packbits(bn.astype(np.uint8), axis=1), post_nat=pn, cwd_nat=cn,
+                        n_ite=10, alpha=0.875)
+    # BCH short: codeword + error patterns + expected
+    rng = np.random.default_rng(102)
+    mc = ch.mc
+    info = rng.integers(0, 2, (6, mc.K_bch)).astype(np.int32)
+    cwb = ch.bch.encode(info)
+    rxb = cwb.copy()
+    for f, ne in enumerate([0, 1, 5, 12, 13, 30]):
+        rxb[f, rng.choice(mc.N_bch, ne, replace=False)] ^= 1
+    out, cwd = ch.bch.decode(rxb)
+    np.savez_compressed(os.path.join(HERE, "kat_bch_short.npz"), rx=np.packbits(rxb.astype(np.uint8), axis=1),
+                        out=np.packbits(out.astype(np.uint8), axis=1), cwd=cwd, info=np.packbits(info.astype(np.uint8), axis=1),
+                        gen=ch.bch.gen().astype(np.uint8))
+    # full chain, 16APSK short: PL frame in, info out, intermediate LLRs
+    ch2 = chain(O, "16APSK-S_8/9")
+    info2, pl, cw2, sigma = make_pl_frames(O, "16APSK-S_8/9", 1, 8.4, seed=103)
+    r = ch2.rx(pl[0], sigma=np.float32(sigma), n_ite=10, alpha=0.875, sched=O.QC, early_stop=True)
+    np.savez_compressed(os.path.join(HERE, "kat_chain_16apsk_short.npz"), pl=pl[0], sigma=np.float32(sigma),
+                        info=np.packbits(info2[0].astype(np.uint8)), llr=r["llr"], out=np.packbits(r["info"].astype(np.uint8)),
+                        n_ite=10, alpha=0.875)
+    # FIR: taps + input + output (state across two calls)
+    taps = O.rrc_taps(0.2, 2, 20)
+    x1 = rng.standard_normal(2 * 500).astype(np.float32); x2 = rng.standard_normal(2 * 300).astype(np.float32)
+    hist = np.zeros(160, np.float32)
+    y1 = O.fir(taps, hist, x1); y2 = O.fir(taps, hist, x2)
+    np.savez_compressed(os.path.join(HERE, "kat_fir_rrc81.npz"), taps=taps, x1=x1, x2=x2, y1=y1, y2=y2)
+
+if __name__ == "__main__":
+    pl_seq(); refs(); src(); kats()
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,67 @@
+"""GPU vs the COMMITTED golden fixtures (tests/golden, made by make_golden.py): the parity
+claim does not depend on rebuilding the oracle on the GPU box."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def Rx():
+    from dvbs2_amd.receiver import Dvbs2Hip
+    return Dvbs2Hip
+
+
+def test_ldpc_golden(Rx):
+    k = np.load(os.path.join(GOLD, "kat_ldpc_short_8_9.npz"))
+    rx = Rx("QPSK-S_8/9", max_frames=2, n_ite=int(k["n_ite"]), alpha=float(k["alpha"]), early_stop=False)
+    V, CWD, post, _ = rx.decode_siho(k["llr"], with_post=True)
+    assert np.array_equal(np.packbits(V.astype(np.uint8), axis=1), k["bits_qc"])
+    assert np.array_equal(CWD, k["cwd_qc"])
+    assert np.max(np.abs(post - k["post_qc"])) <= 1e-4 and np.array_equal(post, k["post_qc"])
+    rx.close()
+
+
+def test_bch_golden(Rx):
+    k = np.load(os.path.join(GOLD, "kat_bch_short.npz"))
+    rx = Rx("QPSK-S_8/9", max_frames=6)
+    x = np.unpackbits(k["rx"], axis=1)[:, :rx.K_ldpc].astype(np.int32)
+    V, CWD = rx.decode_hiho(x)
+    assert np.array_equal(np.packbits(V.astype(np.uint8), axis=1), k["out"]) and np.array_equal(CWD, k["cwd"])
+    rx.close()
+
+
+def test_chain_golden(Rx):
+    k = np.load(os.path.join(GOLD, "kat_chain_16apsk_short.npz"))
+    rx = Rx("16APSK-S_8/9", max_frames=1, n_ite=int(k["n_ite"]), alpha=float(k["alpha"]), early_stop=True)
+    out, c0, c1 = rx.rx_bb(k["pl"], sigma=k["sigma"])
+    assert np.array_equal(np.packbits(out[0].astype(np.uint8)), k["out"]) and c0[0] == 1 and c1[0] == 1
+    x = rx.remove_plh(rx.pl_descramble(k["pl"]))
+    llr = rx.demodulate(k["sigma"], x, deinterleave=True)
+    assert np.all(np.abs(llr[0] - k["llr"]) <= 1e-4 * np.maximum(1.0, np.abs(k["llr"])))
+    rx.close()
+
+
+def test_fir_golden(Rx):
+    k = np.load(os.path.join(GOLD, "kat_fir_rrc81.npz"))
+    rx = Rx("QPSK-S_8/9", max_frames=1, fir_taps=k["taps"])
+    assert np.max(np.abs(rx.filter(k["x1"], 1) - k["y1"])) <= 1e-4
+    assert np.max(np.abs(rx.filter(k["x2"], 1) - k["y2"])) <= 1e-4
+    rx.close()
+
+
+def test_reference_fixed_payload_roundtrip(Rx, O):
+    """conf/src/K_14232.src (the reference's Source_user pattern) through oracle TX -> GPU RX."""
+    from helpers import chain, sigma_for
+    info = np.unpackbits(np.load(os.path.join(GOLD, "src_K_14232.npy")))[:14232].astype(np.int32)
+    ch = chain(O, "QPSK-S_8/9")
+    plf, _ = ch.tx(info)
+    sigma = sigma_for(ch.mc, 4.5)
+    noisy = plf + (sigma * np.random.default_rng(9).standard_normal(plf.size)).astype(np.float32)
+    rx = Rx("QPSK-S_8/9", max_frames=1, n_ite=10, alpha=1.0, early_stop=True)
+    out, c0, c1 = rx.rx_bb(noisy)
+    assert np.array_equal(out[0], info) and c0[0] == 1 and c1[0] == 1
+    rx.close()

