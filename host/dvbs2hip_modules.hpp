@@ -1,0 +1,298 @@
+// dvbs2hip_modules.hpp -- StreamPU-style modules whose codelets call libdvbs2hip.so (the C ABI
+// of include/dvbs2hip.h).  Task and socket names are the reference's, so the socket graph of
+// /root/reference src/mains/TX_RX_BB/main.cpp:83-94 and src/mains/RX/main_sched.cpp:197-241 binds
+// unchanged; each module replaces the aff3ct / dvbs2 module named in its comment.
+//
+// One GPU = one Context (dvbs2hip handle) shared by the modules of a chain; -F (n_frames) is the
+// grid width on the device, so ONE module instance per GPU replaces the 28-40 thread clones of
+// the reference's decoder stage (main_bench.cpp:156-168).  Decoder success is data (CWD socket),
+// errors are spu::tools exceptions.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+#include "../include/dvbs2hip.h"
+#include "spu_compat.hpp"
+
+namespace aff3ct {
+namespace module {
+
+class Context {     // RAII owner of the dvbs2hip handle
+public:
+    Context(const std::string &modcod, int n_frames, int ldpc_n_ite = 50, float ldpc_alpha = 1.0f, bool early_stop = true,
+            int device = 0)
+    {
+        dvbs2hip_cfg cfg;
+        if (dvbs2hip_cfg_from_modcod(modcod.c_str(), &cfg) != DVBS2HIP_OK)
+            throw spu::tools::invalid_argument(__FILE__, __LINE__, __func__, dvbs2hip_last_error(nullptr));   // DVBS2.cpp:319
+        cfg.max_frames = n_frames; cfg.ldpc_n_ite = ldpc_n_ite; cfg.ldpc_alpha = ldpc_alpha;
+        cfg.ldpc_early_stop = early_stop ? 1 : 0; cfg.device = device;
+        const int rc = dvbs2hip_create(&cfg, &h);
+        if (rc != DVBS2HIP_OK) raise(rc, dvbs2hip_last_error(nullptr), __LINE__, __func__);
+        dvbs2hip_get_sizes(h, &sz);
+        n_frames_ = n_frames;
+    }
+    ~Context() { dvbs2hip_destroy(h); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    void check(int rc, int line, const char *func) const { if (rc != DVBS2HIP_OK) raise(rc, dvbs2hip_last_error(h), line, func); }
+    dvbs2hip_t *h = nullptr;
+    dvbs2hip_sizes sz{};
+    int n_frames() const { return n_frames_; }
+
+private:
+    int n_frames_ = 1;
+    [[noreturn]] static void raise(int rc, const char *msg, int line, const char *func)
+    {
+        switch (rc) {
+            case DVBS2HIP_EINVAL: throw spu::tools::invalid_argument(__FILE__, line, func, msg);
+            case DVBS2HIP_ENOMEM: throw spu::tools::cannot_allocate(__FILE__, line, func, msg);
+            case DVBS2HIP_EUNSUPPORTED: throw spu::tools::unimplemented_error(__FILE__, line, func, msg);
+            default: throw spu::tools::runtime_error(__FILE__, line, func, msg);
+        }
+    }
+};
+#define DVBS2HIP_CHK(ctx, call) (ctx)->check((call), __LINE__, __func__)
+
+namespace dec { enum class tsk : size_t { decode_siho = 0, decode_hiho = 0 };
+                namespace sck { enum class decode_siho : size_t { Y_N, CWD, V_K, status }; enum class decode_hiho : size_t { Y_N, CWD, V_K, status }; } }
+namespace mdm { namespace sck { enum class demodulate : size_t { CP, Y_N1, Y_N2, status }; } }
+namespace itl { namespace sck { enum class deinterleave : size_t { itl, nat, status }; } }
+namespace flt { namespace sck { enum class filter : size_t { X_N1, Y_N2, status }; } }
+namespace est { namespace sck { enum class estimate : size_t { X_N, SIG, Eb_N0, Es_N0, status }; } }
+namespace scr { namespace sck { enum class descramble : size_t { Y_N1, Y_N2, status }; } }
+namespace frm { namespace sck { enum class remove_plh : size_t { Y_N1, Y_N2, status }; } }
+namespace mnt { namespace sck { enum class check_errors : size_t { U, V, status }; } }
+namespace rcv { namespace sck { enum class receive : size_t { Y_N1, V_K, CWD_LDPC, CWD_BCH, status }; } }
+
+// common shape: one task, sockets created in enum order, codelet forwards raw pointers
+class Module_hip : public spu::module::Stateful {
+public:
+    template <typename E> spu::runtime::Socket &operator[](E s) { return (*tasks[0])[(size_t)s]; }
+    spu::runtime::Task &operator()(const std::string & = "") { return *tasks[0]; }
+    void set_n_frames(size_t n) override
+    {
+        if ((int)n != ctx->n_frames())
+            throw spu::tools::invalid_argument(__FILE__, __LINE__, __func__, "'n_frames' is fixed by the device context (the -F of the socket is the grid width)");
+    }
+protected:
+    explicit Module_hip(std::shared_ptr<Context> c, const std::string &n) : ctx(std::move(c))
+    {
+        n_frames = (size_t)ctx->n_frames();
+        set_name(n); set_short_name(n);
+    }
+    std::shared_ptr<Context> ctx;
+    int F() const { return ctx->n_frames(); }
+};
+
+// replaces tools::Codec_LDPC<B,Q>::get_decoder_siho() (DVBS2.cpp:418-449; bound main.cpp:65,90-91)
+template <typename B = int, typename Q = float>
+class Decoder_LDPC_hip : public Module_hip {
+public:
+    explicit Decoder_LDPC_hip(std::shared_ptr<Context> c) : Module_hip(std::move(c), "Decoder_LDPC_hip")
+    {
+        static_assert(sizeof(B) == 4 && sizeof(Q) == 4, "B = int32, Q = float (SURVEY.md H6)");
+        auto &t = create_task("decode_siho");
+        auto sY = create_socket_in<Q>(t, "Y_N", ctx->sz.N_ldpc);
+        auto sC = create_socket_out<int8_t>(t, "CWD", 1);
+        auto sV = create_socket_out<B>(t, "V_K", ctx->sz.K_ldpc);
+        create_codelet(t, [sY, sC, sV](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            auto &d = static_cast<Decoder_LDPC_hip &>(m);
+            d.decode_siho(tk[sY].template get_dataptr<const Q>(), tk[sC].template get_dataptr<int8_t>(), tk[sV].template get_dataptr<B>());
+            return 0;
+        });
+    }
+    void decode_siho(const Q *Y_N, int8_t *CWD, B *V_K)
+    { DVBS2HIP_CHK(ctx, dvbs2hip_ldpc_decode_siho(ctx->h, (const float *)Y_N, CWD, (int32_t *)V_K, F())); }
+};
+
+// replaces Decoder_BCH_DVBS2<B,R> (Decoder_BCH_DVBS2.cpp:28-40; built DVBS2.cpp:406-416)
+template <typename B = int, typename R = float>
+class Decoder_BCH_hip : public Module_hip {
+public:
+    explicit Decoder_BCH_hip(std::shared_ptr<Context> c) : Module_hip(std::move(c), "Decoder_BCH_hip")
+    {
+        auto &t = create_task("decode_hiho");
+        auto sY = create_socket_in<B>(t, "Y_N", ctx->sz.K_ldpc);
+        auto sC = create_socket_out<int8_t>(t, "CWD", 1);
+        auto sV = create_socket_out<B>(t, "V_K", ctx->sz.K_bch);
+        create_codelet(t, [sY, sC, sV](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Decoder_BCH_hip &>(m).decode_hiho(tk[sY].template get_dataptr<const B>(), tk[sC].template get_dataptr<int8_t>(), tk[sV].template get_dataptr<B>());
+            return 0;
+        });
+    }
+    void decode_hiho(const B *Y_N, int8_t *CWD, B *V_K)
+    { DVBS2HIP_CHK(ctx, dvbs2hip_bch_decode_hiho(ctx->h, (const int32_t *)Y_N, CWD, (int32_t *)V_K, F())); }
+    // the reference throws unimplemented_error for the soft / codeword variants (Decoder_BCH_DVBS2.cpp:42-61)
+    void decode_siho(const R *, int8_t *, B *) { throw spu::tools::unimplemented_error(__FILE__, __LINE__, __func__); }
+    void decode_hiho_cw(const B *, int8_t *, B *) { throw spu::tools::unimplemented_error(__FILE__, __LINE__, __func__); }
+};
+
+// replaces Modem_generic_fast<B,R,Q,max_star> demodulate (DVBS2.cpp:478-488; bound main.cpp:87-88)
+template <typename Q = float>
+class Modem_hip : public Module_hip {
+public:
+    explicit Modem_hip(std::shared_ptr<Context> c) : Module_hip(std::move(c), "Modem_hip")
+    {
+        auto &t = create_task("demodulate");
+        auto sC = create_socket_in<float>(t, "CP", 1);
+        auto s1 = create_socket_in<Q>(t, "Y_N1", 2 * ctx->sz.N_xfec_sym);
+        auto s2 = create_socket_out<Q>(t, "Y_N2", ctx->sz.N_ldpc);
+        create_codelet(t, [sC, s1, s2](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Modem_hip &>(m).demodulate(tk[sC].template get_dataptr<const float>(), tk[s1].template get_dataptr<const Q>(), tk[s2].template get_dataptr<Q>());
+            return 0;
+        });
+    }
+    void demodulate(const float *CP, const Q *Y_N1, Q *Y_N2) { DVBS2HIP_CHK(ctx, dvbs2hip_demodulate(ctx->h, CP, Y_N1, Y_N2, F())); }
+};
+
+// replaces Interleaver<float,uint32_t>::deinterleave (DVBS2.cpp:451-476; bound main.cpp:56,89)
+class Interleaver_hip : public Module_hip {
+public:
+    explicit Interleaver_hip(std::shared_ptr<Context> c) : Module_hip(std::move(c), "Interleaver_hip")
+    {
+        auto &t = create_task("deinterleave");
+        auto s1 = create_socket_in<float>(t, "itl", ctx->sz.N_ldpc);
+        auto s2 = create_socket_out<float>(t, "nat", ctx->sz.N_ldpc);
+        create_codelet(t, [s1, s2](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Interleaver_hip &>(m).deinterleave(tk[s1].template get_dataptr<const float>(), tk[s2].template get_dataptr<float>());
+            return 0;
+        });
+    }
+    void deinterleave(const float *itl, float *nat) { DVBS2HIP_CHK(ctx, dvbs2hip_deinterleave(ctx->h, itl, nat, F())); }
+};
+
+// replaces Filter_RRC_ccr_naive / Filter_FIR_ccr::filter (Filter_FIR_ccr.cpp:68-142; bound main_sched.cpp:199-201)
+class Filter_FIR_hip : public Module_hip {
+public:
+    Filter_FIR_hip(std::shared_ptr<Context> c, int N) : Module_hip(std::move(c), "Filter_FIR_hip"), N(N)
+    {
+        if (N <= 0 || N % 2) throw spu::tools::invalid_argument(__FILE__, __LINE__, __func__, "'N' has to be a positive even number of floats");
+        auto &t = create_task("filter");
+        auto s1 = create_socket_in<float>(t, "X_N1", N);
+        auto s2 = create_socket_out<float>(t, "Y_N2", N);
+        create_codelet(t, [s1, s2](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Filter_FIR_hip &>(m).filter(tk[s1].template get_dataptr<const float>(), tk[s2].template get_dataptr<float>());
+            return 0;
+        });
+    }
+    void filter(const float *X_N1, float *Y_N2) { DVBS2HIP_CHK(ctx, dvbs2hip_filter(ctx->h, X_N1, Y_N2, N / 2, F())); }
+    void reset() { DVBS2HIP_CHK(ctx, dvbs2hip_filter_reset(ctx->h)); }
+private:
+    int N;
+};
+
+// replaces Estimator_DVBS2<R>::estimate (Estimator_DVBS2.hxx:31-58, Estimator.hxx:103-118)
+class Estimator_hip : public Module_hip {
+public:
+    explicit Estimator_hip(std::shared_ptr<Context> c) : Module_hip(std::move(c), "Estimator_hip")
+    {
+        auto &t = create_task("estimate");
+        auto sX = create_socket_in<float>(t, "X_N", 2 * ctx->sz.N_xfec_sym);
+        auto sS = create_socket_out<float>(t, "SIG", 1);
+        auto sB = create_socket_out<float>(t, "Eb_N0", 1);
+        auto sE = create_socket_out<float>(t, "Es_N0", 1);
+        create_codelet(t, [sX, sS, sB, sE](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Estimator_hip &>(m).estimate(tk[sX].template get_dataptr<const float>(), tk[sS].template get_dataptr<float>(),
+                                                     tk[sB].template get_dataptr<float>(), tk[sE].template get_dataptr<float>());
+            return 0;
+        });
+    }
+    void estimate(const float *X_N, float *SIG, float *Eb_N0, float *Es_N0)
+    { DVBS2HIP_CHK(ctx, dvbs2hip_estimate(ctx->h, X_N, SIG, Eb_N0, Es_N0, F())); }
+};
+
+// replaces Scrambler_PL<D>::descramble (Scrambler_PL.hxx:61-78)
+class Scrambler_PL_hip : public Module_hip {
+public:
+    explicit Scrambler_PL_hip(std::shared_ptr<Context> c) : Module_hip(std::move(c), "Scrambler_PL_hip")
+    {
+        auto &t = create_task("descramble");
+        auto s1 = create_socket_in<float>(t, "Y_N1", 2 * ctx->sz.pl_frame_sym);
+        auto s2 = create_socket_out<float>(t, "Y_N2", 2 * ctx->sz.pl_frame_sym);
+        create_codelet(t, [s1, s2](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Scrambler_PL_hip &>(m).descramble(tk[s1].template get_dataptr<const float>(), tk[s2].template get_dataptr<float>());
+            return 0;
+        });
+    }
+    void descramble(const float *Y_N1, float *Y_N2) { DVBS2HIP_CHK(ctx, dvbs2hip_pl_descramble(ctx->h, Y_N1, Y_N2, F())); }
+};
+
+// replaces Framer<B>::remove_plh (Framer.hxx:330-343)
+class Framer_hip : public Module_hip {
+public:
+    explicit Framer_hip(std::shared_ptr<Context> c) : Module_hip(std::move(c), "Framer_hip")
+    {
+        auto &t = create_task("remove_plh");
+        auto s1 = create_socket_in<float>(t, "Y_N1", 2 * ctx->sz.pl_frame_sym);
+        auto s2 = create_socket_out<float>(t, "Y_N2", 2 * ctx->sz.N_xfec_sym);
+        create_codelet(t, [s1, s2](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Framer_hip &>(m).remove_plh(tk[s1].template get_dataptr<const float>(), tk[s2].template get_dataptr<float>());
+            return 0;
+        });
+    }
+    void remove_plh(const float *Y_N1, float *Y_N2) { DVBS2HIP_CHK(ctx, dvbs2hip_remove_plh(ctx->h, Y_N1, Y_N2, F())); }
+};
+
+// replaces Scrambler_BB<D>::descramble (Scrambler_BB.hxx:51-72)
+template <typename B = int>
+class Scrambler_BB_hip : public Module_hip {
+public:
+    explicit Scrambler_BB_hip(std::shared_ptr<Context> c) : Module_hip(std::move(c), "Scrambler_BB_hip")
+    {
+        auto &t = create_task("descramble");
+        auto s1 = create_socket_in<B>(t, "Y_N1", ctx->sz.K_bch);
+        auto s2 = create_socket_out<B>(t, "Y_N2", ctx->sz.K_bch);
+        create_codelet(t, [s1, s2](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Scrambler_BB_hip &>(m).descramble(tk[s1].template get_dataptr<const B>(), tk[s2].template get_dataptr<B>());
+            return 0;
+        });
+    }
+    void descramble(const B *Y_N1, B *Y_N2) { DVBS2HIP_CHK(ctx, dvbs2hip_bb_descramble(ctx->h, (const int32_t *)Y_N1, (int32_t *)Y_N2, F())); }
+};
+
+// replaces Monitor_BFER<B>::check_errors (DVBS2.cpp:575-591; bound main.cpp:93-94)
+template <typename B = int>
+class Monitor_BFER_hip : public Module_hip {
+public:
+    Monitor_BFER_hip(std::shared_ptr<Context> c, unsigned max_fe = 100) : Module_hip(std::move(c), "Monitor_BFER_hip"), max_fe(max_fe)
+    {
+        auto &t = create_task("check_errors");
+        auto sU = create_socket_in<B>(t, "U", ctx->sz.K_bch);
+        auto sV = create_socket_in<B>(t, "V", ctx->sz.K_bch);
+        create_codelet(t, [sU, sV](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Monitor_BFER_hip &>(m).check_errors(tk[sU].template get_dataptr<const B>(), tk[sV].template get_dataptr<const B>());
+            return 0;
+        });
+    }
+    void check_errors(const B *U, const B *V) { DVBS2HIP_CHK(ctx, dvbs2hip_monitor_check_errors(ctx->h, (const int32_t *)U, (const int32_t *)V, F())); }
+    void get(uint64_t &fra, uint64_t &be, uint64_t &fe) { uint64_t c[3]; DVBS2HIP_CHK(ctx, dvbs2hip_monitor_get(ctx->h, c)); fra = c[0]; be = c[1]; fe = c[2]; }
+    bool is_done() { uint64_t a, b, c; get(a, b, c); return c >= max_fe; }      // stop at max_fe (DVBS2.cpp:136)
+    void reset() { DVBS2HIP_CHK(ctx, dvbs2hip_monitor_reset(ctx->h)); }
+private:
+    unsigned max_fe;
+};
+
+// the fused RX chain (PL descramble ... BB descramble) as ONE task: intermediates stay on the GPU
+template <typename B = int>
+class Receiver_BB_hip : public Module_hip {
+public:
+    explicit Receiver_BB_hip(std::shared_ptr<Context> c) : Module_hip(std::move(c), "Receiver_BB_hip")
+    {
+        auto &t = create_task("receive");
+        auto s1 = create_socket_in<float>(t, "Y_N1", 2 * ctx->sz.pl_frame_sym);
+        auto sV = create_socket_out<B>(t, "V_K", ctx->sz.K_bch);
+        auto sL = create_socket_out<int8_t>(t, "CWD_LDPC", 1);
+        auto sB = create_socket_out<int8_t>(t, "CWD_BCH", 1);
+        create_codelet(t, [s1, sV, sL, sB](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Receiver_BB_hip &>(m).receive(tk[s1].template get_dataptr<const float>(), tk[sV].template get_dataptr<B>(),
+                                                      tk[sL].template get_dataptr<int8_t>(), tk[sB].template get_dataptr<int8_t>());
+            return 0;
+        });
+    }
+    void receive(const float *pl, B *V_K, int8_t *cwd_ldpc, int8_t *cwd_bch)
+    { DVBS2HIP_CHK(ctx, dvbs2hip_rx_bb(ctx->h, pl, nullptr, (int32_t *)V_K, cwd_ldpc, cwd_bch, F())); }
+};
+
+}  // namespace module
+}  // namespace aff3ct
