@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <new>
@@ -43,6 +44,12 @@ struct dvbs2hip_handle {
     int hist_cur = 0;
     unsigned long long *d_ctr = nullptr;
     float *d_gwork = nullptr;
+    // TX mirror (N1)
+    uint32_t *d_enc_tab = nullptr;
+    int32_t *d_enc_deg = nullptr;
+    float *d_plh = nullptr;
+    int enc_stride = 0;
+    unsigned long long bch_g[3] = {0, 0, 0};
     std::map<int, DevBuf> bufs;        // lazily grown staging / intermediate buffers
     // timing
     bool timing = false;
@@ -65,7 +72,7 @@ int fail(dvbs2hip_t *h, int code, const std::string &msg)
             return fail(h, DVBS2HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
-enum BufId { B_IN = 0, B_OUT, B_AUX0, B_AUX1, B_AUX2, B_AUX3, B_LLR, B_PACKED, B_EST, B_CWD0, B_CWD1, B_INFO, B_SIG };
+enum BufId { B_IN = 0, B_OUT, B_AUX0, B_AUX1, B_AUX2, B_AUX3, B_LLR, B_PACKED, B_EST, B_CWD0, B_CWD1, B_INFO, B_SIG, B_TXBCH, B_TXLDPC };
 
 int ensure(dvbs2hip_t *h, int id, size_t bytes, void **out)
 {
@@ -162,6 +169,7 @@ int dvbs2hip_cfg_from_modcod(const char *modcod, dvbs2hip_cfg *cfg)
         cfg->itl_cols = r.itl_cols; cfg->itl_order = r.itl_order;
         cfg->fir_n_taps = 81; cfg->fir_taps = rrc_taps_81; cfg->fir_osf = 2;
         cfg->max_frames = 1; cfg->device = 0; cfg->stream = nullptr; cfg->ldpc_lds_groups = -1;
+        for (int k = 0; k < 7; k++) cfg->pls[k] = r.pls[k];
         return DVBS2HIP_OK;
     }
     g_create_error = name + " mod-cod scheme not supported.";
@@ -238,6 +246,48 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
     bb_prbs(cfg->K_bch, prbs);
     if (upload(h, &h->bch.d_prbs, prbs.data(), prbs.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
 
+    // ---- TX mirror tables: encoder layer table, BCH generator, PLHEADER
+    {
+        const int M = cfg->N_ldpc - cfg->K_ldpc, q = M / 360;
+        std::vector<std::vector<uint32_t>> lay(q);
+        for (int g = 0; g < cfg->ldpc_n_rows; g++)
+            for (int p = cfg->ldpc_row_ptr[g]; p < cfg->ldpc_row_ptr[g + 1]; p++)
+                lay[cfg->ldpc_addr[p] % q].push_back((uint32_t)(cfg->ldpc_addr[p] / q) | ((uint32_t)g << 9));
+        size_t stride = 1;
+        for (auto &l : lay) stride = std::max(stride, l.size());
+        std::vector<uint32_t> tab((size_t)q * stride, 0u);
+        std::vector<int32_t> deg(q);
+        for (int r = 0; r < q; r++) { deg[r] = (int32_t)lay[r].size(); std::copy(lay[r].begin(), lay[r].end(), tab.begin() + (size_t)r * stride); }
+        h->enc_stride = (int)stride;
+        if (upload(h, &h->d_enc_tab, tab.data(), tab.size()) || upload(h, &h->d_enc_deg, deg.data(), deg.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+        const std::vector<uint8_t> g = bch_generator(h->bch);
+        if ((int)g.size() - 1 != cfg->K_ldpc - cfg->K_bch || g.size() > 193) CREATE_FAIL(DVBS2HIP_EINVAL, "BCH generator degree does not match N_bch - K_bch");
+        for (size_t i = 0; i + 1 < g.size(); i++) if (g[i]) h->bch_g[i / 64] |= 1ull << (i % 64);
+        // PLHEADER = 26 SOF + 64 PLS symbols, pi/2-BPSK (Framer.hxx:97-196)
+        static const int G[7][32] = {
+            {1,0,0,1,0,0,0,0,1,0,1,0,1,1,0,0,0,0,1,0,1,1,0,1,1,1,0,1,1,1,0,1}, {0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1},
+            {0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1}, {0,0,0,0,1,1,1,1,0,0,0,0,1,1,1,1,0,0,0,0,1,1,1,1,0,0,0,0,1,1,1,1},
+            {0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1}, {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1},
+            {1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1}};
+        static const int SCR[64] = {0,1,1,1,0,0,0,1,1,0,0,1,1,1,0,1,1,0,0,0,0,0,1,1,1,1,0,0,1,0,0,1,0,1,0,1,0,0,1,1,0,1,0,0,0,0,1,0,0,0,1,0,1,1,0,1,1,1,1,1,1,0,1,0};
+        static const int SOF[26] = {0,1,1,0,0,0,1,1,0,1,0,0,1,0,1,1,1,0,1,0,0,0,0,0,1,0};
+        std::vector<float> plh(180);
+        const float a = (float)(1 / std::sqrt(2.0));
+        for (int i = 0; i < 13; i++) {
+            const int e = 1 - 2 * SOF[2 * i], o = 1 - 2 * SOF[2 * i + 1];
+            plh[4 * i] = a * e; plh[4 * i + 1] = a * e; plh[4 * i + 2] = -1 * a * o; plh[4 * i + 3] = a * o;
+        }
+        for (int i = 0; i < 32; i++) {
+            int c = 0;
+            for (int r = 0; r < 7; r++) c = (c + (cfg->pls[r] & 1) * G[r][i]) % 2;
+            const int e = 1 - 2 * ((c + SCR[2 * i]) % 2), o = 1 - 2 * (((c == 0 ? 1 : 0) + SCR[2 * i + 1]) % 2);
+            float *p = &plh[52 + 4 * i];
+            if ((cfg->pls[0] & 1) == 0) { p[0] = a * e; p[1] = a * e; p[2] = -1 * a * o; p[3] = a * o; }
+            else { p[0] = -1 * a * e; p[1] = a * e; p[2] = -1 * a * o; p[3] = -1 * a * o; }
+        }
+        if (upload(h, &h->d_plh, plh.data(), plh.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+    }
+
     // ---- modem: normalise to unit mean energy in fp32 (tools::Constellation_user)
     const int P = 1 << cfg->bps;
     std::vector<float> cs(2 * P);
@@ -279,7 +329,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
         for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     void *ptrs[] = {h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_exp, h->bch.d_log,
-                    h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork};
+                    h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -645,6 +695,45 @@ int dvbs2hip_rx_bb(dvbs2hip_t *h, const float *pl, const float *sigma, int32_t *
     HIPCHK(h, hipMemcpyAsync(info, dout, nout, hipMemcpyDeviceToHost, h->stream));
     if (cwd_l) HIPCHK(h, hipMemcpyAsync(cwd_l, dc0, F, hipMemcpyDeviceToHost, h->stream));
     if (cwd_b) HIPCHK(h, hipMemcpyAsync(cwd_b, dc1, F, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ N1: TX mirror + AWGN
+int dvbs2hip_tx_bb_dev(dvbs2hip_t *h, const int32_t *info_in, uint64_t seed, const float *sigma, int32_t *info_out, float *pl, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!pl) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    void *dbch, *dldpc;
+    if ((r = ensure(h, B_TXBCH, (size_t)F * ((h->K_ldpc + 31) / 32) * 4, &dbch)) ||
+        (r = ensure(h, B_TXLDPC, (size_t)F * ((h->N_ldpc + 31) / 32) * 4, &dldpc)))
+        return r;
+    TxKParams p;
+    memset(&p, 0, sizeof p);
+    p.info_in = info_in; p.info_out = info_out; p.sigma = sigma; p.pl_out = pl;
+    p.bch_cw = (uint32_t *)dbch; p.ldpc_cw = (uint32_t *)dldpc; p.prbs = h->bch.d_prbs;
+    p.enc_tab = h->d_enc_tab; p.enc_deg = h->d_enc_deg; p.cstl = h->d_cstl; p.plh = h->d_plh; p.pl_seq = h->d_pl_seq;
+    for (int i = 0; i < 3; i++) p.bch_g[i] = h->bch_g[i];
+    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+    p.K_bch = h->K_bch; p.K_ldpc = h->K_ldpc; p.N_ldpc = h->N_ldpc; p.bps = h->bps; p.itl_cols = h->itl_cols; p.itl_order = h->itl_order;
+    p.n_sym = h->n_sym; p.pl_frame = h->pl_frame; p.enc_stride = h->enc_stride; p.n_frames = F;
+    Timer tm(h, DVBS2HIP_K_MISC);
+    HIPCHK(h, tx_launch(p, h->stream));
+    return 0;
+}
+
+int dvbs2hip_tx_bb(dvbs2hip_t *h, const int32_t *info_in, uint64_t seed, const float *sigma, int32_t *info_out, float *pl, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!pl) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const size_t nb = (size_t)F * h->K_bch * 4, npl = (size_t)F * 2 * h->pl_frame * 4;
+    void *din = nullptr, *dinfo, *dpl, *dsig = nullptr;
+    if ((r = ensure(h, B_INFO, nb, &dinfo)) || (r = ensure(h, B_OUT, npl, &dpl))) return r;
+    if (info_in) { if ((r = ensure(h, B_IN, nb, &din))) return r; HIPCHK(h, hipMemcpyAsync(din, info_in, nb, hipMemcpyHostToDevice, h->stream)); }
+    if (sigma) { if ((r = ensure(h, B_SIG, (size_t)F * 4, &dsig))) return r; HIPCHK(h, hipMemcpyAsync(dsig, sigma, (size_t)F * 4, hipMemcpyHostToDevice, h->stream)); }
+    if ((r = dvbs2hip_tx_bb_dev(h, (const int32_t *)din, seed, (const float *)dsig, (int32_t *)dinfo, (float *)dpl, F))) return r;
+    if (info_out) HIPCHK(h, hipMemcpyAsync(info_out, dinfo, nb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(pl, dpl, npl, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }

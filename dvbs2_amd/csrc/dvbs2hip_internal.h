@@ -122,6 +122,28 @@ hipError_t remove_plh_launch(const float *in, float *out, int n_sym, int pl_fram
 hipError_t bb_descramble_launch(const int32_t *in, int32_t *out, const uint32_t *prbs, int K, int F, hipStream_t s);
 hipError_t monitor_launch(const int32_t *U, const int32_t *V, unsigned long long *ctr, int K, int F, hipStream_t s);
 
+// ---------------------------------------------------------------- TX mirror + AWGN (N1)
+struct TxKParams {
+    const int32_t *info_in;     // [F][K_bch] or null: random payload from (seed, frame)
+    int32_t *info_out;          // [F][K_bch] or null
+    const float *sigma;         // [F] or null: no noise
+    float *pl_out;              // [F][2*pl_frame]
+    uint32_t *bch_cw;           // [F][ceil(K_ldpc/32)] work
+    uint32_t *ldpc_cw;          // [F][ceil(N_ldpc/32)] work
+    const uint32_t *prbs;       // BB scrambling sequence, packed
+    const uint32_t *enc_tab;    // [q][enc_stride]: t0 | group << 9
+    const int32_t *enc_deg;     // [q]
+    const float *cstl;          // normalised constellation
+    const float *plh;           // 180 floats: PLHEADER
+    const uint8_t *pl_seq;
+    unsigned long long bch_g[3];  // generator without its leading term, bit i = coeff of x^i
+    uint32_t seed_lo, seed_hi;
+    int32_t K_bch, K_ldpc, N_ldpc, bps, itl_cols, itl_order, n_sym, pl_frame, enc_stride, n_frames;
+};
+hipError_t tx_launch(const TxKParams &p, hipStream_t s);
+// generator polynomial of the t-error-correcting BCH code over GF(2^m): g[i] = coeff of x^i
+std::vector<uint8_t> bch_generator(const BchPlan &pl);
+
 // ---------------------------------------------------------------- FIR (a5)
 hipError_t fir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps_rev,
                       int T, long long n_total, hipStream_t s);

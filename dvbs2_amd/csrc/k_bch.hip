@@ -40,6 +40,34 @@ std::string bch_build_plan(BchPlan &pl, int m, const int32_t *prim, int t, int N
     return "";
 }
 
+// g(x) = lcm of the minimal polynomials of alpha^1 .. alpha^2t (one per cyclotomic coset),
+// as tools::BCH_polynomial_generator builds it (TX_RX_BB/main.cpp:45)
+std::vector<uint8_t> bch_generator(const BchPlan &pl)
+{
+    const int n = pl.n;
+    auto mul = [&](int a, int b) { return (a && b) ? (int)pl.exp_[pl.log_[a] + pl.log_[b]] : 0; };
+    std::vector<uint8_t> g{1};
+    std::vector<char> seen(n, 0);
+    for (int j = 1; j <= 2 * pl.t; j++) {
+        if (seen[j % n]) continue;
+        std::vector<int> mp{1};                        // prod (x + alpha^e) over the coset of j
+        int e = j % n;
+        do {
+            seen[e] = 1;
+            const int a = pl.exp_[e];
+            mp.push_back(0);
+            for (int i = (int)mp.size() - 1; i >= 1; i--) mp[i] = mp[i - 1] ^ mul(mp[i], a);
+            mp[0] = mul(mp[0], a);
+            e = (int)(((long long)e * 2) % n);
+        } while (e != j % n);
+        std::vector<uint8_t> ng(g.size() + mp.size() - 1, 0);
+        for (size_t a = 0; a < g.size(); a++) if (g[a])
+            for (size_t c = 0; c < mp.size(); c++) if (mp[c]) ng[a + c] ^= 1;
+        g.swap(ng);
+    }
+    return g;
+}
+
 __device__ __forceinline__ uint32_t mod_n(uint32_t x, int m, uint32_t n)
 {
     x = (x & n) + (x >> m);

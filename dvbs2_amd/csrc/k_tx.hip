@@ -1,0 +1,184 @@
+// N1 -- TX mirror + AWGN channel on the device, so the Monte-Carlo BER loop of
+// dvbs2_tx_rx_bb (/root/reference src/mains/TX_RX_BB/main.cpp:75-82) never leaves the GPU:
+//   source.generate -> bb_scrambler.scramble -> BCH encode (Encoder_BCH_DVBS2.cpp:28-43)
+//   -> LDPC encode (enc type "LDPC_DVBS2", DVBS2.cpp:427) -> interleave (DVBS2.cpp:451-476)
+//   -> modulate (Modem_generic) -> Framer::generate (Framer.hxx:232-293)
+//   -> Scrambler_PL::scramble (Scrambler_PL.hxx:61-78) -> Channel_AWGN (DVBS2.cpp:593-613)
+// Test-signal generation, not the RX hot path; parity: bit-exact against the oracle TX for
+// given payloads and sigma = 0 (tests/test_tx_gpu.py).  Noise: Philox4x32-10 + Box-Muller,
+// counter = (symbol, frame, stream), so results do not depend on the launch geometry.
+#include "dvbs2hip_internal.h"
+
+namespace dvbs2 {
+
+// ---------------------------------------------------------------- Philox4x32-10
+__device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key)
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * ctr.x;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * ctr.z;
+        ctr = make_uint4((uint32_t)(p1 >> 32) ^ ctr.y ^ key.x, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ ctr.w ^ key.y, (uint32_t)p0);
+        key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
+    }
+    return ctr;
+}
+
+// ---------------------------------------------------------------- source + BB scramble + BCH encode
+// One LANE per frame: the systematic encoder is a 2^m-ary LFSR division, serial in the bit
+// index; the batch supplies the parallelism.  r = N - K <= 192 parity bits in three 64-bit words.
+__global__ void __launch_bounds__(64)
+tx_bch_kernel(const TxKParams p)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= p.n_frames) return;
+    const int K = p.K_bch, r = p.K_ldpc - p.K_bch;
+    const int nw_out = (p.K_ldpc + 31) / 32;
+    uint32_t *cw = p.bch_cw + (size_t)f * nw_out;
+    unsigned long long s0 = 0, s1 = 0, s2 = 0;                 // remainder, bit i = coeff of x^i
+    const unsigned long long g0 = p.bch_g[0], g1 = p.bch_g[1], g2 = p.bch_g[2];
+    const int top = r - 1;
+    uint32_t outw = 0;
+    uint4 rnd = make_uint4(0, 0, 0, 0);
+    for (int k = 0; k < K; k++) {
+        uint32_t u;
+        if (p.info_in) u = (uint32_t)p.info_in[(size_t)f * K + k] & 1u;
+        else {
+            if ((k & 127) == 0) rnd = philox4x32(make_uint4((uint32_t)(k >> 7), (uint32_t)f, 0u, 0u), make_uint2(p.seed_lo, p.seed_hi));
+            const uint32_t w = (k & 127) < 32 ? rnd.x : (k & 127) < 64 ? rnd.y : (k & 127) < 96 ? rnd.z : rnd.w;
+            u = (w >> (k & 31)) & 1u;
+        }
+        if (p.info_out) p.info_out[(size_t)f * K + k] = (int32_t)u;
+        u ^= (p.prbs[k >> 5] >> (k & 31)) & 1u;                 // Scrambler_BB
+        // LFSR step, highest-degree message coefficient first
+        const uint32_t msb = top < 64 ? (uint32_t)(s0 >> top) & 1u : top < 128 ? (uint32_t)(s1 >> (top - 64)) & 1u : (uint32_t)(s2 >> (top - 128)) & 1u;
+        const uint32_t fb = u ^ msb;
+        s2 = (s2 << 1) | (s1 >> 63); s1 = (s1 << 1) | (s0 >> 63); s0 <<= 1;
+        if (fb) { s0 ^= g0; s1 ^= g1; s2 ^= g2; }
+        outw |= u << (k & 31);
+        if ((k & 31) == 31) { cw[k >> 5] = outw; outw = 0; }
+    }
+    // parity, coefficient of x^(r-1) first (DVB-S2 order)
+    for (int j = 0; j < r; j++) {
+        const int d = r - 1 - j, k = K + j;
+        const uint32_t b = d < 64 ? (uint32_t)(s0 >> d) & 1u : d < 128 ? (uint32_t)(s1 >> (d - 64)) & 1u : (uint32_t)(s2 >> (d - 128)) & 1u;
+        outw |= b << (k & 31);
+        if ((k & 31) == 31) { cw[k >> 5] = outw; outw = 0; }
+    }
+    if ((p.K_ldpc & 31) != 0) cw[nw_out - 1] = outw;
+}
+
+// ---------------------------------------------------------------- LDPC IRA encoder (ETSI EN 302 307 5.3.2)
+// One workgroup per frame.  parity accumulator address (a + m q) mod M <=> check (r, t): the same
+// circulant structure the decoder uses; p_c ^= p_{c-1} is a prefix-XOR over c = q t + r.
+__global__ void __launch_bounds__(LDPC_THREADS)
+tx_ldpc_kernel(const TxKParams p)
+{
+    extern __shared__ uint32_t sm[];
+    const int K = p.K_ldpc, M = p.N_ldpc - p.K_ldpc, q = M / LDPC_Z;
+    const int nw_in = (K + 31) / 32, nw_out = (p.N_ldpc + 31) / 32;
+    uint32_t *info = sm;                                     // nw_in words
+    uint8_t *par = reinterpret_cast<uint8_t *>(sm + nw_in);  // [r][t], M bytes
+    uint8_t *tot = par + M;                                  // 360 bytes
+    const int t = threadIdx.x, f = blockIdx.x;
+    const uint32_t *src = p.bch_cw + (size_t)f * nw_in;
+    for (int w = t; w < nw_in; w += LDPC_THREADS) info[w] = src[w];
+    __syncthreads();
+    if (t < LDPC_Z) {
+        uint32_t run = 0;
+        for (int r = 0; r < q; r++) {
+            uint32_t x = 0;
+            const int deg = p.enc_deg[r];
+            for (int j = 0; j < deg; j++) {
+                const uint32_t e = p.enc_tab[r * p.enc_stride + j];     // t0 | group << 9
+                int m = t - (int)(e & 0x1FFu); m += m < 0 ? LDPC_Z : 0;
+                const int idx = (int)(e >> 9) * LDPC_Z + m;
+                x ^= (info[idx >> 5] >> (idx & 31)) & 1u;
+            }
+            run ^= x;
+            par[r * LDPC_Z + t] = (uint8_t)run;               // prefix over r inside column t
+        }
+        tot[t] = (uint8_t)run;
+    }
+    __syncthreads();
+    if (t == 0) { uint32_t e = 0; for (int i = 0; i < LDPC_Z; i++) { const uint32_t v = tot[i]; tot[i] = (uint8_t)e; e ^= v; } }   // exclusive scan over t
+    __syncthreads();
+    uint32_t *dst = p.ldpc_cw + (size_t)f * nw_out;
+    for (int w = t; w < nw_out; w += LDPC_THREADS) {
+        uint32_t word = 0;
+        for (int b = 0; b < 32; b++) {
+            const int i = 32 * w + b;
+            if (i >= p.N_ldpc) break;
+            uint32_t bit;
+            if (i < K) bit = (info[i >> 5] >> (i & 31)) & 1u;
+            else { const int c = i - K, tt = c / q, r = c - tt * q; bit = (uint32_t)(par[r * LDPC_Z + tt] ^ tot[tt]) & 1u; }
+            word |= bit << b;
+        }
+        dst[w] = word;
+    }
+}
+
+// ---------------------------------------------------------------- interleave + modulate + frame + PL scramble + AWGN
+__global__ void __launch_bounds__(256)
+tx_mod_kernel(const TxKParams p)
+{
+    __shared__ float cs[64];
+    const int f = blockIdx.y;
+    if (threadIdx.x < (2 << p.bps)) cs[threadIdx.x] = p.cstl[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // PL symbol index
+    if (i >= p.pl_frame) return;
+    const int n_sym = p.n_sym, n_pil = n_sym / 1440;
+    float2 y;
+    if (i < 90) y = make_float2(p.plh[2 * i], p.plh[2 * i + 1]);
+    else {
+        // inverse of the RX map: position i-90 inside [16 slots data | 36 pilots] blocks
+        const int j = i - 90, blk = j / (1440 + 36), off = j - blk * (1440 + 36);
+        int k = -1;
+        if (blk < n_pil) { if (off < 1440) k = blk * 1440 + off; }
+        else k = n_pil * 1440 + (j - n_pil * (1440 + 36));
+        if (k < 0) y = make_float2(0.70710678118654752440f, 0.70710678118654752440f);     // pilot (Framer.hxx:252-260)
+        else {
+            const uint32_t *cw = p.ldpc_cw + (size_t)f * ((p.N_ldpc + 31) / 32);
+            int idx = 0;
+            for (int b = 0; b < p.bps; b++) {
+                // interleaved bit k*bps+b comes from natural position col*n_rows + row (column/row interleaver)
+                int nat = k * p.bps + b;
+                if (p.itl_cols > 1) { const int row = nat / p.itl_cols, c = nat - row * p.itl_cols; nat = (p.itl_order == 0 ? c : p.itl_cols - 1 - c) * (p.N_ldpc / p.itl_cols) + row; }
+                idx |= (int)((cw[nat >> 5] >> (nat & 31)) & 1u) << b;
+            }
+            y = make_float2(cs[2 * idx], cs[2 * idx + 1]);
+        }
+        switch (p.pl_seq[i - 90] & 3) {                        // multiply by exp(j pi/2 R) (Scrambler_PL.hxx:66-76, scr_flag = true)
+            case 0: break;
+            case 1: y = make_float2(-y.y, y.x); break;
+            case 2: y = make_float2(-y.x, -y.y); break;
+            default: y = make_float2(y.y, -y.x); break;
+        }
+    }
+    if (p.sigma) {
+        const float sg = p.sigma[f];
+        const uint4 r = philox4x32(make_uint4((uint32_t)i, (uint32_t)f, 1u, 0u), make_uint2(p.seed_lo, p.seed_hi));
+        const float u1 = ((float)r.x + 1.0f) * 2.3283064365386963e-10f, u2 = (float)r.y * 2.3283064365386963e-10f;
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cn;
+        sincosf(6.283185307179586f * u2, &sn, &cn);
+        y.x += sg * rad * cn; y.y += sg * rad * sn;
+    }
+    reinterpret_cast<float2 *>(p.pl_out + (size_t)f * 2 * p.pl_frame)[i] = y;
+}
+
+hipError_t tx_launch(const TxKParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(tx_bch_kernel, dim3((p.n_frames + 63) / 64), dim3(64), 0, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t lds = (size_t)((p.K_ldpc + 31) / 32) * 4 + (size_t)(p.N_ldpc - p.K_ldpc) + 512;
+    hipLaunchKernelGGL(tx_ldpc_kernel, dim3(p.n_frames), dim3(LDPC_THREADS), lds, s, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tx_mod_kernel, dim3((p.pl_frame + 255) / 256, p.n_frames), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace dvbs2

@@ -31,7 +31,7 @@ class Cfg(C.Structure):
         ("itl_cols", C.c_int32), ("itl_order", C.c_int32),
         ("fir_n_taps", C.c_int32), ("fir_taps", C.c_void_p), ("fir_osf", C.c_int32),
         ("max_frames", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p),
-        ("ldpc_lds_groups", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("ldpc_lds_groups", C.c_int32), ("pls", C.c_int32 * 7),
     ]
 
 
@@ -82,6 +82,8 @@ ABI = {
     "dvbs2hip_monitor_reset": (C.c_int, [_vp]),
     "dvbs2hip_rx_bb": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_rx_bb_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "dvbs2hip_tx_bb": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _i]),
+    "dvbs2hip_tx_bb_dev": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _i]),
     "dvbs2hip_timing_enable": (C.c_int, [_vp, _i]),
     "dvbs2hip_timing_reset": (C.c_int, [_vp]),
     "dvbs2hip_timing_get": (C.c_int, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -214,6 +214,26 @@ class Dvbs2Hip:
         self._chk(self.L.dvbs2hip_rx_bb_dev(self.h, _ptr(pl_frames), _ptr(sigma), _ptr(info), _ptr(cwd_ldpc),
                                             _ptr(cwd_bch), n_frames))
 
+    # ------------------------------------------------------------------ N1: TX mirror + AWGN
+    def tx_bb(self, n_frames, info=None, seed=0, sigma=None):
+        """-> (info_sent[F,K_bch] int32, pl_frames[F, 2*pl_frame] f32)"""
+        F = int(n_frames)
+        inf = None
+        if info is not None:
+            inf, F2 = self._frames(info, self.K_bch, np.int32)
+            if F2 != F:
+                raise ValueError("info holds %d frames, expected %d" % (F2, F))
+        sg = None
+        if sigma is not None:
+            sg = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, dtype=np.float32).ravel(), (F,)))
+        sent = np.empty((F, self.K_bch), dtype=np.int32)
+        pl = np.empty((F, 2 * self.pl_frame), dtype=np.float32)
+        self._chk(self.L.dvbs2hip_tx_bb(self.h, _ptr(inf), int(seed), _ptr(sg), _ptr(sent), _ptr(pl), F))
+        return sent, pl
+
+    def tx_bb_dev(self, info_in, seed, sigma, info_out, pl_frames, n_frames):
+        self._chk(self.L.dvbs2hip_tx_bb_dev(self.h, _ptr(info_in), int(seed), _ptr(sigma), _ptr(info_out), _ptr(pl_frames), n_frames))
+
     # ------------------------------------------------------------------ measurement
     def timing_enable(self, on=True):
         self._chk(self.L.dvbs2hip_timing_enable(self.h, 1 if on else 0))

@@ -86,7 +86,8 @@ typedef struct dvbs2hip_cfg {
     int32_t device;            /* HIP device ordinal                               */
     void   *stream;            /* hipStream_t to enqueue on, or NULL: own stream   */
     int32_t ldpc_lds_groups;   /* tuning: < 0 = automatic                          */
-    int32_t reserved[7];
+    /* PLS code of the PLHEADER: the 7-entry mod_cod vector of Framer.hxx:111-126 (TX side only) */
+    int32_t pls[7];
 } dvbs2hip_cfg;
 
 /* ------------------------------------------------------------------ lifecycle */
@@ -211,6 +212,21 @@ int dvbs2hip_rx_bb(dvbs2hip_t *h, const float *pl_frames, const float *sigma_in,
                    int8_t *cwd_ldpc, int8_t *cwd_bch, int32_t n_frames);
 int dvbs2hip_rx_bb_dev(dvbs2hip_t *h, const float *pl_frames, const float *sigma_in, int32_t *info_bits,
                        int8_t *cwd_ldpc, int8_t *cwd_bch, int32_t n_frames);
+
+/* ------------------------------------------------------------------ N1: TX mirror + AWGN channel (test-signal side)
+ * One call = the TX half + channel of TX_RX_BB/main.cpp:75-82 on the device:
+ *   Source::generate -> Scrambler_BB::scramble -> Encoder_BCH_DVBS2::encode
+ *   (src/common/Module/Encoder_BCH_DVBS2/Encoder_BCH_DVBS2.cpp:28-43) -> LDPC encode (DVBS2.cpp:427)
+ *   -> Interleaver::interleave -> Modem::modulate -> Framer::generate (Framer.hxx:232-293)
+ *   -> Scrambler_PL::scramble (Scrambler_PL.hxx:61-78) -> Channel_AWGN::add_noise (DVBS2.cpp:593-613).
+ *   info_in  : int32_t[n_frames * K_bch] or NULL (NULL: Source_random, Philox keyed by seed)
+ *   sigma    : float[n_frames] noise std-dev per real dimension, or NULL for no noise
+ *   info_out : int32_t[n_frames * K_bch] the payload that was sent (the monitor's U socket), or NULL
+ *   pl_frames: float[n_frames * 2*pl_frame]                                             */
+int dvbs2hip_tx_bb(dvbs2hip_t *h, const int32_t *info_in, uint64_t seed, const float *sigma, int32_t *info_out,
+                   float *pl_frames, int32_t n_frames);
+int dvbs2hip_tx_bb_dev(dvbs2hip_t *h, const int32_t *info_in, uint64_t seed, const float *sigma, int32_t *info_out,
+                       float *pl_frames, int32_t n_frames);
 
 /* ------------------------------------------------------------------ measurement
  * Per-kernel device time, measured with hipEvents recorded on the handle's stream around
