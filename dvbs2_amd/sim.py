@@ -1,0 +1,127 @@
+"""dvbs2_tx_rx_bb work-alike: the Monte-Carlo BER/FER loop of
+/root/reference src/mains/TX_RX_BB/main.cpp:139-167 with TX, channel, RX and monitor all on the
+GPU(s).  Same flags (DVBS2.cpp:117-149) where they apply to this path, same table as refs/.
+
+  python -m dvbs2_amd.sim --mod-cod QPSK-S_8/9 -m 3.6 -M 3.81 -s 0.1 --dec-implem NMS --dec-ite 10 -F 512
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m dvbs2_amd.sim --mod-cod 16APSK-N_8/9 ...
+
+Frames shard over ranks (independent Philox streams: seed = base + rank); the monitor counters
+{FRA, BE, FE} are summed over ranks once per batch (the RCCL all-reduce that replaces
+tools::Monitor_reduction); every rank stops at the same batch.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(prog="dvbs2_tx_rx_bb (HIP)")
+    ap.add_argument("--mod-cod", default="QPSK-S_8/9")
+    ap.add_argument("-m", "--sim-noise-min", type=float, default=3.2)
+    ap.add_argument("-M", "--sim-noise-max", type=float, default=6.0)
+    ap.add_argument("-s", "--sim-noise-step", type=float, default=0.1)
+    ap.add_argument("-e", "--max-fe", type=int, default=100)
+    ap.add_argument("-F", "--sim-inter-fra", type=int, default=512, help="frames per batch per GPU (grid width)")
+    ap.add_argument("--dec-ite", type=int, default=50)
+    ap.add_argument("--dec-implem", default="NMS", choices=["NMS", "MS"])
+    ap.add_argument("--dec-alpha", type=float, default=1.0)
+    ap.add_argument("--no-early-stop", action="store_true")
+    ap.add_argument("--est-type", default="DVBS2", choices=["DVBS2", "PERFECT"])
+    ap.add_argument("--max-frames", type=int, default=10_000_000, help="cap on frames per noise point (all ranks)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--json", default=None, help="also write the rows as JSON")
+    return ap
+
+
+def run(args, out=sys.stdout):
+    import torch
+    import torch.distributed as dist
+    from . import params as P
+    from .parallel import reduce_counters, reduce_max
+    from .receiver import Dvbs2Hip
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("dvbs2_amd.sim needs a GPU: libdvbs2hip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    mc = P.get_modcod(args.mod_cod)
+    F = args.sim_inter_fra
+    alpha = 1.0 if args.dec_implem == "MS" else args.dec_alpha
+    rx = Dvbs2Hip(mc.name, max_frames=F, n_ite=args.dec_ite, alpha=alpha, early_stop=not args.no_early_stop, device=local_rank)
+    pl = torch.empty((F, 2 * rx.pl_frame), dtype=torch.float32, device=dev)
+    sent = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev)
+    got = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev)
+    sig = torch.empty((F,), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    rows = []
+    if rank == 0:
+        print("# * DVB-S2 (HIP, %d GPU(s)) ---------------------------" % world, file=out)
+        print("#    ** Modulation and coding = %s" % mc.name, file=out)
+        print("#    ** LDPC implem           = %s (alpha %.3f, QC-layer schedule)" % (args.dec_implem, alpha), file=out)
+        print("#    ** LDPC n iterations     = %d" % args.dec_ite, file=out)
+        print("#    ** Estimator             = %s" % args.est_type, file=out)
+        print("#    ** Frames per batch      = %d x %d" % (F, world), file=out)
+        print("# ----------|----------||----------|----------|----------|----------|----------||----------|----------", file=out)
+        print("#     Es/N0 |    Eb/N0 ||      FRA |       BE |       FE |      BER |      FER ||  SIM_THR |    ET/RT", file=out)
+        print("#      (dB) |     (dB) ||          |          |          |          |          ||   (Mb/s) | (hhmmss)", file=out)
+        print("# ----------|----------||----------|----------|----------|----------|----------||----------|----------", file=out)
+    ebn0 = args.sim_noise_min
+    batch_id = 0
+    while ebn0 < args.sim_noise_max - 1e-9:
+        esn0 = P.ebn0_to_esn0(ebn0, mc.code_rate, mc.bps)          # main.cpp:142-146
+        sigma = P.esn0_to_sigma(esn0)
+        sig.fill_(sigma)
+        rx.monitor_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tot = [0, 0, 0]
+        while tot[2] < args.max_fe and tot[0] < args.max_frames:
+            seed = (args.seed << 40) + (batch_id << 8) + rank
+            batch_id += 1
+            rx.tx_bb_dev(None, seed, sig.data_ptr(), sent.data_ptr(), pl.data_ptr(), F)
+            rx.rx_bb_dev(pl.data_ptr(), sig.data_ptr() if args.est_type == "PERFECT" else None, got.data_ptr(), None, None, F)
+            rx.check_errors_dev(sent.data_ptr(), got.data_ptr(), F)
+            tot = reduce_counters(list(rx.monitor_get()), dev)       # syncs the stream; 24-byte all-reduce
+        et = reduce_max(time.perf_counter() - t0, dev)
+        fra, be, fe = tot
+        row = dict(esn0=esn0, ebn0=ebn0, fra=fra, be=be, fe=fe, ber=be / max(1, fra * mc.K_bch), fer=fe / max(1, fra),
+                   thr_mbps=fra * mc.K_bch / et / 1e6, et=et)
+        rows.append(row)
+        if rank == 0:
+            h, m_, s_ = int(et // 3600), int(et % 3600 // 60), int(et % 60)
+            print("  %9.2f | %8.2f || %8d | %8d | %8d | %8.2e | %8.2e || %8.3f | %02dh%02d'%02d" % (
+                esn0, ebn0, fra, be, fe, row["ber"], row["fer"], row["thr_mbps"], h, m_, s_), file=out, flush=True)
+        ebn0 += args.sim_noise_step
+    if rank == 0:
+        print("# End of the simulation", file=out)
+        if args.json:
+            with open(args.json, "w") as fh:
+                json.dump(dict(args=vars(args), n_gpus=world, rows=rows), fh, indent=1)
+    rx.close()
+    return rows
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    run(args)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
