@@ -1,0 +1,71 @@
+"""Per-kernel device time + roofline fractions for every stage of the RX inner path (the
+`--sim-stats` equivalent), measured with the library's hipEvent timers.  GPU box only.
+usage: python tools/bench_kernels.py [out.json]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from dvbs2_amd.receiver import Dvbs2Hip
+from dvbs2_amd import lib_binding as B
+from dvbs2_amd import params as P
+
+dev = torch.device("cuda", 0)
+res = {}
+
+def timed(rx, kid, fn, reps=5):
+    fn(); rx.synchronize()
+    rx.timing_enable(True); rx.timing_reset()
+    for _ in range(reps): fn()
+    ms, n = rx.timing_get(kid); rx.timing_enable(False)
+    return ms / n
+
+def chain_case(modcod, F, n_ite, ebn0):
+    mc = P.get_modcod(modcod)
+    rx = Dvbs2Hip(modcod, max_frames=F, n_ite=n_ite, alpha=1.0, early_stop=False)
+    sigma = P.esn0_to_sigma(P.ebn0_to_esn0(ebn0, mc.code_rate, mc.bps))
+    pl = torch.empty((F, 2 * rx.pl_frame), dtype=torch.float32, device=dev)
+    sent = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev); got = torch.empty_like(sent)
+    sig = torch.full((F,), sigma, dtype=torch.float32, device=dev)
+    rx.tx_bb_dev(None, 1, sig.data_ptr(), sent.data_ptr(), pl.data_ptr(), F); rx.synchronize()
+    f = lambda: rx.rx_bb_dev(pl.data_ptr(), None, got.data_ptr(), None, None, F)
+    out = {}
+    for name, kid in (("front(a7+a6+a3+a4)", B.K_FRONT), ("ldpc(a1)", B.K_LDPC), ("bch+bb(a2+a8)", B.K_BCH)):
+        out[name] = timed(rx, kid, f)
+    rx.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): f()
+    rx.synchronize(); wall = (time.perf_counter() - t0) / 5 * 1e3
+    ok = bool((got == sent).all().item())
+    E = rx.ldpc_edges
+    alg = {"front(a7+a6+a3+a4)": 8 * rx.pl_frame + 4 * rx.N_ldpc, "ldpc(a1)": 16 * E * n_ite + 4 * rx.N_ldpc + 4 * rx.K_ldpc,
+           "bch+bb(a2+a8)": 4 * (rx.K_ldpc + rx.K_bch)}
+    r = {"frames": F, "n_ite": n_ite, "payload_recovered": ok, "chain_wall_ms": wall, "chain_frames_per_s": F / wall * 1e3,
+         "chain_info_gbps": F * rx.K_bch / wall * 1e3 / 1e9, "kernels": {}}
+    for k, ms in out.items():
+        gbs = alg[k] * F / (ms * 1e-3) / 1e9
+        r["kernels"][k] = {"ms": ms, "alg_bytes_per_frame": alg[k], "achieved_GBps": gbs, "frac_of_8TBps": gbs / 8000}
+    tx_ms = timed(rx, B.K_MISC, lambda: rx.tx_bb_dev(None, 1, sig.data_ptr(), sent.data_ptr(), pl.data_ptr(), F))
+    r["tx_mirror_ms"] = tx_ms
+    rx.close()
+    return r
+
+def fir_case(n_cplx, F, reps=20):
+    rx = Dvbs2Hip("32APSK-S_3/4", max_frames=max(F, 1))
+    x = torch.randn((F, 2 * n_cplx), dtype=torch.float32, device=dev); y = torch.empty_like(x)
+    ms = timed(rx, B.K_FIR, lambda: rx.filter_dev(x.data_ptr(), y.data_ptr(), n_cplx, F), reps)
+    rx.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): rx.filter_dev(x.data_ptr(), y.data_ptr(), n_cplx, F)
+    rx.synchronize(); wall = (time.perf_counter() - t0) / reps * 1e3
+    n = n_cplx * F
+    rx.close()
+    return {"n_cplx": n_cplx, "frames": F, "kernel_ms": ms, "call_wall_ms": wall, "GFLOPs": 324 * n / (ms * 1e-3) / 1e9,
+            "GBps": 16 * n / (ms * 1e-3) / 1e9, "frac_fp32_peak_157TF": 324 * n / (ms * 1e-3) / 157.3e12}
+
+res["config3_QPSK-N_8/9_F4096_10ite"] = chain_case("QPSK-N_8/9", 4096, 10, 4.2)
+res["config1_QPSK-S_8/9_F8192_10ite"] = chain_case("QPSK-S_8/9", 8192, 10, 4.4)
+res["config4_16APSK-N_8/9_F4096_20ite"] = chain_case("16APSK-N_8/9", 4096, 20, 8.2)
+res["config5_32APSK-S_3/4_F4096_10ite"] = chain_case("32APSK-S_3/4", 4096, 10, 9.5)
+res["fir_32APSK-S(6804 cplx/frame)"] = [fir_case(6804, F) for F in (1, 8, 64, 4096)]
+res["fir_QPSK-N(66564 cplx/frame)"] = [fir_case(66564, F) for F in (1, 8, 64, 1024)]
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "kernels.json")
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
