@@ -68,6 +68,7 @@ struct LdpcPlan {             // host-side description, built once per handle
     // regular-code fast path (k_ldpc_fast.hip): every layer has exactly deg_max slots
     bool fast = false;
     int fast_mode = 0;            // 0: all posteriors in LDS, 1: all in the global workspace
+    int fast_nf = 1;              // frames decoded per workgroup at once (2 only in global mode)
     std::vector<uint32_t> fast_tab;
     uint32_t *d_fast_tab = nullptr;
 };

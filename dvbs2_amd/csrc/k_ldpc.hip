@@ -121,7 +121,33 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             pl.fast_mode = ((size_t)(pl.n_groups + 1) * grp_bytes * 2 <= lds_limit + 1024) ? 0 : 1;
             if (env_mode) pl.fast_mode = !strcmp(env_mode, "lds") ? 0 : 1;
             if (pl.fast_mode == 0 && (size_t)(pl.n_groups + 1) * grp_bytes > lds_limit) pl.fast_mode = 1;
+            const char *env_nf = getenv("DVBS2HIP_LDPC_NF");
+            pl.fast_nf = 1;      // two frames per lane (DVBS2HIP_LDPC_NF=2) measured slower: 235 VGPRs halve the occupancy
+            if (env_nf && pl.fast_mode == 1) pl.fast_nf = atoi(env_nf) == 2 ? 2 : 1;
+            // mode 2 (hybrid, opt-in: DVBS2HIP_LDPC_FAST_MODE=hybrid): the most-touched bit-groups in LDS
+            // (+ a zero row and a junk row), the rest compactly in the workspace.  Measured SLOWER than the
+            // all-global image on MI355X (20.9 vs 12.6 ms / 4096 frames): the kernel is VALU-issue bound, not
+            // bandwidth bound, and the dual-issue costs instructions.
+            if (env_mode && !strcmp(env_mode, "hybrid")) pl.fast_mode = 2;
+            if (pl.fast_mode == 2) pl.fast_nf = 1;
+            std::vector<uint32_t> gbase(pl.n_groups), glds(pl.n_groups, 0u);
+            int n_l = 0, n_g = 0;
+            if (pl.fast_mode == 2) {
+                int cap = (int)(lds_limit / grp_bytes) - 2;
+                if (env_grp) cap = std::min(cap, std::max(0, atoi(env_grp)));
+                cap = std::min(cap, pl.n_groups);
+                for (int i = 0; i < pl.n_groups; i++) {
+                    const int g = order[i];
+                    if (i < cap) { gbase[g] = (uint32_t)(n_l++ * LDPC_Z); glds[g] = 1u; }
+                    else gbase[g] = (uint32_t)(n_g++ * LDPC_Z);
+                }
+            } else
+                for (int g = 0; g < pl.n_groups; g++) { gbase[g] = (uint32_t)(g * LDPC_Z); glds[g] = pl.fast_mode == 0 ? 1u : 0u; }
+            for (int g = 0; g < pl.n_groups; g++) pl.groups[g] = {gbase[g], glds[g]};
             pl.fast_tab.assign((size_t)q * LDPC_FAST_STRIDE, 0u);
+            auto pack = [&](const Slot &sl) {
+                return (uint32_t)(sl.t0 * 4) | ((gbase[sl.group] * 4u) << 11) | (pl.fast_mode == 2 && glds[sl.group] ? (1u << 29) : 0u);
+            };
             for (int r = 0; r < q; r++) {
                 uint32_t *T = &pl.fast_tab[(size_t)r * LDPC_FAST_STRIDE];
                 uint32_t prim = 0; int nc = 0;
@@ -129,25 +155,23 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 for (int lvl = 1; lvl <= 3; lvl++)
                     for (size_t j = 0; j < layers[r].size(); j++)
                         if (layers[r][j].lvl == lvl) {
-                            const Slot &sl = layers[r][j];
-                            T[32 + nc] = (uint32_t)(sl.t0 * 4) | ((uint32_t)(sl.group * LDPC_Z * 4) << 11);
+                            T[32 + nc] = pack(layers[r][j]);
                             T[48 + nc] = (uint32_t)j | ((uint32_t)lvl << 8);
                             nc++;
                         }
                 for (size_t j = 0; j < layers[r].size(); j++) {
-                    const Slot &sl = layers[r][j];
-                    // byte shift (11 bits) | byte offset of the bit-group, group g at word 360 g
-                    T[j] = (uint32_t)(sl.t0 * 4) | ((uint32_t)(sl.group * LDPC_Z * 4) << 11);
-                    if (sl.lvl == 0) prim |= 1u << j;
+                    // byte shift (11 bits) | byte offset of the bit-group in its store (18 bits) | LDS flag
+                    T[j] = pack(layers[r][j]);
+                    if (layers[r][j].lvl == 0) prim |= 1u << j;
                 }
                 T[27] = prim; T[28] = (uint32_t)nc;
             }
-            // workspace of one workgroup: [posteriors (global mode) | packed c->v state 3 M words]
-            pl.glb_post_words = pl.fast_mode == 1 ? pl.n_groups * LDPC_Z : 0;
-            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1) * LDPC_Z : 0;
+            // workspace of one workgroup: [posteriors kept in global memory | packed c->v state 3 M words]
+            pl.glb_post_words = pl.fast_mode == 1 ? pl.n_groups * LDPC_Z : pl.fast_mode == 2 ? n_g * LDPC_Z : 0;
+            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1) * LDPC_Z : pl.fast_mode == 2 ? (n_l + 2) * LDPC_Z : 0;
             pl.gwork_words = pl.glb_post_words + 3 * M;
             pl.lds_bytes = (size_t)pl.lds_post_words * 4;
-            pl.hybrid = false; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : 0;
+            pl.hybrid = pl.fast_mode == 2; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : n_l;
         }
     }
     if (pl.n_groups > 255) return "LDPC: more than 255 bit-groups not supported by the packed entry format";

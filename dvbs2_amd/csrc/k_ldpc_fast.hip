@@ -12,7 +12,9 @@
 //     per layer and kept in VGPRs for the store pass; global posteriors go through ONE raw
 //     buffer descriptor (32-bit voffset + SGPR soffset, no 64-bit address math);
 //   * latency.  All 27 posterior loads of a check are issued before the first is used; the
-//     next layer's packed c->v state (private to the lane) is prefetched under the compute.
+//     next layer's packed c->v state (private to the lane) is prefetched under the compute;
+//     and (NF = 2) every lane works on the same check of TWO frames at once: two independent
+//     dependency chains per lane, table unpacking and address arithmetic paid once for both.
 //
 // Posterior image: bit-group g at word 360 g (info groups, then parity groups regrouped
 // [r][t]), either entirely in LDS (N = 16200: 64.8 KB, two workgroups per CU) or entirely
@@ -20,204 +22,373 @@
 // and therefore stays L2 / Infinity-Cache resident.  Packed c->v state always lives in the
 // workspace: 12 B per check per layer, coalesced, prefetched.
 #include "dvbs2hip_internal.h"
+#include <cstdlib>
 
 namespace dvbs2 {
 
 typedef __attribute__((address_space(3))) float lds_float;
 typedef const __attribute__((address_space(4))) uint32_t *const_u32;
+typedef const __attribute__((address_space(4))) unsigned long long *const_u64;
+constexpr uint32_t FE_LDS = 1u << 29;       // fast-table entry: the bit-group lives in LDS (hybrid mode)
 
 constexpr uint32_t OOB = 0x7FFFF000u;       // beyond every workspace: loads return 0, stores are dropped
 constexpr int ROW_BYTES = LDPC_Z * 4;
 
+// Packed per-check state of the fast path: bits 31..27 = slot of the minimum, bit (DEG-1-j) = sign of
+// the message on slot j (the order v_alignbit shifts them in).  Decompresses to the exact fp32 message.
+template <int DEG>
 __device__ __forceinline__ float c2v_unpack_dyn(float c1, float c2, uint32_t pk, uint32_t j)
 {
     const float mag = ((pk >> 27) == j) ? c1 : c2;
-    return __uint_as_float(__float_as_uint(mag) | ((pk << (31u - j)) & 0x80000000u));
+    return __uint_as_float(__float_as_uint(mag) | ((pk << ((32u - DEG) + j)) & 0x80000000u));
 }
 
-template <int DEG, int MODE>     // MODE 0: posteriors in LDS, 1: posteriors in the global workspace
-__global__ void __launch_bounds__(LDPC_THREADS, 3)
+template <int MODE>
+struct FastCtx {
+    __amdgpu_buffer_rsrc_t rs;   // the workgroup's whole workspace slot
+    lds_float *lpost;            // MODE 0: posterior image in LDS
+    const_u32 tab;               // layer table
+    uint32_t t4;                 // 4 * lane
+    uint32_t c2v_base;           // byte offset of the packed state inside one frame's workspace
+    uint32_t redirect;           // where dropped stores go (OOB voffset / LDS dummy row)
+    uint32_t zero_row, junk_row; // MODE 2: byte offsets of the always-zero and the write-only LDS rows
+    int M, q;
+    float alpha;
+
+    __device__ __forceinline__ float post_ld(uint32_t off, uint32_t soff) const
+    {
+        if (MODE == 0) return lpost[(off + soff) >> 2];
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, soff, 0));
+    }
+    __device__ __forceinline__ void post_st(uint32_t off, uint32_t soff, float v) const
+    {
+        if (MODE == 0) lpost[(off + soff) >> 2] = v;
+        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, off, soff, 0);
+    }
+    __device__ __forceinline__ float st_ld(uint32_t fo, int arr, int r) const
+    {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t4, fo + c2v_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u, 0));
+    }
+    __device__ __forceinline__ void st_st(uint32_t fo, int arr, int r, float v) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, t4, fo + c2v_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u, 0);
+    }
+};
+
+// one decoding iteration (all q layers) for NA frames whose workspaces start at byte offsets fo[]
+template <int DEG, int MODE, int NA>
+__device__ __forceinline__ void fast_iteration(const FastCtx<MODE> &c, const uint32_t (&fo)[NA], float (&nx)[NA][3], bool act, int t)
+{
+    const int q = c.q;
+    for (int r = 0; r < q; r++) {
+        const const_u32 T = c.tab + r * LDPC_FAST_STRIDE;
+        uint32_t E[DEG];
+#pragma unroll
+        for (int j = 0; j < DEG; j++) E[j] = T[j];
+        const uint32_t prim = T[27];
+        const int ncf = (int)T[28];
+        const bool mask0 = (r == 0) && (t == 0);        // p_{c-1} of check 0 does not exist
+        float v[NA][DEG];
+        uint32_t w[DEG];
+        float c1o[NA], c2o[NA], cst1[NA], cst2[NA];
+        uint32_t pko[NA], pkn[NA];
+        if (act) {
+            // ---- pass 1a: every posterior load of the check(s) in flight before any use
+#pragma unroll
+            for (int j = 0; j < DEG; j++) {
+                const uint32_t d = c.t4 - (E[j] & 0x7FFu);
+                if (MODE == 2) {
+                    // hybrid image, no branch: issue BOTH an LDS read and a buffer load; the one
+                    // that does not apply hits the all-zero LDS row / an out-of-range offset
+                    const bool il = (E[j] & FE_LDS) != 0u;
+                    const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
+                    w[j] = min(d, d + (uint32_t)ROW_BYTES);
+                    const float a = c.lpost[(w[j] + (il ? base : c.zero_row)) >> 2];
+                    const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rs, w[j] + (il ? OOB : 0u), base + fo[0], 0));
+                    v[0][j] = il ? a : b;
+                } else {
+                    w[j] = min(d, d + (uint32_t)ROW_BYTES) + (MODE == 0 ? (E[j] >> 11) : 0u);   // LDS: full address
+#pragma unroll
+                    for (int k = 0; k < NA; k++) v[k][j] = c.post_ld(w[j], (MODE == 0 ? 0u : (E[j] >> 11)) + fo[k]);
+                }
+            }
+            const int rn = r + 1 < q ? r + 1 : 0;
+#pragma unroll
+            for (int k = 0; k < NA; k++) {
+                c1o[k] = nx[k][0]; c2o[k] = nx[k][1]; pko[k] = __float_as_uint(nx[k][2]);
+                // prefetch the next layer's packed state (private to this lane)
+                nx[k][0] = c.st_ld(fo[k], 0, rn); nx[k][1] = c.st_ld(fo[k], 1, rn); nx[k][2] = c.st_ld(fo[k], 2, rn);
+            }
+        }
+        // ---- pass 1b: v->c = posterior - old c->v ; running min1 / min2 / sign
+        float mn1[NA], mn2[NA];
+        uint32_t sacc[NA], tot[NA];
+#pragma unroll
+        for (int k = 0; k < NA; k++) { mn1[k] = INFINITY; mn2[k] = INFINITY; sacc[k] = 0u; tot[k] = 0u; cst1[k] = 0.f; cst2[k] = 0.f; pkn[k] = 0u; }
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < DEG; j++) {
+#pragma unroll
+                for (int k = 0; k < NA; k++) {
+                    float x = v[k][j] - c2v_unpack_dyn<DEG>(c1o[k], c2o[k], pko[k], (uint32_t)j);
+                    if (j == DEG - 1 && mask0) x = INFINITY;
+                    v[k][j] = x;
+                    const float a = fabsf(x);
+                    mn2[k] = __builtin_amdgcn_fmed3f(mn1[k], mn2[k], a);
+                    mn1[k] = fminf(mn1[k], a);
+                    sacc[k] = __builtin_amdgcn_alignbit(sacc[k], __float_as_uint(x), 31);      // shift the sign bit in
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NA; k++) {
+                cst1[k] = mn2[k] * c.alpha; cst2[k] = mn1[k] * c.alpha;
+                // all new signs at once: sign(new_j) = (parity of all signs) ^ sign(x_j)
+                tot[k] = (uint32_t)(__popc(sacc[k]) & 1);
+                pkn[k] = sacc[k] ^ (tot[k] ? ((1u << DEG) - 1u) : 0u);
+            }
+        }
+        if (ncf > 0) __syncthreads();         // every read of the layer precedes its writes
+        if (act) {
+            // ---- pass 2: new c->v ; posterior = v->c + new c->v.  Duplicate edges (not in
+            //      `prim`) and the absent edge are redirected, not branched around.
+            uint32_t idxn[NA];
+            float m1s[NA], m2s[NA];       // output magnitudes carrying the total sign
+#pragma unroll
+            for (int k = 0; k < NA; k++) {
+                idxn[k] = 0u;
+                m1s[k] = __uint_as_float(__float_as_uint(cst1[k]) | (tot[k] << 31));
+                m2s[k] = __uint_as_float(__float_as_uint(cst2[k]) | (tot[k] << 31));
+            }
+#pragma unroll
+            for (int j = 0; j < DEG; j++) {
+                uint32_t off = ((prim >> j) & 1u) ? w[j] : c.redirect;
+                if (j == DEG - 1 && mask0) off = c.redirect;
+                uint32_t la = 0u, go = 0u, hbase = 0u;
+                if (MODE == 2) {
+                    const bool il = (E[j] & FE_LDS) != 0u, pr = ((prim >> j) & 1u) != 0u;
+                    hbase = (E[j] >> 11) & 0x3FFFFu;
+                    la = w[j] + ((il && pr) ? hbase : c.junk_row);
+                    go = w[j] + ((!il && pr) ? 0u : OOB);
+                    if (j == DEG - 1 && mask0) { la = c.junk_row + c.t4; go = OOB; }
+                }
+#pragma unroll
+                for (int k = 0; k < NA; k++) {
+                    const float x = v[k][j];
+                    const bool ismin = fabsf(x) == mn1[k];
+                    const float mag = ismin ? m1s[k] : m2s[k];
+                    const float nw = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(x) & 0x80000000u));
+                    idxn[k] = ismin ? (uint32_t)j : idxn[k];
+                    if (MODE == 2) {
+                        c.lpost[la >> 2] = x + nw;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, x + nw), c.rs, go, hbase + fo[0], 0);
+                    } else c.post_st(off, (MODE == 0 ? 0u : (E[j] >> 11)) + fo[k], x + nw);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NA; k++) {
+                pkn[k] |= idxn[k] << 27;
+                c.st_st(fo[k], 0, r, cst1[k]); c.st_st(fo[k], 1, r, cst2[k]); c.st_st(fo[k], 2, r, __uint_as_float(pkn[k]));
+                if (q == 1) { nx[k][0] = cst1[k]; nx[k][1] = cst2[k]; nx[k][2] = __uint_as_float(pkn[k]); }
+            }
+        }
+        // ---- duplicate edges of a bit-group inside this layer: ordered delta updates
+        uint32_t prev_lvl = 0u;
+        for (int i = 0; i < ncf; i++) {
+            const uint32_t e = T[32 + i], meta = T[48 + i];
+            const uint32_t j = meta & 31u, lvl = meta >> 8;
+            if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
+            if (act) {
+                const uint32_t d = c.t4 - (e & 0x7FFu);
+                const uint32_t off = min(d, d + (uint32_t)ROW_BYTES);
+#pragma unroll
+                for (int k = 0; k < NA; k++) {
+                    const float nw = c2v_unpack_dyn<DEG>(cst1[k], cst2[k], pkn[k], j);
+                    const float od = c2v_unpack_dyn<DEG>(c1o[k], c2o[k], pko[k], j);
+                    if (MODE == 2) {
+                        const uint32_t hb = (e >> 11) & 0x3FFFFu;
+                        if (e & FE_LDS) { const float L = c.lpost[(off + hb) >> 2]; c.lpost[(off + hb) >> 2] = L + (nw - od); }
+                        else {
+                            const float L = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rs, off, hb + fo[0], 0));
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, L + (nw - od)), c.rs, off, hb + fo[0], 0);
+                        }
+                    } else {
+                        const float L = c.post_ld(off, (e >> 11) + fo[k]);
+                        c.post_st(off, (e >> 11) + fo[k], L + (nw - od));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// syndrome of the hard decisions of one frame (enable_syndrome, depth 1): this lane's checks
+template <int DEG, int MODE>
+__device__ __forceinline__ int fast_syndrome(const FastCtx<MODE> &c, uint32_t fo, bool act, int t)
+{
+    int bad = 0;
+    if (act)
+        for (int r = 0; r < c.q; r++) {
+            const const_u32 T = c.tab + r * LDPC_FAST_STRIDE;
+            uint32_t x = 0u;
+#pragma unroll
+            for (int j = 0; j < DEG; j++) {
+                const uint32_t e = T[j];
+                const uint32_t d = c.t4 - (e & 0x7FFu);
+                const uint32_t wo = min(d, d + (uint32_t)ROW_BYTES);
+                float L;
+                if (MODE == 2) {
+                    const uint32_t hb = (e >> 11) & 0x3FFFFu;
+                    if (e & FE_LDS) L = c.lpost[(wo + hb) >> 2];
+                    else L = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rs, wo, hb + fo, 0));
+                } else L = c.post_ld(wo, (e >> 11) + fo);
+                const bool absent = (j == DEG - 1) && (r == 0) && (t == 0);
+                x ^= (!absent && L < 0.f) ? 1u : 0u;
+            }
+            bad |= (int)x;
+        }
+    return bad;
+}
+
+template <int DEG, int MODE, int NF>     // MODE 0: posteriors in LDS, 1: in the global workspace; NF frames per workgroup
+__global__ void __launch_bounds__(LDPC_THREADS, NF == 2 ? 2 : 3)
 ldpc_fast_kernel(const LdpcKParams p)
 {
     extern __shared__ float smem[];
-    lds_float *lpost = (lds_float *)smem;
     const int t = threadIdx.x;
     const bool act = t < LDPC_Z;
-    const int M = p.M, q = p.q;
-    const const_u32 tab = (const_u32)p.fast_tab;
-    const uint32_t t4 = (uint32_t)t * 4u;
-    const uint32_t c2v_base = (uint32_t)p.glb_post_words * 4u;         // byte offset of the packed state
-    const uint32_t dummy = (uint32_t)p.n_groups * ROW_BYTES + t4;       // LDS dummy row (mode 0)
-    const uint32_t redirect = MODE == 0 ? dummy : OOB;
-
-    // one descriptor for the workgroup's whole workspace slot (wave-uniform by construction)
-    float *gwork = p.gwork + (size_t)blockIdx.x * p.gwork_words;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gwork, 0, p.gwork_words * 4, 0x00020000);
-
-#define POST_LD(off, soff) (MODE == 0 ? lpost[((off) + (soff)) >> 2] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (off), (soff), 0)))
-#define POST_ST(off, soff, val) do { if (MODE == 0) lpost[((off) + (soff)) >> 2] = (val); \
-        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)(val)), rs, (off), (soff), 0); } while (0)
-#define ST_LD(arr, r_) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t4, c2v_base + (uint32_t)((arr) * M + (r_) * LDPC_Z) * 4u, 0))
-#define ST_ST(arr, r_, val) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, (float)(val)), rs, t4, c2v_base + (uint32_t)((arr) * M + (r_) * LDPC_Z) * 4u, 0)
-
-    for (int f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
-        const float *Y = p.llr + (size_t)f * p.N;
-        // ---- channel LLRs -> posterior image; packed state := 0
-        if (act) {
-            for (int g = 0; g < p.n_groups; g++) {
-                const int src = g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info);
-                POST_ST(t4, (uint32_t)g * ROW_BYTES, Y[src]);
-            }
-            for (int r = 0; r < q; r++) { ST_ST(0, r, 0.f); ST_ST(1, r, 0.f); ST_ST(2, r, 0.f); }
+    const int q = p.q;
+    float *gwork = p.gwork + (size_t)blockIdx.x * NF * p.gwork_words;
+    FastCtx<MODE> c;
+    c.rs = __builtin_amdgcn_make_buffer_rsrc(gwork, 0, NF * p.gwork_words * 4, 0x00020000);   // wave-uniform by construction
+    c.lpost = (lds_float *)smem;
+    c.tab = (const_u32)p.fast_tab;
+    c.t4 = (uint32_t)t * 4u;
+    c.c2v_base = (uint32_t)p.glb_post_words * 4u;
+    c.redirect = MODE == 0 ? (uint32_t)p.n_groups * ROW_BYTES + c.t4 : OOB;
+    c.zero_row = (uint32_t)(p.lds_post_words - 2 * LDPC_Z) * 4u;      // MODE 2: last two rows of the LDS image
+    c.junk_row = c.zero_row + ROW_BYTES;
+    c.M = p.M; c.q = q; c.alpha = p.alpha;
+    const const_u64 groups = (const_u64)p.groups;
+    // where bit-group g lives: word offset (low) and LDS flag (high); modes 0 / 1 are uniform
+    auto grp_ld = [&](int g, uint32_t idx4, uint32_t fo) -> float {
+        if (MODE == 2) {
+            const unsigned long long gl = groups[g];
+            const uint32_t b = (uint32_t)gl * 4u;
+            if (gl >> 32) return c.lpost[(b + idx4) >> 2];
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rs, idx4, b + fo, 0));
         }
+        return c.post_ld(idx4, (uint32_t)g * ROW_BYTES + fo);
+    };
+    auto grp_st = [&](int g, uint32_t idx4, uint32_t fo, float v) {
+        if (MODE == 2) {
+            const unsigned long long gl = groups[g];
+            const uint32_t b = (uint32_t)gl * 4u;
+            if (gl >> 32) c.lpost[(b + idx4) >> 2] = v;
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), c.rs, idx4, b + fo, 0);
+        } else c.post_st(idx4, (uint32_t)g * ROW_BYTES + fo, v);
+    };
+    if (MODE == 2) {   // the zero row is read by every edge that lives in global memory
+        if (act) { c.lpost[(c.zero_row + c.t4) >> 2] = 0.f; c.lpost[(c.junk_row + c.t4) >> 2] = 0.f; }
+        __syncthreads();
+    }
+    const uint32_t fstride = (uint32_t)p.gwork_words * 4u;      // bytes between the two frames' workspaces
+
+    for (int f0 = blockIdx.x * NF; f0 < p.n_frames; f0 += gridDim.x * NF) {
+        const int nfr = (p.n_frames - f0) < NF ? (p.n_frames - f0) : NF;
+        // ---- channel LLRs -> posterior image; packed state := 0
+        if (act)
+            for (int k = 0; k < nfr; k++) {
+                const float *Y = p.llr + (size_t)(f0 + k) * p.N;
+                const uint32_t fo = (uint32_t)k * fstride;
+                for (int g = 0; g < p.n_groups; g++) {
+                    const int src = g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info);
+                    grp_st(g, c.t4, fo, Y[src]);
+                }
+                for (int r = 0; r < q; r++) { c.st_st(fo, 0, r, 0.f); c.st_st(fo, 1, r, 0.f); c.st_st(fo, 2, r, 0.f); }
+            }
         __syncthreads();
 
-        int it = 0;
-        bool ok = false;
-        float nx1 = 0.f, nx2 = 0.f, nxk = 0.f;
-        while (it < p.n_ite) {
-            for (int r = 0; r < q; r++) {
-                const const_u32 T = tab + r * LDPC_FAST_STRIDE;
-                uint32_t E[DEG];
+        int it[NF];
+        bool ok[NF], live[NF];
 #pragma unroll
-                for (int j = 0; j < DEG; j++) E[j] = T[j];
-                const uint32_t prim = T[27];
-                const int ncf = (int)T[28];
-                const bool mask0 = (r == 0) && (t == 0);        // p_{c-1} of check 0 does not exist
-                float v[DEG];
-                uint32_t w[DEG];
-                float cst1 = 0.f, cst2 = 0.f, mn1 = INFINITY, mn2 = INFINITY;
-                const float c1o = nx1, c2o = nx2;
-                const uint32_t pko = __float_as_uint(nxk);
-                uint32_t sacc = 0u, pkn = 0u, idxn = 0u;
-                if (act) {
-                    // ---- pass 1a: every posterior load of the check in flight before any use
-#pragma unroll
-                    for (int j = 0; j < DEG; j++) {
-                        const uint32_t d = t4 - (E[j] & 0x7FFu);
-                        w[j] = min(d, d + (uint32_t)ROW_BYTES) + (MODE == 0 ? (E[j] >> 11) : 0u);   // LDS: full address
-                        v[j] = POST_LD(w[j], MODE == 0 ? 0u : (E[j] >> 11));
-                    }
-                    {   // prefetch the next layer's packed state (private to this lane)
-                        const int rn = r + 1 < q ? r + 1 : 0;
-                        nx1 = ST_LD(0, rn); nx2 = ST_LD(1, rn); nxk = ST_LD(2, rn);
-                    }
-                    // ---- pass 1b: v->c = posterior - old c->v ; running min1 / min2 / sign
-#pragma unroll
-                    for (int j = 0; j < DEG; j++) {
-                        float x = v[j] - c2v_unpack_dyn(c1o, c2o, pko, (uint32_t)j);
-                        if (j == DEG - 1 && mask0) x = INFINITY;
-                        v[j] = x;
-                        const float a = fabsf(x);
-                        mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);
-                        mn1 = fminf(mn1, a);
-                        sacc ^= __float_as_uint(x);
-                    }
-                    cst1 = mn2 * p.alpha;
-                    cst2 = mn1 * p.alpha;
+        for (int k = 0; k < NF; k++) { it[k] = 0; ok[k] = false; live[k] = k < nfr; }
+        // ---- two frames per lane while both are live
+        if (NF == 2 && live[NF - 1]) {
+            const uint32_t fo[2] = {0u, fstride};
+            float nx[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            while (it[0] < p.n_ite) {
+                fast_iteration<DEG, MODE, 2>(c, fo, nx, act, t);
+                it[0]++; it[NF - 1]++;
+                if (p.early_stop || it[0] == p.n_ite) {
+                    const int b0 = fast_syndrome<DEG, MODE>(c, fo[0], act, t), b1 = fast_syndrome<DEG, MODE>(c, fo[1], act, t);
+                    ok[0] = !__syncthreads_or(b0);
+                    ok[NF - 1] = !__syncthreads_or(b1);
+                    if (ok[0] || ok[NF - 1]) break;
                 }
-                if (ncf > 0) __syncthreads();         // every read of the layer precedes its writes
-                if (act) {
-                    // ---- pass 2: new c->v ; posterior = v->c + new c->v.  Duplicate edges (not in
-                    //      `prim`) and the absent edge are redirected, not branched around.
-#pragma unroll
-                    for (int j = 0; j < DEG; j++) {
-                        const float x = v[j];
-                        const bool ismin = fabsf(x) == mn1;
-                        const float mag = ismin ? cst1 : cst2;
-                        const uint32_t s = (sacc ^ __float_as_uint(x)) & 0x80000000u;
-                        const float nw = __uint_as_float(__float_as_uint(mag) | s);
-                        pkn |= s >> (31 - j);
-                        idxn = ismin ? (uint32_t)j : idxn;
-                        uint32_t off = ((prim >> j) & 1u) ? w[j] : redirect;
-                        if (j == DEG - 1 && mask0) off = redirect;
-                        POST_ST(off, MODE == 0 ? 0u : (E[j] >> 11), x + nw);
-                    }
-                    pkn |= idxn << 27;
-                    ST_ST(0, r, cst1); ST_ST(1, r, cst2); ST_ST(2, r, __uint_as_float(pkn));
-                    if (q == 1) { nx1 = cst1; nx2 = cst2; nxk = __uint_as_float(pkn); }
-                }
-                // ---- duplicate edges of a bit-group inside this layer: ordered delta updates
-                uint32_t prev_lvl = 0u;
-                for (int k = 0; k < ncf; k++) {
-                    const uint32_t e = T[32 + k], meta = T[48 + k];
-                    const uint32_t j = meta & 31u, lvl = meta >> 8;
-                    if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
-                    if (act) {
-                        const uint32_t d = t4 - (e & 0x7FFu);
-                        const uint32_t off = min(d, d + (uint32_t)ROW_BYTES);
-                        const float nw = c2v_unpack_dyn(cst1, cst2, pkn, j);
-                        const float od = c2v_unpack_dyn(c1o, c2o, pko, j);
-                        const float L = POST_LD(off, e >> 11);
-                        POST_ST(off, e >> 11, L + (nw - od));
-                    }
-                }
-                __syncthreads();
             }
-            it++;
-            if (p.early_stop || it == p.n_ite) {
-                // ---- syndrome of the hard decisions (enable_syndrome, depth 1)
-                int bad = 0;
-                if (act)
-                    for (int r = 0; r < q; r++) {
-                        const const_u32 T = tab + r * LDPC_FAST_STRIDE;
-                        uint32_t x = 0u;
+            live[0] = !ok[0] && it[0] < p.n_ite;
+            live[NF - 1] = !ok[NF - 1] && it[NF - 1] < p.n_ite;
+        }
+        // ---- whatever is still live continues alone (odd tail, or its partner converged first)
 #pragma unroll
-                        for (int j = 0; j < DEG; j++) {
-                            const uint32_t e = T[j];
-                            const uint32_t d = t4 - (e & 0x7FFu);
-                            const float L = POST_LD(min(d, d + (uint32_t)ROW_BYTES), e >> 11);
-                            const bool absent = (j == DEG - 1) && (r == 0) && (t == 0);
-                            x ^= (!absent && L < 0.f) ? 1u : 0u;
-                        }
-                        bad |= (int)x;
-                    }
-                ok = !__syncthreads_or(bad);
-                if (ok) break;
+        for (int k = 0; k < NF; k++) {
+            if (!live[k]) continue;
+            const uint32_t fo[1] = {(uint32_t)k * fstride};
+            float nx[1][3] = {{0.f, 0.f, 0.f}};
+            if (act) { nx[0][0] = c.st_ld(fo[0], 0, 0); nx[0][1] = c.st_ld(fo[0], 1, 0); nx[0][2] = c.st_ld(fo[0], 2, 0); }
+            while (it[k] < p.n_ite) {
+                fast_iteration<DEG, MODE, 1>(c, fo, nx, act, t);
+                it[k]++;
+                if (p.early_stop || it[k] == p.n_ite) {
+                    ok[k] = !__syncthreads_or(fast_syndrome<DEG, MODE>(c, fo[0], act, t));
+                    if (ok[k]) break;
+                }
             }
         }
 
         // ---- outputs
-        if (t == 0) {
-            if (p.cwd) p.cwd[f] = ok ? 1 : 0;
-            if (p.ites) p.ites[f] = it;
-        }
-        if (act) {
-            for (int g = 0; g < p.n_info; g++) {
-                const float L = POST_LD(t4, (uint32_t)g * ROW_BYTES);
-                if (p.bits) p.bits[(size_t)f * p.K + g * LDPC_Z + t] = L < 0.f ? 1 : 0;
-                if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + t] = L;
+        for (int k = 0; k < nfr; k++) {
+            const int f = f0 + k;
+            const uint32_t fo = (uint32_t)k * fstride;
+            if (t == 0) {
+                if (p.cwd) p.cwd[f] = ok[k] ? 1 : 0;
+                if (p.ites) p.ites[f] = it[k];
             }
-            if (p.post)
-                for (int g = p.n_info; g < p.n_groups; g++)
-                    p.post[(size_t)f * p.N + p.K + q * t + (g - p.n_info)] = POST_LD(t4, (uint32_t)g * ROW_BYTES);
-        }
-        if (p.packed) {
-            // bit i of word w = info bit 32 w + i (tail bits zero)
-            const int n_words = (p.K + 31) / 32;
-            for (int wd = t; wd < n_words; wd += LDPC_THREADS) {
-                uint32_t word = 0u;
-                for (int b = 0; b < 32; b++) {
-                    const int k = 32 * wd + b;
-                    if (k >= p.K) break;
-                    const float L = POST_LD((uint32_t)k * 4u, 0u);
-                    word |= (L < 0.f ? 1u : 0u) << b;
+            if (act) {
+                for (int g = 0; g < p.n_info; g++) {
+                    const float L = grp_ld(g, c.t4, fo);
+                    if (p.bits) p.bits[(size_t)f * p.K + g * LDPC_Z + t] = L < 0.f ? 1 : 0;
+                    if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + t] = L;
                 }
-                p.packed[(size_t)f * n_words + wd] = word;
+                if (p.post)
+                    for (int g = p.n_info; g < p.n_groups; g++)
+                        p.post[(size_t)f * p.N + p.K + q * t + (g - p.n_info)] = grp_ld(g, c.t4, fo);
+            }
+            if (p.packed) {
+                // bit i of word w = info bit 32 w + i (tail bits zero)
+                const int n_words = (p.K + 31) / 32;
+                for (int wd = t; wd < n_words; wd += LDPC_THREADS) {
+                    uint32_t word = 0u;
+                    for (int b = 0; b < 32; b++) {
+                        const int i = 32 * wd + b;
+                        if (i >= p.K) break;
+                        const int g = i / LDPC_Z;
+                        const float L = grp_ld(g, (uint32_t)(i - g * LDPC_Z) * 4u, fo);
+                        word |= (L < 0.f ? 1u : 0u) << b;
+                    }
+                    p.packed[(size_t)f * n_words + wd] = word;
+                }
             }
         }
-        __syncthreads();     // the posterior image is reused by the next frame of this workgroup
+        __syncthreads();     // the posterior image is reused by the next frames of this workgroup
     }
-#undef POST_LD
-#undef POST_ST
-#undef ST_LD
-#undef ST_ST
 }
 
-template <int DEG, int MODE>
+template <int DEG, int MODE, int NF>
 static hipError_t fast_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
 {
-    auto kern = ldpc_fast_kernel<DEG, MODE>;
+    auto kern = ldpc_fast_kernel<DEG, MODE, NF>;
     static size_t configured = 0;
     if (pl.lds_bytes > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -225,30 +396,34 @@ static hipError_t fast_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_
         if (e != hipSuccess) return e;
         configured = pl.lds_bytes;
     }
-    const int grid = p.n_frames < pl.grid_max ? p.n_frames : pl.grid_max;
+    const int groups = (p.n_frames + NF - 1) / NF;
+    const int grid = groups < pl.grid_max ? groups : pl.grid_max;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_THREADS), pl.lds_bytes, s, p);
     return hipGetLastError();
 }
 
-template <int DEG, int MODE>
+template <int DEG, int MODE, int NF>
 static int fast_occ(const LdpcPlan &pl)
 {
-    auto kern = ldpc_fast_kernel<DEG, MODE>;
+    auto kern = ldpc_fast_kernel<DEG, MODE, NF>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, LDPC_THREADS, pl.lds_bytes) != hipSuccess) nb = 1;
+    if (const char *ev = getenv("DVBS2HIP_LDPC_BLOCKS_PER_CU")) { const int cap = atoi(ev); if (cap >= 1 && cap < nb) nb = cap; }
     return nb < 1 ? 1 : nb;
 }
 
-#define FAST_DISPATCH(FN, ...)                                                                  \
-    (pl.deg_max == 27 ? (pl.fast_mode == 0 ? FN<27, 0>(__VA_ARGS__) : FN<27, 1>(__VA_ARGS__))   \
-                      : (pl.fast_mode == 0 ? FN<11, 0>(__VA_ARGS__) : FN<11, 1>(__VA_ARGS__)))
+#define FAST_DISPATCH_D(D, FN, ...)                                                             \
+    (pl.fast_mode == 0 ? FN<D, 0, 1>(__VA_ARGS__)                                                \
+     : pl.fast_mode == 2 ? FN<D, 2, 1>(__VA_ARGS__)                                              \
+     : (pl.fast_nf == 2 ? FN<D, 1, 2>(__VA_ARGS__) : FN<D, 1, 1>(__VA_ARGS__)))
+#define FAST_DISPATCH(FN, ...) (pl.deg_max == 27 ? FAST_DISPATCH_D(27, FN, __VA_ARGS__) : FAST_DISPATCH_D(11, FN, __VA_ARGS__))
 
 int ldpc_fast_blocks_per_cu(const LdpcPlan &pl) { return FAST_DISPATCH(fast_occ, pl); }
 
 hipError_t ldpc_fast_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
-    p.fast_tab = pl.d_fast_tab;
+    p.fast_tab = pl.d_fast_tab; p.groups = pl.d_groups;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.lds_post_words = pl.lds_post_words; p.glb_post_words = pl.glb_post_words; p.gwork_words = pl.gwork_words;
     return FAST_DISPATCH(fast_inst, pl, p, s);
