@@ -240,7 +240,8 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
     e = bch_build_plan(h->bch, cfg->bch_m, cfg->bch_prim, cfg->bch_t, cfg->K_ldpc, cfg->K_bch);
     if (!e.empty()) CREATE_FAIL(DVBS2HIP_EINVAL, e);
     if (upload(h, &h->bch.d_exp, h->bch.exp_.data(), h->bch.exp_.size()) ||
-        upload(h, &h->bch.d_log, h->bch.log_.data(), h->bch.log_.size()))
+        upload(h, &h->bch.d_log, h->bch.log_.data(), h->bch.log_.size()) ||
+        upload(h, &h->bch.d_syn_tab, h->bch.syn_tab.data(), h->bch.syn_tab.size()))
         CREATE_FAIL(DVBS2HIP_EHIP, h->err);
     std::vector<uint32_t> prbs;
     bb_prbs(cfg->K_bch, prbs);
@@ -328,7 +329,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     for (auto &kv : h->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
         for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_exp, h->bch.d_log,
+    void *ptrs[] = {h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);

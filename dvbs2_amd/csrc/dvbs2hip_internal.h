@@ -89,13 +89,18 @@ struct BchPlan {
     std::vector<uint16_t> exp_, log_;
     uint16_t *d_exp = nullptr, *d_log = nullptr;   // exp has 2n entries (no modulo on sums)
     uint32_t *d_prbs = nullptr;                    // BB scrambler sequence, packed, K bits
+    // syndrome tables, one set per odd j = 1, 3, .., 2t-1 (see k_bch.hip):
+    //   [0 .. 256)            bit-reversed byte
+    //   [256 + 768 k ..)      for the k-th odd j: 256 x (u(x) x^m mod m_j(x)) | 256 x eval(low byte) | 256 x eval(high byte)
+    std::vector<uint16_t> syn_tab;
+    uint16_t *d_syn_tab = nullptr;
 };
 struct BchKParams {
     const int32_t *in_bits;     // [F][N] or null
     const uint32_t *in_packed;  // [F][ceil(N/32)] or null
     int32_t *out_bits;          // [F][K]
     int8_t *cwd;                // [F] or null
-    const uint16_t *exp_, *log_;
+    const uint16_t *exp_, *log_, *syn_tab;
     const uint32_t *prbs;       // packed K-bit BB descrambling sequence or null (no descramble)
     int32_t N, K, m, n, t, n_frames;
 };

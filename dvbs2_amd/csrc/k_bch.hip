@@ -37,6 +37,46 @@ std::string bch_build_plan(BchPlan &pl, int m, const int32_t *prim, int t, int N
         x <<= 1; if (x >> m) x ^= pm;
     }
     pl.exp_[2 * (size_t)n] = 1;
+
+    // ---- syndrome tables.  For odd j the minimal polynomial m_j(x) of alpha^j has degree m (DVB-S2
+    // codes), GF(2)[x]/m_j is a field and r(x) -> r(alpha^j) factors through r mod m_j: the frame is
+    // reduced modulo m_j byte by byte like a CRC, and only the m-bit remainder is evaluated.
+    if (N % 8) return "BCH: N must be a multiple of 8";
+    auto mul = [&](int a, int b) { return (a && b) ? (int)pl.exp_[pl.log_[a] + pl.log_[b]] : 0; };
+    pl.syn_tab.assign(256 + (size_t)768 * t, 0);
+    for (int b = 0; b < 256; b++) { int r = 0; for (int i = 0; i < 8; i++) if (b >> i & 1) r |= 1 << (7 - i); pl.syn_tab[b] = (uint16_t)r; }
+    for (int kj = 0; kj < t; kj++) {
+        const int j = 2 * kj + 1;
+        std::vector<int> mp{1};                        // m_j(x) = prod over the coset of j of (x + alpha^e)
+        int e = j % n;
+        do {
+            const int a = pl.exp_[e];
+            mp.push_back(0);
+            for (int i = (int)mp.size() - 1; i >= 1; i--) mp[i] = mp[i - 1] ^ mul(mp[i], a);
+            mp[0] = mul(mp[0], a);
+            e = (int)(((long long)e * 2) % n);
+        } while (e != j % n);
+        if ((int)mp.size() - 1 != m) return "BCH: minimal polynomial of degree != m (not a DVB-S2 code)";
+        uint32_t poly = 0;                             // m_j without its leading term
+        for (int i = 0; i < m; i++) { if (mp[i] > 1) return "BCH: minimal polynomial not over GF(2)"; if (mp[i]) poly |= 1u << i; }
+        uint16_t *T = &pl.syn_tab[256 + (size_t)768 * kj];
+        for (int u = 0; u < 256; u++) {                // (u(x) x^m) mod m_j
+            uint32_t r = 0;
+            for (int i = 7; i >= 0; i--) {             // feed u's bits, highest degree first, through the LFSR
+                const uint32_t fb = ((r >> (m - 1)) & 1u) ^ ((u >> i) & 1u);
+                r = (r << 1) & ((1u << m) - 1u);
+                if (fb) r ^= poly;
+            }
+            T[u] = (uint16_t)r;
+            // evaluation of a remainder byte at alpha^j: sum_b bit_b alpha^(j (b + 8 half))
+            uint32_t lo = 0, hi = 0;
+            for (int bb = 0; bb < 8; bb++) if (u >> bb & 1) {
+                lo ^= pl.exp_[(int)(((long long)j * bb) % n)];
+                if (bb + 8 < m) hi ^= pl.exp_[(int)(((long long)j * (bb + 8)) % n)];
+            }
+            T[256 + u] = (uint16_t)lo; T[512 + u] = (uint16_t)hi;
+        }
+    }
     return "";
 }
 
@@ -81,7 +121,7 @@ constexpr int BCH_TMAX = 12;
 __global__ void __launch_bounds__(BCH_THREADS)
 bch_decode_kernel(const BchKParams p)
 {
-    extern __shared__ uint32_t words[];             // ceil(N/32) packed received bits
+    extern __shared__ uint32_t words[];             // ceil(N/32) packed received bits, then the syndrome tables
     __shared__ uint32_t S[2 * BCH_TMAX + 2];        // S[1..2t]
     __shared__ int Cs[2 * BCH_TMAX + 4], Bs[2 * BCH_TMAX + 4], Ts[2 * BCH_TMAX + 4];
     __shared__ int s_L, s_status, s_nroots, s_any;
@@ -90,6 +130,9 @@ bch_decode_kernel(const BchKParams p)
     const int N = p.N, K = p.K, t = p.t, m = p.m;
     const uint32_t n = (uint32_t)p.n;
     const int nw = (N + 31) / 32;
+    uint16_t *stab = reinterpret_cast<uint16_t *>(words + nw);
+    for (int i = tid; i < 256 + 768 * t; i += BCH_THREADS) stab[i] = p.syn_tab[i];
+    __syncthreads();
 
     for (int f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
         // ---- 1. bit image
@@ -110,28 +153,37 @@ bch_decode_kernel(const BchKParams p)
         if (tid == 0) { s_L = 0; s_status = 0; s_nroots = 0; s_any = 0; }
         __syncthreads();
 
-        // ---- 2. odd syndromes S_j = sum_i r_i alpha^(j (N-1-i))
-        uint32_t acc[BCH_TMAX];
+        // ---- 2. odd syndromes S_j = r(alpha^j): each lane reduces its chunk of bytes modulo the
+        //      minimal polynomial m_j (table-driven, CRC style, tables in LDS), evaluates the m-bit
+        //      remainder at alpha^j and shifts it to the chunk's place: x alpha^(8 j bytes_after).
+        {
+            const int nbytes = N / 8;
+            const int L = (nbytes + BCH_THREADS - 1) / BCH_THREADS;          // bytes per lane
+            const int b0 = tid * L, b1 = min(b0 + L, nbytes);
+            uint32_t rem[BCH_TMAX];
 #pragma unroll
-        for (int k = 0; k < BCH_TMAX; k++) acc[k] = 0u;
-        for (int w = tid; w < nw; w += BCH_THREADS) {
-            uint32_t x = words[w];
-            while (x) {
-                const int b = __ffs(x) - 1;
-                x &= x - 1;
-                const uint32_t d = (uint32_t)(N - 1 - (32 * w + b));
+            for (int kk = 0; kk < BCH_TMAX; kk++) rem[kk] = 0u;
+            const uint32_t lowmask = (1u << (m - 8)) - 1u;
+            for (int by = b0; by < b1; by++) {
+                const uint32_t raw = (words[by >> 2] >> ((by & 3) * 8)) & 0xFFu;
+                const uint32_t B = stab[raw];                                 // first bit = highest degree
 #pragma unroll
-                for (int k = 0; k < BCH_TMAX; k++)
-                    if (k < t) acc[k] ^= p.exp_[mod_n((uint32_t)(2 * k + 1) * d, m, n)];
+                for (int kk = 0; kk < BCH_TMAX; kk++)
+                    if (kk < t) rem[kk] = (uint32_t)stab[256 + 768 * kk + (rem[kk] >> (m - 8))] ^ ((rem[kk] & lowmask) << 8) ^ B;
             }
+            const uint32_t after = (uint32_t)(nbytes - b1);                   // bytes behind this chunk
+#pragma unroll
+            for (int kk = 0; kk < BCH_TMAX; kk++)
+                if (kk < t) {
+                    uint32_t v = 0u;
+                    if (b1 > b0) {
+                        v = (uint32_t)stab[256 + 768 * kk + 256 + (rem[kk] & 0xFFu)] ^ (uint32_t)stab[256 + 768 * kk + 512 + (rem[kk] >> 8)];
+                        if (v) v = p.exp_[(uint32_t)p.log_[v] + mod_n(mod_n((uint32_t)(2 * kk + 1) * 8u, m, n) * after, m, n)];
+                    }
+                    for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o);
+                    if (lane == 0 && v) atomicXor(&S[2 * kk + 1], v);
+                }
         }
-#pragma unroll
-        for (int k = 0; k < BCH_TMAX; k++)
-            if (k < t) {
-                uint32_t a = acc[k];
-                for (int o = 32; o > 0; o >>= 1) a ^= __shfl_xor(a, o);
-                if (lane == 0 && a) atomicXor(&S[2 * k + 1], a);
-            }
         __syncthreads();
         if (tid == 0) {
             int any = 0;
@@ -217,10 +269,12 @@ bch_decode_kernel(const BchKParams p)
 
 hipError_t bch_launch(const BchPlan &pl, BchKParams p, hipStream_t s)
 {
-    p.exp_ = pl.d_exp; p.log_ = pl.d_log;
+    p.exp_ = pl.d_exp; p.log_ = pl.d_log; p.syn_tab = pl.d_syn_tab;
     p.N = pl.N; p.K = pl.K; p.m = pl.m; p.n = pl.n; p.t = pl.t;
-    const size_t lds = (size_t)((pl.N + 31) / 32) * 4;
-    hipLaunchKernelGGL(bch_decode_kernel, dim3(p.n_frames), dim3(BCH_THREADS), lds, s, p);
+    const size_t lds = (size_t)((pl.N + 31) / 32) * 4 + (256 + (size_t)768 * pl.t) * 2;
+    // persistent-ish grid: the tables are staged into LDS once per workgroup
+    const int grid = p.n_frames < 4096 ? p.n_frames : 4096;
+    hipLaunchKernelGGL(bch_decode_kernel, dim3(grid), dim3(BCH_THREADS), lds, s, p);
     return hipGetLastError();
 }
 
