@@ -234,7 +234,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         CREATE_FAIL(DVBS2HIP_EHIP, h->err);
     if (lp.fast && upload(h, &lp.d_fast_tab, lp.fast_tab.data(), lp.fast_tab.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
     lp.grid_max = ldpc_blocks_per_cu(lp) * h->n_cus;
-    if (lp.gwork_words > 0) CREATE_HIP(hipMalloc((void **)&h->d_gwork, (size_t)lp.grid_max * (lp.fast ? lp.fast_nf : 1) * lp.gwork_words * sizeof(float)));
+    if (lp.gwork_words > 0) CREATE_HIP(hipMalloc((void **)&h->d_gwork, (size_t)lp.grid_max * (lp.fast ? lp.fast_nf * lp.fast_wf : 1) * lp.gwork_words * sizeof(float)));
 
     // ---- BCH
     e = bch_build_plan(h->bch, cfg->bch_m, cfg->bch_prim, cfg->bch_t, cfg->K_ldpc, cfg->K_bch);

@@ -68,7 +68,8 @@ struct LdpcPlan {             // host-side description, built once per handle
     // regular-code fast path (k_ldpc_fast.hip): every layer has exactly deg_max slots
     bool fast = false;
     int fast_mode = 0;            // 0: all posteriors in LDS, 1: all in the global workspace
-    int fast_nf = 1;              // frames decoded per workgroup at once (2 only in global mode)
+    int fast_nf = 1;              // frames per LANE (2 only in global mode; measured slower, opt-in)
+    int fast_wf = 1;              // frames per WORKGROUP: 2 = 12-wave workgroups, one frame per half (balanced SIMDs)
     std::vector<uint32_t> fast_tab;
     uint32_t *d_fast_tab = nullptr;
 };

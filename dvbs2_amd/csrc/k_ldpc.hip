@@ -130,6 +130,12 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             // bandwidth bound, and the dual-issue costs instructions.
             if (env_mode && !strcmp(env_mode, "hybrid")) pl.fast_mode = 2;
             if (pl.fast_mode == 2) pl.fast_nf = 1;
+            {   // 12-wave workgroups (one frame per half) unless a variant that does not support them is forced
+                const char *env_wf = getenv("DVBS2HIP_LDPC_WF");
+                pl.fast_wf = (pl.fast_mode != 2 && pl.fast_nf == 1) ? 2 : 1;
+                if (env_wf && atoi(env_wf) == 1) pl.fast_wf = 1;
+                if (pl.fast_wf == 2 && pl.fast_mode == 0 && 2 * (size_t)(pl.n_groups + 1) * grp_bytes > lds_limit) pl.fast_wf = 1;
+            }
             std::vector<uint32_t> gbase(pl.n_groups), glds(pl.n_groups, 0u);
             int n_l = 0, n_g = 0;
             if (pl.fast_mode == 2) {

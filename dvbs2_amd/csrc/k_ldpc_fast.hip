@@ -385,6 +385,125 @@ ldpc_fast_kernel(const LdpcKParams p)
     }
 }
 
+// ---- two frames per workgroup, one per HALF of a 12-wave workgroup.  A 6-wave workgroup cannot
+// sit evenly on the CU's 4 SIMDs (2+2+1+1); two of them land 4+4+2+2 and the busiest SIMD then sets
+// the pace: measured, one 6-wave workgroup per CU runs as fast per frame as two.  Twelve waves are
+// dealt 3+3+3+3.  The halves share nothing but the barriers (both decode the same layer at the same
+// time); each has its own workspace slot, LDS image, iteration count and early-stop decision.
+template <int DEG, int MODE>
+__global__ void __launch_bounds__(2 * LDPC_THREADS, 3)
+ldpc_fast2_kernel(const LdpcKParams p)
+{
+    extern __shared__ float smem[];
+    __shared__ int s_flag[2];
+    const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / LDPC_THREADS);     // wave-uniform, and provably so
+    const int t = (int)threadIdx.x - half * LDPC_THREADS;
+    const bool lane_ok = t < LDPC_Z;
+    const int q = p.q;
+    float *gwork = p.gwork + (size_t)(blockIdx.x * 2 + half) * p.gwork_words;
+    FastCtx<MODE> c;
+    c.rs = __builtin_amdgcn_make_buffer_rsrc(gwork, 0, p.gwork_words * 4, 0x00020000);
+    c.lpost = (lds_float *)smem + (size_t)half * p.lds_post_words;
+    c.tab = (const_u32)p.fast_tab;
+    c.t4 = (uint32_t)t * 4u;
+    c.c2v_base = (uint32_t)p.glb_post_words * 4u;
+    c.redirect = MODE == 0 ? (uint32_t)p.n_groups * ROW_BYTES + c.t4 : OOB;
+    c.zero_row = 0u; c.junk_row = 0u;
+    c.M = p.M; c.q = q; c.alpha = p.alpha;
+    const uint32_t fo[1] = {0u};
+
+    for (int fb = blockIdx.x * 2; fb < p.n_frames; fb += gridDim.x * 2) {
+        const int f = fb + half;
+        const bool have = f < p.n_frames;
+        const bool act = lane_ok && have;
+        if (act) {
+            const float *Y = p.llr + (size_t)f * p.N;
+            for (int g = 0; g < p.n_groups; g++) {
+                const int src = g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info);
+                c.post_st(c.t4, (uint32_t)g * ROW_BYTES, Y[src]);
+            }
+            for (int r = 0; r < q; r++) { c.st_st(0u, 0, r, 0.f); c.st_st(0u, 1, r, 0.f); c.st_st(0u, 2, r, 0.f); }
+        }
+        __syncthreads();
+        int it = 0;
+        bool ok = false, live = have;
+        float nx[1][3] = {{0.f, 0.f, 0.f}};
+        for (;;) {
+            if (t == 0) s_flag[half] = 0;
+            if (!__syncthreads_or(live ? 1 : 0)) break;          // also orders the flag reset
+            fast_iteration<DEG, MODE, 1>(c, fo, nx, act && live, t);
+            int bad = 0;
+            bool check = false;
+            if (live) {
+                it++;
+                check = p.early_stop || it == p.n_ite;
+                if (check) bad = fast_syndrome<DEG, MODE>(c, 0u, act, t);
+            }
+            if (bad) atomicOr(&s_flag[half], 1);
+            __syncthreads();
+            if (live && check) { ok = s_flag[half] == 0; if (ok || it == p.n_ite) live = false; }
+            __syncthreads();                                      // flags are read before the next reset
+        }
+        if (have) {
+            if (t == 0) {
+                if (p.cwd) p.cwd[f] = ok ? 1 : 0;
+                if (p.ites) p.ites[f] = it;
+            }
+            if (act) {
+                for (int g = 0; g < p.n_info; g++) {
+                    const float L = c.post_ld(c.t4, (uint32_t)g * ROW_BYTES);
+                    if (p.bits) p.bits[(size_t)f * p.K + g * LDPC_Z + t] = L < 0.f ? 1 : 0;
+                    if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + t] = L;
+                }
+                if (p.post)
+                    for (int g = p.n_info; g < p.n_groups; g++)
+                        p.post[(size_t)f * p.N + p.K + q * t + (g - p.n_info)] = c.post_ld(c.t4, (uint32_t)g * ROW_BYTES);
+            }
+            if (p.packed) {
+                const int n_words = (p.K + 31) / 32;
+                for (int wd = t; wd < n_words; wd += LDPC_THREADS) {
+                    uint32_t word = 0u;
+                    for (int b = 0; b < 32; b++) {
+                        const int i = 32 * wd + b;
+                        if (i >= p.K) break;
+                        word |= (c.post_ld((uint32_t)i * 4u, 0u) < 0.f ? 1u : 0u) << b;
+                    }
+                    p.packed[(size_t)f * n_words + wd] = word;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int DEG, int MODE>
+static hipError_t fast2_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
+{
+    auto kern = ldpc_fast2_kernel<DEG, MODE>;
+    static size_t configured = 0;
+    const size_t lds = 2 * pl.lds_bytes;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    const int groups = (p.n_frames + 1) / 2;
+    const int grid = groups < pl.grid_max ? groups : pl.grid_max;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * LDPC_THREADS), lds, s, p);
+    return hipGetLastError();
+}
+
+template <int DEG, int MODE>
+static int fast2_occ(const LdpcPlan &pl)
+{
+    auto kern = ldpc_fast2_kernel<DEG, MODE>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * pl.lds_bytes));
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 2 * LDPC_THREADS, 2 * pl.lds_bytes) != hipSuccess) nb = 1;
+    if (const char *ev = getenv("DVBS2HIP_LDPC_BLOCKS_PER_CU")) { const int cap = atoi(ev); if (cap >= 1 && cap < nb) nb = cap; }
+    return nb < 1 ? 1 : nb;
+}
+
 template <int DEG, int MODE, int NF>
 static hipError_t fast_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
 {
@@ -419,13 +538,22 @@ static int fast_occ(const LdpcPlan &pl)
      : (pl.fast_nf == 2 ? FN<D, 1, 2>(__VA_ARGS__) : FN<D, 1, 1>(__VA_ARGS__)))
 #define FAST_DISPATCH(FN, ...) (pl.deg_max == 27 ? FAST_DISPATCH_D(27, FN, __VA_ARGS__) : FAST_DISPATCH_D(11, FN, __VA_ARGS__))
 
-int ldpc_fast_blocks_per_cu(const LdpcPlan &pl) { return FAST_DISPATCH(fast_occ, pl); }
+#define FAST2_DISPATCH(FN, ...)                                                                   \
+    (pl.deg_max == 27 ? (pl.fast_mode == 0 ? FN<27, 0>(__VA_ARGS__) : FN<27, 1>(__VA_ARGS__))      \
+                      : (pl.fast_mode == 0 ? FN<11, 0>(__VA_ARGS__) : FN<11, 1>(__VA_ARGS__)))
+
+int ldpc_fast_blocks_per_cu(const LdpcPlan &pl)
+{
+    if (pl.fast_wf == 2) return FAST2_DISPATCH(fast2_occ, pl);
+    return FAST_DISPATCH(fast_occ, pl);
+}
 
 hipError_t ldpc_fast_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
     p.fast_tab = pl.d_fast_tab; p.groups = pl.d_groups;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.lds_post_words = pl.lds_post_words; p.glb_post_words = pl.glb_post_words; p.gwork_words = pl.gwork_words;
+    if (pl.fast_wf == 2) return FAST2_DISPATCH(fast2_inst, pl, p, s);
     return FAST_DISPATCH(fast_inst, pl, p, s);
 }
 

@@ -12,9 +12,9 @@ for modcod in ("QPSK-N_8/9",):
     g = torch.Generator(device=dev); g.manual_seed(1)
     llr = (1.0 + 0.33 * torch.randn((F, N), generator=g, device=dev)) * (2 / 0.33 ** 2)
     bits = torch.empty((F, K), dtype=torch.int32, device=dev); cwd = torch.empty((F,), dtype=torch.int8, device=dev)
-    for cfg in sys.argv[1:] or ["global:0"]:
+    for cfg in sys.argv[1:] or ["global:1", "global:2"]:
         nf, bpc = cfg.split(":")
-        os.environ["DVBS2HIP_LDPC_FAST_MODE"] = nf; os.environ["DVBS2HIP_ABLATE"] = bpc; os.environ["DVBS2HIP_LDPC_NF"] = "1"
+        os.environ["DVBS2HIP_LDPC_FAST_MODE"] = nf; os.environ["DVBS2HIP_LDPC_WF"] = bpc; os.environ["DVBS2HIP_LDPC_NF"] = "1"
         rx = Dvbs2Hip(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=False)
         rx.decode_siho_dev(llr.data_ptr(), cwd.data_ptr(), bits.data_ptr(), F); rx.synchronize()
         if ref is None: ref = bits.clone()
