@@ -47,6 +47,7 @@ struct LdpcKParams {
     int32_t gwork_words;     // global words per frame in total (posteriors + c2v state)
     int32_t n_frames, n_ite, early_stop;
     float alpha;
+    int32_t pipe;              // fast path: software-pipelined layers (table sorted early-first, T[29] = n_early)
     const uint32_t *fast_tab;  // regular-code fast path: [q][LDPC_FAST_STRIDE] (see k_ldpc_fast.hip)
 };
 
@@ -69,6 +70,7 @@ struct LdpcPlan {             // host-side description, built once per handle
     bool fast = false;
     int fast_mode = 0;            // 0: all posteriors in LDS, 1: all in the global workspace
     int fast_nf = 1;              // frames per LANE (2 only in global mode; measured slower, opt-in)
+    bool fast_pipe = false;       // software-pipelined iteration: bit-exact but measured SLOWER (opt-in: DVBS2HIP_LDPC_PIPE=1)
     int fast_wf = 1;              // frames per WORKGROUP: 2 = 12-wave workgroups, one frame per half (balanced SIMDs)
     std::vector<uint32_t> fast_tab;
     uint32_t *d_fast_tab = nullptr;

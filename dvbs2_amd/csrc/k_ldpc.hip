@@ -154,23 +154,34 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             auto pack = [&](const Slot &sl) {
                 return (uint32_t)(sl.t0 * 4) | ((gbase[sl.group] * 4u) << 11) | (pl.fast_mode == 2 && glds[sl.group] ? (1u << 29) : 0u);
             };
+            if (const char *ev = getenv("DVBS2HIP_LDPC_PIPE")) pl.fast_pipe = atoi(ev) != 0;
             for (int r = 0; r < q; r++) {
                 uint32_t *T = &pl.fast_tab[(size_t)r * LDPC_FAST_STRIDE];
                 uint32_t prim = 0; int nc = 0;
+                // slot order: EARLY slots first (bit-group not touched by the previous layer, cyclically),
+                // then the late ones; the absent-for-check-0 parity slot stays last.  Conflict levels were
+                // fixed above in table order and travel with the slot.
+                std::vector<char> prev_touch(pl.n_groups, 0);
+                for (const Slot &sl : layers[(r + q - 1) % q]) prev_touch[sl.group] = 1;
+                std::vector<Slot> ord;
+                for (const Slot &sl : layers[r]) if (!prev_touch[sl.group]) ord.push_back(sl);
+                const int n_early = (int)ord.size();
+                for (const Slot &sl : layers[r]) if (prev_touch[sl.group]) ord.push_back(sl);
+                if (!ord.empty() && layers[r].back().mask0 && !ord.back().mask0) return "LDPC: internal: masked slot must stay last";
                 // conflict list sorted by level
                 for (int lvl = 1; lvl <= 3; lvl++)
-                    for (size_t j = 0; j < layers[r].size(); j++)
-                        if (layers[r][j].lvl == lvl) {
-                            T[32 + nc] = pack(layers[r][j]);
+                    for (size_t j = 0; j < ord.size(); j++)
+                        if (ord[j].lvl == lvl) {
+                            T[32 + nc] = pack(ord[j]);
                             T[48 + nc] = (uint32_t)j | ((uint32_t)lvl << 8);
                             nc++;
                         }
-                for (size_t j = 0; j < layers[r].size(); j++) {
+                for (size_t j = 0; j < ord.size(); j++) {
                     // byte shift (11 bits) | byte offset of the bit-group in its store (18 bits) | LDS flag
-                    T[j] = pack(layers[r][j]);
-                    if (layers[r][j].lvl == 0) prim |= 1u << j;
+                    T[j] = pack(ord[j]);
+                    if (ord[j].lvl == 0) prim |= 1u << j;
                 }
-                T[27] = prim; T[28] = (uint32_t)nc;
+                T[27] = prim; T[28] = (uint32_t)nc; T[29] = (uint32_t)n_early;
             }
             // workspace of one workgroup: [posteriors kept in global memory | packed c->v state 3 M words]
             pl.glb_post_words = pl.fast_mode == 1 ? pl.n_groups * LDPC_Z : pl.fast_mode == 2 ? n_g * LDPC_Z : 0;

@@ -222,6 +222,282 @@ __device__ __forceinline__ void fast_iteration(const FastCtx<MODE> &c, const uin
     }
 }
 
+
+// ---- software-pipelined iteration (one frame per lane).  EXPERIMENTAL, off by default: bit-exact, but on
+// MI355X it lost to the plain iteration (N=16200 3/5: 4.8 vs 3.4 ms; at DEG 27 it needs > 256 VGPRs and
+// spills: 49.8 vs 11.5 ms), see DESIGN.md section 6.  Host-side, the slots of every layer are
+// sorted "early first": a slot is EARLY when its bit-group is not touched by the previous layer, so
+// its posterior can be loaded -- and folded into min1/min2/sign, which do not depend on the order --
+// before the previous layer's stores have drained.  Per layer r:
+//     early loads of layer r+1  ->  pass 2 of layer r (stores)  ->  pass 1b of r+1 on the early slots
+//     ->  barrier  ->  late loads of r+1  ->  pass 1b on the late slots
+// so the store drain, the barrier and most of the load latency sit under arithmetic.  Partial slot
+// ranges run as suffixes of unrolled sequences entered through one jump (no per-slot branch).
+template <int DEG>
+struct PipeBuf {
+    float v[DEG];        // posterior, then v->c
+    uint32_t w[DEG];     // byte offset of the posterior (bit-group base folded in)
+    float c1o, c2o, mn1, mn2;
+    uint32_t pko, sgn;   // old packed state; collected sign bits (bit DEG-1-j = sign of slot j)
+};
+
+template <int DEG, int MODE>
+__device__ __forceinline__ void pipe_addr(const FastCtx<MODE> &c, const_u32 T, PipeBuf<DEG> &X)
+{
+#pragma unroll
+    for (int j = 0; j < DEG; j++) {
+        const uint32_t e = T[j];
+        const uint32_t d = c.t4 - (e & 0x7FFu);
+        X.w[j] = min(d, d + (uint32_t)ROW_BYTES) + (e >> 11);
+    }
+}
+
+#define PIPE_LD(j) X.v[j] = c.post_ld(X.w[j], fo)
+#define PIPE_1B(j)                                                                                     \
+    do {                                                                                               \
+        float x_ = X.v[j] - c2v_unpack_dyn<DEG>(X.c1o, X.c2o, X.pko, (uint32_t)(j));                   \
+        if ((j) == DEG - 1 && m0) x_ = INFINITY;                                                       \
+        X.v[j] = x_;                                                                                   \
+        const float a_ = fabsf(x_);                                                                    \
+        X.mn2 = __builtin_amdgcn_fmed3f(X.mn1, X.mn2, a_);                                             \
+        X.mn1 = fminf(X.mn1, a_);                                                                      \
+        X.sgn |= (__float_as_uint(x_) >> 31) << (DEG - 1 - (j));                                       \
+    } while (0)
+
+template <int DEG, int MODE>
+__device__ __forceinline__ void pipe_loads_from(const FastCtx<MODE> &c, uint32_t fo, PipeBuf<DEG> &X, int first)
+{
+    switch (first) {
+            case 0: if (0 < DEG) { PIPE_LD(0); } [[fallthrough]];
+            case 1: if (1 < DEG) { PIPE_LD(1); } [[fallthrough]];
+            case 2: if (2 < DEG) { PIPE_LD(2); } [[fallthrough]];
+            case 3: if (3 < DEG) { PIPE_LD(3); } [[fallthrough]];
+            case 4: if (4 < DEG) { PIPE_LD(4); } [[fallthrough]];
+            case 5: if (5 < DEG) { PIPE_LD(5); } [[fallthrough]];
+            case 6: if (6 < DEG) { PIPE_LD(6); } [[fallthrough]];
+            case 7: if (7 < DEG) { PIPE_LD(7); } [[fallthrough]];
+            case 8: if (8 < DEG) { PIPE_LD(8); } [[fallthrough]];
+            case 9: if (9 < DEG) { PIPE_LD(9); } [[fallthrough]];
+            case 10: if (10 < DEG) { PIPE_LD(10); } [[fallthrough]];
+            case 11: if (11 < DEG) { PIPE_LD(11); } [[fallthrough]];
+            case 12: if (12 < DEG) { PIPE_LD(12); } [[fallthrough]];
+            case 13: if (13 < DEG) { PIPE_LD(13); } [[fallthrough]];
+            case 14: if (14 < DEG) { PIPE_LD(14); } [[fallthrough]];
+            case 15: if (15 < DEG) { PIPE_LD(15); } [[fallthrough]];
+            case 16: if (16 < DEG) { PIPE_LD(16); } [[fallthrough]];
+            case 17: if (17 < DEG) { PIPE_LD(17); } [[fallthrough]];
+            case 18: if (18 < DEG) { PIPE_LD(18); } [[fallthrough]];
+            case 19: if (19 < DEG) { PIPE_LD(19); } [[fallthrough]];
+            case 20: if (20 < DEG) { PIPE_LD(20); } [[fallthrough]];
+            case 21: if (21 < DEG) { PIPE_LD(21); } [[fallthrough]];
+            case 22: if (22 < DEG) { PIPE_LD(22); } [[fallthrough]];
+            case 23: if (23 < DEG) { PIPE_LD(23); } [[fallthrough]];
+            case 24: if (24 < DEG) { PIPE_LD(24); } [[fallthrough]];
+            case 25: if (25 < DEG) { PIPE_LD(25); } [[fallthrough]];
+            case 26: if (26 < DEG) { PIPE_LD(26); } [[fallthrough]];
+            default: break;
+    }
+}
+template <int DEG, int MODE>
+__device__ __forceinline__ void pipe_loads_below(const FastCtx<MODE> &c, uint32_t fo, PipeBuf<DEG> &X, int count)
+{
+    switch (count) {
+            case 27: if (26 < DEG) { PIPE_LD(26); } [[fallthrough]];
+            case 26: if (25 < DEG) { PIPE_LD(25); } [[fallthrough]];
+            case 25: if (24 < DEG) { PIPE_LD(24); } [[fallthrough]];
+            case 24: if (23 < DEG) { PIPE_LD(23); } [[fallthrough]];
+            case 23: if (22 < DEG) { PIPE_LD(22); } [[fallthrough]];
+            case 22: if (21 < DEG) { PIPE_LD(21); } [[fallthrough]];
+            case 21: if (20 < DEG) { PIPE_LD(20); } [[fallthrough]];
+            case 20: if (19 < DEG) { PIPE_LD(19); } [[fallthrough]];
+            case 19: if (18 < DEG) { PIPE_LD(18); } [[fallthrough]];
+            case 18: if (17 < DEG) { PIPE_LD(17); } [[fallthrough]];
+            case 17: if (16 < DEG) { PIPE_LD(16); } [[fallthrough]];
+            case 16: if (15 < DEG) { PIPE_LD(15); } [[fallthrough]];
+            case 15: if (14 < DEG) { PIPE_LD(14); } [[fallthrough]];
+            case 14: if (13 < DEG) { PIPE_LD(13); } [[fallthrough]];
+            case 13: if (12 < DEG) { PIPE_LD(12); } [[fallthrough]];
+            case 12: if (11 < DEG) { PIPE_LD(11); } [[fallthrough]];
+            case 11: if (10 < DEG) { PIPE_LD(10); } [[fallthrough]];
+            case 10: if (9 < DEG) { PIPE_LD(9); } [[fallthrough]];
+            case 9: if (8 < DEG) { PIPE_LD(8); } [[fallthrough]];
+            case 8: if (7 < DEG) { PIPE_LD(7); } [[fallthrough]];
+            case 7: if (6 < DEG) { PIPE_LD(6); } [[fallthrough]];
+            case 6: if (5 < DEG) { PIPE_LD(5); } [[fallthrough]];
+            case 5: if (4 < DEG) { PIPE_LD(4); } [[fallthrough]];
+            case 4: if (3 < DEG) { PIPE_LD(3); } [[fallthrough]];
+            case 3: if (2 < DEG) { PIPE_LD(2); } [[fallthrough]];
+            case 2: if (1 < DEG) { PIPE_LD(1); } [[fallthrough]];
+            case 1: if (0 < DEG) { PIPE_LD(0); } [[fallthrough]];
+            default: break;
+    }
+}
+template <int DEG>
+__device__ __forceinline__ void pipe_1b_from(PipeBuf<DEG> &X, bool m0, int first)
+{
+    switch (first) {
+            case 0: if (0 < DEG) { PIPE_1B(0); } [[fallthrough]];
+            case 1: if (1 < DEG) { PIPE_1B(1); } [[fallthrough]];
+            case 2: if (2 < DEG) { PIPE_1B(2); } [[fallthrough]];
+            case 3: if (3 < DEG) { PIPE_1B(3); } [[fallthrough]];
+            case 4: if (4 < DEG) { PIPE_1B(4); } [[fallthrough]];
+            case 5: if (5 < DEG) { PIPE_1B(5); } [[fallthrough]];
+            case 6: if (6 < DEG) { PIPE_1B(6); } [[fallthrough]];
+            case 7: if (7 < DEG) { PIPE_1B(7); } [[fallthrough]];
+            case 8: if (8 < DEG) { PIPE_1B(8); } [[fallthrough]];
+            case 9: if (9 < DEG) { PIPE_1B(9); } [[fallthrough]];
+            case 10: if (10 < DEG) { PIPE_1B(10); } [[fallthrough]];
+            case 11: if (11 < DEG) { PIPE_1B(11); } [[fallthrough]];
+            case 12: if (12 < DEG) { PIPE_1B(12); } [[fallthrough]];
+            case 13: if (13 < DEG) { PIPE_1B(13); } [[fallthrough]];
+            case 14: if (14 < DEG) { PIPE_1B(14); } [[fallthrough]];
+            case 15: if (15 < DEG) { PIPE_1B(15); } [[fallthrough]];
+            case 16: if (16 < DEG) { PIPE_1B(16); } [[fallthrough]];
+            case 17: if (17 < DEG) { PIPE_1B(17); } [[fallthrough]];
+            case 18: if (18 < DEG) { PIPE_1B(18); } [[fallthrough]];
+            case 19: if (19 < DEG) { PIPE_1B(19); } [[fallthrough]];
+            case 20: if (20 < DEG) { PIPE_1B(20); } [[fallthrough]];
+            case 21: if (21 < DEG) { PIPE_1B(21); } [[fallthrough]];
+            case 22: if (22 < DEG) { PIPE_1B(22); } [[fallthrough]];
+            case 23: if (23 < DEG) { PIPE_1B(23); } [[fallthrough]];
+            case 24: if (24 < DEG) { PIPE_1B(24); } [[fallthrough]];
+            case 25: if (25 < DEG) { PIPE_1B(25); } [[fallthrough]];
+            case 26: if (26 < DEG) { PIPE_1B(26); } [[fallthrough]];
+            default: break;
+    }
+}
+template <int DEG>
+__device__ __forceinline__ void pipe_1b_below(PipeBuf<DEG> &X, bool m0, int count)
+{
+    switch (count) {
+            case 27: if (26 < DEG) { PIPE_1B(26); } [[fallthrough]];
+            case 26: if (25 < DEG) { PIPE_1B(25); } [[fallthrough]];
+            case 25: if (24 < DEG) { PIPE_1B(24); } [[fallthrough]];
+            case 24: if (23 < DEG) { PIPE_1B(23); } [[fallthrough]];
+            case 23: if (22 < DEG) { PIPE_1B(22); } [[fallthrough]];
+            case 22: if (21 < DEG) { PIPE_1B(21); } [[fallthrough]];
+            case 21: if (20 < DEG) { PIPE_1B(20); } [[fallthrough]];
+            case 20: if (19 < DEG) { PIPE_1B(19); } [[fallthrough]];
+            case 19: if (18 < DEG) { PIPE_1B(18); } [[fallthrough]];
+            case 18: if (17 < DEG) { PIPE_1B(17); } [[fallthrough]];
+            case 17: if (16 < DEG) { PIPE_1B(16); } [[fallthrough]];
+            case 16: if (15 < DEG) { PIPE_1B(15); } [[fallthrough]];
+            case 15: if (14 < DEG) { PIPE_1B(14); } [[fallthrough]];
+            case 14: if (13 < DEG) { PIPE_1B(13); } [[fallthrough]];
+            case 13: if (12 < DEG) { PIPE_1B(12); } [[fallthrough]];
+            case 12: if (11 < DEG) { PIPE_1B(11); } [[fallthrough]];
+            case 11: if (10 < DEG) { PIPE_1B(10); } [[fallthrough]];
+            case 10: if (9 < DEG) { PIPE_1B(9); } [[fallthrough]];
+            case 9: if (8 < DEG) { PIPE_1B(8); } [[fallthrough]];
+            case 8: if (7 < DEG) { PIPE_1B(7); } [[fallthrough]];
+            case 7: if (6 < DEG) { PIPE_1B(6); } [[fallthrough]];
+            case 6: if (5 < DEG) { PIPE_1B(5); } [[fallthrough]];
+            case 5: if (4 < DEG) { PIPE_1B(4); } [[fallthrough]];
+            case 4: if (3 < DEG) { PIPE_1B(3); } [[fallthrough]];
+            case 3: if (2 < DEG) { PIPE_1B(2); } [[fallthrough]];
+            case 2: if (1 < DEG) { PIPE_1B(1); } [[fallthrough]];
+            case 1: if (0 < DEG) { PIPE_1B(0); } [[fallthrough]];
+            default: break;
+    }
+}
+
+// finishes layer r held in X (pass 1b done for every slot) and prepares layer r+1 in Y
+template <int DEG, int MODE>
+__device__ __forceinline__ void pipe_layer(const FastCtx<MODE> &c, uint32_t fo, float (&nx)[3], bool act, int t, int r,
+                                           PipeBuf<DEG> &X, PipeBuf<DEG> &Y)
+{
+    const int q = c.q;
+    const const_u32 T = c.tab + r * LDPC_FAST_STRIDE;
+    const uint32_t prim = T[27];
+    const int ncf = (int)T[28];
+    const bool more = r + 1 < q;
+    const const_u32 Tn = c.tab + (more ? r + 1 : 0) * LDPC_FAST_STRIDE;
+    const int ne = more ? (int)Tn[29] : 0;
+    const bool mask0 = (r == 0) && (t == 0);
+    float cst1 = 0.f, cst2 = 0.f;
+    uint32_t tot = 0u, pkn = 0u;
+    if (act) {
+        cst1 = X.mn2 * c.alpha; cst2 = X.mn1 * c.alpha;
+        tot = (uint32_t)(__popc(X.sgn) & 1);
+        pkn = X.sgn ^ (tot ? ((1u << DEG) - 1u) : 0u);
+        if (more) {
+            // ---- layer r+1: addresses of every slot, loads of the early ones, packed state
+            pipe_addr<DEG, MODE>(c, Tn, Y);
+            pipe_loads_below<DEG, MODE>(c, fo, Y, ne);
+            Y.c1o = nx[0]; Y.c2o = nx[1]; Y.pko = __float_as_uint(nx[2]);
+            Y.mn1 = INFINITY; Y.mn2 = INFINITY; Y.sgn = 0u;
+            const int rn = r + 2 < q ? r + 2 : 0;
+            nx[0] = c.st_ld(fo, 0, rn); nx[1] = c.st_ld(fo, 1, rn); nx[2] = c.st_ld(fo, 2, rn);
+        }
+    }
+    if (ncf > 0) __syncthreads();         // every read of layer r precedes its writes
+    if (act) {
+        // ---- pass 2 of layer r
+        uint32_t idxn = 0u;
+        const float m1s = __uint_as_float(__float_as_uint(cst1) | (tot << 31)), m2s = __uint_as_float(__float_as_uint(cst2) | (tot << 31));
+#pragma unroll
+        for (int j = 0; j < DEG; j++) {
+            uint32_t off = ((prim >> j) & 1u) ? X.w[j] : c.redirect;
+            if (j == DEG - 1 && mask0) off = c.redirect;
+            const float x = X.v[j];
+            const bool ismin = fabsf(x) == X.mn1;
+            const float mag = ismin ? m1s : m2s;
+            const float nw = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(x) & 0x80000000u));
+            idxn = ismin ? (uint32_t)j : idxn;
+            c.post_st(off, fo, x + nw);
+        }
+        pkn |= idxn << 27;
+        c.st_st(fo, 0, r, cst1); c.st_st(fo, 1, r, cst2); c.st_st(fo, 2, r, __uint_as_float(pkn));
+    }
+    // ---- duplicate edges of a bit-group inside layer r: ordered delta updates
+    uint32_t prev_lvl = 0u;
+    for (int i = 0; i < ncf; i++) {
+        const uint32_t e = T[32 + i], meta = T[48 + i];
+        const uint32_t j = meta & 31u, lvl = meta >> 8;
+        if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
+        if (act) {
+            const uint32_t d = c.t4 - (e & 0x7FFu);
+            const uint32_t off = min(d, d + (uint32_t)ROW_BYTES) + (e >> 11);
+            const float nw = c2v_unpack_dyn<DEG>(cst1, cst2, pkn, j);
+            const float od = c2v_unpack_dyn<DEG>(X.c1o, X.c2o, X.pko, j);
+            const float L = c.post_ld(off, fo);
+            c.post_st(off, fo, L + (nw - od));
+        }
+    }
+    // ---- layer r+1, early slots: arithmetic while the stores of layer r drain
+    if (act && more) pipe_1b_below<DEG>(Y, false, ne);
+    __syncthreads();
+    if (act && more) {
+        pipe_loads_from<DEG, MODE>(c, fo, Y, ne);
+        pipe_1b_from<DEG>(Y, false, ne);
+    }
+}
+
+template <int DEG, int MODE>
+__device__ __forceinline__ void fast_iteration_pipe(const FastCtx<MODE> &c, uint32_t fo, float (&nx)[3], bool act, int t)
+{
+    PipeBuf<DEG> A, B;
+    const int q = c.q;
+    // ---- prologue: layer 0 in full (the previous iteration ended with a barrier)
+    if (act) {
+        pipe_addr<DEG, MODE>(c, c.tab, A);
+        pipe_loads_from<DEG, MODE>(c, fo, A, 0);
+        A.c1o = nx[0]; A.c2o = nx[1]; A.pko = __float_as_uint(nx[2]);
+        A.mn1 = INFINITY; A.mn2 = INFINITY; A.sgn = 0u;
+        const int rn = 1 < q ? 1 : 0;
+        nx[0] = c.st_ld(fo, 0, rn); nx[1] = c.st_ld(fo, 1, rn); nx[2] = c.st_ld(fo, 2, rn);
+        pipe_1b_from<DEG>(A, t == 0, 0);
+    }
+    int r = 0;
+    for (; r + 1 < q; r += 2) {
+        pipe_layer<DEG, MODE>(c, fo, nx, act, t, r, A, B);
+        pipe_layer<DEG, MODE>(c, fo, nx, act, t, r + 1, B, A);
+    }
+    if (r < q) pipe_layer<DEG, MODE>(c, fo, nx, act, t, r, A, B);
+}
+#undef PIPE_LD
+#undef PIPE_1B
+
 // syndrome of the hard decisions of one frame (enable_syndrome, depth 1): this lane's checks
 template <int DEG, int MODE>
 __device__ __forceinline__ int fast_syndrome(const FastCtx<MODE> &c, uint32_t fo, bool act, int t)
@@ -390,7 +666,7 @@ ldpc_fast_kernel(const LdpcKParams p)
 // the pace: measured, one 6-wave workgroup per CU runs as fast per frame as two.  Twelve waves are
 // dealt 3+3+3+3.  The halves share nothing but the barriers (both decode the same layer at the same
 // time); each has its own workspace slot, LDS image, iteration count and early-stop decision.
-template <int DEG, int MODE>
+template <int DEG, int MODE, bool PIPE>
 __global__ void __launch_bounds__(2 * LDPC_THREADS, 3)
 ldpc_fast2_kernel(const LdpcKParams p)
 {
@@ -431,7 +707,8 @@ ldpc_fast2_kernel(const LdpcKParams p)
         for (;;) {
             if (t == 0) s_flag[half] = 0;
             if (!__syncthreads_or(live ? 1 : 0)) break;          // also orders the flag reset
-            fast_iteration<DEG, MODE, 1>(c, fo, nx, act && live, t);
+            if (PIPE) fast_iteration_pipe<DEG, MODE>(c, 0u, nx[0], act && live, t);
+            else fast_iteration<DEG, MODE, 1>(c, fo, nx, act && live, t);
             int bad = 0;
             bool check = false;
             if (live) {
@@ -476,10 +753,10 @@ ldpc_fast2_kernel(const LdpcKParams p)
     }
 }
 
-template <int DEG, int MODE>
+template <int DEG, int MODE, bool PIPE>
 static hipError_t fast2_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
 {
-    auto kern = ldpc_fast2_kernel<DEG, MODE>;
+    auto kern = ldpc_fast2_kernel<DEG, MODE, PIPE>;
     static size_t configured = 0;
     const size_t lds = 2 * pl.lds_bytes;
     if (lds > configured) {
@@ -493,16 +770,114 @@ static hipError_t fast2_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream
     return hipGetLastError();
 }
 
-template <int DEG, int MODE>
+template <int DEG, int MODE, bool PIPE>
 static int fast2_occ(const LdpcPlan &pl)
 {
-    auto kern = ldpc_fast2_kernel<DEG, MODE>;
+    auto kern = ldpc_fast2_kernel<DEG, MODE, PIPE>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * pl.lds_bytes));
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 2 * LDPC_THREADS, 2 * pl.lds_bytes) != hipSuccess) nb = 1;
     if (const char *ev = getenv("DVBS2HIP_LDPC_BLOCKS_PER_CU")) { const int cap = atoi(ev); if (cap >= 1 && cap < nb) nb = cap; }
     return nb < 1 ? 1 : nb;
 }
+
+// ---- one frame per 6-wave workgroup, software-pipelined layers (up to 256 VGPRs)
+template <int DEG, int MODE>
+__global__ void __launch_bounds__(LDPC_THREADS, 2)
+ldpc_fastp_kernel(const LdpcKParams p)
+{
+    extern __shared__ float smem[];
+    const int t = threadIdx.x;
+    const bool act = t < LDPC_Z;
+    const int q = p.q;
+    float *gwork = p.gwork + (size_t)blockIdx.x * p.gwork_words;
+    FastCtx<MODE> c;
+    c.rs = __builtin_amdgcn_make_buffer_rsrc(gwork, 0, p.gwork_words * 4, 0x00020000);
+    c.lpost = (lds_float *)smem;
+    c.tab = (const_u32)p.fast_tab;
+    c.t4 = (uint32_t)t * 4u;
+    c.c2v_base = (uint32_t)p.glb_post_words * 4u;
+    c.redirect = MODE == 0 ? (uint32_t)p.n_groups * ROW_BYTES + c.t4 : OOB;
+    c.zero_row = 0u; c.junk_row = 0u;
+    c.M = p.M; c.q = q; c.alpha = p.alpha;
+    for (int f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
+        if (act) {
+            const float *Y = p.llr + (size_t)f * p.N;
+            for (int g = 0; g < p.n_groups; g++) {
+                const int src = g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info);
+                c.post_st(c.t4, (uint32_t)g * ROW_BYTES, Y[src]);
+            }
+            for (int r = 0; r < q; r++) { c.st_st(0u, 0, r, 0.f); c.st_st(0u, 1, r, 0.f); c.st_st(0u, 2, r, 0.f); }
+        }
+        __syncthreads();
+        int it = 0;
+        bool ok = false;
+        float nx[3] = {0.f, 0.f, 0.f};
+        while (it < p.n_ite) {
+            fast_iteration_pipe<DEG, MODE>(c, 0u, nx, act, t);
+            it++;
+            if (p.early_stop || it == p.n_ite) {
+                ok = !__syncthreads_or(fast_syndrome<DEG, MODE>(c, 0u, act, t));
+                if (ok) break;
+            }
+        }
+        if (t == 0) {
+            if (p.cwd) p.cwd[f] = ok ? 1 : 0;
+            if (p.ites) p.ites[f] = it;
+        }
+        if (act) {
+            for (int g = 0; g < p.n_info; g++) {
+                const float L = c.post_ld(c.t4, (uint32_t)g * ROW_BYTES);
+                if (p.bits) p.bits[(size_t)f * p.K + g * LDPC_Z + t] = L < 0.f ? 1 : 0;
+                if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + t] = L;
+            }
+            if (p.post)
+                for (int g = p.n_info; g < p.n_groups; g++)
+                    p.post[(size_t)f * p.N + p.K + q * t + (g - p.n_info)] = c.post_ld(c.t4, (uint32_t)g * ROW_BYTES);
+        }
+        if (p.packed) {
+            const int n_words = (p.K + 31) / 32;
+            for (int wd = t; wd < n_words; wd += LDPC_THREADS) {
+                uint32_t word = 0u;
+                for (int b = 0; b < 32; b++) {
+                    const int i = 32 * wd + b;
+                    if (i >= p.K) break;
+                    word |= (c.post_ld((uint32_t)i * 4u, 0u) < 0.f ? 1u : 0u) << b;
+                }
+                p.packed[(size_t)f * n_words + wd] = word;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int DEG, int MODE>
+static hipError_t fastp_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
+{
+    auto kern = ldpc_fastp_kernel<DEG, MODE>;
+    static size_t configured = 0;
+    if (pl.lds_bytes > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
+        if (e != hipSuccess) return e;
+        configured = pl.lds_bytes;
+    }
+    const int grid = p.n_frames < pl.grid_max ? p.n_frames : pl.grid_max;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_THREADS), pl.lds_bytes, s, p);
+    return hipGetLastError();
+}
+template <int DEG, int MODE>
+static int fastp_occ(const LdpcPlan &pl)
+{
+    auto kern = ldpc_fastp_kernel<DEG, MODE>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, LDPC_THREADS, pl.lds_bytes) != hipSuccess) nb = 1;
+    if (const char *ev = getenv("DVBS2HIP_LDPC_BLOCKS_PER_CU")) { const int cap = atoi(ev); if (cap >= 1 && cap < nb) nb = cap; }
+    return nb < 1 ? 1 : nb;
+}
+#define FASTP_DISPATCH(FN, ...)                                                                   \
+    (pl.deg_max == 27 ? (pl.fast_mode == 0 ? FN<27, 0>(__VA_ARGS__) : FN<27, 1>(__VA_ARGS__))      \
+                      : (pl.fast_mode == 0 ? FN<11, 0>(__VA_ARGS__) : FN<11, 1>(__VA_ARGS__)))
 
 template <int DEG, int MODE, int NF>
 static hipError_t fast_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
@@ -538,22 +913,26 @@ static int fast_occ(const LdpcPlan &pl)
      : (pl.fast_nf == 2 ? FN<D, 1, 2>(__VA_ARGS__) : FN<D, 1, 1>(__VA_ARGS__)))
 #define FAST_DISPATCH(FN, ...) (pl.deg_max == 27 ? FAST_DISPATCH_D(27, FN, __VA_ARGS__) : FAST_DISPATCH_D(11, FN, __VA_ARGS__))
 
+// (the pipelined iteration needs ~230 VGPRs at DEG 27: more than the 168 a 12-wave workgroup may use)
 #define FAST2_DISPATCH(FN, ...)                                                                   \
-    (pl.deg_max == 27 ? (pl.fast_mode == 0 ? FN<27, 0>(__VA_ARGS__) : FN<27, 1>(__VA_ARGS__))      \
-                      : (pl.fast_mode == 0 ? FN<11, 0>(__VA_ARGS__) : FN<11, 1>(__VA_ARGS__)))
+    (pl.deg_max == 27 ? (pl.fast_mode == 0 ? FN<27, 0, false>(__VA_ARGS__) : FN<27, 1, false>(__VA_ARGS__))      \
+                      : (pl.fast_pipe ? (pl.fast_mode == 0 ? FN<11, 0, true>(__VA_ARGS__) : FN<11, 1, true>(__VA_ARGS__)) \
+                                      : (pl.fast_mode == 0 ? FN<11, 0, false>(__VA_ARGS__) : FN<11, 1, false>(__VA_ARGS__))))
 
 int ldpc_fast_blocks_per_cu(const LdpcPlan &pl)
 {
     if (pl.fast_wf == 2) return FAST2_DISPATCH(fast2_occ, pl);
+    if (pl.fast_pipe && pl.fast_mode != 2 && pl.fast_nf == 1) return FASTP_DISPATCH(fastp_occ, pl);
     return FAST_DISPATCH(fast_occ, pl);
 }
 
 hipError_t ldpc_fast_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
-    p.fast_tab = pl.d_fast_tab; p.groups = pl.d_groups;
+    p.fast_tab = pl.d_fast_tab; p.groups = pl.d_groups; p.pipe = pl.fast_pipe ? 1 : 0;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.lds_post_words = pl.lds_post_words; p.glb_post_words = pl.glb_post_words; p.gwork_words = pl.gwork_words;
     if (pl.fast_wf == 2) return FAST2_DISPATCH(fast2_inst, pl, p, s);
+    if (pl.fast_pipe && pl.fast_mode != 2 && pl.fast_nf == 1) return FASTP_DISPATCH(fastp_inst, pl, p, s);
     return FAST_DISPATCH(fast_inst, pl, p, s);
 }
 

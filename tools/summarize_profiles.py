@@ -10,8 +10,8 @@ PROF = os.path.join(ROOT, "profiles")
 os.makedirs(PROF, exist_ok=True)
 
 def first(pattern):
-    g = sorted(glob.glob(os.path.join(OUT, pattern)))
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(OUT, pattern)), key=os.path.getmtime)
+    return g[-1] if g else None
 
 def short(name):
     name = name.replace("void ", "")
