@@ -49,7 +49,7 @@ struct dvbs2hip_handle {
     int32_t *d_enc_deg = nullptr;
     float *d_plh = nullptr;
     int enc_stride = 0;
-    unsigned long long bch_g[3] = {0, 0, 0};
+    unsigned long long *d_bch_tab = nullptr;
     std::map<int, DevBuf> bufs;        // lazily grown staging / intermediate buffers
     // timing
     bool timing = false;
@@ -263,7 +263,27 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         if (upload(h, &h->d_enc_tab, tab.data(), tab.size()) || upload(h, &h->d_enc_deg, deg.data(), deg.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
         const std::vector<uint8_t> g = bch_generator(h->bch);
         if ((int)g.size() - 1 != cfg->K_ldpc - cfg->K_bch || g.size() > 193) CREATE_FAIL(DVBS2HIP_EINVAL, "BCH generator degree does not match N_bch - K_bch");
-        for (size_t i = 0; i + 1 < g.size(); i++) if (g[i]) h->bch_g[i / 64] |= 1ull << (i % 64);
+        {   // byte-wise encoder table: T[u] = (u(x) x^r) mod g(x), u's bit 7 = highest degree
+            const int r = (int)g.size() - 1;
+            unsigned long long gl[3] = {0, 0, 0};
+            for (int i = 0; i < r; i++) if (g[i]) gl[i / 64] |= 1ull << (i % 64);
+            std::vector<unsigned long long> tab(256 * 3, 0ull);
+            for (int u = 0; u < 256; u++) {
+                unsigned long long s[3] = {0, 0, 0};
+                for (int b = 7; b >= 0; b--) {
+                    const int top = r - 1;
+                    const unsigned fb = (unsigned)((s[top / 64] >> (top % 64)) & 1ull) ^ ((u >> b) & 1u);
+                    s[2] = (s[2] << 1) | (s[1] >> 63); s[1] = (s[1] << 1) | (s[0] >> 63); s[0] <<= 1;
+                    for (int w = 0; w < 3; w++) {       // keep r bits
+                        const int lo = 64 * w;
+                        if (r <= lo) s[w] = 0; else if (r < lo + 64) s[w] &= (1ull << (r - lo)) - 1ull;
+                    }
+                    if (fb) { s[0] ^= gl[0]; s[1] ^= gl[1]; s[2] ^= gl[2]; }
+                }
+                tab[3 * u] = s[0]; tab[3 * u + 1] = s[1]; tab[3 * u + 2] = s[2];
+            }
+            if (upload(h, &h->d_bch_tab, tab.data(), tab.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+        }
         // PLHEADER = 26 SOF + 64 PLS symbols, pi/2-BPSK (Framer.hxx:97-196)
         static const int G[7][32] = {
             {1,0,0,1,0,0,0,0,1,0,1,0,1,1,0,0,0,0,1,0,1,1,0,1,1,1,0,1,1,1,0,1}, {0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1},
@@ -330,7 +350,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
         for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     void *ptrs[] = {h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
-                    h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh};
+                    h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -714,7 +734,7 @@ int dvbs2hip_tx_bb_dev(dvbs2hip_t *h, const int32_t *info_in, uint64_t seed, con
     p.info_in = info_in; p.info_out = info_out; p.sigma = sigma; p.pl_out = pl;
     p.bch_cw = (uint32_t *)dbch; p.ldpc_cw = (uint32_t *)dldpc; p.prbs = h->bch.d_prbs;
     p.enc_tab = h->d_enc_tab; p.enc_deg = h->d_enc_deg; p.cstl = h->d_cstl; p.plh = h->d_plh; p.pl_seq = h->d_pl_seq;
-    for (int i = 0; i < 3; i++) p.bch_g[i] = h->bch_g[i];
+    p.bch_tab = h->d_bch_tab;
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
     p.K_bch = h->K_bch; p.K_ldpc = h->K_ldpc; p.N_ldpc = h->N_ldpc; p.bps = h->bps; p.itl_cols = h->itl_cols; p.itl_order = h->itl_order;
     p.n_sym = h->n_sym; p.pl_frame = h->pl_frame; p.enc_stride = h->enc_stride; p.n_frames = F;

@@ -145,7 +145,7 @@ struct TxKParams {
     const float *cstl;          // normalised constellation
     const float *plh;           // 180 floats: PLHEADER
     const uint8_t *pl_seq;
-    unsigned long long bch_g[3];  // generator without its leading term, bit i = coeff of x^i
+    const unsigned long long *bch_tab;  // [256][3]: (u(x) x^r) mod g(x), byte-wise systematic encoder
     uint32_t seed_lo, seed_hi;
     int32_t K_bch, K_ldpc, N_ldpc, bps, itl_cols, itl_order, n_sym, pl_frame, enc_stride, n_frames;
 };

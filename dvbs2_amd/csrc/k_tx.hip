@@ -24,41 +24,67 @@ __device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key)
     return ctr;
 }
 
-// ---------------------------------------------------------------- source + BB scramble + BCH encode
-// One LANE per frame: the systematic encoder is a 2^m-ary LFSR division, serial in the bit
-// index; the batch supplies the parallelism.  r = N - K <= 192 parity bits in three 64-bit words.
-__global__ void __launch_bounds__(64)
-tx_bch_kernel(const TxKParams p)
+// ---------------------------------------------------------------- source + BB scramble (coalesced, one workgroup per frame)
+__global__ void __launch_bounds__(256)
+tx_src_kernel(const TxKParams p)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ uint32_t wsm[];                          // payload, packed
+    const int f = blockIdx.x, tid = threadIdx.x, K = p.K_bch;
+    const int nwk = (K + 31) / 32, nw_out = (p.K_ldpc + 31) / 32;
+    for (int w = tid; w < nwk; w += 256) {
+        uint32_t word = 0u;
+        if (p.info_in) {
+            const int32_t *src = p.info_in + (size_t)f * K + 32 * w;
+            for (int b = 0; b < 32 && 32 * w + b < K; b++) word |= ((uint32_t)src[b] & 1u) << b;
+        } else {
+            const uint4 r = philox4x32(make_uint4((uint32_t)(w >> 2), (uint32_t)f, 0u, 0u), make_uint2(p.seed_lo, p.seed_hi));
+            word = (w & 3) == 0 ? r.x : (w & 3) == 1 ? r.y : (w & 3) == 2 ? r.z : r.w;
+            if (32 * w + 32 > K) word &= (1u << (K - 32 * w)) - 1u;
+        }
+        wsm[w] = word;
+        p.bch_cw[(size_t)f * nw_out + w] = word ^ p.prbs[w];    // Scrambler_BB (prbs tail bits are zero)
+    }
+    __syncthreads();
+    if (p.info_out)
+        for (int k = tid; k < K; k += 256) p.info_out[(size_t)f * K + k] = (int32_t)((wsm[k >> 5] >> (k & 31)) & 1u);
+}
+
+// ---------------------------------------------------------------- BCH parity (Encoder_BCH_DVBS2.cpp:28-43)
+// One LANE per frame: the systematic encoder is a polynomial division, serial along the frame; the
+// batch supplies the parallelism.  A byte per step through a 256-entry table of (u(x) x^r) mod g(x)
+// held in LDS, r = N - K <= 192 parity bits in three 64-bit words.
+__global__ void __launch_bounds__(64)
+tx_bchpar_kernel(const TxKParams p)
+{
+    __shared__ unsigned long long T[256][3];
+    __shared__ uint8_t brev[256];
+    for (int i = threadIdx.x; i < 256; i += 64) {
+        T[i][0] = p.bch_tab[3 * i]; T[i][1] = p.bch_tab[3 * i + 1]; T[i][2] = p.bch_tab[3 * i + 2];
+        uint32_t r = 0; for (int b = 0; b < 8; b++) if (i >> b & 1) r |= 1u << (7 - b);
+        brev[i] = (uint8_t)r;
+    }
+    __syncthreads();
+    const int f = blockIdx.x * 64 + threadIdx.x;
     if (f >= p.n_frames) return;
     const int K = p.K_bch, r = p.K_ldpc - p.K_bch;
     const int nw_out = (p.K_ldpc + 31) / 32;
     uint32_t *cw = p.bch_cw + (size_t)f * nw_out;
-    unsigned long long s0 = 0, s1 = 0, s2 = 0;                 // remainder, bit i = coeff of x^i
-    const unsigned long long g0 = p.bch_g[0], g1 = p.bch_g[1], g2 = p.bch_g[2];
-    const int top = r - 1;
-    uint32_t outw = 0;
-    uint4 rnd = make_uint4(0, 0, 0, 0);
-    for (int k = 0; k < K; k++) {
-        uint32_t u;
-        if (p.info_in) u = (uint32_t)p.info_in[(size_t)f * K + k] & 1u;
-        else {
-            if ((k & 127) == 0) rnd = philox4x32(make_uint4((uint32_t)(k >> 7), (uint32_t)f, 0u, 0u), make_uint2(p.seed_lo, p.seed_hi));
-            const uint32_t w = (k & 127) < 32 ? rnd.x : (k & 127) < 64 ? rnd.y : (k & 127) < 96 ? rnd.z : rnd.w;
-            u = (w >> (k & 31)) & 1u;
-        }
-        if (p.info_out) p.info_out[(size_t)f * K + k] = (int32_t)u;
-        u ^= (p.prbs[k >> 5] >> (k & 31)) & 1u;                 // Scrambler_BB
-        // LFSR step, highest-degree message coefficient first
-        const uint32_t msb = top < 64 ? (uint32_t)(s0 >> top) & 1u : top < 128 ? (uint32_t)(s1 >> (top - 64)) & 1u : (uint32_t)(s2 >> (top - 128)) & 1u;
-        const uint32_t fb = u ^ msb;
-        s2 = (s2 << 1) | (s1 >> 63); s1 = (s1 << 1) | (s0 >> 63); s0 <<= 1;
-        if (fb) { s0 ^= g0; s1 ^= g1; s2 ^= g2; }
-        outw |= u << (k & 31);
-        if ((k & 31) == 31) { cw[k >> 5] = outw; outw = 0; }
+    unsigned long long s0 = 0, s1 = 0, s2 = 0;
+    const int tw = (r - 8) >> 6, ts = (r - 8) & 63;            // where the top byte of the remainder sits
+    const unsigned long long m1 = r >= 128 ? ~0ull : r > 64 ? (1ull << (r - 64)) - 1ull : 0ull;
+    const unsigned long long m2 = r >= 192 ? ~0ull : r > 128 ? (1ull << (r - 128)) - 1ull : 0ull;
+    uint32_t word = 0;
+    for (int by = 0; by < K / 8; by++) {
+        if ((by & 3) == 0) word = cw[by >> 2];
+        const uint32_t raw = (word >> ((by & 3) * 8)) & 0xFFu;
+        const uint32_t top = (uint32_t)((tw == 0 ? s0 : tw == 1 ? s1 : s2) >> ts) & 0xFFu;
+        const uint32_t idx = top ^ brev[raw];
+        s2 = ((s2 << 8) | (s1 >> 56)) & m2; s1 = ((s1 << 8) | (s0 >> 56)) & m1; s0 <<= 8;
+        if (r <= 64) s0 &= (r == 64 ? ~0ull : (1ull << r) - 1ull);
+        s0 ^= T[idx][0]; s1 ^= T[idx][1]; s2 ^= T[idx][2];
     }
-    // parity, coefficient of x^(r-1) first (DVB-S2 order)
+    // parity, coefficient of x^(r-1) first (DVB-S2 order), appended at bit K of the packed frame
+    uint32_t outw = (K & 31) ? cw[K >> 5] : 0u;
     for (int j = 0; j < r; j++) {
         const int d = r - 1 - j, k = K + j;
         const uint32_t b = d < 64 ? (uint32_t)(s0 >> d) & 1u : d < 128 ? (uint32_t)(s1 >> (d - 64)) & 1u : (uint32_t)(s2 >> (d - 128)) & 1u;
@@ -170,8 +196,11 @@ tx_mod_kernel(const TxKParams p)
 
 hipError_t tx_launch(const TxKParams &p, hipStream_t s)
 {
-    hipLaunchKernelGGL(tx_bch_kernel, dim3((p.n_frames + 63) / 64), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(tx_src_kernel, dim3(p.n_frames), dim3(256), (size_t)((p.K_bch + 31) / 32) * 4, s, p);
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tx_bchpar_kernel, dim3((p.n_frames + 63) / 64), dim3(64), 0, s, p);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t lds = (size_t)((p.K_ldpc + 31) / 32) * 4 + (size_t)(p.N_ldpc - p.K_ldpc) + 512;
     hipLaunchKernelGGL(tx_ldpc_kernel, dim3(p.n_frames), dim3(LDPC_THREADS), lds, s, p);
