@@ -42,6 +42,9 @@ struct dvbs2hip_handle {
     float *d_taps_rev = nullptr;
     float *d_hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
+    float *d_taps = nullptr;            // natural order (shaping filter)
+    float *d_uphist[2] = {nullptr, nullptr};
+    int uphist_cur = 0;
     unsigned long long *d_ctr = nullptr;
     float *d_gwork = nullptr;
     // TX mirror (N1)
@@ -331,6 +334,8 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         if (upload(h, &h->d_taps_rev, rev.data(), rev.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
         const size_t hb = sizeof(float) * 2 * (size_t)(h->fir_T > 1 ? h->fir_T - 1 : 1);
         for (int i = 0; i < 2; i++) { CREATE_HIP(hipMalloc((void **)&h->d_hist[i], hb)); CREATE_HIP(hipMemset(h->d_hist[i], 0, hb)); }
+        if (upload(h, &h->d_taps, cfg->fir_taps, (size_t)h->fir_T)) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+        for (int i = 0; i < 2; i++) { CREATE_HIP(hipMalloc((void **)&h->d_uphist[i], hb)); CREATE_HIP(hipMemset(h->d_uphist[i], 0, hb)); }
     }
     CREATE_HIP(hipMalloc((void **)&h->d_ctr, 3 * sizeof(unsigned long long)));
     CREATE_HIP(hipMemset(h->d_ctr, 0, 3 * sizeof(unsigned long long)));
@@ -350,7 +355,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
         for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     void *ptrs[] = {h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
-                    h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab};
+                    h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -568,7 +573,61 @@ int dvbs2hip_filter_reset(dvbs2hip_t *h)
 {
     if (!h) return DVBS2HIP_EINVAL;
     if (h->fir_T > 1)
-        for (int i = 0; i < 2; i++) HIPCHK(h, hipMemsetAsync(h->d_hist[i], 0, sizeof(float) * 2 * (h->fir_T - 1), h->stream));
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(h, hipMemsetAsync(h->d_hist[i], 0, sizeof(float) * 2 * (h->fir_T - 1), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->d_uphist[i], 0, sizeof(float) * 2 * (h->fir_T - 1), h->stream));
+        }
+    return 0;
+}
+
+// ------------------------------------------------------------------ N2: shaping filter, channel noise, perfect timing
+int dvbs2hip_shape_filter_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X || !Y) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    if (h->fir_T <= 0) return fail(h, DVBS2HIP_EUNSUPPORTED, "handle was created without filter taps");
+    if (n_cplx < 1) return fail(h, DVBS2HIP_EINVAL, "'n_cplx' has to be greater than 0");
+    Timer tm(h, DVBS2HIP_K_FIR);
+    HIPCHK(h, upfir_launch(X, Y, h->d_uphist[h->uphist_cur], h->d_uphist[h->uphist_cur ^ 1], h->d_taps, h->fir_T, h->fir_osf,
+                           (long long)n_cplx * F, h->stream));
+    h->uphist_cur ^= 1;
+    return 0;
+}
+
+int dvbs2hip_shape_filter(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx, int32_t F)
+{
+    const size_t n = (size_t)2 * (n_cplx > 0 ? n_cplx : 0);
+    return host_wrap(h, X, n, Y, n * (h ? h->fir_osf : 1), F, [&](const float *a, float *b) { return dvbs2hip_shape_filter_dev(h, a, b, n_cplx, F); });
+}
+
+int dvbs2hip_add_noise_dev(dvbs2hip_t *h, const float *CP, const float *X, float *Y, uint64_t seed, int32_t n_elmts, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!CP || !X || !Y) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    if (n_elmts < 2 || (n_elmts & 1)) return fail(h, DVBS2HIP_EINVAL, "'n_elmts' has to be a positive even number");
+    Timer tm(h, DVBS2HIP_K_MISC);
+    HIPCHK(h, awgn_launch(X, Y, CP, seed, n_elmts / 2, F, h->stream));
+    return 0;
+}
+
+int dvbs2hip_add_noise(dvbs2hip_t *h, const float *CP, const float *X, float *Y, uint64_t seed, int32_t n_elmts, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!CP) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    void *dsig;
+    if ((r = ensure(h, B_SIG, (size_t)F * 4, &dsig))) return r;
+    HIPCHK(h, hipMemcpyAsync(dsig, CP, (size_t)F * 4, hipMemcpyHostToDevice, h->stream));
+    const size_t n = n_elmts > 0 ? (size_t)n_elmts : 0;
+    return host_wrap(h, X, n, Y, n, F, [&](const float *a, float *b) { return dvbs2hip_add_noise_dev(h, (const float *)dsig, a, b, seed, n_elmts, F); });
+}
+
+int dvbs2hip_extract_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx_out, int32_t osf, int64_t offset, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X || !Y) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    if (n_cplx_out < 1 || osf < 1) return fail(h, DVBS2HIP_EINVAL, "'n_cplx_out' and 'osf' have to be greater than 0");
+    Timer tm(h, DVBS2HIP_K_MISC);
+    HIPCHK(h, decimate_launch(X, Y, (long long)n_cplx_out * F, osf, offset, (long long)n_cplx_out * F * osf, h->stream));
     return 0;
 }
 

@@ -157,4 +157,9 @@ std::vector<uint8_t> bch_generator(const BchPlan &pl);
 hipError_t fir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps_rev,
                       int T, long long n_total, hipStream_t s);
 
+hipError_t upfir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps, int T, int osf,
+                        long long n_in, hipStream_t s);
+hipError_t decimate_launch(const float *x, float *y, long long n_out, int osf, long long offset, long long n_in, hipStream_t s);
+hipError_t awgn_launch(const float *x, float *y, const float *sigma, unsigned long long seed, long long n_pairs, int F, hipStream_t s);
+
 }  // namespace dvbs2

@@ -109,4 +109,73 @@ hipError_t fir_launch(const float *x, float *y, const float *hist_in, float *his
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------- N2: TX shaping filter (polyphase up-sampling FIR)
+// Replaces Filter_UPRRC_ccr_naive / Filter_UPFIR_ccr_naive::_filter
+// (/root/reference src/common/Module/Filter/Filter_UPFIR/Filter_UPFIR_ccr_naive.cpp:52-66): a bank of
+// `osf` FIRs, branch f holds taps H[f], H[f+osf], ..; output sample i*osf + f = branch f at input i:
+//     y[i*osf + f] = sum_m H[f + m*osf] * x[i - m]
+// One lane per output sample, inputs staged in LDS; x[<0] = tail of the previous call.
+constexpr int UP_THREADS = 256;
+__global__ void __launch_bounds__(UP_THREADS)
+upfir_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const float2 *__restrict__ hist_in, const float *__restrict__ taps,
+             int T, int osf, int Hin, long long n_in)
+{
+    extern __shared__ float2 xt[];                 // (UP_THREADS / osf + Hin) input samples, then the taps
+    const int per_blk = UP_THREADS / osf;          // input samples per workgroup
+    float *tp = reinterpret_cast<float *>(xt + per_blk + Hin);
+    const long long in0 = (long long)blockIdx.x * per_blk;
+    for (int s = threadIdx.x; s < per_blk + Hin; s += UP_THREADS) {
+        const long long gi = in0 - Hin + s;
+        float2 v = make_float2(0.f, 0.f);
+        if (gi < 0) v = hist_in[Hin + gi]; else if (gi < n_in) v = x[gi];
+        xt[s] = v;
+    }
+    for (int s = threadIdx.x; s < T; s += UP_THREADS) tp[s] = taps[s];
+    __syncthreads();
+    const int li = threadIdx.x / osf, f = threadIdx.x - li * osf;
+    const long long i = in0 + li;
+    if (li >= per_blk || i >= n_in) return;
+    float2 acc = make_float2(0.f, 0.f);
+    for (int m = 0, j = f; j < T; m++, j += osf) {
+        const float2 v = xt[Hin + li - m];
+        acc.x = fmaf(tp[j], v.x, acc.x); acc.y = fmaf(tp[j], v.y, acc.y);
+    }
+    y[i * osf + f] = acc;
+}
+
+hipError_t upfir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps, int T, int osf,
+                        long long n_in, hipStream_t s)
+{
+    if (T < 1 || T > FIR_TMAX || osf < 1 || osf > 16) return hipErrorInvalidValue;
+    const int Hin = (T - 1) / osf;                 // input samples of memory
+    const int per_blk = UP_THREADS / osf;
+    const size_t lds = sizeof(float2) * (size_t)(per_blk + Hin) + sizeof(float) * (size_t)T;
+    const unsigned grid = (unsigned)((n_in + per_blk - 1) / per_blk);
+    hipLaunchKernelGGL(upfir_kernel, dim3(grid), dim3(UP_THREADS), lds, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<float2 *>(y),
+                       reinterpret_cast<const float2 *>(hist_in), taps, T, osf, Hin, n_in);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (Hin > 0)
+        hipLaunchKernelGGL(fir_hist_kernel, dim3((Hin + 63) / 64), dim3(64), 0, s, reinterpret_cast<const float2 *>(x),
+                           reinterpret_cast<const float2 *>(hist_in), reinterpret_cast<float2 *>(hist_out), Hin, n_in);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- perfect-timing extraction: y[i] = x[offset + i * osf]
+// (what Synchronizer_timing_perfect does once the delay is known: DVBS2.cpp:558-570)
+__global__ void decimate_kernel(const float2 *x, float2 *y, long long n_out, int osf, long long offset, long long n_in)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const long long s = offset + i * osf;
+    y[i] = (s >= 0 && s < n_in) ? x[s] : make_float2(0.f, 0.f);
+}
+hipError_t decimate_launch(const float *x, float *y, long long n_out, int osf, long long offset, long long n_in, hipStream_t s)
+{
+    hipLaunchKernelGGL(decimate_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(x),
+                       reinterpret_cast<float2 *>(y), n_out, osf, offset, n_in);
+    return hipGetLastError();
+}
+
 }  // namespace dvbs2

@@ -194,6 +194,28 @@ tx_mod_kernel(const TxKParams p)
     reinterpret_cast<float2 *>(p.pl_out + (size_t)f * 2 * p.pl_frame)[i] = y;
 }
 
+// Channel_AWGN::add_noise (DVBS2.cpp:593-613): Y = X + sigma[f] * n, n ~ N(0,1) per real value.
+// Philox counter = (pair index, frame, stream 2): independent of the launch geometry.
+__global__ void awgn_kernel(const float2 *x, float2 *y, const float *sigma, uint32_t seed_lo, uint32_t seed_hi, long long n_pairs)
+{
+    const int f = blockIdx.y;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const uint4 r = philox4x32(make_uint4((uint32_t)i, (uint32_t)f, 2u, (uint32_t)(i >> 32)), make_uint2(seed_lo, seed_hi));
+    const float u1 = ((float)r.x + 1.0f) * 2.3283064365386963e-10f, u2 = (float)r.y * 2.3283064365386963e-10f;
+    const float rad = sigma[f] * sqrtf(-2.0f * logf(u1));
+    float sn, cn;
+    sincosf(6.283185307179586f * u2, &sn, &cn);
+    const float2 v = x[(size_t)f * n_pairs + i];
+    y[(size_t)f * n_pairs + i] = make_float2(v.x + rad * cn, v.y + rad * sn);
+}
+hipError_t awgn_launch(const float *x, float *y, const float *sigma, unsigned long long seed, long long n_pairs, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(awgn_kernel, dim3((unsigned)((n_pairs + 255) / 256), F), dim3(256), 0, s, reinterpret_cast<const float2 *>(x),
+                       reinterpret_cast<float2 *>(y), sigma, (uint32_t)seed, (uint32_t)(seed >> 32), n_pairs);
+    return hipGetLastError();
+}
+
 hipError_t tx_launch(const TxKParams &p, hipStream_t s)
 {
     hipLaunchKernelGGL(tx_src_kernel, dim3(p.n_frames), dim3(256), (size_t)((p.K_bch + 31) / 32) * 4, s, p);

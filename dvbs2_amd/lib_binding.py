@@ -84,6 +84,11 @@ ABI = {
     "dvbs2hip_rx_bb_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_tx_bb": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _i]),
     "dvbs2hip_tx_bb_dev": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _i]),
+    "dvbs2hip_shape_filter": (C.c_int, [_vp, _vp, _vp, _i, _i]),
+    "dvbs2hip_shape_filter_dev": (C.c_int, [_vp, _vp, _vp, _i, _i]),
+    "dvbs2hip_add_noise": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, _i, _i]),
+    "dvbs2hip_add_noise_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, _i, _i]),
+    "dvbs2hip_extract_dev": (C.c_int, [_vp, _vp, _vp, _i, _i, C.c_int64, _i]),
     "dvbs2hip_timing_enable": (C.c_int, [_vp, _i]),
     "dvbs2hip_timing_reset": (C.c_int, [_vp]),
     "dvbs2hip_timing_get": (C.c_int, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

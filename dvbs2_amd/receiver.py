@@ -234,6 +234,29 @@ class Dvbs2Hip:
     def tx_bb_dev(self, info_in, seed, sigma, info_out, pl_frames, n_frames):
         self._chk(self.L.dvbs2hip_tx_bb_dev(self.h, _ptr(info_in), int(seed), _ptr(sigma), _ptr(info_out), _ptr(pl_frames), n_frames))
 
+    # ------------------------------------------------------------------ N2: shaping filter, noise, perfect timing
+    def shape_filter(self, X_N1, n_frames=1, osf=2):
+        X = np.ascontiguousarray(X_N1, dtype=np.float32).ravel()
+        out = np.empty(X.size * osf, dtype=np.float32)
+        self._chk(self.L.dvbs2hip_shape_filter(self.h, _ptr(X), _ptr(out), X.size // (2 * n_frames), n_frames))
+        return out
+
+    def shape_filter_dev(self, X, Y, n_cplx, n_frames):
+        self._chk(self.L.dvbs2hip_shape_filter_dev(self.h, _ptr(X), _ptr(Y), n_cplx, n_frames))
+
+    def add_noise(self, sigma, X_N, seed=0, n_frames=1):
+        X = np.ascontiguousarray(X_N, dtype=np.float32).ravel()
+        sg = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, dtype=np.float32).ravel(), (n_frames,)))
+        out = np.empty_like(X)
+        self._chk(self.L.dvbs2hip_add_noise(self.h, _ptr(sg), _ptr(X), _ptr(out), int(seed), X.size // n_frames, n_frames))
+        return out
+
+    def add_noise_dev(self, sigma, X, Y, seed, n_elmts, n_frames):
+        self._chk(self.L.dvbs2hip_add_noise_dev(self.h, _ptr(sigma), _ptr(X), _ptr(Y), int(seed), n_elmts, n_frames))
+
+    def extract_dev(self, X, Y, n_cplx_out, osf, offset, n_frames):
+        self._chk(self.L.dvbs2hip_extract_dev(self.h, _ptr(X), _ptr(Y), n_cplx_out, osf, int(offset), n_frames))
+
     # ------------------------------------------------------------------ measurement
     def timing_enable(self, on=True):
         self._chk(self.L.dvbs2hip_timing_enable(self.h, 1 if on else 0))

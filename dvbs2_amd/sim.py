@@ -35,6 +35,10 @@ def build_parser():
     ap.add_argument("--est-type", default="DVBS2", choices=["DVBS2", "PERFECT"])
     ap.add_argument("--max-frames", type=int, default=10_000_000, help="cap on frames per noise point (all ranks)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--filtered", action="store_true",
+                    help="TX shaping filter -> AWGN at the sample rate -> matched filter -> perfect-timing extraction "
+                         "(the filtered loop of src/mains/TX_RX/main.cpp with --perfect-sync); the last frame of every batch "
+                         "is cut by the filters' delay and not counted")
     ap.add_argument("--json", default=None, help="also write the rows as JSON")
     return ap
 
@@ -65,6 +69,10 @@ def run(args, out=sys.stdout):
     sent = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev)
     got = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev)
     sig = torch.empty((F,), dtype=torch.float32, device=dev)
+    osf, delay = 2, 80                       # Shaping_filter.hpp:24-28: osf 2, two group delays of 20 symbols
+    if args.filtered:
+        up = torch.empty((F, 2 * rx.pl_frame * osf), dtype=torch.float32, device=dev)
+        up2 = torch.empty_like(up)
     torch.cuda.synchronize()
 
     rows = []
@@ -92,9 +100,16 @@ def run(args, out=sys.stdout):
         while tot[2] < args.max_fe and tot[0] < args.max_frames:
             seed = (args.seed << 40) + (batch_id << 8) + rank
             batch_id += 1
-            rx.tx_bb_dev(None, seed, sig.data_ptr(), sent.data_ptr(), pl.data_ptr(), F)
+            if args.filtered:
+                rx.tx_bb_dev(None, seed, None, sent.data_ptr(), pl.data_ptr(), F)
+                rx.shape_filter_dev(pl.data_ptr(), up.data_ptr(), rx.pl_frame, F)
+                rx.add_noise_dev(sig.data_ptr(), up.data_ptr(), up2.data_ptr(), seed, 2 * rx.pl_frame * osf, F)
+                rx.filter_dev(up2.data_ptr(), up.data_ptr(), rx.pl_frame * osf, F)
+                rx.extract_dev(up.data_ptr(), pl.data_ptr(), rx.pl_frame, osf, delay, F)
+            else:
+                rx.tx_bb_dev(None, seed, sig.data_ptr(), sent.data_ptr(), pl.data_ptr(), F)
             rx.rx_bb_dev(pl.data_ptr(), sig.data_ptr() if args.est_type == "PERFECT" else None, got.data_ptr(), None, None, F)
-            rx.check_errors_dev(sent.data_ptr(), got.data_ptr(), F)
+            rx.check_errors_dev(sent.data_ptr(), got.data_ptr(), F - 1 if args.filtered else F)
             tot = reduce_counters(list(rx.monitor_get()), dev)       # syncs the stream; 24-byte all-reduce
         et = reduce_max(time.perf_counter() - t0, dev)
         fra, be, fe = tot

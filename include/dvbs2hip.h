@@ -228,6 +228,21 @@ int dvbs2hip_tx_bb(dvbs2hip_t *h, const int32_t *info_in, uint64_t seed, const f
 int dvbs2hip_tx_bb_dev(dvbs2hip_t *h, const int32_t *info_in, uint64_t seed, const float *sigma, int32_t *info_out,
                        float *pl_frames, int32_t n_frames);
 
+/* ------------------------------------------------------------------ N2: TX shaping filter, channel noise, perfect timing
+ * replaces: Filter_UPRRC_ccr_naive::filter -> Filter_UPFIR_ccr_naive::_filter
+ * -- src/common/Module/Filter/Filter_UPFIR/Filter_UPFIR_ccr_naive.cpp:52-66 (polyphase bank of `fir_osf` FIRs built
+ * from the handle's taps), bound src/mains/TX_RX/main.cpp:212,223.  Keeps (n_taps-1)/osf input samples between calls.
+ *   X_N1: float[n_frames * 2*n_cplx]  ->  Y_N2: float[n_frames * 2*n_cplx*osf]                    */
+int dvbs2hip_shape_filter(dvbs2hip_t *h, const float *X_N1, float *Y_N2, int32_t n_cplx, int32_t n_frames);
+int dvbs2hip_shape_filter_dev(dvbs2hip_t *h, const float *X_N1, float *Y_N2, int32_t n_cplx, int32_t n_frames);
+/* replaces: Channel_AWGN::add_noise(CP, X_N, Y_N) -- built DVBS2.cpp:593-613, bound TX_RX_BB/main.cpp:81-82.
+ *   CP: float[n_frames] sigma per real value; X_N, Y_N: float[n_frames * n_elmts] (n_elmts even)   */
+int dvbs2hip_add_noise(dvbs2hip_t *h, const float *CP, const float *X_N, float *Y_N, uint64_t seed, int32_t n_elmts, int32_t n_frames);
+int dvbs2hip_add_noise_dev(dvbs2hip_t *h, const float *CP, const float *X_N, float *Y_N, uint64_t seed, int32_t n_elmts, int32_t n_frames);
+/* perfect-timing extraction (Synchronizer_timing_perfect, DVBS2.cpp:558-570): the batch is ONE stream,
+ * Y[i] = X[offset + i*osf] for i < n_frames*n_cplx_out; samples outside the batch read as zero.      */
+int dvbs2hip_extract_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx_out, int32_t osf, int64_t offset, int32_t n_frames);
+
 /* ------------------------------------------------------------------ measurement
  * Per-kernel device time, measured with hipEvents recorded on the handle's stream around
  * each launch while timing is enabled (the equivalent of `--sim-stats`,

@@ -65,3 +65,50 @@ def test_rrc_matched_pair_is_nyquist(O, Rx, P):
     want = sym.reshape(-1, 2)[:1900]
     assert np.max(np.abs(got - want)) < 2e-3
     rx.close()
+
+
+def test_shape_filter_matches_oracle_and_keeps_state(O, Rx, P):
+    """N2: polyphase up-sampling SRRC (Filter_UPFIR_ccr_naive.cpp:52-66) vs the oracle, 1e-4."""
+    taps = P.rrc_taps(0.2, 2, 20)
+    rng = np.random.default_rng(15)
+    rx = Rx("32APSK-S_3/4", max_frames=4)
+    hist = np.zeros(2 * 80, np.float32)
+    for n, F in ((3402, 2), (7, 1), (1000, 3)):
+        x = rng.standard_normal(F * 2 * n).astype(np.float32)
+        y = rx.shape_filter(x, n_frames=F, osf=2)
+        yo = O.upfir(taps, 2, hist, x)
+        assert y.size == 2 * x.size and np.max(np.abs(y - yo)) <= TOL
+    rx.close()
+
+
+def test_filtered_loop_awgn_extract(O, Rx, P):
+    """TX shaping -> AWGN -> matched filter -> perfect-timing extraction gives back the symbols
+    (+ noise of the requested variance): the filtered loop of BASELINE config 5."""
+    import ctypes
+    from dvbs2_amd import lib_binding as B
+    rng = np.random.default_rng(16)
+    n, F = 3402, 4
+    rx = Rx("32APSK-S_3/4", max_frames=F)
+    sym = (rng.integers(0, 2, F * 2 * n) * 2.0 - 1.0).astype(np.float32) * np.float32(np.sqrt(0.5))
+    up = rx.shape_filter(sym, n_frames=F, osf=2)
+    clean = rx.filter(up, n_frames=F).reshape(-1, 2)
+    got = clean[80::2][: F * n - 40]                      # two group delays of 40 samples
+    assert np.max(np.abs(got - sym.reshape(-1, 2)[: F * n - 40])) < 2e-3
+    sigma = 0.25
+    noisy = rx.add_noise(sigma, up, seed=3, n_frames=F)
+    d = (noisy - up).astype(np.float64)
+    assert abs(d.mean()) < 3e-3 and abs(d.std() - sigma) < 3e-3
+    assert np.array_equal(noisy, rx.add_noise(sigma, up, seed=3, n_frames=F))          # reproducible
+    assert not np.array_equal(noisy, rx.add_noise(sigma, up, seed=4, n_frames=F))
+    # extract_dev through raw device buffers (dvbs2hip_malloc / memcpy helpers)
+    L = rx.L
+    din, dout = ctypes.c_void_p(), ctypes.c_void_p()
+    mf = rx.filter(up, n_frames=F) if False else clean.astype(np.float32).ravel()
+    assert L.dvbs2hip_malloc(rx.h, ctypes.byref(din), mf.nbytes) == 0 and L.dvbs2hip_malloc(rx.h, ctypes.byref(dout), mf.nbytes // 2) == 0
+    assert L.dvbs2hip_memcpy_h2d(rx.h, din, mf.ctypes.data_as(ctypes.c_void_p), mf.nbytes) == 0
+    rx.extract_dev(din.value, dout.value, n, 2, 80, F)
+    out = np.empty(F * 2 * n, np.float32)
+    assert L.dvbs2hip_memcpy_d2h(rx.h, out.ctypes.data_as(ctypes.c_void_p), dout, out.nbytes) == 0
+    assert np.array_equal(out.reshape(-1, 2)[: F * n - 40], got) and not out.reshape(-1, 2)[F * n - 40:].any()
+    L.dvbs2hip_free(rx.h, din); L.dvbs2hip_free(rx.h, dout)
+    rx.close()
