@@ -237,6 +237,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         CREATE_FAIL(DVBS2HIP_EHIP, h->err);
     if (lp.fast && upload(h, &lp.d_fast_tab, lp.fast_tab.data(), lp.fast_tab.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
     lp.grid_max = ldpc_blocks_per_cu(lp) * h->n_cus;
+    if (const char *ev = getenv("DVBS2HIP_LDPC_GRID_MAX")) { const int g = atoi(ev); if (g >= 1 && g < lp.grid_max) lp.grid_max = g; }   // scaling experiments
     if (lp.gwork_words > 0) CREATE_HIP(hipMalloc((void **)&h->d_gwork, (size_t)lp.grid_max * (lp.fast ? lp.fast_nf * lp.fast_wf : 1) * lp.gwork_words * sizeof(float)));
 
     // ---- BCH

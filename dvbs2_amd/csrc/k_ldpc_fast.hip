@@ -33,6 +33,9 @@ constexpr uint32_t FE_LDS = 1u << 29;       // fast-table entry: the bit-group l
 
 constexpr uint32_t OOB = 0x7FFFF000u;       // beyond every workspace: loads return 0, stores are dropped
 constexpr int ROW_BYTES = LDPC_Z * 4;
+#ifndef ST_AUX
+#define ST_AUX 0        // cache policy of the packed-state traffic (2 = nt)
+#endif
 
 // Packed per-check state of the fast path: bits 31..27 = slot of the minimum, bit (DEG-1-j) = sign of
 // the message on slot j (the order v_alignbit shifts them in).  Decompresses to the exact fp32 message.
@@ -67,11 +70,11 @@ struct FastCtx {
     }
     __device__ __forceinline__ float st_ld(uint32_t fo, int arr, int r) const
     {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t4, fo + c2v_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u, 0));
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t4, fo + c2v_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u, ST_AUX));
     }
     __device__ __forceinline__ void st_st(uint32_t fo, int arr, int r, float v) const
     {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, t4, fo + c2v_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, t4, fo + c2v_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u, ST_AUX);
     }
 };
 

@@ -106,6 +106,10 @@ void orc_upfir(const float *taps, int T, int osf, float *hist, const float *x, f
 /* decode F frames with `threads` threads (frames sharded); returns seconds */
 double orc_ldpc_decode_batch(const orc_ldpc *c, const float *llr, int F, int sched, int n_ite,
                              float alpha, int32_t *bits, int threads);
+/* inter-frame SIMD flavour (16 frames per vector, `--dec-simd INTER` of the reference): NMS, natural
+ * row order, fixed n_ite, bit-identical to the scalar decoder; returns seconds */
+double orc_ldpc_decode_batch_inter(const orc_ldpc *c, const float *llr, int F, int n_ite, float alpha,
+                                   int32_t *bits, int threads);
 #ifdef __cplusplus
 }
 #endif

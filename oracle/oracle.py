@@ -43,6 +43,8 @@ def lib():
         L.orc_ldpc_decode.argtypes = [vp, vp, ci, ci, ci, cf, ci, vp, vp, vp]
         L.orc_ldpc_decode_batch.restype = C.c_double
         L.orc_ldpc_decode_batch.argtypes = [vp, vp, ci, ci, ci, cf, vp, ci]
+        L.orc_ldpc_decode_batch_inter.restype = C.c_double
+        L.orc_ldpc_decode_batch_inter.argtypes = [vp, vp, ci, ci, cf, vp, ci]
         L.orc_bch_create.restype = vp
         L.orc_bch_create.argtypes = [ci, vp, ci, ci, ci]
         L.orc_bch_destroy.argtypes = [vp]
@@ -139,6 +141,14 @@ class Ldpc:
         bits = np.empty((llr.shape[0], self.K), dtype=np.int32)
         sec = lib().orc_ldpc_decode_batch(self.h, _p(llr), llr.shape[0], sched, n_ite, alpha,
                                           _p(bits), threads)
+        return bits, sec
+
+
+    def decode_batch_inter_timed(self, llr, n_ite=10, alpha=1.0, threads=1):
+        """inter-frame SIMD CPU flavour (16 frames per vector), natural order NMS"""
+        llr = _f32(llr).reshape(-1, self.N)
+        bits = np.empty((llr.shape[0], self.K), dtype=np.int32)
+        sec = lib().orc_ldpc_decode_batch_inter(self.h, _p(llr), llr.shape[0], n_ite, alpha, _p(bits), threads)
         return bits, sec
 
 

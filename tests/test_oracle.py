@@ -93,6 +93,16 @@ def test_ldpc_kat_and_self_checks(O):
             assert np.array_equal(b, info) and c[0] == 1 and it[0] == 1
 
 
+def test_inter_frame_simd_flavour_is_bit_identical(O):
+    """The CPU baseline's `--dec-simd INTER` flavour (16 frames per vector) = the scalar decoder."""
+    ch = chain(O, "QPSK-S_8/9")
+    _, llr, _ = make_llrs(O, "QPSK-S_8/9", 21, 3.7, seed=9)
+    b1, _ = ch.ldpc.decode_batch_timed(llr, 6, 0.875, O.NATURAL, threads=2)
+    b2, _ = ch.ldpc.decode_batch_inter_timed(llr, 6, 0.875, threads=2)
+    b3, _, _, _ = ch.ldpc.decode(llr, 6, 0.875, sched=O.NATURAL, early_stop=False)
+    assert np.array_equal(b1, b2) and np.array_equal(b1, b3)
+
+
 def test_two_schedules_agree_statistically(O):
     """Natural-order (AFF3CT) and QC-layer (GPU) schedules are different Gauss-Seidel orders of
     the same decoder: same fixed points, close iteration counts."""
