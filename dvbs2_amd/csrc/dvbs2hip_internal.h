@@ -47,6 +47,7 @@ struct LdpcKParams {
     int32_t gwork_words;     // global words per frame in total (posteriors + c2v state)
     int32_t n_frames, n_ite, early_stop;
     float alpha;
+    int32_t inf_row;           // fast path: byte offset of the +inf row (padded layers) or -1
     int32_t pipe;              // fast path: software-pipelined layers (table sorted early-first, T[29] = n_early)
     const uint32_t *fast_tab;  // regular-code fast path: [q][LDPC_FAST_STRIDE] (see k_ldpc_fast.hip)
 };
@@ -68,6 +69,9 @@ struct LdpcPlan {             // host-side description, built once per handle
     LdpcGroup *d_groups = nullptr;
     // regular-code fast path (k_ldpc_fast.hip): every layer has exactly deg_max slots
     bool fast = false;
+    int fast_deg = 0;             // slots per layer in the unrolled kernel (11, 13 or 27)
+    bool fast_pad = false;        // layers padded with NULL slots (irregular code)
+    int fast_inf_row = -1;        // byte offset of the +inf row the NULL slots read, or -1
     int fast_mode = 0;            // 0: all posteriors in LDS, 1: all in the global workspace
     int fast_nf = 1;              // frames per LANE (2 only in global mode; measured slower, opt-in)
     bool fast_pipe = false;       // software-pipelined iteration: bit-exact but measured SLOWER (opt-in: DVBS2HIP_LDPC_PIPE=1)

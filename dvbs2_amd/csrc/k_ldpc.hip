@@ -104,10 +104,12 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
 
     // ---- regular-code fast path: uniform check degree (11 or 27), few same-layer duplicates
     {
-        bool regular = (pl.deg_max == 11 || pl.deg_max == 27);
+        // slots per layer in the unrolled kernel: 11 or 27 when every check has that degree, else the
+        // layers are padded to 13 / 27 slots with NULL slots that read a row of +inf and store nowhere
+        bool regular = pl.deg_max <= 27, uniform = true;
         int maxc = 0;
         for (int r = 0; r < q && regular; r++) {
-            if (pl.layer_deg[r] != pl.deg_max) regular = false;
+            if (pl.layer_deg[r] != pl.deg_max) uniform = false;
             int c = 0;
             for (const Slot &s : layers[r]) c += s.lvl > 0;
             maxc = std::max(maxc, c);
@@ -116,11 +118,14 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
         if (env_path && !strcmp(env_path, "generic")) regular = false;
         if (regular && maxc <= LDPC_FAST_MAXC) {
             pl.fast = true;
+            pl.fast_deg = (uniform && pl.deg_max == 11) ? 11 : (uniform && pl.deg_max == 27) ? 27 : pl.deg_max <= 13 ? 13 : 27;
+            pl.fast_pad = !(uniform && pl.deg_max == pl.fast_deg);
+            const int xrows = pl.fast_pad ? 1 : 0;        // the +inf row
             const char *env_mode = getenv("DVBS2HIP_LDPC_FAST_MODE");
             // short frames: the whole posterior image (N fp32 + one dummy row) fits LDS twice per CU
-            pl.fast_mode = ((size_t)(pl.n_groups + 1) * grp_bytes * 2 <= lds_limit + 1024) ? 0 : 1;
+            pl.fast_mode = ((size_t)(pl.n_groups + 1 + xrows) * grp_bytes * 2 <= lds_limit + 1024) ? 0 : 1;
             if (env_mode) pl.fast_mode = !strcmp(env_mode, "lds") ? 0 : 1;
-            if (pl.fast_mode == 0 && (size_t)(pl.n_groups + 1) * grp_bytes > lds_limit) pl.fast_mode = 1;
+            if (pl.fast_mode == 0 && (size_t)(pl.n_groups + 1 + xrows) * grp_bytes > lds_limit) pl.fast_mode = 1;
             const char *env_nf = getenv("DVBS2HIP_LDPC_NF");
             pl.fast_nf = 1;      // two frames per lane (DVBS2HIP_LDPC_NF=2) measured slower: 235 VGPRs halve the occupancy
             if (env_nf && pl.fast_mode == 1) pl.fast_nf = atoi(env_nf) == 2 ? 2 : 1;
@@ -134,7 +139,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 const char *env_wf = getenv("DVBS2HIP_LDPC_WF");
                 pl.fast_wf = (pl.fast_mode != 2 && pl.fast_nf == 1) ? 2 : 1;
                 if (env_wf && atoi(env_wf) == 1) pl.fast_wf = 1;
-                if (pl.fast_wf == 2 && pl.fast_mode == 0 && 2 * (size_t)(pl.n_groups + 1) * grp_bytes > lds_limit) pl.fast_wf = 1;
+                if (pl.fast_wf == 2 && pl.fast_mode == 0 && 2 * (size_t)(pl.n_groups + 1 + xrows) * grp_bytes > lds_limit) pl.fast_wf = 1;
             }
             std::vector<uint32_t> gbase(pl.n_groups), glds(pl.n_groups, 0u);
             int n_l = 0, n_g = 0;
@@ -151,7 +156,10 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 for (int g = 0; g < pl.n_groups; g++) { gbase[g] = (uint32_t)(g * LDPC_Z); glds[g] = pl.fast_mode == 0 ? 1u : 0u; }
             for (int g = 0; g < pl.n_groups; g++) pl.groups[g] = {gbase[g], glds[g]};
             pl.fast_tab.assign((size_t)q * LDPC_FAST_STRIDE, 0u);
+            // +inf row: LDS image = [groups | junk row | inf row]; global image = [groups | inf row]
+            const uint32_t inf_row_words = (uint32_t)((pl.n_groups + (pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z);
             auto pack = [&](const Slot &sl) {
+                if (sl.group < 0) return (inf_row_words * 4u) << 11;
                 return (uint32_t)(sl.t0 * 4) | ((gbase[sl.group] * 4u) << 11) | (pl.fast_mode == 2 && glds[sl.group] ? (1u << 29) : 0u);
             };
             if (const char *ev = getenv("DVBS2HIP_LDPC_PIPE")) pl.fast_pipe = atoi(ev) != 0;
@@ -162,16 +170,18 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 // then the late ones; the absent-for-check-0 parity slot stays last.  Conflict levels were
                 // fixed above in table order and travel with the slot.
                 std::vector<char> prev_touch(pl.n_groups, 0);
-                for (const Slot &sl : layers[(r + q - 1) % q]) prev_touch[sl.group] = 1;
+                for (const Slot &sl : layers[(r + q - 1) % q]) prev_touch[sl.group] = 1;      // (layers[] hold real slots only)
                 std::vector<Slot> ord;
                 for (const Slot &sl : layers[r]) if (!prev_touch[sl.group]) ord.push_back(sl);
                 const int n_early = (int)ord.size();
                 for (const Slot &sl : layers[r]) if (prev_touch[sl.group]) ord.push_back(sl);
                 if (!ord.empty() && layers[r].back().mask0 && !ord.back().mask0) return "LDPC: internal: masked slot must stay last";
+                // NULL slots (group -1) go in front of the last real slot, which keeps position fast_deg-1
+                while ((int)ord.size() < pl.fast_deg) ord.insert(ord.end() - 1, Slot{-1, 0, 0, 0});
                 // conflict list sorted by level
                 for (int lvl = 1; lvl <= 3; lvl++)
                     for (size_t j = 0; j < ord.size(); j++)
-                        if (ord[j].lvl == lvl) {
+                        if (ord[j].lvl == lvl && ord[j].group >= 0) {
                             T[32 + nc] = pack(ord[j]);
                             T[48 + nc] = (uint32_t)j | ((uint32_t)lvl << 8);
                             nc++;
@@ -179,13 +189,15 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 for (size_t j = 0; j < ord.size(); j++) {
                     // byte shift (11 bits) | byte offset of the bit-group in its store (18 bits) | LDS flag
                     T[j] = pack(ord[j]);
-                    if (ord[j].lvl == 0) prim |= 1u << j;
+                    if (ord[j].lvl == 0 && ord[j].group >= 0) prim |= 1u << j;
                 }
                 T[27] = prim; T[28] = (uint32_t)nc; T[29] = (uint32_t)n_early;
             }
             // workspace of one workgroup: [posteriors kept in global memory | packed c->v state 3 M words]
-            pl.glb_post_words = pl.fast_mode == 1 ? pl.n_groups * LDPC_Z : pl.fast_mode == 2 ? n_g * LDPC_Z : 0;
-            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1) * LDPC_Z : pl.fast_mode == 2 ? (n_l + 2) * LDPC_Z : 0;
+            pl.glb_post_words = pl.fast_mode == 1 ? (pl.n_groups + xrows) * LDPC_Z : pl.fast_mode == 2 ? n_g * LDPC_Z : 0;
+            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1 + xrows) * LDPC_Z : pl.fast_mode == 2 ? (n_l + 2) * LDPC_Z : 0;
+            pl.fast_inf_row = pl.fast_pad ? (int)(inf_row_words * 4u) : -1;
+            if (pl.fast_pad && pl.fast_mode == 2) return "LDPC: hybrid mode does not support padded layers";
             pl.gwork_words = pl.glb_post_words + 3 * M;
             pl.lds_bytes = (size_t)pl.lds_post_words * 4;
             pl.hybrid = pl.fast_mode == 2; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : n_l;

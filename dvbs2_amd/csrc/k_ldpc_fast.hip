@@ -585,6 +585,7 @@ ldpc_fast_kernel(const LdpcKParams p)
                     grp_st(g, c.t4, fo, Y[src]);
                 }
                 for (int r = 0; r < q; r++) { c.st_st(fo, 0, r, 0.f); c.st_st(fo, 1, r, 0.f); c.st_st(fo, 2, r, 0.f); }
+                if (p.inf_row >= 0) c.post_st(c.t4, (uint32_t)p.inf_row + fo, INFINITY);     // what NULL slots read
             }
         __syncthreads();
 
@@ -702,6 +703,7 @@ ldpc_fast2_kernel(const LdpcKParams p)
                 c.post_st(c.t4, (uint32_t)g * ROW_BYTES, Y[src]);
             }
             for (int r = 0; r < q; r++) { c.st_st(0u, 0, r, 0.f); c.st_st(0u, 1, r, 0.f); c.st_st(0u, 2, r, 0.f); }
+            if (p.inf_row >= 0) c.post_st(c.t4, (uint32_t)p.inf_row, INFINITY);               // what NULL slots read
         }
         __syncthreads();
         int it = 0;
@@ -811,6 +813,7 @@ ldpc_fastp_kernel(const LdpcKParams p)
                 c.post_st(c.t4, (uint32_t)g * ROW_BYTES, Y[src]);
             }
             for (int r = 0; r < q; r++) { c.st_st(0u, 0, r, 0.f); c.st_st(0u, 1, r, 0.f); c.st_st(0u, 2, r, 0.f); }
+            if (p.inf_row >= 0) c.post_st(c.t4, (uint32_t)p.inf_row, INFINITY);               // what NULL slots read
         }
         __syncthreads();
         int it = 0;
@@ -879,7 +882,7 @@ static int fastp_occ(const LdpcPlan &pl)
     return nb < 1 ? 1 : nb;
 }
 #define FASTP_DISPATCH(FN, ...)                                                                   \
-    (pl.deg_max == 27 ? (pl.fast_mode == 0 ? FN<27, 0>(__VA_ARGS__) : FN<27, 1>(__VA_ARGS__))      \
+    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0>(__VA_ARGS__) : FN<27, 1>(__VA_ARGS__))     \
                       : (pl.fast_mode == 0 ? FN<11, 0>(__VA_ARGS__) : FN<11, 1>(__VA_ARGS__)))
 
 template <int DEG, int MODE, int NF>
@@ -914,28 +917,29 @@ static int fast_occ(const LdpcPlan &pl)
     (pl.fast_mode == 0 ? FN<D, 0, 1>(__VA_ARGS__)                                                \
      : pl.fast_mode == 2 ? FN<D, 2, 1>(__VA_ARGS__)                                              \
      : (pl.fast_nf == 2 ? FN<D, 1, 2>(__VA_ARGS__) : FN<D, 1, 1>(__VA_ARGS__)))
-#define FAST_DISPATCH(FN, ...) (pl.deg_max == 27 ? FAST_DISPATCH_D(27, FN, __VA_ARGS__) : FAST_DISPATCH_D(11, FN, __VA_ARGS__))
+#define FAST_DISPATCH(FN, ...) (pl.fast_deg == 27 ? FAST_DISPATCH_D(27, FN, __VA_ARGS__) : pl.fast_deg == 13 ? FAST_DISPATCH_D(13, FN, __VA_ARGS__) : FAST_DISPATCH_D(11, FN, __VA_ARGS__))
 
 // (the pipelined iteration needs ~230 VGPRs at DEG 27: more than the 168 a 12-wave workgroup may use)
 #define FAST2_DISPATCH(FN, ...)                                                                   \
-    (pl.deg_max == 27 ? (pl.fast_mode == 0 ? FN<27, 0, false>(__VA_ARGS__) : FN<27, 1, false>(__VA_ARGS__))      \
+    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, false>(__VA_ARGS__) : FN<27, 1, false>(__VA_ARGS__))      \
+     : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0, false>(__VA_ARGS__) : FN<13, 1, false>(__VA_ARGS__))     \
                       : (pl.fast_pipe ? (pl.fast_mode == 0 ? FN<11, 0, true>(__VA_ARGS__) : FN<11, 1, true>(__VA_ARGS__)) \
                                       : (pl.fast_mode == 0 ? FN<11, 0, false>(__VA_ARGS__) : FN<11, 1, false>(__VA_ARGS__))))
 
 int ldpc_fast_blocks_per_cu(const LdpcPlan &pl)
 {
     if (pl.fast_wf == 2) return FAST2_DISPATCH(fast2_occ, pl);
-    if (pl.fast_pipe && pl.fast_mode != 2 && pl.fast_nf == 1) return FASTP_DISPATCH(fastp_occ, pl);
+    if (pl.fast_pipe && pl.fast_mode != 2 && pl.fast_nf == 1 && pl.fast_deg != 13) return FASTP_DISPATCH(fastp_occ, pl);
     return FAST_DISPATCH(fast_occ, pl);
 }
 
 hipError_t ldpc_fast_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
-    p.fast_tab = pl.d_fast_tab; p.groups = pl.d_groups; p.pipe = pl.fast_pipe ? 1 : 0;
+    p.fast_tab = pl.d_fast_tab; p.groups = pl.d_groups; p.pipe = pl.fast_pipe ? 1 : 0; p.inf_row = pl.fast_inf_row;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.lds_post_words = pl.lds_post_words; p.glb_post_words = pl.glb_post_words; p.gwork_words = pl.gwork_words;
     if (pl.fast_wf == 2) return FAST2_DISPATCH(fast2_inst, pl, p, s);
-    if (pl.fast_pipe && pl.fast_mode != 2 && pl.fast_nf == 1) return FASTP_DISPATCH(fastp_inst, pl, p, s);
+    if (pl.fast_pipe && pl.fast_mode != 2 && pl.fast_nf == 1 && pl.fast_deg != 13) return FASTP_DISPATCH(fastp_inst, pl, p, s);
     return FAST_DISPATCH(fast_inst, pl, p, s);
 }
 
