@@ -68,8 +68,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libdvbs2hip has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # under torch.distributed.run even one rank goes through RCCL
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev)
 
     from dvbs2_amd import params as P
@@ -112,17 +113,17 @@ def main():
     rx.timing_enable(True)
     rx.timing_reset()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     rx.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = reduce_max(elapsed, dev) if world > 1 else elapsed
+    elapsed = reduce_max(elapsed, dev)
     k_ms, k_n = rx.timing_get(B.K_LDPC)          # HIP events on the launch stream, per launch
     rx.timing_enable(False)
 
@@ -130,7 +131,7 @@ def main():
     ref = torch.from_numpy(info).to(dev)[sel]
     be_f = (bits != ref).sum(dim=1)
     ctr = [int(F), int(be_f.sum().item()), int((be_f > 0).sum().item())]
-    ctr = reduce_counters(ctr, dev) if world > 1 else ctr
+    ctr = reduce_counters(ctr, dev)
     n_cwd = int(cwd.sum().item())
 
     frames_total = world * F * args.steps
@@ -167,7 +168,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     rx.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -118,3 +118,32 @@ def test_ldpc_normal_frame_full_batch_properties(O, Rx):
     Vo, _, _, _ = ch.ldpc.decode(llr[:3], n_ite=10, alpha=1.0, sched=O.QC, early_stop=False)
     assert np.array_equal(V[:3], Vo)
     rx.close()
+
+
+@pytest.mark.parametrize("modcod", ["QPSK-S_8/9", "QPSK-N_8/9", "32APSK-S_3/4"])
+def test_ldpc_ties_zeros_and_extremes_match_oracle(O, Rx, modcod):
+    """Edge cases of the check-node rule: every |LLR| equal (min1 == min2 ties everywhere: the
+    packed state keeps ONE minimum position, the oracle compares values), exact zeros (sign of
+    zero, -0.0 messages), huge magnitudes, an all-zero frame."""
+    ch = chain(O, modcod)
+    mc = ch.mc
+    rng = np.random.default_rng(33)
+    info = rng.integers(0, 2, (1, mc.K_ldpc)).astype(np.int32)
+    cw = ch.ldpc.encode(info)[0]
+    s = (1.0 - 2.0 * cw).astype(np.float32)
+    frames = []
+    x = s.copy(); x[rng.choice(mc.N_ldpc, mc.N_ldpc // 400, replace=False)] *= -1; frames.append(x)           # hard +-1: ties
+    x = s.copy() * 2.5; x[rng.choice(mc.N_ldpc, mc.N_ldpc // 100, replace=False)] = 0.0; frames.append(x)     # erasures (exact 0)
+    x = s.copy() * 3e4; x[rng.choice(mc.N_ldpc, mc.N_ldpc // 50, replace=False)] *= -1e-3; frames.append(x)   # huge dynamic range
+    frames.append(np.zeros(mc.N_ldpc, np.float32))                                                            # nothing received
+    x = s.copy(); x[::2] = -0.0; frames.append(x)                                                             # negative zeros
+    llr = np.stack(frames)
+    F = llr.shape[0]
+    for early in (False, True):
+        rx = Rx(modcod, max_frames=F, n_ite=8, alpha=0.75, early_stop=early)
+        V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+        Vo, posto, cwdo, iteso = ch.ldpc.decode(llr, n_ite=8, alpha=0.75, sched=O.QC, early_stop=early)
+        assert np.array_equal(V, Vo) and np.array_equal(CWD, cwdo) and np.array_equal(ites, iteso)
+        assert np.array_equal(post.view(np.uint32), posto.view(np.uint32)), "bit patterns (incl. the sign of zero) must match"
+        rx.close()
+    assert np.array_equal(V[1], info[0])      # 1 % erasures are filled in
