@@ -187,8 +187,8 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
     if (cfg->bps < 1 || cfg->bps > 5 || !cfg->cstl) return fail(nullptr, DVBS2HIP_EINVAL, "'bps' has to be in [1,5] with a constellation");
     if (cfg->N_ldpc <= 0 || cfg->N_ldpc % cfg->bps) return fail(nullptr, DVBS2HIP_EINVAL, "'N_ldpc' has to be a positive multiple of 'bps'");
     if (cfg->itl_cols > 1 && cfg->N_ldpc % cfg->itl_cols) return fail(nullptr, DVBS2HIP_EINVAL, "'N_ldpc' has to be a multiple of 'itl_cols'");
-    if (cfg->ldpc_implem != DVBS2HIP_IMPLEM_NMS && cfg->ldpc_implem != DVBS2HIP_IMPLEM_MS)
-        return fail(nullptr, DVBS2HIP_EUNSUPPORTED, "LDPC implem not supported (NMS and MS only)");
+    if (cfg->ldpc_implem != DVBS2HIP_IMPLEM_NMS && cfg->ldpc_implem != DVBS2HIP_IMPLEM_MS && cfg->ldpc_implem != DVBS2HIP_IMPLEM_SPA)
+        return fail(nullptr, DVBS2HIP_EUNSUPPORTED, "LDPC implem not supported (NMS, MS and SPA only)");
     if (!cfg->ldpc_row_ptr || !cfg->ldpc_addr || !cfg->bch_prim) return fail(nullptr, DVBS2HIP_EINVAL, "missing code tables");
     if (cfg->ldpc_n_ite < 1) return fail(nullptr, DVBS2HIP_EINVAL, "'ldpc_n_ite' has to be greater than 0");
     if (cfg->fir_n_taps < 0 || cfg->fir_n_taps > 257 || (cfg->fir_n_taps > 0 && !cfg->fir_taps))
@@ -227,7 +227,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
     if (lds_limit < 32 * 1024) lds_limit = 32 * 1024;
     lds_limit -= 512;                                    // static LDS of the kernel + slack
     std::string e = ldpc_build_plan(h->ldpc, cfg->N_ldpc, cfg->K_ldpc, cfg->ldpc_n_rows, cfg->ldpc_row_ptr, cfg->ldpc_addr,
-                                    cfg->ldpc_lds_groups, lds_limit);
+                                    cfg->ldpc_lds_groups, lds_limit, cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA);
     if (!e.empty()) CREATE_FAIL(DVBS2HIP_EINVAL, e);
     LdpcPlan &lp = h->ldpc;
     if (upload(h, &lp.d_entries, lp.entries.data(), lp.entries.size()) ||

@@ -69,6 +69,7 @@ struct LdpcPlan {             // host-side description, built once per handle
     LdpcGroup *d_groups = nullptr;
     // regular-code fast path (k_ldpc_fast.hip): every layer has exactly deg_max slots
     bool fast = false;
+    bool spa = false;             // sum-product check node: per-edge fp32 messages instead of the packed min-sum state
     int fast_deg = 0;             // slots per layer in the unrolled kernel (11, 13 or 27)
     bool fast_pad = false;        // layers padded with NULL slots (irregular code)
     int fast_inf_row = -1;        // byte offset of the +inf row the NULL slots read, or -1
@@ -86,7 +87,7 @@ int ldpc_fast_blocks_per_cu(const LdpcPlan &pl);
 
 // builds the layer tables; returns empty string on success, else the error text
 std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,
-                            const int32_t *addr, int lds_groups_req, size_t lds_limit_bytes);
+                            const int32_t *addr, int lds_groups_req, size_t lds_limit_bytes, bool spa = false);
 hipError_t ldpc_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
 int ldpc_blocks_per_cu(const LdpcPlan &pl);
 

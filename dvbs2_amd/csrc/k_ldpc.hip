@@ -31,8 +31,9 @@ namespace dvbs2 {
 // host: layer tables
 // ------------------------------------------------------------------------------------------
 std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,
-                            const int32_t *addr, int lds_groups_req, size_t lds_limit)
+                            const int32_t *addr, int lds_groups_req, size_t lds_limit, bool spa)
 {
+    pl.spa = spa;
     if (N <= 0 || K <= 0 || K >= N) return "LDPC: need 0 < K < N";
     const int M = N - K;
     if (M % LDPC_Z || K % LDPC_Z) return "LDPC: N-K and K must be multiples of 360";
@@ -128,17 +129,18 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             if (pl.fast_mode == 0 && (size_t)(pl.n_groups + 1 + xrows) * grp_bytes > lds_limit) pl.fast_mode = 1;
             const char *env_nf = getenv("DVBS2HIP_LDPC_NF");
             pl.fast_nf = 1;      // two frames per lane (DVBS2HIP_LDPC_NF=2) measured slower: 235 VGPRs halve the occupancy
-            if (env_nf && pl.fast_mode == 1) pl.fast_nf = atoi(env_nf) == 2 ? 2 : 1;
+            if (env_nf && pl.fast_mode == 1 && !spa) pl.fast_nf = atoi(env_nf) == 2 ? 2 : 1;
             // mode 2 (hybrid, opt-in: DVBS2HIP_LDPC_FAST_MODE=hybrid): the most-touched bit-groups in LDS
             // (+ a zero row and a junk row), the rest compactly in the workspace.  Measured SLOWER than the
             // all-global image on MI355X (20.9 vs 12.6 ms / 4096 frames): the kernel is VALU-issue bound, not
             // bandwidth bound, and the dual-issue costs instructions.
-            if (env_mode && !strcmp(env_mode, "hybrid")) pl.fast_mode = 2;
+            if (env_mode && !strcmp(env_mode, "hybrid") && !spa) pl.fast_mode = 2;
             if (pl.fast_mode == 2) pl.fast_nf = 1;
             {   // 12-wave workgroups (one frame per half) unless a variant that does not support them is forced
                 const char *env_wf = getenv("DVBS2HIP_LDPC_WF");
                 pl.fast_wf = (pl.fast_mode != 2 && pl.fast_nf == 1) ? 2 : 1;
-                if (env_wf && atoi(env_wf) == 1) pl.fast_wf = 1;
+                if (env_wf && atoi(env_wf) == 1 && !spa) pl.fast_wf = 1;
+                if (spa) { pl.fast_nf = 1; pl.fast_wf = 2; }       // the SPA kernel exists in the two-frame-workgroup form only
                 if (pl.fast_wf == 2 && pl.fast_mode == 0 && 2 * (size_t)(pl.n_groups + 1 + xrows) * grp_bytes > lds_limit) pl.fast_wf = 1;
             }
             std::vector<uint32_t> gbase(pl.n_groups), glds(pl.n_groups, 0u);
@@ -162,7 +164,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 if (sl.group < 0) return (inf_row_words * 4u) << 11;
                 return (uint32_t)(sl.t0 * 4) | ((gbase[sl.group] * 4u) << 11) | (pl.fast_mode == 2 && glds[sl.group] ? (1u << 29) : 0u);
             };
-            if (const char *ev = getenv("DVBS2HIP_LDPC_PIPE")) pl.fast_pipe = atoi(ev) != 0;
+            if (const char *ev = getenv("DVBS2HIP_LDPC_PIPE")) pl.fast_pipe = atoi(ev) != 0 && !spa;
             for (int r = 0; r < q; r++) {
                 uint32_t *T = &pl.fast_tab[(size_t)r * LDPC_FAST_STRIDE];
                 uint32_t prim = 0; int nc = 0;
@@ -198,7 +200,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1 + xrows) * LDPC_Z : pl.fast_mode == 2 ? (n_l + 2) * LDPC_Z : 0;
             pl.fast_inf_row = pl.fast_pad ? (int)(inf_row_words * 4u) : -1;
             if (pl.fast_pad && pl.fast_mode == 2) return "LDPC: hybrid mode does not support padded layers";
-            pl.gwork_words = pl.glb_post_words + 3 * M;
+            pl.gwork_words = pl.glb_post_words + (spa ? pl.fast_deg * M : 3 * M);      // SPA: one fp32 message per edge slot
             pl.lds_bytes = (size_t)pl.lds_post_words * 4;
             pl.hybrid = pl.fast_mode == 2; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : n_l;
         }
@@ -216,6 +218,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 (LdpcEntry)s.t0 | ((gl.base / LDPC_Z) << LE_SLOT_SHIFT) | (gl.lds ? LE_LDS : 0u) |
                 (s.mask0 ? LE_MASK0 : 0u) | ((uint32_t)s.lvl << LE_LVL_SHIFT);
         }
+    if (spa && !pl.fast) return "LDPC: SPA is only implemented for codes the fast path accepts (check degree <= 27)";
     return "";
 }
 

@@ -665,12 +665,91 @@ ldpc_fast_kernel(const LdpcKParams p)
     }
 }
 
+// ---- sum-product (SPA, the reference's default --dec-implem): same schedule, same posterior image,
+// but the c->v messages are kept per edge (fp32, [layer][slot][360] in the workspace) and the check
+// node is the exact boxplus of the other v->c, by forward / backward recursions:
+//     a [+] b = sign(a) sign(b) min(|a|,|b|) + log(1 + e^-|a+b|) - log(1 + e^-|a-b|)
+// on the hardware exp2 / log2 units (absolute error ~1e-7 per operation).  +inf is the neutral
+// element, which is also what absent / NULL slots carry.  Restated in the oracle (chk_update_spa).
+__device__ __forceinline__ float boxplus(float a, float b)
+{
+    const float mn = fminf(fabsf(a), fabsf(b));
+    const float sg = __uint_as_float(__float_as_uint(mn) | ((__float_as_uint(a) ^ __float_as_uint(b)) & 0x80000000u));
+    const float r = sg + (__logf(1.0f + __expf(-fabsf(a + b))) - __logf(1.0f + __expf(-fabsf(a - b))));
+    return a == INFINITY ? b : (b == INFINITY ? a : r);
+}
+
+template <int DEG, int MODE>
+__device__ __forceinline__ void fast_iteration_spa(const FastCtx<MODE> &c, bool act, int t)
+{
+    const int q = c.q;
+    for (int r = 0; r < q; r++) {
+        const const_u32 T = c.tab + r * LDPC_FAST_STRIDE;
+        uint32_t E[DEG];
+#pragma unroll
+        for (int j = 0; j < DEG; j++) E[j] = T[j];
+        const uint32_t prim = T[27];
+        const int ncf = (int)T[28];
+        const bool mask0 = (r == 0) && (t == 0);
+        const uint32_t mbase = c.c2v_base + (uint32_t)(r * DEG) * ROW_BYTES;      // messages of this layer: [slot][360]
+        float x[DEG], od[DEG], nw[DEG];
+        uint32_t w[DEG];
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < DEG; j++) {
+                const uint32_t d = c.t4 - (E[j] & 0x7FFu);
+                w[j] = min(d, d + (uint32_t)ROW_BYTES) + (MODE == 0 ? (E[j] >> 11) : 0u);
+                x[j] = c.post_ld(w[j], MODE == 0 ? 0u : (E[j] >> 11));
+                od[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rs, c.t4, mbase + (uint32_t)j * ROW_BYTES, 0));
+            }
+#pragma unroll
+            for (int j = 0; j < DEG; j++) {
+                x[j] = x[j] - od[j];
+                if (j == DEG - 1 && mask0) x[j] = INFINITY;
+            }
+            float acc = INFINITY;
+#pragma unroll
+            for (int j = 0; j < DEG; j++) { nw[j] = acc; acc = boxplus(acc, x[j]); }           // forward: all before j
+            acc = INFINITY;
+#pragma unroll
+            for (int j = DEG - 1; j >= 0; j--) { nw[j] = boxplus(nw[j], acc); acc = boxplus(acc, x[j]); }   // x backward: all after j
+        }
+        if (ncf > 0) __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < DEG; j++) {
+                uint32_t off = ((prim >> j) & 1u) ? w[j] : c.redirect;
+                if (j == DEG - 1 && mask0) off = c.redirect;
+                c.post_st(off, MODE == 0 ? 0u : (E[j] >> 11), x[j] + nw[j]);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, nw[j]), c.rs, c.t4, mbase + (uint32_t)j * ROW_BYTES, 0);
+            }
+        }
+        // duplicate edges of a bit-group inside this layer: ordered delta updates, level by level
+        uint32_t lvm[3] = {0u, 0u, 0u};
+        for (int i = 0; i < ncf; i++) { const uint32_t meta = T[48 + i]; lvm[(meta >> 8) - 1u] |= 1u << (meta & 31u); }
+        for (int lvl = 0; lvl < 3; lvl++) {
+            if (!lvm[lvl]) break;
+            __syncthreads();
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < DEG; j++)
+                    if ((lvm[lvl] >> j) & 1u) {
+                        const uint32_t so = MODE == 0 ? 0u : (E[j] >> 11);
+                        const float L = c.post_ld(w[j], so);
+                        c.post_st(w[j], so, L + (nw[j] - od[j]));
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- two frames per workgroup, one per HALF of a 12-wave workgroup.  A 6-wave workgroup cannot
 // sit evenly on the CU's 4 SIMDs (2+2+1+1); two of them land 4+4+2+2 and the busiest SIMD then sets
 // the pace: measured, one 6-wave workgroup per CU runs as fast per frame as two.  Twelve waves are
 // dealt 3+3+3+3.  The halves share nothing but the barriers (both decode the same layer at the same
 // time); each has its own workspace slot, LDS image, iteration count and early-stop decision.
-template <int DEG, int MODE, bool PIPE>
+template <int DEG, int MODE, bool PIPE, bool SPA = false>
 __global__ void __launch_bounds__(2 * LDPC_THREADS, 3)
 ldpc_fast2_kernel(const LdpcKParams p)
 {
@@ -702,7 +781,8 @@ ldpc_fast2_kernel(const LdpcKParams p)
                 const int src = g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info);
                 c.post_st(c.t4, (uint32_t)g * ROW_BYTES, Y[src]);
             }
-            for (int r = 0; r < q; r++) { c.st_st(0u, 0, r, 0.f); c.st_st(0u, 1, r, 0.f); c.st_st(0u, 2, r, 0.f); }
+            if (SPA) { for (int e = 0; e < q * DEG; e++) __builtin_amdgcn_raw_buffer_store_b32(0u, c.rs, c.t4, c.c2v_base + (uint32_t)e * ROW_BYTES, 0); }
+            else for (int r = 0; r < q; r++) { c.st_st(0u, 0, r, 0.f); c.st_st(0u, 1, r, 0.f); c.st_st(0u, 2, r, 0.f); }
             if (p.inf_row >= 0) c.post_st(c.t4, (uint32_t)p.inf_row, INFINITY);               // what NULL slots read
         }
         __syncthreads();
@@ -712,7 +792,8 @@ ldpc_fast2_kernel(const LdpcKParams p)
         for (;;) {
             if (t == 0) s_flag[half] = 0;
             if (!__syncthreads_or(live ? 1 : 0)) break;          // also orders the flag reset
-            if (PIPE) fast_iteration_pipe<DEG, MODE>(c, 0u, nx[0], act && live, t);
+            if (SPA) fast_iteration_spa<DEG, MODE>(c, act && live, t);
+            else if (PIPE) fast_iteration_pipe<DEG, MODE>(c, 0u, nx[0], act && live, t);
             else fast_iteration<DEG, MODE, 1>(c, fo, nx, act && live, t);
             int bad = 0;
             bool check = false;
@@ -758,10 +839,10 @@ ldpc_fast2_kernel(const LdpcKParams p)
     }
 }
 
-template <int DEG, int MODE, bool PIPE>
+template <int DEG, int MODE, bool PIPE, bool SPA = false>
 static hipError_t fast2_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
 {
-    auto kern = ldpc_fast2_kernel<DEG, MODE, PIPE>;
+    auto kern = ldpc_fast2_kernel<DEG, MODE, PIPE, SPA>;
     static size_t configured = 0;
     const size_t lds = 2 * pl.lds_bytes;
     if (lds > configured) {
@@ -775,10 +856,10 @@ static hipError_t fast2_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream
     return hipGetLastError();
 }
 
-template <int DEG, int MODE, bool PIPE>
+template <int DEG, int MODE, bool PIPE, bool SPA = false>
 static int fast2_occ(const LdpcPlan &pl)
 {
-    auto kern = ldpc_fast2_kernel<DEG, MODE, PIPE>;
+    auto kern = ldpc_fast2_kernel<DEG, MODE, PIPE, SPA>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * pl.lds_bytes));
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 2 * LDPC_THREADS, 2 * pl.lds_bytes) != hipSuccess) nb = 1;
@@ -926,8 +1007,14 @@ static int fast_occ(const LdpcPlan &pl)
                       : (pl.fast_pipe ? (pl.fast_mode == 0 ? FN<11, 0, true>(__VA_ARGS__) : FN<11, 1, true>(__VA_ARGS__)) \
                                       : (pl.fast_mode == 0 ? FN<11, 0, false>(__VA_ARGS__) : FN<11, 1, false>(__VA_ARGS__))))
 
+#define FASTSPA_DISPATCH(FN, ...)                                                                                  \
+    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, false, true>(__VA_ARGS__) : FN<27, 1, false, true>(__VA_ARGS__))   \
+     : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0, false, true>(__VA_ARGS__) : FN<13, 1, false, true>(__VA_ARGS__)) \
+                         : (pl.fast_mode == 0 ? FN<11, 0, false, true>(__VA_ARGS__) : FN<11, 1, false, true>(__VA_ARGS__)))
+
 int ldpc_fast_blocks_per_cu(const LdpcPlan &pl)
 {
+    if (pl.spa) return FASTSPA_DISPATCH(fast2_occ, pl);
     if (pl.fast_wf == 2) return FAST2_DISPATCH(fast2_occ, pl);
     if (pl.fast_pipe && pl.fast_mode != 2 && pl.fast_nf == 1 && pl.fast_deg != 13) return FASTP_DISPATCH(fastp_occ, pl);
     return FAST_DISPATCH(fast_occ, pl);
@@ -938,6 +1025,7 @@ hipError_t ldpc_fast_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
     p.fast_tab = pl.d_fast_tab; p.groups = pl.d_groups; p.pipe = pl.fast_pipe ? 1 : 0; p.inf_row = pl.fast_inf_row;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.lds_post_words = pl.lds_post_words; p.glb_post_words = pl.glb_post_words; p.gwork_words = pl.gwork_words;
+    if (pl.spa) return FASTSPA_DISPATCH(fast2_inst, pl, p, s);
     if (pl.fast_wf == 2) return FAST2_DISPATCH(fast2_inst, pl, p, s);
     if (pl.fast_pipe && pl.fast_mode != 2 && pl.fast_nf == 1 && pl.fast_deg != 13) return FASTP_DISPATCH(fastp_inst, pl, p, s);
     return FAST_DISPATCH(fast_inst, pl, p, s);

@@ -29,7 +29,7 @@ def _ptr(a):
 class Dvbs2Hip:
     def __init__(self, modcod: str = "QPSK-S_8/9", max_frames: int = 1, n_ite: int = 50, alpha: float = 1.0,
                  early_stop: bool = True, device: int = 0, stream: int | None = None, fir_taps=None,
-                 fir_osf: int = 2, lds_groups: int = -1):
+                 fir_osf: int = 2, lds_groups: int = -1, implem: str = "NMS"):
         self.L = B.load()
         self.h = None
         self.mc = P.get_modcod(modcod)            # raises ValueError like DVBS2.cpp:319
@@ -40,6 +40,9 @@ class Dvbs2Hip:
         cfg.max_frames = int(max_frames)
         cfg.ldpc_n_ite = int(n_ite)
         cfg.ldpc_alpha = float(alpha)
+        if implem not in ("NMS", "MS", "SPA"):
+            raise ValueError("implem has to be NMS, MS or SPA")
+        cfg.ldpc_implem = {"NMS": 0, "MS": 1, "SPA": 2}[implem]
         cfg.ldpc_early_stop = 1 if early_stop else 0
         cfg.device = int(device)
         cfg.stream = stream

@@ -29,7 +29,7 @@ def build_parser():
     ap.add_argument("-e", "--max-fe", type=int, default=100)
     ap.add_argument("-F", "--sim-inter-fra", type=int, default=512, help="frames per batch per GPU (grid width)")
     ap.add_argument("--dec-ite", type=int, default=50)
-    ap.add_argument("--dec-implem", default="NMS", choices=["NMS", "MS"])
+    ap.add_argument("--dec-implem", default="NMS", choices=["NMS", "MS", "SPA"])
     ap.add_argument("--dec-alpha", type=float, default=1.0)
     ap.add_argument("--no-early-stop", action="store_true")
     ap.add_argument("--est-type", default="DVBS2", choices=["DVBS2", "PERFECT"])
@@ -64,7 +64,8 @@ def run(args, out=sys.stdout):
     mc = P.get_modcod(args.mod_cod)
     F = args.sim_inter_fra
     alpha = 1.0 if args.dec_implem == "MS" else args.dec_alpha
-    rx = Dvbs2Hip(mc.name, max_frames=F, n_ite=args.dec_ite, alpha=alpha, early_stop=not args.no_early_stop, device=local_rank)
+    rx = Dvbs2Hip(mc.name, max_frames=F, n_ite=args.dec_ite, alpha=alpha, early_stop=not args.no_early_stop, device=local_rank,
+                  implem=args.dec_implem)
     pl = torch.empty((F, 2 * rx.pl_frame), dtype=torch.float32, device=dev)
     sent = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev)
     got = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev)

@@ -42,8 +42,8 @@ typedef enum {
 
 typedef struct dvbs2hip_handle dvbs2hip_t;
 
-/* LDPC check-node rule (--dec-implem, DVBS2.cpp:117-149).  SPA is not implemented yet. */
-enum { DVBS2HIP_IMPLEM_NMS = 0, DVBS2HIP_IMPLEM_MS = 1 };
+/* LDPC check-node rule (--dec-implem, DVBS2.cpp:117-149; the reference's default is SPA) */
+enum { DVBS2HIP_IMPLEM_NMS = 0, DVBS2HIP_IMPLEM_MS = 1, DVBS2HIP_IMPLEM_SPA = 2 };
 /* Interleaver read order (DVBS2.cpp:300-317) */
 enum { DVBS2HIP_ITL_TOP_LEFT = 0, DVBS2HIP_ITL_TOP_RIGHT = 1 };
 

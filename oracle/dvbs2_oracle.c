@@ -153,19 +153,27 @@ static void chk_update_nms(const float *v2c, int d, float alpha, float *out)
     }
 }
 
+/* exact sum-product check node: c->v_j = boxplus of all the OTHER v->c, evaluated with forward and
+ * backward boxplus recursions in fp32:
+ *     a [+] b = sign(a) sign(b) min(|a|,|b|) + log1p(exp(-|a+b|)) - log1p(exp(-|a-b|))
+ * (numerically equal to 2 atanh(tanh(a/2) tanh(b/2)), the form AFF3CT's Update_rule_SPA uses, without
+ * the saturation of tanh in fp32).  +inf is the neutral element. */
+static inline float boxplus(float a, float b)
+{
+    if (a == INFINITY) return b;
+    if (b == INFINITY) return a;
+    const float mn = fminf(fabsf(a), fabsf(b));
+    const float sg = (f_signbit(a) ^ f_signbit(b)) ? -mn : mn;
+    return sg + (log1pf(expf(-fabsf(a + b))) - log1pf(expf(-fabsf(a - b))));
+}
 static void chk_update_spa(const float *v2c, int d, float *out)
 {
-    /* exact sum-product in the tanh domain with forward/backward products (double) */
-    double fw[64], bw[64], th[64];
-    for (int j = 0; j < d; j++) {
-        double x = tanh(0.5 * (double)v2c[j]);
-        if (x > 0.999999999999) x = 0.999999999999;
-        if (x < -0.999999999999) x = -0.999999999999;
-        th[j] = x;
-    }
-    fw[0] = 1.0; for (int j = 1; j < d; j++) fw[j] = fw[j - 1] * th[j - 1];
-    bw[d - 1] = 1.0; for (int j = d - 2; j >= 0; j--) bw[j] = bw[j + 1] * th[j + 1];
-    for (int j = 0; j < d; j++) out[j] = (float)(2.0 * atanh(fw[j] * bw[j]));
+    float fw[64], bw[64];
+    fw[0] = INFINITY;
+    for (int j = 1; j < d; j++) fw[j] = boxplus(fw[j - 1], v2c[j - 1]);
+    bw[d - 1] = INFINITY;
+    for (int j = d - 2; j >= 0; j--) bw[j] = boxplus(bw[j + 1], v2c[j + 1]);
+    for (int j = 0; j < d; j++) out[j] = boxplus(fw[j], bw[j]);
 }
 
 int orc_ldpc_decode(const orc_ldpc *c, const float *llr, int implem, int sched, int n_ite,

@@ -147,3 +147,30 @@ def test_ldpc_ties_zeros_and_extremes_match_oracle(O, Rx, modcod):
         assert np.array_equal(post.view(np.uint32), posto.view(np.uint32)), "bit patterns (incl. the sign of zero) must match"
         rx.close()
     assert np.array_equal(V[1], info[0])      # 1 % erasures are filled in
+
+
+@pytest.mark.parametrize("modcod,ebn0", [("QPSK-S_8/9", 3.9), ("QPSK-S_3/5", 1.8), ("32APSK-S_3/4", 3.0), ("QPSK-N_8/9", 3.9)])
+def test_ldpc_spa_matches_oracle(O, Rx, modcod, ebn0):
+    """--dec-implem SPA (the reference's default): exact boxplus check node.  The GPU evaluates the
+    exp/log terms on the hardware exp2/log2 units, the oracle with libm, so the parity bar is the
+    soft one: |posterior difference| <= 1e-4 * max(1, |posterior|) after 1 and 2 iterations (before
+    rounding differences can be amplified), and identical hard decisions / iteration counts for
+    frames that converge."""
+    ch = chain(O, modcod)
+    F = 4
+    _, llr, cw = make_llrs(O, modcod, F, ebn0, seed=17)
+    for n_ite in (1, 2):
+        rx = Rx(modcod, max_frames=F, n_ite=n_ite, early_stop=False, implem="SPA")
+        V, CWD, post, _ = rx.decode_siho(llr, with_post=True)
+        Vo, posto, cwdo, _ = ch.ldpc.decode(llr, n_ite=n_ite, implem=O.SPA, sched=O.QC, early_stop=False)
+        assert np.all(np.abs(post - posto) <= 1e-4 * np.maximum(1.0, np.abs(posto))), float(np.abs(post - posto).max())
+        assert (V != Vo).mean() < 1e-4
+        rx.close()
+    rx = Rx(modcod, max_frames=F, n_ite=50, early_stop=True, implem="SPA")
+    V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+    Vo, posto, cwdo, iteso = ch.ldpc.decode(llr, n_ite=50, implem=O.SPA, sched=O.QC, early_stop=True)
+    conv = (CWD == 1) & (cwdo == 1)
+    assert conv.sum() >= F - 1
+    assert np.array_equal(V[conv], Vo[conv]) and np.all(np.abs(ites[conv] - iteso[conv]) <= 1)
+    assert np.array_equal(V[conv], cw[conv][:, :ch.mc.K_ldpc])
+    rx.close()
