@@ -14,3 +14,6 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_BUSY_CYCLES TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/prof_sq2" -- python3 $ARGS > "$OUT/prof_sq2.log" 2>&1
 find "$OUT" -name "*.csv" | head -40
 tail -2 "$OUT/prof_stats.log"
+# calibration of FETCH_SIZE / WRITE_SIZE on a known dword-per-lane copy (1.06 GB read + 1.06 GB written per launch)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_cal_fetch" -- python3 $REPO/tools/calibrate_fetch.py > "$OUT/prof_cal_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_cal_write" -- python3 $REPO/tools/calibrate_fetch.py > "$OUT/prof_cal_write.log" 2>&1
