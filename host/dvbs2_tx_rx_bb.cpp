@@ -1,0 +1,91 @@
+// dvbs2_tx_rx_bb (HIP) -- the reference's Monte-Carlo BER/FER simulator
+// (/root/reference src/mains/TX_RX_BB/main.cpp:28-192) with TX, channel, RX and monitor on one MI355X,
+// written against the C ABI only (include/dvbs2hip.h): device buffers from dvbs2hip_malloc, the
+// `_dev` entry points chained on the handle's stream, one 24-byte counter read per batch.
+// Same flags where they apply to this path (src/common/Factory/DVBS2/DVBS2.cpp:117-149), same table
+// as refs/TX_RX_BB/*.txt.  (Multi-GPU runs use the Python twin, dvbs2_amd/sim.py, under torchrun.)
+//
+//   dvbs2_tx_rx_bb --mod-cod QPSK-S_8/9 -m 3.6 -M 3.81 -s 0.1 --dec-implem SPA --dec-ite 50 -F 2048
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../include/dvbs2hip.h"
+
+#define CHK(call) do { int rc__ = (call); if (rc__) { std::fprintf(stderr, "%s: %s\n", #call, dvbs2hip_last_error(h)); return 3; } } while (0)
+
+int main(int argc, char **argv)
+{
+    std::string modcod = "QPSK-S_8/9", implem = "SPA", est = "DVBS2";
+    double ebn0_min = 3.2, ebn0_max = 6.0, step = 0.1;     // DVBS2.cpp:121-123
+    int F = 512, n_ite = 50, max_fe = 100;                 // DVBS2.cpp:135-142 (implem SPA, 50 ite, 100 frame errors)
+    long long max_frames = 10000000;
+    float alpha = 1.0f;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
+        if (a == "--mod-cod") modcod = next();
+        else if (a == "-m" || a == "--sim-noise-min") ebn0_min = std::atof(next());
+        else if (a == "-M" || a == "--sim-noise-max") ebn0_max = std::atof(next());
+        else if (a == "-s" || a == "--sim-noise-step") step = std::atof(next());
+        else if (a == "-e" || a == "--max-fe") max_fe = std::atoi(next());
+        else if (a == "-F" || a == "--sim-inter-fra") F = std::atoi(next());
+        else if (a == "--dec-ite") n_ite = std::atoi(next());
+        else if (a == "--dec-implem") implem = next();
+        else if (a == "--dec-alpha") alpha = (float)std::atof(next());
+        else if (a == "--est-type") est = next();
+        else if (a == "--max-frames") max_frames = std::atoll(next());
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    dvbs2hip_t *h = nullptr;
+    dvbs2hip_cfg cfg;
+    if (dvbs2hip_cfg_from_modcod(modcod.c_str(), &cfg)) { std::fprintf(stderr, "%s\n", dvbs2hip_last_error(nullptr)); return 3; }
+    cfg.max_frames = F; cfg.ldpc_n_ite = n_ite; cfg.ldpc_alpha = alpha; cfg.ldpc_early_stop = 1;
+    cfg.ldpc_implem = implem == "SPA" ? DVBS2HIP_IMPLEM_SPA : implem == "MS" ? DVBS2HIP_IMPLEM_MS : DVBS2HIP_IMPLEM_NMS;
+    if (implem != "SPA" && implem != "MS" && implem != "NMS") { std::fprintf(stderr, "--dec-implem has to be SPA, MS or NMS\n"); return 2; }
+    if (dvbs2hip_create(&cfg, &h)) { std::fprintf(stderr, "%s\n", dvbs2hip_last_error(nullptr)); return 3; }
+    dvbs2hip_sizes sz;
+    CHK(dvbs2hip_get_sizes(h, &sz));
+    void *d_pl, *d_sent, *d_got, *d_sig;
+    CHK(dvbs2hip_malloc(h, &d_pl, (size_t)F * 2 * sz.pl_frame_sym * sizeof(float)));
+    CHK(dvbs2hip_malloc(h, &d_sent, (size_t)F * sz.K_bch * sizeof(int32_t)));
+    CHK(dvbs2hip_malloc(h, &d_got, (size_t)F * sz.K_bch * sizeof(int32_t)));
+    CHK(dvbs2hip_malloc(h, &d_sig, (size_t)F * sizeof(float)));
+
+    std::printf("# * DVB-S2 (HIP) ------------------------------------\n#    ** Modulation and coding = %s\n#    ** LDPC implem           = %s\n"
+                "#    ** LDPC n iterations     = %d\n#    ** Frames per batch (-F)  = %d\n", modcod.c_str(), implem.c_str(), n_ite, F);
+    std::printf("# ----------|----------||----------|----------|----------|----------|----------||----------|----------\n"
+                "#     Es/N0 |    Eb/N0 ||      FRA |       BE |       FE |      BER |      FER ||  SIM_THR |    ET/RT\n"
+                "#      (dB) |     (dB) ||          |          |          |          |          ||   (Mb/s) | (hhmmss)\n"
+                "# ----------|----------||----------|----------|----------|----------|----------||----------|----------\n");
+    const double R = (double)sz.K_bch / sz.N_ldpc;                       // main.cpp:142
+    unsigned long long batch = 0;
+    for (double ebn0 = ebn0_min; ebn0 < ebn0_max - 1e-9; ebn0 += step) {
+        const double esn0 = ebn0 + 10.0 * std::log10(R * sz.bps);         // main.cpp:143-146
+        const float sigma = (float)std::sqrt(1.0 / (2.0 * std::pow(10.0, esn0 / 10.0)));
+        std::vector<float> sig(F, sigma);
+        CHK(dvbs2hip_memcpy_h2d(h, d_sig, sig.data(), sig.size() * sizeof(float)));
+        CHK(dvbs2hip_monitor_reset(h));
+        uint64_t c[3] = {0, 0, 0};
+        const auto t0 = std::chrono::steady_clock::now();
+        while (c[2] < (uint64_t)max_fe && (long long)c[0] < max_frames) {     // Monitor_BFER: stop at max_fe (DVBS2.cpp:136)
+            CHK(dvbs2hip_tx_bb_dev(h, nullptr, (batch++ << 8), (const float *)d_sig, (int32_t *)d_sent, (float *)d_pl, F));
+            CHK(dvbs2hip_rx_bb_dev(h, (const float *)d_pl, est == "PERFECT" ? (const float *)d_sig : nullptr, (int32_t *)d_got, nullptr, nullptr, F));
+            CHK(dvbs2hip_monitor_check_errors_dev(h, (const int32_t *)d_sent, (const int32_t *)d_got, F));
+            CHK(dvbs2hip_monitor_get(h, c));
+        }
+        const double et = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const int hh = (int)(et / 3600), mm = (int)(et / 60) % 60, ss = (int)et % 60;
+        std::printf("  %9.2f | %8.2f || %8llu | %8llu | %8llu | %8.2e | %8.2e || %8.3f | %02dh%02d'%02d\n", esn0, ebn0, (unsigned long long)c[0],
+                    (unsigned long long)c[1], (unsigned long long)c[2], (double)c[1] / ((double)c[0] * sz.K_bch), (double)c[2] / (double)c[0],
+                    (double)c[0] * sz.K_bch / et / 1e6, hh, mm, ss);
+        std::fflush(stdout);
+    }
+    std::printf("# End of the simulation\n");
+    dvbs2hip_free(h, d_pl); dvbs2hip_free(h, d_sent); dvbs2hip_free(h, d_got); dvbs2hip_free(h, d_sig);
+    dvbs2hip_destroy(h);
+    return 0;
+}

@@ -45,3 +45,20 @@ def test_host_rx_graph_on_gpu(O, tmp_path, modcod, ebn0):
     assert "mismatches 0" in r.stdout and "FRA %d BE 0 FE 0" % (F * batches) in r.stdout
     out = np.fromfile(pout, dtype=np.int32).reshape(F * batches, -1)
     assert np.array_equal(out, info)
+
+
+@pytest.mark.gpu
+def test_cpp_tx_rx_bb_reproduces_a_reference_row():
+    """The C++ work-alike of dvbs2_tx_rx_bb (C ABI only) on one row of refs/TX_RX_BB/QPSK_8_9.txt."""
+    import json
+    build()
+    exe = os.path.join(ROOT, "host", "dvbs2_tx_rx_bb")
+    r = subprocess.run([exe, "--mod-cod", "QPSK-S_8/9", "-m", "3.7", "-M", "3.71", "--dec-implem", "SPA", "--dec-ite", "50", "-F", "2048"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    row = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("#")][0]
+    f = [x.strip() for x in row.replace("||", "|").split("|")]
+    fer, fe = float(f[6]), int(f[4])
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "refs_tx_rx_bb.json")))["QPSK_8_9.txt"]["rows"][1]
+    assert abs(float(f[0]) - ref["esn0"]) < 0.0051 and fe >= 100
+    assert ref["fer"] / 2.5 <= fer <= ref["fer"] * 2.5

@@ -64,6 +64,24 @@ res["config3_QPSK-N_8/9_F4096_10ite"] = chain_case("QPSK-N_8/9", 4096, 10, 4.2)
 res["config1_QPSK-S_8/9_F8192_10ite"] = chain_case("QPSK-S_8/9", 8192, 10, 4.4)
 res["config4_16APSK-N_8/9_F4096_20ite"] = chain_case("16APSK-N_8/9", 4096, 20, 8.2)
 res["config5_32APSK-S_3/4_F4096_10ite"] = chain_case("32APSK-S_3/4", 4096, 10, 9.5)
+def latency_case(modcod, F, reps=50):
+    """small-batch latency of one fused-chain call (launch-bound regime, BASELINE config 5)"""
+    mc = P.get_modcod(modcod)
+    rx = Dvbs2Hip(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=True)
+    sigma = P.esn0_to_sigma(P.ebn0_to_esn0(12.0, mc.code_rate, mc.bps))
+    pl = torch.empty((F, 2 * rx.pl_frame), dtype=torch.float32, device=dev); sent = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev)
+    got = torch.empty_like(sent); sig = torch.full((F,), sigma, dtype=torch.float32, device=dev)
+    rx.tx_bb_dev(None, 1, sig.data_ptr(), sent.data_ptr(), pl.data_ptr(), F); rx.synchronize()
+    f = lambda: (rx.rx_bb_dev(pl.data_ptr(), sig.data_ptr(), got.data_ptr(), None, None, F), rx.synchronize())
+    for _ in range(5): f()
+    t0 = time.perf_counter()
+    for _ in range(reps): f()
+    us = (time.perf_counter() - t0) / reps * 1e6
+    ok = bool((got == sent).all().item()); rx.close()
+    return {"modcod": modcod, "frames": F, "call_latency_us": us, "frames_per_s": F / us * 1e6, "payload_recovered": ok}
+
+res["latency_rx_bb_32APSK-S_3/4"] = [latency_case("32APSK-S_3/4", F) for F in (1, 8, 64)]
+res["latency_rx_bb_QPSK-S_8/9"] = [latency_case("QPSK-S_8/9", F) for F in (1, 8, 64)]
 res["fir_32APSK-S(6804 cplx/frame)"] = [fir_case(6804, F) for F in (1, 8, 64, 4096)]
 res["fir_QPSK-N(66564 cplx/frame)"] = [fir_case(66564, F) for F in (1, 8, 64, 1024)]
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "kernels.json")
