@@ -455,7 +455,10 @@ template <int DEG, bool HYBRID, bool C2V_LDS>
 static hipError_t launch_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
 {
     auto kern = ldpc_layered_nms_kernel<DEG, HYBRID, C2V_LDS>;
-    static size_t configured = 0;
+    static size_t configured_dev[64] = {0};
+    int dev__ = 0;
+    (void)hipGetDevice(&dev__);
+    size_t &configured = configured_dev[dev__ & 63];
     if (pl.lds_bytes > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);

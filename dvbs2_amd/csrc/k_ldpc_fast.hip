@@ -843,7 +843,10 @@ template <int DEG, int MODE, bool PIPE, bool SPA = false>
 static hipError_t fast2_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
 {
     auto kern = ldpc_fast2_kernel<DEG, MODE, PIPE, SPA>;
-    static size_t configured = 0;
+    static size_t configured_dev[64] = {0};
+    int dev__ = 0;
+    (void)hipGetDevice(&dev__);
+    size_t &configured = configured_dev[dev__ & 63];
     const size_t lds = 2 * pl.lds_bytes;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -942,7 +945,10 @@ template <int DEG, int MODE>
 static hipError_t fastp_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
 {
     auto kern = ldpc_fastp_kernel<DEG, MODE>;
-    static size_t configured = 0;
+    static size_t configured_dev[64] = {0};
+    int dev__ = 0;
+    (void)hipGetDevice(&dev__);
+    size_t &configured = configured_dev[dev__ & 63];
     if (pl.lds_bytes > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
         if (e != hipSuccess) return e;
@@ -970,7 +976,10 @@ template <int DEG, int MODE, int NF>
 static hipError_t fast_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
 {
     auto kern = ldpc_fast_kernel<DEG, MODE, NF>;
-    static size_t configured = 0;
+    static size_t configured_dev[64] = {0};
+    int dev__ = 0;
+    (void)hipGetDevice(&dev__);
+    size_t &configured = configured_dev[dev__ & 63];
     if (pl.lds_bytes > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);

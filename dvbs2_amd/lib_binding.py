@@ -109,6 +109,16 @@ def load(build_if_missing: bool = True):
     """Loads libdvbs2hip.so (building it with hipcc when the in-tree copy is absent)."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process: PyTorch-ROCm loads its OWN bundled libamdhip64 by absolute path.  If
+        # libdvbs2hip.so (linked against /opt/rocm's) initialises HIP first, torch's copy then finds no device.
+        # Importing torch first makes the dynamic loader resolve our DT_NEEDED libamdhip64 to the copy torch
+        # already loaded.  (Hosts without PyTorch -- the C++ side -- are unaffected.)
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         path = _build.LIB
         if not os.path.exists(path):
             if not build_if_missing:

@@ -66,3 +66,34 @@ def test_abi_error_behaviour(O, Rx):
     rx.close()
     with pytest.raises(Dvbs2HipError):
         Rx("QPSK-S_8/9", max_frames=0)
+
+
+def test_external_stream_reset_and_two_handles(O, Rx):
+    """cfg.stream: the handle enqueues on the caller's HIP stream (here torch's current stream), so
+    torch.cuda.Event sees its kernels; two handles coexist on one device; reset() clears the filter
+    memory and the monitor counters."""
+    import torch
+    modcod = "QPSK-S_8/9"
+    F = 4
+    info, pl, cw, sigma = make_pl_frames(O, modcod, F, 4.6, seed=47)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        rx = Rx(modcod, max_frames=F, n_ite=10, early_stop=True, stream=s.cuda_stream)
+        assert rx.stream == s.cuda_stream
+        other = Rx("16APSK-S_8/9", max_frames=2)                       # a second handle, own stream
+        d_pl = torch.from_numpy(pl).cuda()
+        d_out = torch.empty((F, rx.K_bch), dtype=torch.int32, device="cuda")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        rx.rx_bb_dev(d_pl.data_ptr(), None, d_out.data_ptr(), None, None, F)
+        e1.record(s)
+        s.synchronize()
+        assert e0.elapsed_time(e1) > 0.0
+        assert np.array_equal(d_out.cpu().numpy(), info)
+    rx.check_errors(info, info)
+    x = np.ones(2 * 100, np.float32)
+    y1 = rx.filter(x, 1)
+    rx.reset()
+    assert rx.monitor_get() == (0, 0, 0)
+    assert np.array_equal(rx.filter(x, 1), y1)                           # same output again: the filter memory was cleared
+    other.close(); rx.close()
