@@ -17,8 +17,22 @@
 //     magnitudes, 27 sign bits and the 5-bit position of the minimum = 12 bytes per check
 //     instead of 4 bytes per edge, and decompress bit-exactly to the fp32 messages.
 //
+// This file holds (1) the host-side PLAN: layer tables, storage policy and the choice between the
+// kernels, and (2) the GENERIC table-driven kernel (per-slot flags, hybrid LDS/global image), which is
+// the fallback for codes the fast path (k_ldpc_fast.hip) rejects -- check degree above 27 or more than
+// 16 duplicate edges per layer -- and the subject of `DVBS2HIP_LDPC_PATH=generic` experiments.  Every
+// DVB-S2 code shipped here runs on the fast path.
+//
 // Schedule and arithmetic are restated in oracle/dvbs2_oracle.c (ORC_SCHED_QC) and the two
 // must agree bit for bit: tests/test_ldpc_gpu.py.
+//
+// Tuning / experiment knobs (environment, read when a handle is created):
+//   DVBS2HIP_LDPC_PATH=generic        force the generic kernel
+//   DVBS2HIP_LDPC_FAST_MODE=lds|global|hybrid   posterior image of the fast path
+//   DVBS2HIP_LDPC_WF=1                6-wave one-frame workgroups instead of 12-wave two-frame ones
+//   DVBS2HIP_LDPC_NF=2, DVBS2HIP_LDPC_PIPE=1    two frames per lane / software-pipelined layers (slower)
+//   DVBS2HIP_LDPC_C2V=lds|global, DVBS2HIP_LDPC_LDS_GROUPS=n   generic kernel storage policy
+//   DVBS2HIP_LDPC_BLOCKS_PER_CU, DVBS2HIP_LDPC_GRID_MAX, DVBS2HIP_LDS_LIMIT   occupancy / scaling experiments
 #include "dvbs2hip_internal.h"
 #include <algorithm>
 #include <cstdlib>

@@ -582,7 +582,7 @@ ldpc_fast_kernel(const LdpcKParams p)
                 const uint32_t fo = (uint32_t)k * fstride;
                 for (int g = 0; g < p.n_groups; g++) {
                     const int src = g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info);
-                    grp_st(g, c.t4, fo, Y[src]);
+                    grp_st(g, c.t4, fo, __builtin_nontemporal_load(&Y[src]));
                 }
                 for (int r = 0; r < q; r++) { c.st_st(fo, 0, r, 0.f); c.st_st(fo, 1, r, 0.f); c.st_st(fo, 2, r, 0.f); }
                 if (p.inf_row >= 0) c.post_st(c.t4, (uint32_t)p.inf_row + fo, INFINITY);     // what NULL slots read
@@ -638,7 +638,7 @@ ldpc_fast_kernel(const LdpcKParams p)
             if (act) {
                 for (int g = 0; g < p.n_info; g++) {
                     const float L = grp_ld(g, c.t4, fo);
-                    if (p.bits) p.bits[(size_t)f * p.K + g * LDPC_Z + t] = L < 0.f ? 1 : 0;
+                    if (p.bits) __builtin_nontemporal_store((int32_t)(L < 0.f ? 1 : 0), &p.bits[(size_t)f * p.K + g * LDPC_Z + t]);
                     if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + t] = L;
                 }
                 if (p.post)
@@ -779,7 +779,7 @@ ldpc_fast2_kernel(const LdpcKParams p)
             const float *Y = p.llr + (size_t)f * p.N;
             for (int g = 0; g < p.n_groups; g++) {
                 const int src = g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info);
-                c.post_st(c.t4, (uint32_t)g * ROW_BYTES, Y[src]);
+                c.post_st(c.t4, (uint32_t)g * ROW_BYTES, __builtin_nontemporal_load(&Y[src]));      // read-once stream: keep it out of the caches
             }
             if (SPA) { for (int e = 0; e < q * DEG; e++) __builtin_amdgcn_raw_buffer_store_b32(0u, c.rs, c.t4, c.c2v_base + (uint32_t)e * ROW_BYTES, 0); }
             else for (int r = 0; r < q; r++) { c.st_st(0u, 0, r, 0.f); c.st_st(0u, 1, r, 0.f); c.st_st(0u, 2, r, 0.f); }
@@ -815,7 +815,7 @@ ldpc_fast2_kernel(const LdpcKParams p)
             if (act) {
                 for (int g = 0; g < p.n_info; g++) {
                     const float L = c.post_ld(c.t4, (uint32_t)g * ROW_BYTES);
-                    if (p.bits) p.bits[(size_t)f * p.K + g * LDPC_Z + t] = L < 0.f ? 1 : 0;
+                    if (p.bits) __builtin_nontemporal_store((int32_t)(L < 0.f ? 1 : 0), &p.bits[(size_t)f * p.K + g * LDPC_Z + t]);
                     if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + t] = L;
                 }
                 if (p.post)
@@ -894,7 +894,7 @@ ldpc_fastp_kernel(const LdpcKParams p)
             const float *Y = p.llr + (size_t)f * p.N;
             for (int g = 0; g < p.n_groups; g++) {
                 const int src = g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info);
-                c.post_st(c.t4, (uint32_t)g * ROW_BYTES, Y[src]);
+                c.post_st(c.t4, (uint32_t)g * ROW_BYTES, __builtin_nontemporal_load(&Y[src]));      // read-once stream: keep it out of the caches
             }
             for (int r = 0; r < q; r++) { c.st_st(0u, 0, r, 0.f); c.st_st(0u, 1, r, 0.f); c.st_st(0u, 2, r, 0.f); }
             if (p.inf_row >= 0) c.post_st(c.t4, (uint32_t)p.inf_row, INFINITY);               // what NULL slots read
@@ -918,7 +918,7 @@ ldpc_fastp_kernel(const LdpcKParams p)
         if (act) {
             for (int g = 0; g < p.n_info; g++) {
                 const float L = c.post_ld(c.t4, (uint32_t)g * ROW_BYTES);
-                if (p.bits) p.bits[(size_t)f * p.K + g * LDPC_Z + t] = L < 0.f ? 1 : 0;
+                if (p.bits) __builtin_nontemporal_store((int32_t)(L < 0.f ? 1 : 0), &p.bits[(size_t)f * p.K + g * LDPC_Z + t]);
                 if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + t] = L;
             }
             if (p.post)

@@ -1,7 +1,7 @@
 """Manual bring-up script (not a test): python tests/gpu_quick.py"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from oracle import oracle as O
 from dvbs2_amd.receiver import Dvbs2Hip
