@@ -28,7 +28,7 @@
 //
 // Tuning / experiment knobs (environment, read when a handle is created):
 //   DVBS2HIP_LDPC_PATH=generic        force the generic kernel
-//   DVBS2HIP_LDPC_FAST_MODE=lds|global|hybrid   posterior image of the fast path
+//   DVBS2HIP_LDPC_FAST_MODE=lds|global|static|hybrid   posterior image of the fast path (static = default for N = 64800)
 //   DVBS2HIP_LDPC_WF=1                6-wave one-frame workgroups instead of 12-wave two-frame ones
 //   DVBS2HIP_LDPC_NF=2, DVBS2HIP_LDPC_PIPE=1    two frames per lane / software-pipelined layers (slower)
 //   DVBS2HIP_LDPC_C2V=lds|global, DVBS2HIP_LDPC_LDS_GROUPS=n   generic kernel storage policy
@@ -159,7 +159,59 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             }
             std::vector<uint32_t> gbase(pl.n_groups), glds(pl.n_groups, 0u);
             int n_l = 0, n_g = 0;
-            if (pl.fast_mode == 2) {
+            // mode 3 (STATIC hybrid, normal frames): pick the LDS-resident bit-groups so that EVERY layer has
+            // exactly NL = 9 of its 27 slots in LDS; the kernel then knows at compile time which slots are LDS
+            // accesses.  Greedy fill + randomised local search on sum_r (NL - count_r)^2 (deterministic seed).
+            std::vector<char> in_lds(pl.n_groups, 0);
+            {
+                const int NL = 9;
+                const char *ewf = getenv("DVBS2HIP_LDPC_WF"), *enf = getenv("DVBS2HIP_LDPC_NF");
+                const bool env_wf_is_1 = ewf && atoi(ewf) == 1, env_nf_is_2 = enf && atoi(enf) == 2;
+                const bool want = (env_mode && !strcmp(env_mode, "static")) || (!env_mode && pl.fast_mode == 1 && !env_wf_is_1 && !env_nf_is_2 && !pl.fast_pipe);
+                if (want && !spa && pl.fast_deg == 27 && !pl.fast_pad) {
+                    const int cap = (int)(lds_limit / 2 / grp_bytes) - 1;            // two frames per CU, one junk row each
+                    std::vector<std::vector<int>> mult(pl.n_groups, std::vector<int>(q, 0));
+                    for (int r = 0; r < q; r++) for (const Slot &sl : layers[r]) mult[sl.group][r]++;
+                    const int banned = n_rows + q - 1;                                // its layer-0 slot is the absent-for-check-0 one: keep it last
+                    std::vector<int> cnt(q, 0);
+                    int size = 0;
+                    auto fits = [&](int g) { for (int r = 0; r < q; r++) if (cnt[r] + mult[g][r] > NL) return false; return true; };
+                    auto add = [&](int g, int s) { in_lds[g] = s > 0; size += s; for (int r = 0; r < q; r++) cnt[r] += s * mult[g][r]; };
+                    for (;;) {
+                        int best = 0, bg = -1;
+                        for (int i = 0; i < pl.n_groups && size < cap; i++) {
+                            const int g = order[i];
+                            if (in_lds[g] || g == banned || !fits(g)) continue;
+                            if (touches[g] > best) { best = touches[g]; bg = g; }
+                        }
+                        if (bg < 0) break;
+                        add(bg, +1);
+                    }
+                    auto cost = [&]() { int c = 0; for (int r = 0; r < q; r++) c += (NL - cnt[r]) * (NL - cnt[r]); return c; };
+                    uint32_t rng = 12345u;
+                    auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+                    int c0 = cost();
+                    for (int it = 0; it < 400000 && c0 > 0; it++) {
+                        int g_out = -1, g_in = -1;
+                        if (rnd() & 1) { do { g_out = (int)(rnd() % pl.n_groups); } while (!in_lds[g_out]); }
+                        if (rnd() % 10 != 0) { do { g_in = (int)(rnd() % pl.n_groups); } while (in_lds[g_in] || g_in == banned); }
+                        if (g_out >= 0) add(g_out, -1);
+                        bool ok = true;
+                        if (g_in >= 0) { ok = fits(g_in) && size < cap; if (ok) add(g_in, +1); }
+                        const int c1 = ok ? cost() : 1 << 30;
+                        if (ok && (c1 <= c0 || rnd() % 500 == 0)) c0 = c1;
+                        else { if (ok && g_in >= 0) add(g_in, -1); if (g_out >= 0) add(g_out, +1); }
+                    }
+                    if (c0 == 0) { pl.fast_mode = 3; pl.fast_nf = 1; pl.fast_wf = 2; pl.fast_pipe = false; }
+                    else std::fill(in_lds.begin(), in_lds.end(), 0);
+                }
+            }
+            if (pl.fast_mode == 3) {
+                for (int g = 0; g < pl.n_groups; g++) {
+                    if (in_lds[g]) { gbase[g] = (uint32_t)(n_l++ * LDPC_Z); glds[g] = 1u; }
+                    else gbase[g] = (uint32_t)(n_g++ * LDPC_Z);
+                }
+            } else if (pl.fast_mode == 2) {
                 int cap = (int)(lds_limit / grp_bytes) - 2;
                 if (env_grp) cap = std::min(cap, std::max(0, atoi(env_grp)));
                 cap = std::min(cap, pl.n_groups);
@@ -176,7 +228,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             const uint32_t inf_row_words = (uint32_t)((pl.n_groups + (pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z);
             auto pack = [&](const Slot &sl) {
                 if (sl.group < 0) return (inf_row_words * 4u) << 11;
-                return (uint32_t)(sl.t0 * 4) | ((gbase[sl.group] * 4u) << 11) | (pl.fast_mode == 2 && glds[sl.group] ? (1u << 29) : 0u);
+                return (uint32_t)(sl.t0 * 4) | ((gbase[sl.group] * 4u) << 11) | (pl.fast_mode >= 2 && glds[sl.group] ? (1u << 29) : 0u);
             };
             if (const char *ev = getenv("DVBS2HIP_LDPC_PIPE")) pl.fast_pipe = atoi(ev) != 0 && !spa;
             for (int r = 0; r < q; r++) {
@@ -188,9 +240,16 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 std::vector<char> prev_touch(pl.n_groups, 0);
                 for (const Slot &sl : layers[(r + q - 1) % q]) prev_touch[sl.group] = 1;      // (layers[] hold real slots only)
                 std::vector<Slot> ord;
-                for (const Slot &sl : layers[r]) if (!prev_touch[sl.group]) ord.push_back(sl);
-                const int n_early = (int)ord.size();
-                for (const Slot &sl : layers[r]) if (prev_touch[sl.group]) ord.push_back(sl);
+                int n_early = 0;
+                if (pl.fast_mode == 3) {      // static hybrid: the LDS-resident slots first (exactly 9 of them), then the others
+                    for (const Slot &sl : layers[r]) if (in_lds[sl.group]) ord.push_back(sl);
+                    if ((int)ord.size() != 9) return "LDPC: internal: static hybrid balance broken";
+                    for (const Slot &sl : layers[r]) if (!in_lds[sl.group]) ord.push_back(sl);
+                } else {
+                    for (const Slot &sl : layers[r]) if (!prev_touch[sl.group]) ord.push_back(sl);
+                    n_early = (int)ord.size();
+                    for (const Slot &sl : layers[r]) if (prev_touch[sl.group]) ord.push_back(sl);
+                }
                 if (!ord.empty() && layers[r].back().mask0 && !ord.back().mask0) return "LDPC: internal: masked slot must stay last";
                 // NULL slots (group -1) go in front of the last real slot, which keeps position fast_deg-1
                 while ((int)ord.size() < pl.fast_deg) ord.insert(ord.end() - 1, Slot{-1, 0, 0, 0});
@@ -210,13 +269,14 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 T[27] = prim; T[28] = (uint32_t)nc; T[29] = (uint32_t)n_early;
             }
             // workspace of one workgroup: [posteriors kept in global memory | packed c->v state 3 M words]
-            pl.glb_post_words = pl.fast_mode == 1 ? (pl.n_groups + xrows) * LDPC_Z : pl.fast_mode == 2 ? n_g * LDPC_Z : 0;
-            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1 + xrows) * LDPC_Z : pl.fast_mode == 2 ? (n_l + 2) * LDPC_Z : 0;
+            pl.glb_post_words = pl.fast_mode == 1 ? (pl.n_groups + xrows) * LDPC_Z : pl.fast_mode >= 2 ? n_g * LDPC_Z : 0;
+            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1 + xrows) * LDPC_Z : pl.fast_mode == 2 ? (n_l + 2) * LDPC_Z
+                              : pl.fast_mode == 3 ? (n_l + 1) * LDPC_Z : 0;
             pl.fast_inf_row = pl.fast_pad ? (int)(inf_row_words * 4u) : -1;
             if (pl.fast_pad && pl.fast_mode == 2) return "LDPC: hybrid mode does not support padded layers";
             pl.gwork_words = pl.glb_post_words + (spa ? pl.fast_deg * M : 3 * M);      // SPA: one fp32 message per edge slot
             pl.lds_bytes = (size_t)pl.lds_post_words * 4;
-            pl.hybrid = pl.fast_mode == 2; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : n_l;
+            pl.hybrid = pl.fast_mode >= 2; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : n_l;
         }
     }
     if (pl.n_groups > 255) return "LDPC: more than 255 bit-groups not supported by the packed entry format";

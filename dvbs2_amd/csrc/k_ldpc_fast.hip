@@ -29,7 +29,12 @@ namespace dvbs2 {
 typedef __attribute__((address_space(3))) float lds_float;
 typedef const __attribute__((address_space(4))) uint32_t *const_u32;
 typedef const __attribute__((address_space(4))) unsigned long long *const_u64;
-constexpr uint32_t FE_LDS = 1u << 29;       // fast-table entry: the bit-group lives in LDS (hybrid mode)
+constexpr uint32_t FE_LDS = 1u << 29;       // fast-table entry: the bit-group lives in LDS (hybrid modes)
+// MODE 3 = STATIC hybrid: the host picks the LDS-resident bit-groups so that EVERY layer has exactly
+// NL_STATIC of its 27 slots in LDS and sorts them first: slot j < NL_STATIC is an LDS access, the
+// others are buffer accesses -- decided at compile time, no per-slot branch, select or dual issue.
+constexpr int NL_STATIC = 9;
+__host__ __device__ constexpr bool slot_in_lds(int mode, int j) { return mode == 0 || (mode == 3 && j < NL_STATIC); }
 
 constexpr uint32_t OOB = 0x7FFFF000u;       // beyond every workspace: loads return 0, stores are dropped
 constexpr int ROW_BYTES = LDPC_Z * 4;
@@ -67,6 +72,24 @@ struct FastCtx {
     {
         if (MODE == 0) lpost[(off + soff) >> 2] = v;
         else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, off, soff, 0);
+    }
+    // slot-indexed access: after unrolling, j is a constant and MODE 3's `j < NL_STATIC` folds away
+    __device__ __forceinline__ float slot_ld(int j, uint32_t w, uint32_t e, uint32_t fo) const
+    {
+        if (MODE == 3) {
+            const uint32_t base = (e >> 11) & 0x3FFFFu;
+            if (j < NL_STATIC) return lpost[(w + base) >> 2];
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, w, base + fo, 0));
+        }
+        return post_ld(w, (MODE == 0 ? 0u : (e >> 11)) + fo);
+    }
+    __device__ __forceinline__ void slot_st(int j, uint32_t w, bool keep, uint32_t e, uint32_t fo, float v) const
+    {
+        if (MODE == 3) {
+            const uint32_t base = (e >> 11) & 0x3FFFFu;
+            if (j < NL_STATIC) lpost[(keep ? w + base : junk_row + t4) >> 2] = v;
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, keep ? w : OOB, base + fo, 0);
+        } else post_st(keep ? w : redirect, (MODE == 0 ? 0u : (e >> 11)) + fo, v);
     }
     __device__ __forceinline__ float st_ld(uint32_t fo, int arr, int r) const
     {
@@ -112,7 +135,7 @@ __device__ __forceinline__ void fast_iteration(const FastCtx<MODE> &c, const uin
                 } else {
                     w[j] = min(d, d + (uint32_t)ROW_BYTES) + (MODE == 0 ? (E[j] >> 11) : 0u);   // LDS: full address
 #pragma unroll
-                    for (int k = 0; k < NA; k++) v[k][j] = c.post_ld(w[j], (MODE == 0 ? 0u : (E[j] >> 11)) + fo[k]);
+                    for (int k = 0; k < NA; k++) v[k][j] = c.slot_ld(j, w[j], E[j], fo[k]);
                 }
             }
             const int rn = r + 1 < q ? r + 1 : 0;
@@ -164,8 +187,8 @@ __device__ __forceinline__ void fast_iteration(const FastCtx<MODE> &c, const uin
             }
 #pragma unroll
             for (int j = 0; j < DEG; j++) {
-                uint32_t off = ((prim >> j) & 1u) ? w[j] : c.redirect;
-                if (j == DEG - 1 && mask0) off = c.redirect;
+                const bool keep = ((prim >> j) & 1u) != 0u && !(j == DEG - 1 && mask0);     // else: store dropped / redirected
+                const uint32_t off = keep ? w[j] : c.redirect;
                 uint32_t la = 0u, go = 0u, hbase = 0u;
                 if (MODE == 2) {
                     const bool il = (E[j] & FE_LDS) != 0u, pr = ((prim >> j) & 1u) != 0u;
@@ -184,7 +207,8 @@ __device__ __forceinline__ void fast_iteration(const FastCtx<MODE> &c, const uin
                     if (MODE == 2) {
                         c.lpost[la >> 2] = x + nw;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, x + nw), c.rs, go, hbase + fo[0], 0);
-                    } else c.post_st(off, (MODE == 0 ? 0u : (E[j] >> 11)) + fo[k], x + nw);
+                    } else if (MODE == 3) c.slot_st(j, w[j], keep, E[j], fo[k], x + nw);
+                    else c.post_st(off, (MODE == 0 ? 0u : (E[j] >> 11)) + fo[k], x + nw);
                 }
             }
 #pragma unroll
@@ -207,7 +231,7 @@ __device__ __forceinline__ void fast_iteration(const FastCtx<MODE> &c, const uin
                 for (int k = 0; k < NA; k++) {
                     const float nw = c2v_unpack_dyn<DEG>(cst1[k], cst2[k], pkn[k], j);
                     const float od = c2v_unpack_dyn<DEG>(c1o[k], c2o[k], pko[k], j);
-                    if (MODE == 2) {
+                    if (MODE >= 2) {
                         const uint32_t hb = (e >> 11) & 0x3FFFFu;
                         if (e & FE_LDS) { const float L = c.lpost[(off + hb) >> 2]; c.lpost[(off + hb) >> 2] = L + (nw - od); }
                         else {
@@ -516,7 +540,7 @@ __device__ __forceinline__ int fast_syndrome(const FastCtx<MODE> &c, uint32_t fo
                 const uint32_t d = c.t4 - (e & 0x7FFu);
                 const uint32_t wo = min(d, d + (uint32_t)ROW_BYTES);
                 float L;
-                if (MODE == 2) {
+                if (MODE >= 2) {
                     const uint32_t hb = (e >> 11) & 0x3FFFFu;
                     if (e & FE_LDS) L = c.lpost[(wo + hb) >> 2];
                     else L = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rs, wo, hb + fo, 0));
@@ -767,9 +791,28 @@ ldpc_fast2_kernel(const LdpcKParams p)
     c.t4 = (uint32_t)t * 4u;
     c.c2v_base = (uint32_t)p.glb_post_words * 4u;
     c.redirect = MODE == 0 ? (uint32_t)p.n_groups * ROW_BYTES + c.t4 : OOB;
-    c.zero_row = 0u; c.junk_row = 0u;
+    c.zero_row = 0u; c.junk_row = (uint32_t)(p.lds_post_words - LDPC_Z) * 4u;      // MODE 3: last row of the LDS image
     c.M = p.M; c.q = q; c.alpha = p.alpha;
     const uint32_t fo[1] = {0u};
+    const const_u64 groups = (const_u64)p.groups;
+    // where bit-group g lives (MODE 3: group table; modes 0 / 1: group g at row g)
+    auto grp_ld = [&](int g, uint32_t idx4) -> float {
+        if (MODE == 3) {
+            const unsigned long long gl = groups[g];
+            const uint32_t b = (uint32_t)gl * 4u;
+            if (gl >> 32) return c.lpost[(b + idx4) >> 2];
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c.rs, idx4, b, 0));
+        }
+        return c.post_ld(idx4, (uint32_t)g * ROW_BYTES);
+    };
+    auto grp_st = [&](int g, uint32_t idx4, float v) {
+        if (MODE == 3) {
+            const unsigned long long gl = groups[g];
+            const uint32_t b = (uint32_t)gl * 4u;
+            if (gl >> 32) c.lpost[(b + idx4) >> 2] = v;
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), c.rs, idx4, b, 0);
+        } else c.post_st(idx4, (uint32_t)g * ROW_BYTES, v);
+    };
 
     for (int fb = blockIdx.x * 2; fb < p.n_frames; fb += gridDim.x * 2) {
         const int f = fb + half;
@@ -779,7 +822,7 @@ ldpc_fast2_kernel(const LdpcKParams p)
             const float *Y = p.llr + (size_t)f * p.N;
             for (int g = 0; g < p.n_groups; g++) {
                 const int src = g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info);
-                c.post_st(c.t4, (uint32_t)g * ROW_BYTES, __builtin_nontemporal_load(&Y[src]));      // read-once stream: keep it out of the caches
+                grp_st(g, c.t4, __builtin_nontemporal_load(&Y[src]));      // read-once stream: keep it out of the caches
             }
             if (SPA) { for (int e = 0; e < q * DEG; e++) __builtin_amdgcn_raw_buffer_store_b32(0u, c.rs, c.t4, c.c2v_base + (uint32_t)e * ROW_BYTES, 0); }
             else for (int r = 0; r < q; r++) { c.st_st(0u, 0, r, 0.f); c.st_st(0u, 1, r, 0.f); c.st_st(0u, 2, r, 0.f); }
@@ -814,13 +857,13 @@ ldpc_fast2_kernel(const LdpcKParams p)
             }
             if (act) {
                 for (int g = 0; g < p.n_info; g++) {
-                    const float L = c.post_ld(c.t4, (uint32_t)g * ROW_BYTES);
+                    const float L = grp_ld(g, c.t4);
                     if (p.bits) __builtin_nontemporal_store((int32_t)(L < 0.f ? 1 : 0), &p.bits[(size_t)f * p.K + g * LDPC_Z + t]);
                     if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + t] = L;
                 }
                 if (p.post)
                     for (int g = p.n_info; g < p.n_groups; g++)
-                        p.post[(size_t)f * p.N + p.K + q * t + (g - p.n_info)] = c.post_ld(c.t4, (uint32_t)g * ROW_BYTES);
+                        p.post[(size_t)f * p.N + p.K + q * t + (g - p.n_info)] = grp_ld(g, c.t4);
             }
             if (p.packed) {
                 const int n_words = (p.K + 31) / 32;
@@ -829,7 +872,8 @@ ldpc_fast2_kernel(const LdpcKParams p)
                     for (int b = 0; b < 32; b++) {
                         const int i = 32 * wd + b;
                         if (i >= p.K) break;
-                        word |= (c.post_ld((uint32_t)i * 4u, 0u) < 0.f ? 1u : 0u) << b;
+                        const int g = i / LDPC_Z;
+                        word |= (grp_ld(g, (uint32_t)(i - g * LDPC_Z) * 4u) < 0.f ? 1u : 0u) << b;
                     }
                     p.packed[(size_t)f * n_words + wd] = word;
                 }
@@ -1011,7 +1055,7 @@ static int fast_occ(const LdpcPlan &pl)
 
 // (the pipelined iteration needs ~230 VGPRs at DEG 27: more than the 168 a 12-wave workgroup may use)
 #define FAST2_DISPATCH(FN, ...)                                                                   \
-    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, false>(__VA_ARGS__) : FN<27, 1, false>(__VA_ARGS__))      \
+    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, false>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3, false>(__VA_ARGS__) : FN<27, 1, false>(__VA_ARGS__))      \
      : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0, false>(__VA_ARGS__) : FN<13, 1, false>(__VA_ARGS__))     \
                       : (pl.fast_pipe ? (pl.fast_mode == 0 ? FN<11, 0, true>(__VA_ARGS__) : FN<11, 1, true>(__VA_ARGS__)) \
                                       : (pl.fast_mode == 0 ? FN<11, 0, false>(__VA_ARGS__) : FN<11, 1, false>(__VA_ARGS__))))
