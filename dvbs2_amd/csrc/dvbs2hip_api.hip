@@ -236,6 +236,11 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         upload(h, &lp.d_groups, lp.groups.data(), lp.groups.size()))
         CREATE_FAIL(DVBS2HIP_EHIP, h->err);
     if (lp.fast && upload(h, &lp.d_fast_tab, lp.fast_tab.data(), lp.fast_tab.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+    if (lp.fast_wg8) {
+        if (upload(h, &lp.d_w8_tab, lp.w8_tab.data(), lp.w8_tab.size()) || upload(h, &lp.d_w8_rows, lp.w8_rows.data(), lp.w8_rows.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+        CREATE_HIP(hipMalloc((void **)&lp.d_cu_ctr, (LDPC_CU_CTR_WORDS + LDPC_PROF_WORDS) * sizeof(uint32_t)));
+        CREATE_HIP(hipMemset(lp.d_cu_ctr, 0, LDPC_CU_CTR_WORDS * sizeof(uint32_t)));
+    }
     lp.grid_max = ldpc_blocks_per_cu(lp) * h->n_cus;
     if (const char *ev = getenv("DVBS2HIP_LDPC_GRID_MAX")) { const int g = atoi(ev); if (g >= 1 && g < lp.grid_max) lp.grid_max = g; }   // scaling experiments
     if (lp.gwork_words > 0) CREATE_HIP(hipMalloc((void **)&h->d_gwork, (size_t)lp.grid_max * (lp.fast ? lp.fast_nf * lp.fast_wf : 1) * lp.gwork_words * sizeof(float)));
@@ -355,7 +360,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     for (auto &kv : h->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
         for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
+    void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);

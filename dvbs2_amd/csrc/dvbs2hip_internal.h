@@ -50,6 +50,15 @@ struct LdpcKParams {
     int32_t inf_row;           // fast path: byte offset of the +inf row (padded layers) or -1
     int32_t pipe;              // fast path: software-pipelined layers (table sorted early-first, T[29] = n_early)
     const uint32_t *fast_tab;  // regular-code fast path: [q][LDPC_FAST_STRIDE] (see k_ldpc_fast.hip)
+    uint32_t *cu_ctr;          // 8-wave workgroups: per-CU arrival counter (zeroed before the launch) or null
+    struct {                   // k_ldpc_wg8.hip
+        const uint32_t *tab;   // [q][LDPC_FAST_STRIDE]: byte shift | byte offset of the bit-group row << 11 | LDS flag << 29
+        const uint32_t *rows;  // bit-group of LDS row l (nl of them), then of global row l (ng)
+        uint32_t st_base;      // byte offset of the packed c->v state in the workgroup's global slot
+        uint32_t lds_junk;     // byte offset of the write-only LDS row (the +inf row of padded codes follows it)
+        int32_t lds_bytes, pad;
+        int32_t nl_info, nl, ng_info, ng;
+    } w8;
 };
 
 struct LdpcPlan {             // host-side description, built once per handle
@@ -77,13 +86,24 @@ struct LdpcPlan {             // host-side description, built once per handle
     int fast_nf = 1;              // frames per LANE (2 only in global mode; measured slower, opt-in)
     bool fast_pipe = false;       // software-pipelined iteration: bit-exact but measured SLOWER (opt-in: DVBS2HIP_LDPC_PIPE=1)
     int fast_wf = 1;              // frames per WORKGROUP: 2 = 12-wave workgroups, one frame per half (balanced SIMDs)
+    bool fast_wg8 = false;        // one frame per 8-wave workgroup, SIMD-aware roles, two independent workgroups per CU (k_ldpc_wg8.hip)
+    bool w8_dups_in_lds = false;  // static hybrid: every bit-group with two edges in one layer is LDS-resident
+    std::vector<uint32_t> w8_tab, w8_rows;
+    uint32_t *d_w8_tab = nullptr, *d_w8_rows = nullptr;
+    uint32_t w8_st_base = 0, w8_lds_junk = 0;
+    int w8_lds_bytes = 0, w8_gwork_words = 0, w8_nl_info = 0, w8_nl = 0, w8_ng_info = 0, w8_ng = 0;
     std::vector<uint32_t> fast_tab;
     uint32_t *d_fast_tab = nullptr;
+    uint32_t *d_cu_ctr = nullptr; // [LDPC_CU_CTR_WORDS]
 };
+constexpr int LDPC_PROF_WORDS = 1024 * 64;   // development aid (LDPC_PHASE_PROF builds): per-wave phase timers
+constexpr int LDPC_CU_CTR_WORDS = 4096;    // key = XCC_ID << 8 | SE_ID << 5 | SH_ID << 4 | CU_ID
 constexpr int LDPC_FAST_STRIDE = 64;   // dwords per layer: 27 entries | prim mask | n_conf | 16 conf entries | 16 conf meta
 constexpr int LDPC_FAST_MAXC = 16;
 hipError_t ldpc_fast_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
 int ldpc_fast_blocks_per_cu(const LdpcPlan &pl);
+hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
+int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl);
 
 // builds the layer tables; returns empty string on success, else the error text
 std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,

@@ -177,6 +177,22 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                     int size = 0;
                     auto fits = [&](int g) { for (int r = 0; r < q; r++) if (cnt[r] + mult[g][r] > NL) return false; return true; };
                     auto add = [&](int g, int s) { in_lds[g] = s > 0; size += s; for (int r = 0; r < q; r++) cnt[r] += s * mult[g][r]; };
+                    // bit-groups with two edges in one layer go in first and stay: the duplicate-edge replay and the
+                    // store redirection of k_ldpc_wg8.hip then never leave LDS (DVBS2HIP_LDPC_LOCK_DUPS=0 to compare)
+                    std::vector<char> locked(pl.n_groups, 0);
+                    {
+                        const char *el = getenv("DVBS2HIP_LDPC_LOCK_DUPS");
+                        bool lock_ok = !(el && atoi(el) == 0);
+                        std::vector<int> dups;
+                        for (int g = 0; g < pl.n_groups && lock_ok; g++) {
+                            bool d = false;
+                            for (int r = 0; r < q; r++) d |= mult[g][r] > 1;
+                            if (d) { if (g == banned) lock_ok = false; dups.push_back(g); }
+                        }
+                        for (int g : dups) { if (!lock_ok) break; if (fits(g) && size < cap) { add(g, +1); locked[g] = 1; } else lock_ok = false; }
+                        if (!lock_ok) { for (int g = 0; g < pl.n_groups; g++) if (in_lds[g]) add(g, -1); std::fill(locked.begin(), locked.end(), 0); }
+                        pl.w8_dups_in_lds = lock_ok;
+                    }
                     for (;;) {
                         int best = 0, bg = -1;
                         for (int i = 0; i < pl.n_groups && size < cap; i++) {
@@ -193,7 +209,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                     int c0 = cost();
                     for (int it = 0; it < 400000 && c0 > 0; it++) {
                         int g_out = -1, g_in = -1;
-                        if (rnd() & 1) { do { g_out = (int)(rnd() % pl.n_groups); } while (!in_lds[g_out]); }
+                        if (rnd() & 1) { do { g_out = (int)(rnd() % pl.n_groups); } while (!in_lds[g_out]); if (locked[g_out]) g_out = -1; }
                         if (rnd() % 10 != 0) { do { g_in = (int)(rnd() % pl.n_groups); } while (in_lds[g_in] || g_in == banned); }
                         if (g_out >= 0) add(g_out, -1);
                         bool ok = true;
@@ -203,7 +219,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                         else { if (ok && g_in >= 0) add(g_in, -1); if (g_out >= 0) add(g_out, +1); }
                     }
                     if (c0 == 0) { pl.fast_mode = 3; pl.fast_nf = 1; pl.fast_wf = 2; pl.fast_pipe = false; }
-                    else std::fill(in_lds.begin(), in_lds.end(), 0);
+                    else { std::fill(in_lds.begin(), in_lds.end(), 0); pl.w8_dups_in_lds = false; }
                 }
             }
             if (pl.fast_mode == 3) {
@@ -231,8 +247,18 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 return (uint32_t)(sl.t0 * 4) | ((gbase[sl.group] * 4u) << 11) | (pl.fast_mode >= 2 && glds[sl.group] ? (1u << 29) : 0u);
             };
             if (const char *ev = getenv("DVBS2HIP_LDPC_PIPE")) pl.fast_pipe = atoi(ev) != 0 && !spa;
+            // k_ldpc_wg8.hip: same slot order, its own image layout -- LDS: [rows | junk | +inf]; global: [junk | +inf | rows]
+            pl.w8_tab.assign((size_t)q * LDPC_FAST_STRIDE, 0u);
+            const int w8_lrows = pl.fast_mode == 0 ? pl.n_groups : pl.fast_mode == 3 ? n_l : 0;
+            auto pack8 = [&](const Slot &sl) -> uint32_t {
+                if (sl.group < 0) return (uint32_t)((pl.fast_mode == 0 ? (w8_lrows + 1) * LDPC_Z * 4 : LDPC_Z * 4)) << 11;      // the +inf row
+                const bool il = pl.fast_mode == 0 || (pl.fast_mode == 3 && glds[sl.group]);
+                const uint32_t base = il ? gbase[sl.group] * 4u : 2u * LDPC_Z * 4u + gbase[sl.group] * 4u;
+                return (uint32_t)(sl.t0 * 4) | (base << 11) | (il ? (1u << 29) : 0u);
+            };
             for (int r = 0; r < q; r++) {
                 uint32_t *T = &pl.fast_tab[(size_t)r * LDPC_FAST_STRIDE];
+                uint32_t *T8 = &pl.w8_tab[(size_t)r * LDPC_FAST_STRIDE];
                 uint32_t prim = 0; int nc = 0;
                 // slot order: EARLY slots first (bit-group not touched by the previous layer, cyclically),
                 // then the late ones; the absent-for-check-0 parity slot stays last.  Conflict levels were
@@ -257,16 +283,34 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 for (int lvl = 1; lvl <= 3; lvl++)
                     for (size_t j = 0; j < ord.size(); j++)
                         if (ord[j].lvl == lvl && ord[j].group >= 0) {
-                            T[32 + nc] = pack(ord[j]);
-                            T[48 + nc] = (uint32_t)j | ((uint32_t)lvl << 8);
+                            T[32 + nc] = pack(ord[j]); T8[32 + nc] = pack8(ord[j]);
+                            T[48 + nc] = T8[48 + nc] = (uint32_t)j | ((uint32_t)lvl << 8);
+                            if (pl.fast_mode == 3 && !glds[ord[j].group]) pl.w8_dups_in_lds = false;
                             nc++;
                         }
                 for (size_t j = 0; j < ord.size(); j++) {
                     // byte shift (11 bits) | byte offset of the bit-group in its store (18 bits) | LDS flag
-                    T[j] = pack(ord[j]);
+                    T[j] = pack(ord[j]); T8[j] = pack8(ord[j]);
                     if (ord[j].lvl == 0 && ord[j].group >= 0) prim |= 1u << j;
                 }
                 T[27] = prim; T[28] = (uint32_t)nc; T[29] = (uint32_t)n_early;
+                T8[27] = prim; T8[28] = (uint32_t)nc;
+            }
+            {   // image rows in storage order: LDS rows then global rows (bit-groups ascend inside each: info first)
+                std::vector<int> lrow, grow;
+                for (int g = 0; g < pl.n_groups; g++) ((pl.fast_mode == 0 || (pl.fast_mode == 3 && glds[g])) ? lrow : grow).push_back(g);
+                pl.w8_nl = (int)lrow.size(); pl.w8_ng = (int)grow.size();
+                pl.w8_nl_info = (int)std::count_if(lrow.begin(), lrow.end(), [&](int g) { return g < pl.n_info; });
+                pl.w8_ng_info = (int)std::count_if(grow.begin(), grow.end(), [&](int g) { return g < pl.n_info; });
+                pl.w8_rows.clear();
+                for (int g : lrow) pl.w8_rows.push_back((uint32_t)g);
+                for (int g : grow) pl.w8_rows.push_back((uint32_t)g);
+                for (size_t i = 0; i < lrow.size(); i++) if ((int)gbase[lrow[i]] != (int)i * LDPC_Z) return "LDPC: internal: LDS row order";
+                for (size_t i = 0; i < grow.size(); i++) if ((int)gbase[grow[i]] != (int)i * LDPC_Z) return "LDPC: internal: global row order";
+                pl.w8_lds_junk = (uint32_t)(pl.w8_nl * LDPC_Z * 4);
+                pl.w8_lds_bytes = (pl.w8_nl + 1 + (pl.fast_pad && pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z * 4 + 64;
+                pl.w8_st_base = (uint32_t)((2 + pl.w8_ng) * LDPC_Z * 4);
+                pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + 3 * M;
             }
             // workspace of one workgroup: [posteriors kept in global memory | packed c->v state 3 M words]
             pl.glb_post_words = pl.fast_mode == 1 ? (pl.n_groups + xrows) * LDPC_Z : pl.fast_mode >= 2 ? n_g * LDPC_Z : 0;
@@ -277,6 +321,16 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             pl.gwork_words = pl.glb_post_words + (spa ? pl.fast_deg * M : 3 * M);      // SPA: one fp32 message per edge slot
             pl.lds_bytes = (size_t)pl.lds_post_words * 4;
             pl.hybrid = pl.fast_mode >= 2; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : n_l;
+            // production shape: one frame per 8-wave workgroup, two independent workgroups per CU (k_ldpc_fast.hip);
+            // DVBS2HIP_LDPC_WG=12 keeps the two-frames-per-12-wave-workgroup kernel
+            {
+                const char *env_wg = getenv("DVBS2HIP_LDPC_WG");
+                const bool w8_ok = pl.fast_mode == 0 || pl.fast_mode == 1 || (pl.fast_mode == 3 && pl.w8_dups_in_lds);
+                if (!spa && pl.fast_wf == 2 && pl.fast_nf == 1 && !pl.fast_pipe && w8_ok && (size_t)pl.w8_lds_bytes <= lds_limit + 512 &&
+                    !(env_wg && atoi(env_wg) == 12)) {
+                    pl.fast_wg8 = true; pl.fast_wf = 1; pl.gwork_words = pl.w8_gwork_words;
+                }
+            }
         }
     }
     if (pl.n_groups > 255) return "LDPC: more than 255 bit-groups not supported by the packed entry format";
@@ -556,6 +610,7 @@ static int occ_inst(const LdpcPlan &pl)
 }
 int ldpc_blocks_per_cu(const LdpcPlan &pl)
 {
+    if (pl.fast && pl.fast_wg8) return ldpc_wg8_blocks_per_cu(pl);
     if (pl.fast) return ldpc_fast_blocks_per_cu(pl);
     const bool small = pl.ent_stride == 13;
 #define OCC(H, C) (small ? occ_inst<13, H, C>(pl) : occ_inst<LDPC_MAX_SLOTS, H, C>(pl))
@@ -566,6 +621,7 @@ int ldpc_blocks_per_cu(const LdpcPlan &pl)
 
 hipError_t ldpc_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
+    if (pl.fast && pl.fast_wg8) return ldpc_wg8_launch(pl, p, s);
     if (pl.fast) return ldpc_fast_launch(pl, p, s);
     p.entries = pl.d_entries; p.layer_deg = pl.d_layer_deg; p.layer_lvl = pl.d_layer_lvl; p.groups = pl.d_groups;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;

@@ -1,0 +1,401 @@
+// a1, production kernel -- layered NMS, one frame per EIGHT-wave workgroup (six waves work), two
+// independent workgroups per CU.  Same schedule and arithmetic as k_ldpc_fast.hip / the oracle
+// (bit-exact), rebuilt around what a per-phase cycle profile of that kernel showed on MI355X
+// (DESIGN.md section 6): 30 % of its time was frame I/O issued as ~180 dependent HBM round trips,
+// 12 % the replay of same-layer duplicate edges through global memory, and the layer loop itself
+// was VALU-issue bound (~610 VALU per layer and wave).
+//
+//  * Workgroup shape.  The dispatcher deals the waves of a workgroup round-robin over the CU's four
+//    SIMDs (tools/probe_placement.hip): 6 waves sit 2+2+1+1, 8 waves 2+2+2+2.  Every wave reads its
+//    SIMD from HW_REG_HW_ID and the workgroup learns from a per-CU arrival counter whether it is the
+//    first or the second one on its CU (F); the first wave on every SIMD works, the second one only on
+//    SIMDs {0,1} (F = 0) or {2,3} (F = 1): the CU's two workgroups load every SIMD with exactly three
+//    working waves and share no barrier, so one frame's I/O and memory phases overlap the other
+//    frame's arithmetic.  The two idle waves only attend the barriers.  Placement is a performance
+//    matter only: any assignment of the six roles decodes correctly.
+//  * Frame I/O in batches of 8 independent loads per lane (rows of the posterior image in storage
+//    order, LDS rows then global rows); hard decisions for the fused chain are packed with wave
+//    ballots instead of 32 strided loads per word.
+//  * Static hybrid image (N = 64800): 9 of the 27 slots of every layer are LDS-resident, known at
+//    compile time, AND every bit-group with two edges in one layer is among them -- the duplicate-edge
+//    replay and the store redirection then never leave LDS, and stores to global memory need no select.
+//  * VALU per edge: byte-addressed LDS (one add per access), sign/magnitude merges as single
+//    v_and_or / v_bitop3 with the sign mask in an SGPR, store redirection selected on the scalar unit.
+#include "dvbs2hip_internal.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace dvbs2 {
+
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef const __attribute__((address_space(4))) uint32_t *const_u32;
+
+constexpr int W8_NL = 9;                    // MODE 3: LDS-resident slots per layer (the first ones)
+constexpr int W8_ROW = LDPC_Z * 4;          // bytes per bit-group row
+constexpr uint32_t W8_OOB = 0x7FFFF000u;    // voffset beyond every workspace: the store is dropped
+__host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode == 0 || (mode == 3 && j < W8_NL); }
+
+#ifdef LDPC_PHASE_PROF
+#define PROF_MARK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[i] += (uint32_t)(n_ - pt_); pt_ = n_; } while (0)
+#else
+#define PROF_MARK(i)
+#endif
+
+// (a & m) | b in one VALU operation (the compiler emits v_and + v_or)
+__device__ __forceinline__ float and_or(uint32_t a, uint32_t m_sgpr, float b)
+{
+    float r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m_sgpr), "v"(b));
+    return r;
+}
+
+// message on slot j from the packed per-check state: magnitude c1 at the recorded minimum, c2 elsewhere
+// (both >= 0); sign = bit (DEG-1-j) of pk.  `sb` = 0x80000000 held in an SGPR.
+template <int DEG>
+__device__ __forceinline__ float w8_unpack(float c1, float c2, uint32_t pk, uint32_t j, uint32_t sb)
+{
+    const float mag = ((pk >> 27) == j) ? c1 : c2;
+    return and_or(pk << ((32u - DEG) + j), sb, mag);
+}
+
+template <int DEG, int MODE>      // MODE 0: image in LDS, 1: in the workgroup's global slot, 3: static hybrid
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+ldpc_wg8_kernel(const LdpcKParams p)
+{
+    extern __shared__ float smem[];
+    lds_char *const L = (lds_char *)(lds_float *)smem;
+    lds_int *const s_misc = (lds_int *)(L + p.w8.lds_bytes - 64);      // [0..7] SIMD of wave w, [8] F
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    const uint32_t hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);            // HW_REG_HW_ID
+    const int simd = (int)((hw >> 4) & 3u);
+    if (lane == 0) s_misc[wave] = simd;
+    if (threadIdx.x == 0) {
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);        // HW_REG_XCC_ID
+        const uint32_t key = (xcc & 15u) << 8 | ((hw >> 13) & 7u) << 5 | ((hw >> 12) & 1u) << 4 | ((hw >> 8) & 15u);
+        s_misc[8] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[key], 1u) & 1u) : 0;
+    }
+    __syncthreads();
+    int role;
+    {
+        int k = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int w = 0; w < 8; w++) {
+            const int s = s_misc[w];
+            c0 += s == 0; c1 += s == 1; c2 += s == 2; c3 += s == 3;
+            if (w < wave && s == simd) k++;
+        }
+        const bool balanced = c0 == 2 && c1 == 2 && c2 == 2 && c3 == 2;
+        if (!balanced) role = wave < 6 ? wave : -1;
+        else if (k == 0) role = simd;
+        else role = ((simd >> 1) == s_misc[8]) ? 4 + (simd & 1) : -1;
+        role = __builtin_amdgcn_readfirstlane(role);
+    }
+    const int t = role * 64 + lane;
+    const bool act = role >= 0 && t < LDPC_Z;
+    const uint32_t t4 = (uint32_t)t * 4u;
+    const int q = p.q, M = p.M;
+    float *gwork = p.gwork + (size_t)blockIdx.x * p.gwork_words;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gwork, 0, p.gwork_words * 4, 0x00020000);
+    const const_u32 tab = (const_u32)p.w8.tab;
+    const const_u32 rows = (const_u32)p.w8.rows;
+    const uint32_t st_base = p.w8.st_base;                   // packed state: [c1][c2][pk], each [q][360]
+    const uint32_t ljunk = p.w8.lds_junk;                    // LDS junk row (write-only)
+    uint32_t SB = 0x80000000u;
+    asm volatile("" : "+s"(SB));                             // the sign mask as an SGPR operand (VOP3 takes no literal)
+    auto gld = [&](uint32_t voff, uint32_t soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0)); };
+    auto gst = [&](uint32_t voff, uint32_t soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, 0); };
+    auto lld = [&](uint32_t a) -> float { return *(lds_float *)(L + a); };
+    auto lst = [&](uint32_t a, float v) { *(lds_float *)(L + a) = v; };
+    auto st_off = [&](int arr, int r) { return st_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u; };
+    const int nl_info = p.w8.nl_info, nl = p.w8.nl, ng_info = p.w8.ng_info, ng = p.w8.ng;
+    const uint32_t grow0 = 2u * W8_ROW;                      // global image: [junk row][+inf row][group rows ..]
+#ifdef LDPC_PHASE_PROF
+    uint32_t prof[12];
+    for (int i = 0; i < 12; i++) prof[i] = 0u;
+    const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long pt_ = prof_t0;
+#endif
+
+    for (int f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
+        // ---- channel LLRs -> posterior image, 8 independent loads per lane in flight; packed state := 0
+        if (act) {
+            const float *Y = p.llr + (size_t)f * p.N;
+            auto src_of = [&](int g) { return g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info); };
+            // info groups stream in once (coalesced rows): non-temporal; the parity groups are a stride-q
+            // gather of one 4 M-byte region that all q groups share: cached loads
+            for (int l0 = 0; l0 < nl; l0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int l = l0 + k < nl ? l0 + k : nl - 1;
+                    const int g = (int)rows[l];
+                    v[k] = l < nl_info ? __builtin_nontemporal_load(&Y[src_of(g)]) : Y[src_of(g)];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (l0 + k < nl) lst((uint32_t)(l0 + k) * W8_ROW + t4, v[k]);
+            }
+            for (int l0 = 0; l0 < ng; l0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int l = l0 + k < ng ? l0 + k : ng - 1;
+                    const int g = (int)rows[nl + l];
+                    v[k] = l < ng_info ? __builtin_nontemporal_load(&Y[src_of(g)]) : Y[src_of(g)];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (l0 + k < ng) gst(t4, grow0 + (uint32_t)(l0 + k) * W8_ROW, v[k]);
+            }
+            for (int r = 0; r < q; r++) { gst(t4, st_off(0, r), 0.f); gst(t4, st_off(1, r), 0.f); gst(t4, st_off(2, r), 0.f); }
+            if (p.w8.pad) { if (MODE == 0) lst(ljunk + W8_ROW + t4, INFINITY); else gst(t4, W8_ROW, INFINITY); }     // what NULL slots read
+        }
+        if (p.packed && role >= 0) {
+            const int n_words = (p.K + 31) / 32;
+            for (int wd = t; wd < n_words; wd += LDPC_THREADS) p.packed[(size_t)f * n_words + wd] = 0u;
+        }
+        __syncthreads();
+        PROF_MARK(8);
+
+        int it = 0;
+        bool ok = false;
+        float nx1 = 0.f, nx2 = 0.f, nxk = 0.f;           // packed state of the next layer (prefetched)
+        while (it < p.n_ite) {
+            for (int r = 0; r < q; r++) {
+                const const_u32 T = tab + r * LDPC_FAST_STRIDE;
+                uint32_t E[DEG];
+#pragma unroll
+                for (int j = 0; j < DEG; j++) E[j] = T[j];
+                const uint32_t prim = T[27];
+                const int ncf = (int)T[28];
+                const bool mask0 = (r == 0) && (t == 0);        // p_{c-1} of check 0 does not exist
+                float v[DEG];
+                uint32_t w[DEG];
+                const float c1o = nx1, c2o = nx2;
+                const uint32_t pko = __float_as_uint(nxk);
+                float mn1 = INFINITY, mn2 = INFINITY, cst1 = 0.f, cst2 = 0.f;
+                uint32_t sacc = 0u, tot = 0u, pkn = 0u;
+                if (act) {
+                    // ---- pass 1a: every posterior load of the check in flight before any use
+#pragma unroll
+                    for (int j = 0; j < DEG; j++) {
+                        const uint32_t d = t4 - (E[j] & 0x7FFu);
+                        const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
+                        w[j] = min(d, d + (uint32_t)W8_ROW);
+                        v[j] = w8_slot_lds(MODE, j) ? lld(w[j] + base) : gld(w[j], base);
+                    }
+                    const int rn = r + 1 < q ? r + 1 : 0;
+                    nx1 = gld(t4, st_off(0, rn)); nx2 = gld(t4, st_off(1, rn)); nxk = gld(t4, st_off(2, rn));
+                    PROF_MARK(0);
+                    // ---- pass 1b: v->c = posterior - old c->v ; running min1 / min2 / signs
+                    const uint32_t idxo = pko >> 27;
+#pragma unroll
+                    for (int j = 0; j < DEG; j++) {
+                        const float mag = (idxo == (uint32_t)j) ? c1o : c2o;
+                        const float old = and_or(pko << ((32u - DEG) + j), SB, mag);          // sign bit of slot j | magnitude (>= 0)
+                        float x = v[j] - old;
+                        if (j == DEG - 1 && mask0) x = INFINITY;
+                        v[j] = x;
+                        const float a = fabsf(x);
+                        mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);
+                        mn1 = fminf(mn1, a);
+                        sacc = __builtin_amdgcn_alignbit(sacc, __float_as_uint(x), 31);      // shift the sign bit in
+                    }
+                    cst1 = mn2 * p.alpha; cst2 = mn1 * p.alpha;
+                    tot = (uint32_t)(__popc(sacc) & 1);                                       // parity of all signs
+                    pkn = sacc ^ (tot ? ((1u << DEG) - 1u) : 0u);                             // sign(new_j) = tot ^ sign(x_j)
+                }
+                PROF_MARK(1);
+                if (ncf > 0) __syncthreads();         // every read of the layer precedes its writes
+                PROF_MARK(2);
+                if (act) {
+                    // ---- pass 2: new c->v ; posterior = v->c + new c->v.  Duplicate edges (not in `prim`) go to
+                    //      the junk row (selected on the scalar unit), the absent edge of lane 0 is dropped.
+                    uint32_t idxn = 0u;
+                    float m1s = __uint_as_float(__float_as_uint(cst1) | (tot << 31));        // output magnitudes carrying the total sign
+                    float m2s = __uint_as_float(__float_as_uint(cst2) | (tot << 31));
+                    asm volatile("" : "+v"(m1s), "+v"(m2s));      // keep the sign folded in: one select + one bit-op per edge
+#pragma unroll
+                    for (int j = 0; j < DEG; j++) {
+                        const float x = v[j];
+                        const bool ismin = fabsf(x) == mn1;
+                        const float mag = ismin ? m1s : m2s;
+                        const float nw = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(x) & SB));
+                        idxn = ismin ? (uint32_t)j : idxn;
+                        asm volatile("" : "+v"(idxn));            // select now: the comparison mask dies here instead of piling up 27 SGPR pairs
+                        const bool pr = ((prim >> j) & 1u) != 0u;                             // wave-uniform
+                        const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
+                        if (w8_slot_lds(MODE, j)) {
+                            uint32_t a = w[j] + (pr ? base : ljunk);
+                            if (j == DEG - 1 && mask0) a = ljunk;
+                            lst(a, x + nw);
+                        } else {
+                            // MODE 3: the duplicate edges all live in LDS, a global slot is always primary
+                            const uint32_t sb = (MODE == 3 || pr) ? base : 0u;                // global junk row = row 0
+                            const uint32_t vo = (j == DEG - 1 && mask0) ? W8_OOB : w[j];
+                            gst(vo, sb, x + nw);
+                        }
+                    }
+                    pkn |= idxn << 27;
+                    gst(t4, st_off(0, r), cst1); gst(t4, st_off(1, r), cst2); gst(t4, st_off(2, r), __uint_as_float(pkn));
+                    if (q == 1) { nx1 = cst1; nx2 = cst2; nxk = __uint_as_float(pkn); }
+                }
+                PROF_MARK(3);
+                // ---- duplicate edges of a bit-group inside this layer: ordered delta updates, level by level
+                uint32_t prev_lvl = 0u;
+                for (int i = 0; i < ncf; i++) {
+                    const uint32_t e = T[32 + i], meta = T[48 + i];
+                    const uint32_t j = meta & 31u, lvl = meta >> 8;
+                    if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
+                    if (act) {
+                        const uint32_t d = t4 - (e & 0x7FFu);
+                        const uint32_t off = min(d, d + (uint32_t)W8_ROW), base = (e >> 11) & 0x3FFFFu;
+                        const float nw = w8_unpack<DEG>(cst1, cst2, pkn, j, SB), od = w8_unpack<DEG>(c1o, c2o, pko, j, SB);
+                        if (MODE != 1) { const float Lv = lld(off + base); lst(off + base, Lv + (nw - od)); }
+                        else { const float Lv = gld(off, base); gst(off, base, Lv + (nw - od)); }
+                    }
+                }
+                PROF_MARK(4);
+                __syncthreads();
+                PROF_MARK(5);
+            }
+            it++;
+            if (p.early_stop || it == p.n_ite) {
+                // ---- syndrome of the hard decisions (this lane's check of every layer)
+                int bad = 0;
+                if (act)
+                    for (int r = 0; r < q; r++) {
+                        const const_u32 T = tab + r * LDPC_FAST_STRIDE;
+                        uint32_t x = 0u;
+#pragma unroll
+                        for (int j = 0; j < DEG; j++) {
+                            const uint32_t e = T[j];
+                            const uint32_t d = t4 - (e & 0x7FFu);
+                            const uint32_t wo = min(d, d + (uint32_t)W8_ROW), base = (e >> 11) & 0x3FFFFu;
+                            const float Lv = w8_slot_lds(MODE, j) ? lld(wo + base) : gld(wo, base);
+                            const bool absent = (j == DEG - 1) && (r == 0) && (t == 0);
+                            x ^= (!absent && Lv < 0.f) ? 1u : 0u;                              // NULL slots read +inf
+                        }
+                        bad |= (int)x;
+                    }
+                ok = !__syncthreads_or(bad);
+                PROF_MARK(6);
+                if (ok) break;
+            }
+        }
+
+        // ---- outputs: hard decisions of the info bits (image rows in storage order, 8 loads in flight)
+        if (threadIdx.x == 0) {
+            if (p.cwd) p.cwd[f] = ok ? 1 : 0;
+            if (p.ites) p.ites[f] = it;
+        }
+        const int n_words = (p.K + 31) / 32;
+        auto emit = [&](int g, float Lv) {
+            if (act) {
+                if (g < p.n_info) {
+                    if (p.bits) __builtin_nontemporal_store((int32_t)(Lv < 0.f ? 1 : 0), &p.bits[(size_t)f * p.K + g * LDPC_Z + t]);
+                    if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + t] = Lv;
+                } else if (p.post) p.post[(size_t)f * p.N + p.K + q * t + (g - p.n_info)] = Lv;
+            }
+            if (p.packed && role >= 0 && g < p.n_info) {
+                // 64 lanes = 64 consecutive info bits starting at bit o of the frame; o is a multiple of 8
+                const unsigned long long m = __ballot(act && Lv < 0.f);
+                const int o = g * LDPC_Z + role * 64, sh = o & 31;
+                const unsigned long long lo = m << sh;
+                const uint32_t hi = sh ? (uint32_t)(m >> (64 - sh)) : 0u;
+                const uint32_t part = lane == 0 ? (uint32_t)lo : lane == 1 ? (uint32_t)(lo >> 32) : hi;
+                const int wd = (o >> 5) + lane;
+                if (lane < 3 && part && wd < n_words) atomicOr(&p.packed[(size_t)f * n_words + wd], part);
+            }
+        };
+        const int nl_out = p.post ? nl : nl_info, ng_out = p.post ? ng : ng_info;
+        if (role >= 0) {
+            for (int l0 = 0; l0 < nl_out; l0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = act ? lld((uint32_t)(l0 + k < nl_out ? l0 + k : nl_out - 1) * W8_ROW + t4) : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (l0 + k < nl_out) emit((int)rows[l0 + k], v[k]);
+            }
+            for (int l0 = 0; l0 < ng_out; l0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = act ? gld(t4, grow0 + (uint32_t)(l0 + k < ng_out ? l0 + k : ng_out - 1) * W8_ROW) : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (l0 + k < ng_out) emit((int)rows[nl + l0 + k], v[k]);
+            }
+        }
+        __syncthreads();     // the posterior image is reused by the next frame of this workgroup
+        PROF_MARK(7);
+    }
+#ifdef LDPC_PHASE_PROF
+    if (lane == 0 && p.cu_ctr) {
+        prof[11] = (uint32_t)(__builtin_amdgcn_s_memtime() - prof_t0);
+        for (int i = 0; i < 12; i++) p.cu_ctr[LDPC_CU_CTR_WORDS + ((int)blockIdx.x * 8 + wave) * 12 + i] = role >= 0 ? prof[i] : 0u;
+    }
+#endif
+}
+
+template <int DEG, int MODE>
+static hipError_t wg8_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
+{
+    auto kern = ldpc_wg8_kernel<DEG, MODE>;
+    static size_t configured_dev[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t &configured = configured_dev[dev & 63];
+    const size_t lds = (size_t)pl.w8_lds_bytes;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    const int grid = p.n_frames < pl.grid_max ? p.n_frames : pl.grid_max;
+    if (p.cu_ctr) { hipError_t e = hipMemsetAsync(p.cu_ctr, 0, LDPC_CU_CTR_WORDS * sizeof(uint32_t), s); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
+#ifdef LDPC_PHASE_PROF
+    {   // development aid: average ticks per phase over the working waves
+        (void)hipStreamSynchronize(s);
+        std::vector<uint32_t> hbuf((size_t)grid * 8 * 12);
+        (void)hipMemcpy(hbuf.data(), p.cu_ctr + LDPC_CU_CTR_WORDS, hbuf.size() * 4, hipMemcpyDeviceToHost);
+        double acc[12] = {0}; int nw = 0;
+        for (int w = 0; w < grid * 8; w++) { if (!hbuf[(size_t)w * 12 + 11]) continue; nw++; for (int i = 0; i < 12; i++) acc[i] += hbuf[(size_t)w * 12 + i]; }
+        static const char *nm[12] = {"1a issue", "1b", "mid barrier", "pass 2", "replay", "end barrier", "syndrome", "output", "input", "-", "-", "TOTAL"};
+        fprintf(stderr, "[ldpc phase prof] %d working waves\n", nw);
+        for (int i = 0; i < 12; i++) if (nm[i][0] != '-') fprintf(stderr, "  %-12s %12.0f ticks/wave  %5.1f %%\n", nm[i], acc[i] / (nw ? nw : 1), 100.0 * acc[i] / (acc[11] > 0 ? acc[11] : 1));
+    }
+#endif
+    return hipGetLastError();
+}
+
+template <int DEG, int MODE>
+static int wg8_occ(const LdpcPlan &pl)
+{
+    auto kern = ldpc_wg8_kernel<DEG, MODE>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.w8_lds_bytes);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 512, (size_t)pl.w8_lds_bytes) != hipSuccess) nb = 1;
+    if (nb > 2) nb = 2;          // the role assignment balances exactly two workgroups per CU
+    if (const char *ev = getenv("DVBS2HIP_LDPC_BLOCKS_PER_CU")) { const int cap = atoi(ev); if (cap >= 1 && cap < nb) nb = cap; }
+    return nb < 1 ? 1 : nb;
+}
+
+#define WG8_DISPATCH(FN, ...)                                                                                                              \
+    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3>(__VA_ARGS__) : FN<27, 1>(__VA_ARGS__)) \
+     : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0>(__VA_ARGS__) : FN<13, 1>(__VA_ARGS__))                                           \
+                         : (pl.fast_mode == 0 ? FN<11, 0>(__VA_ARGS__) : FN<11, 1>(__VA_ARGS__)))
+
+int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl) { return WG8_DISPATCH(wg8_occ, pl); }
+
+hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
+{
+    p.cu_ctr = pl.d_cu_ctr;
+    p.w8.tab = pl.d_w8_tab; p.w8.rows = pl.d_w8_rows;
+    p.w8.st_base = pl.w8_st_base; p.w8.lds_junk = pl.w8_lds_junk; p.w8.lds_bytes = pl.w8_lds_bytes; p.w8.pad = pl.fast_pad ? 1 : 0;
+    p.w8.nl_info = pl.w8_nl_info; p.w8.nl = pl.w8_nl; p.w8.ng_info = pl.w8_ng_info; p.w8.ng = pl.w8_ng;
+    p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
+    p.gwork_words = pl.w8_gwork_words;
+    return WG8_DISPATCH(wg8_inst, pl, p, s);
+}
+
+}  // namespace dvbs2
