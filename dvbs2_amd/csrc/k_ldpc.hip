@@ -294,7 +294,13 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                     if (ord[j].lvl == 0 && ord[j].group >= 0) prim |= 1u << j;
                 }
                 T[27] = prim; T[28] = (uint32_t)nc; T[29] = (uint32_t)n_early;
+                // wg8: ncf | slot of entry 0 << 8 | level << 13 | slot of entry 1 << 16 | level << 21 ; entries 0 and 1
                 T8[27] = prim; T8[28] = (uint32_t)nc;
+                for (int i = 0; i < 2 && i < nc; i++) {
+                    T8[28] |= ((T8[48 + i] & 31u) | ((T8[48 + i] >> 8) << 5)) << (8 + 8 * i);
+                    T8[29 + i] = T8[32 + i];
+                }
+                if (nc > 0 && (T8[48] >> 8) != 1u) return "LDPC: internal: first conflict entry is not of level 1";
             }
             {   // image rows in storage order: LDS rows then global rows (bit-groups ascend inside each: info first)
                 std::vector<int> lrow, grow;

@@ -35,6 +35,7 @@ typedef const __attribute__((address_space(4))) uint32_t *const_u32;
 
 constexpr int W8_NL = 9;                    // MODE 3: LDS-resident slots per layer (the first ones)
 constexpr int W8_ROW = LDPC_Z * 4;          // bytes per bit-group row
+constexpr int W8_IO = 16;                  // independent loads per lane in flight during frame I/O
 constexpr uint32_t W8_OOB = 0x7FFFF000u;    // voffset beyond every workspace: the store is dropped
 __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode == 0 || (mode == 3 && j < W8_NL); }
 
@@ -119,33 +120,33 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #endif
 
     for (int f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
-        // ---- channel LLRs -> posterior image, 8 independent loads per lane in flight; packed state := 0
+        // ---- channel LLRs -> posterior image, W8_IO independent loads per lane in flight; packed state := 0
         if (act) {
             const float *Y = p.llr + (size_t)f * p.N;
             auto src_of = [&](int g) { return g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info); };
             // info groups stream in once (coalesced rows): non-temporal; the parity groups are a stride-q
             // gather of one 4 M-byte region that all q groups share: cached loads
-            for (int l0 = 0; l0 < nl; l0 += 8) {
-                float v[8];
+            for (int l0 = 0; l0 < nl; l0 += W8_IO) {
+                float v[W8_IO];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < W8_IO; k++) {
                     const int l = l0 + k < nl ? l0 + k : nl - 1;
                     const int g = (int)rows[l];
                     v[k] = l < nl_info ? __builtin_nontemporal_load(&Y[src_of(g)]) : Y[src_of(g)];
                 }
 #pragma unroll
-                for (int k = 0; k < 8; k++) if (l0 + k < nl) lst((uint32_t)(l0 + k) * W8_ROW + t4, v[k]);
+                for (int k = 0; k < W8_IO; k++) if (l0 + k < nl) lst((uint32_t)(l0 + k) * W8_ROW + t4, v[k]);
             }
-            for (int l0 = 0; l0 < ng; l0 += 8) {
-                float v[8];
+            for (int l0 = 0; l0 < ng; l0 += W8_IO) {
+                float v[W8_IO];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < W8_IO; k++) {
                     const int l = l0 + k < ng ? l0 + k : ng - 1;
                     const int g = (int)rows[nl + l];
                     v[k] = l < ng_info ? __builtin_nontemporal_load(&Y[src_of(g)]) : Y[src_of(g)];
                 }
 #pragma unroll
-                for (int k = 0; k < 8; k++) if (l0 + k < ng) gst(t4, grow0 + (uint32_t)(l0 + k) * W8_ROW, v[k]);
+                for (int k = 0; k < W8_IO; k++) if (l0 + k < ng) gst(t4, grow0 + (uint32_t)(l0 + k) * W8_ROW, v[k]);
             }
             for (int r = 0; r < q; r++) { gst(t4, st_off(0, r), 0.f); gst(t4, st_off(1, r), 0.f); gst(t4, st_off(2, r), 0.f); }
             if (p.w8.pad) { if (MODE == 0) lst(ljunk + W8_ROW + t4, INFINITY); else gst(t4, W8_ROW, INFINITY); }     // what NULL slots read
@@ -160,14 +161,18 @@ ldpc_wg8_kernel(const LdpcKParams p)
         int it = 0;
         bool ok = false;
         float nx1 = 0.f, nx2 = 0.f, nxk = 0.f;           // packed state of the next layer (prefetched)
+        // layer table of the NEXT layer, fetched under the end-of-layer barrier: 27 slots | prim | conflict info | 2 conflict entries
+        uint32_t TE[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) TE[j] = tab[j];
         while (it < p.n_ite) {
             for (int r = 0; r < q; r++) {
                 const const_u32 T = tab + r * LDPC_FAST_STRIDE;
                 uint32_t E[DEG];
 #pragma unroll
-                for (int j = 0; j < DEG; j++) E[j] = T[j];
-                const uint32_t prim = T[27];
-                const int ncf = (int)T[28];
+                for (int j = 0; j < DEG; j++) E[j] = TE[j];
+                const uint32_t prim = TE[27], cinfo = TE[28], ce0 = TE[29], ce1 = TE[30];
+                const int ncf = (int)(cinfo & 0xFFu);
                 const bool mask0 = (r == 0) && (t == 0);        // p_{c-1} of check 0 does not exist
                 float v[DEG];
                 uint32_t w[DEG];
@@ -241,21 +246,41 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     if (q == 1) { nx1 = cst1; nx2 = cst2; nxk = __uint_as_float(pkn); }
                 }
                 PROF_MARK(3);
-                // ---- duplicate edges of a bit-group inside this layer: ordered delta updates, level by level
-                uint32_t prev_lvl = 0u;
-                for (int i = 0; i < ncf; i++) {
-                    const uint32_t e = T[32 + i], meta = T[48 + i];
-                    const uint32_t j = meta & 31u, lvl = meta >> 8;
-                    if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
+                // ---- duplicate edges of a bit-group inside this layer: ordered delta updates, level by level.  The
+                //      first two (nearly always all of them, both of level 1) travel with the layer table.
+                if (ncf > 0) {
+                    auto addr_of = [&](uint32_t e) { const uint32_t d = t4 - (e & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
+                    auto delta_of = [&](uint32_t j) { return w8_unpack<DEG>(cst1, cst2, pkn, j, SB) - w8_unpack<DEG>(c1o, c2o, pko, j, SB); };
+                    const uint32_t j0 = (cinfo >> 8) & 31u, j1 = (cinfo >> 16) & 31u, lvl1 = (cinfo >> 21) & 3u;
+                    const bool two = ncf > 1 && lvl1 == 1u;         // entry 1 commutes with entry 0 (another bit-group)
+                    __syncthreads();                                // the primary writes of the layer are in place
                     if (act) {
-                        const uint32_t d = t4 - (e & 0x7FFu);
-                        const uint32_t off = min(d, d + (uint32_t)W8_ROW), base = (e >> 11) & 0x3FFFFu;
-                        const float nw = w8_unpack<DEG>(cst1, cst2, pkn, j, SB), od = w8_unpack<DEG>(c1o, c2o, pko, j, SB);
-                        if (MODE != 1) { const float Lv = lld(off + base); lst(off + base, Lv + (nw - od)); }
-                        else { const float Lv = gld(off, base); gst(off, base, Lv + (nw - od)); }
+                        const uint32_t o0 = addr_of(ce0), b0 = (ce0 >> 11) & 0x3FFFFu, o1 = addr_of(ce1), b1 = (ce1 >> 11) & 0x3FFFFu;
+                        float L0, L1 = 0.f;
+                        if (MODE != 1) { L0 = lld(o0 + b0); if (two) L1 = lld(o1 + b1); }
+                        else { L0 = gld(o0, b0); if (two) L1 = gld(o1, b1); }
+                        const float n0 = L0 + delta_of(j0), n1 = L1 + delta_of(j1);
+                        if (MODE != 1) { lst(o0 + b0, n0); if (two) lst(o1 + b1, n1); }
+                        else { gst(o0, b0, n0); if (two) gst(o1, b1, n1); }
+                    }
+                    uint32_t prev_lvl = 1u;
+                    for (int i = two ? 2 : 1; i < ncf; i++) {
+                        const uint32_t e = T[32 + i], meta = T[48 + i];
+                        const uint32_t j = meta & 31u, lvl = meta >> 8;
+                        if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
+                        if (act) {
+                            const uint32_t off = addr_of(e), base = (e >> 11) & 0x3FFFFu;
+                            if (MODE != 1) { const float Lv = lld(off + base); lst(off + base, Lv + delta_of(j)); }
+                            else { const float Lv = gld(off, base); gst(off, base, Lv + delta_of(j)); }
+                        }
                     }
                 }
                 PROF_MARK(4);
+                {
+                    const const_u32 Tn = tab + (r + 1 < q ? r + 1 : 0) * LDPC_FAST_STRIDE;
+#pragma unroll
+                    for (int j = 0; j < 32; j++) TE[j] = Tn[j];
+                }
                 __syncthreads();
                 PROF_MARK(5);
             }
@@ -266,17 +291,19 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 if (act)
                     for (int r = 0; r < q; r++) {
                         const const_u32 T = tab + r * LDPC_FAST_STRIDE;
-                        uint32_t x = 0u;
+                        float Lv[DEG];
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
                             const uint32_t e = T[j];
                             const uint32_t d = t4 - (e & 0x7FFu);
                             const uint32_t wo = min(d, d + (uint32_t)W8_ROW), base = (e >> 11) & 0x3FFFFu;
-                            const float Lv = w8_slot_lds(MODE, j) ? lld(wo + base) : gld(wo, base);
-                            const bool absent = (j == DEG - 1) && (r == 0) && (t == 0);
-                            x ^= (!absent && Lv < 0.f) ? 1u : 0u;                              // NULL slots read +inf
+                            Lv[j] = w8_slot_lds(MODE, j) ? lld(wo + base) : gld(wo, base);
                         }
-                        bad |= (int)x;
+                        if (r == 0 && t == 0) Lv[DEG - 1] = 0.f;                               // absent edge
+                        uint32_t x = 0u;
+#pragma unroll
+                        for (int j = 0; j < DEG; j++) x ^= __float_as_uint(Lv[j]);             // NULL slots read +inf
+                        bad |= (int)(x >> 31);
                     }
                 ok = !__syncthreads_or(bad);
                 PROF_MARK(6);
@@ -284,7 +311,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
             }
         }
 
-        // ---- outputs: hard decisions of the info bits (image rows in storage order, 8 loads in flight)
+        // ---- outputs: hard decisions of the info bits (image rows in storage order, W8_IO loads in flight)
         if (threadIdx.x == 0) {
             if (p.cwd) p.cwd[f] = ok ? 1 : 0;
             if (p.ites) p.ites[f] = it;
@@ -310,19 +337,19 @@ ldpc_wg8_kernel(const LdpcKParams p)
         };
         const int nl_out = p.post ? nl : nl_info, ng_out = p.post ? ng : ng_info;
         if (role >= 0) {
-            for (int l0 = 0; l0 < nl_out; l0 += 8) {
-                float v[8];
+            for (int l0 = 0; l0 < nl_out; l0 += W8_IO) {
+                float v[W8_IO];
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = act ? lld((uint32_t)(l0 + k < nl_out ? l0 + k : nl_out - 1) * W8_ROW + t4) : 0.f;
+                for (int k = 0; k < W8_IO; k++) v[k] = act ? lld((uint32_t)(l0 + k < nl_out ? l0 + k : nl_out - 1) * W8_ROW + t4) : 0.f;
 #pragma unroll
-                for (int k = 0; k < 8; k++) if (l0 + k < nl_out) emit((int)rows[l0 + k], v[k]);
+                for (int k = 0; k < W8_IO; k++) if (l0 + k < nl_out) emit((int)rows[l0 + k], v[k]);
             }
-            for (int l0 = 0; l0 < ng_out; l0 += 8) {
-                float v[8];
+            for (int l0 = 0; l0 < ng_out; l0 += W8_IO) {
+                float v[W8_IO];
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = act ? gld(t4, grow0 + (uint32_t)(l0 + k < ng_out ? l0 + k : ng_out - 1) * W8_ROW) : 0.f;
+                for (int k = 0; k < W8_IO; k++) v[k] = act ? gld(t4, grow0 + (uint32_t)(l0 + k < ng_out ? l0 + k : ng_out - 1) * W8_ROW) : 0.f;
 #pragma unroll
-                for (int k = 0; k < 8; k++) if (l0 + k < ng_out) emit((int)rows[nl + l0 + k], v[k]);
+                for (int k = 0; k < W8_IO; k++) if (l0 + k < ng_out) emit((int)rows[nl + l0 + k], v[k]);
             }
         }
         __syncthreads();     // the posterior image is reused by the next frame of this workgroup
