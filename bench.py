@@ -160,7 +160,7 @@ def main():
         "ber": {"FRA": ctr[0], "BE": ctr[1], "FE": ctr[2], "cwd_rank0": n_cwd},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": _pmc_traffic(),
-                     "kernel": "ldpc_fast2_kernel<27,3,false>", "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_n,
+                     "kernel": rx.ldpc_kernel_name(), "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_n,
                      "algorithmic_bytes_per_launch": bytes_per_frame * F},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -58,6 +58,7 @@ struct dvbs2hip_handle {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[DVBS2HIP_K_COUNT];
     std::string err;
+    std::string ldpc_name;
 };
 
 namespace {
@@ -368,6 +369,22 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
 }
 
 const char *dvbs2hip_last_error(const dvbs2hip_t *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
+{
+    if (!h) return "";
+    if (h->ldpc_name.empty()) {
+        const LdpcPlan &pl = h->ldpc;
+        char buf[96];
+        if (!pl.fast) snprintf(buf, sizeof buf, "ldpc_layered_nms_kernel<%d,%s,%s>", pl.ent_stride, pl.hybrid ? "true" : "false", pl.c2v_lds ? "true" : "false");
+        else if (pl.spa) snprintf(buf, sizeof buf, "ldpc_fast2_kernel<%d,%d,false,true>", pl.fast_deg, pl.fast_mode);
+        else if (pl.fast_wg8) snprintf(buf, sizeof buf, "ldpc_wg8_kernel<%d,%d>", pl.fast_deg, pl.fast_mode);
+        else if (pl.fast_wf == 2) snprintf(buf, sizeof buf, "ldpc_fast2_kernel<%d,%d,%s,false>", pl.fast_deg, pl.fast_mode, pl.fast_pipe ? "true" : "false");
+        else snprintf(buf, sizeof buf, "ldpc_fast_kernel<%d,%d,%d>", pl.fast_deg, pl.fast_mode, pl.fast_nf);
+        const_cast<dvbs2hip_t *>(h)->ldpc_name = buf;
+    }
+    return h->ldpc_name.c_str();
+}
 
 int dvbs2hip_reset(dvbs2hip_t *h)
 {

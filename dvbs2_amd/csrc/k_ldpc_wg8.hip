@@ -227,7 +227,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         const float mag = ismin ? m1s : m2s;
                         const float nw = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(x) & SB));
                         idxn = ismin ? (uint32_t)j : idxn;
-                        asm volatile("" : "+v"(idxn));            // select now: the comparison mask dies here instead of piling up 27 SGPR pairs
+                        asm("" : "+v"(idxn));                     // select now: the comparison mask dies here instead of piling up 27 SGPR pairs
                         const bool pr = ((prim >> j) & 1u) != 0u;                             // wave-uniform
                         const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
                         if (w8_slot_lds(MODE, j)) {

@@ -49,6 +49,7 @@ ABI = {
     "dvbs2hip_create": (C.c_int, [C.POINTER(Cfg), C.POINTER(_vp)]),
     "dvbs2hip_destroy": (None, [_vp]),
     "dvbs2hip_last_error": (C.c_char_p, [_vp]),
+    "dvbs2hip_ldpc_kernel_name": (C.c_char_p, [_vp]),
     "dvbs2hip_reset": (C.c_int, [_vp]),
     "dvbs2hip_set_ldpc_params": (C.c_int, [_vp, _i, _f, _i]),
     "dvbs2hip_get_stream": (_vp, [_vp]),

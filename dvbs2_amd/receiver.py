@@ -261,6 +261,9 @@ class Dvbs2Hip:
         self._chk(self.L.dvbs2hip_extract_dev(self.h, _ptr(X), _ptr(Y), n_cplx_out, osf, int(offset), n_frames))
 
     # ------------------------------------------------------------------ measurement
+    def ldpc_kernel_name(self) -> str:
+        return self.L.dvbs2hip_ldpc_kernel_name(self.h).decode()
+
     def timing_enable(self, on=True):
         self._chk(self.L.dvbs2hip_timing_enable(self.h, 1 if on else 0))
 

@@ -103,6 +103,8 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out);
 void dvbs2hip_destroy(dvbs2hip_t *h);
 /* text of the last error on this handle (or of the last failed create when h == NULL) */
 const char *dvbs2hip_last_error(const dvbs2hip_t *h);
+/* name of the LDPC kernel instantiation the plan selected for this MODCOD (diagnostics, bench.py's roofline line) */
+const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h);
 /* Interface_reset: clears the filter state and the monitor counters */
 int dvbs2hip_reset(dvbs2hip_t *h);
 /* change --dec-ite / alpha / early-stop without rebuilding tables */
