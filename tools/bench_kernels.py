@@ -63,7 +63,7 @@ def fir_case(n_cplx, F, reps=20):
 res["config3_QPSK-N_8/9_F4096_10ite"] = chain_case("QPSK-N_8/9", 4096, 10, 4.2)
 res["config1_QPSK-S_8/9_F8192_10ite"] = chain_case("QPSK-S_8/9", 8192, 10, 4.4)
 res["config4_16APSK-N_8/9_F4096_20ite"] = chain_case("16APSK-N_8/9", 4096, 20, 8.2)
-res["config5_32APSK-S_3/4_F4096_10ite"] = chain_case("32APSK-S_3/4", 4096, 10, 9.5)
+res["config5_32APSK-S_3/4_F4096_10ite"] = chain_case("32APSK-S_3/4", 4096, 10, 10.5)
 def latency_case(modcod, F, reps=50):
     """small-batch latency of one fused-chain call (launch-bound regime, BASELINE config 5)"""
     mc = P.get_modcod(modcod)
