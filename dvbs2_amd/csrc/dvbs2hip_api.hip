@@ -54,6 +54,21 @@ struct dvbs2hip_handle {
     int enc_stride = 0;
     unsigned long long *d_bch_tab = nullptr;
     std::map<int, DevBuf> bufs;        // lazily grown staging / intermediate buffers
+    // frame synchronizer (N4): device-resident state of Synchronizer_frame_DVBS2_fast
+    struct {
+        bool ready = false;
+        float alpha = 0.9f, trigger = 30.f;    // factory defaults, Factory/Module/Synchronizer_frame/Synchronizer_frame.hpp:26-27
+        int vec_width = 8;                     // mipp::N<float>() of the reference build (AVX2)
+        int nbuff2 = 0;
+        float *xh[2] = {nullptr, nullptr};     // last 64 input samples (the correlators' memories + reg_channel)
+        float *sofh[2] = {nullptr, nullptr};   // last 64 cor_SOF samples (SOF_PLSC_delay)
+        float *cv = nullptr;                   // corr_vec
+        float *buff2[2] = {nullptr, nullptr};  // output_delay.buff2
+        int *st[2] = {nullptr, nullptr};       // output_delay {head2, first_time}
+        float *yprev = nullptr;                // the output frame of the previous call
+        float *metric = nullptr;               // max_corr of the last frame
+        int xh_cur = 0, sofh_cur = 0, od_cur = 0;
+    } sfm;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[DVBS2HIP_K_COUNT];
@@ -76,7 +91,8 @@ int fail(dvbs2hip_t *h, int code, const std::string &msg)
             return fail(h, DVBS2HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
-enum BufId { B_IN = 0, B_OUT, B_AUX0, B_AUX1, B_AUX2, B_AUX3, B_LLR, B_PACKED, B_EST, B_CWD0, B_CWD1, B_INFO, B_SIG, B_TXBCH, B_TXLDPC };
+enum BufId { B_IN = 0, B_OUT, B_AUX0, B_AUX1, B_AUX2, B_AUX3, B_LLR, B_PACKED, B_EST, B_CWD0, B_CWD1, B_INFO, B_SIG, B_TXBCH, B_TXLDPC,
+             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY };
 
 int ensure(dvbs2hip_t *h, int id, size_t bytes, void **out)
 {
@@ -361,6 +377,9 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     for (auto &kv : h->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
         for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
+                        h->sfm.yprev, h->sfm.metric};
+    for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -651,6 +670,177 @@ int dvbs2hip_extract_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx
     if (n_cplx_out < 1 || osf < 1) return fail(h, DVBS2HIP_EINVAL, "'n_cplx_out' and 'osf' have to be greater than 0");
     Timer tm(h, DVBS2HIP_K_MISC);
     HIPCHK(h, decimate_launch(X, Y, (long long)n_cplx_out * F, osf, offset, (long long)n_cplx_out * F * osf, h->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ N4: frame synchronizer (Synchronizer_frame_DVBS2_fast)
+static int sfm_state_reset(dvbs2hip_t *h, bool all)
+{
+    const int n = h->pl_frame;
+    auto &S = h->sfm;
+    const float one[2] = {1.f, 0.f};                                               // reg_channel = (1, 0), .cpp:19 / :309
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(h, hipMemsetAsync(S.xh[i], 0, sizeof(float) * 2 * 64, h->stream));
+        HIPCHK(h, hipMemsetAsync(S.buff2[i], 0, sizeof(float) * (size_t)S.nbuff2, h->stream));
+        const int st[2] = {0, 1};                                                  // head2 = 0, first_time = true
+        HIPCHK(h, hipMemcpyAsync(S.st[i], st, sizeof st, hipMemcpyHostToDevice, h->stream));
+        if (all) HIPCHK(h, hipMemsetAsync(S.sofh[i], 0, sizeof(float) * 2 * 64, h->stream));
+    }
+    HIPCHK(h, hipMemcpyAsync(S.xh[S.xh_cur] + 2 * 63, one, sizeof one, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(S.cv, 0, sizeof(float) * (size_t)n, h->stream));
+    if (all) { HIPCHK(h, hipMemsetAsync(S.yprev, 0, sizeof(float) * 2 * (size_t)n, h->stream)); HIPCHK(h, hipMemsetAsync(S.metric, 0, sizeof(float), h->stream)); }
+    HIPCHK(h, hipStreamSynchronize(h->stream));                                    // `one` / `st` live on this stack
+    return 0;
+}
+
+static int sfm_ready(dvbs2hip_t *h)
+{
+    auto &S = h->sfm;
+    if (S.ready) return 0;
+    const int n = h->pl_frame;
+    S.nbuff2 = 4 * (n + 1);                                                        // Variable_delay_cc_naive(N, N/2, N/2): buff2(4 (max_delay + 1))
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(h, hipMalloc((void **)&S.xh[i], sizeof(float) * 2 * 64));
+        HIPCHK(h, hipMalloc((void **)&S.sofh[i], sizeof(float) * 2 * 64));
+        HIPCHK(h, hipMalloc((void **)&S.buff2[i], sizeof(float) * (size_t)S.nbuff2));
+        HIPCHK(h, hipMalloc((void **)&S.st[i], sizeof(int) * 2));
+    }
+    HIPCHK(h, hipMalloc((void **)&S.cv, sizeof(float) * (size_t)n));
+    HIPCHK(h, hipMalloc((void **)&S.yprev, sizeof(float) * 2 * (size_t)n));
+    HIPCHK(h, hipMalloc((void **)&S.metric, sizeof(float)));
+    int r = sfm_state_reset(h, true);
+    if (r) return r;
+    S.ready = true;
+    return 0;
+}
+
+int dvbs2hip_sync_frame_set_params(dvbs2hip_t *h, float alpha, float trigger, int32_t vec_width)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    if (vec_width < 1) return fail(h, DVBS2HIP_EINVAL, "'vec_width' has to be greater than 0");
+    h->sfm.alpha = alpha; h->sfm.trigger = trigger; h->sfm.vec_width = vec_width;
+    return 0;
+}
+
+int dvbs2hip_sync_frame_reset(dvbs2hip_t *h)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    if (hipSetDevice(h->device) != hipSuccess) return fail(h, DVBS2HIP_EHIP, "hipSetDevice failed");
+    int r = sfm_ready(h); if (r) return r;
+    return sfm_state_reset(h, false);                                              // .cpp:304-318: SOF_PLSC_delay keeps its memory
+}
+
+int dvbs2hip_sync_frame_synchronize1_dev(dvbs2hip_t *h, const float *X_N1, float *cor_SOF, float *cor_PLSC, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X_N1 || !cor_SOF || !cor_PLSC) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    if ((r = sfm_ready(h))) return r;
+    auto &S = h->sfm;
+    Timer tm(h, DVBS2HIP_K_MISC);
+    HIPCHK(h, sync_corr_launch(X_N1, S.xh[S.xh_cur], S.xh[S.xh_cur ^ 1], cor_SOF, cor_PLSC, (long long)h->pl_frame * F, h->stream));
+    S.xh_cur ^= 1;
+    return 0;
+}
+
+int dvbs2hip_sync_frame_synchronize2_dev(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, const float *cor_PLSC, int32_t *DEL, int32_t *FLG,
+                                         float *TRI, float *Y_N2, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    int32_t *delay = DEL;
+    if (!X_N1 || !cor_SOF || !cor_PLSC || !delay || !Y_N2) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    if ((r = sfm_ready(h))) return r;
+    auto &S = h->sfm;
+    const int n = h->pl_frame;
+    void *corr, *met;
+    if ((r = ensure(h, B_SFM_CORR, sizeof(float) * (size_t)n * F, &corr)) || (r = ensure(h, B_SFM_MET, sizeof(float) * (size_t)F, &met))) return r;
+    Timer tm(h, DVBS2HIP_K_MISC);
+    if (TRI) met = TRI;
+    HIPCHK(h, sync_metric_launch(cor_SOF, S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], cor_PLSC, S.cv, (float *)corr, delay, (float *)met, FLG, S.trigger,
+                                 n, F, S.alpha, S.vec_width, h->stream));
+    S.sofh_cur ^= 1;
+    for (int f = 0; f < F; f++) {           // the delay line is a recurrence from frame to frame; its state stays on the device
+        const float *yp = f == 0 ? S.yprev : Y_N2 + (size_t)2 * n * (f - 1);
+        HIPCHK(h, sync_vdelay_launch(X_N1 + (size_t)2 * n * f, yp, Y_N2 + (size_t)2 * n * f, S.buff2[S.od_cur], S.buff2[S.od_cur ^ 1], S.st[S.od_cur],
+                                     S.st[S.od_cur ^ 1], delay + f, n, S.nbuff2, h->stream));
+        S.od_cur ^= 1;
+    }
+    HIPCHK(h, hipMemcpyAsync(S.yprev, Y_N2 + (size_t)2 * n * (F - 1), sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(S.metric, (float *)met + (F - 1), sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+int dvbs2hip_sync_frame_synchronize_dev(dvbs2hip_t *h, const float *X_N1, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    const size_t nb = sizeof(float) * 2 * (size_t)h->pl_frame * F;
+    void *cs, *cp;
+    if ((r = ensure(h, B_SFM_SOF, nb, &cs)) || (r = ensure(h, B_SFM_PLSC, nb, &cp))) return r;
+    if ((r = dvbs2hip_sync_frame_synchronize1_dev(h, X_N1, (float *)cs, (float *)cp, F))) return r;
+    return dvbs2hip_sync_frame_synchronize2_dev(h, X_N1, (const float *)cs, (const float *)cp, DEL, FLG, TRI, Y_N2, F);
+}
+
+int dvbs2hip_sync_frame_synchronize1(dvbs2hip_t *h, const float *X_N1, float *cor_SOF, float *cor_PLSC, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X_N1 || !cor_SOF || !cor_PLSC) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const size_t nb = sizeof(float) * 2 * (size_t)h->pl_frame * F;
+    void *din, *cs, *cp;
+    if ((r = ensure(h, B_IN, nb, &din)) || (r = ensure(h, B_SFM_SOF, nb, &cs)) || (r = ensure(h, B_SFM_PLSC, nb, &cp))) return r;
+    HIPCHK(h, hipMemcpyAsync(din, X_N1, nb, hipMemcpyHostToDevice, h->stream));
+    if ((r = dvbs2hip_sync_frame_synchronize1_dev(h, (const float *)din, (float *)cs, (float *)cp, F))) return r;
+    HIPCHK(h, hipMemcpyAsync(cor_SOF, cs, nb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(cor_PLSC, cp, nb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// host-socket forms of synchronize2 / synchronize: DEL, FLG, TRI have one entry per frame (Synchronizer_frame.hxx:42-44); FLG, TRI may be NULL
+static int sfm_host(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, const float *cor_PLSC, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X_N1 || !DEL || !Y_N2) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const size_t nb = sizeof(float) * 2 * (size_t)h->pl_frame * F;
+    void *din, *dout, *cs = nullptr, *cp = nullptr, *dd;
+    if ((r = ensure(h, B_IN, nb, &din)) || (r = ensure(h, B_OUT, nb, &dout)) || (r = ensure(h, B_SFM_DLY, (sizeof(int32_t) * 2 + sizeof(float)) * (size_t)F, &dd))) return r;
+    int32_t *d_del = (int32_t *)dd, *d_flg = d_del + F;
+    float *d_tri = (float *)(d_flg + F);
+    HIPCHK(h, hipMemcpyAsync(din, X_N1, nb, hipMemcpyHostToDevice, h->stream));
+    if (cor_SOF) {
+        if ((r = ensure(h, B_SFM_SOF, nb, &cs)) || (r = ensure(h, B_SFM_PLSC, nb, &cp))) return r;
+        HIPCHK(h, hipMemcpyAsync(cs, cor_SOF, nb, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(cp, cor_PLSC, nb, hipMemcpyHostToDevice, h->stream));
+        r = dvbs2hip_sync_frame_synchronize2_dev(h, (const float *)din, (const float *)cs, (const float *)cp, d_del, d_flg, d_tri, (float *)dout, F);
+    } else r = dvbs2hip_sync_frame_synchronize_dev(h, (const float *)din, d_del, d_flg, d_tri, (float *)dout, F);
+    if (r) return r;
+    HIPCHK(h, hipMemcpyAsync(DEL, d_del, sizeof(int32_t) * (size_t)F, hipMemcpyDeviceToHost, h->stream));
+    if (FLG) HIPCHK(h, hipMemcpyAsync(FLG, d_flg, sizeof(int32_t) * (size_t)F, hipMemcpyDeviceToHost, h->stream));
+    if (TRI) HIPCHK(h, hipMemcpyAsync(TRI, d_tri, sizeof(float) * (size_t)F, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(Y_N2, dout, nb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int dvbs2hip_sync_frame_synchronize2(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, const float *cor_PLSC, int32_t *DEL, int32_t *FLG,
+                                     float *TRI, float *Y_N2, int32_t F)
+{
+    if (h && (!cor_SOF || !cor_PLSC)) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    return sfm_host(h, X_N1, cor_SOF, cor_PLSC, DEL, FLG, TRI, Y_N2, F);
+}
+
+int dvbs2hip_sync_frame_synchronize(dvbs2hip_t *h, const float *X_N1, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t F)
+{
+    return sfm_host(h, X_N1, nullptr, nullptr, DEL, FLG, TRI, Y_N2, F);
+}
+
+int dvbs2hip_sync_frame_get_metric(dvbs2hip_t *h, float *max_corr, int32_t *packet_flag)
+{
+    if (!h || !max_corr || !packet_flag) return DVBS2HIP_EINVAL;
+    if (hipSetDevice(h->device) != hipSuccess) return fail(h, DVBS2HIP_EHIP, "hipSetDevice failed");
+    int r = sfm_ready(h); if (r) return r;
+    float m = 0.f;
+    HIPCHK(h, hipMemcpyAsync(&m, h->sfm.metric, sizeof m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *max_corr = m; *packet_flag = m > h->sfm.trigger ? 1 : 0;                      // _get_metric / _get_packet_flag, .hpp:59-60
     return 0;
 }
 

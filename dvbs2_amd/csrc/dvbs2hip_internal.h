@@ -187,4 +187,11 @@ hipError_t upfir_launch(const float *x, float *y, const float *hist_in, float *h
 hipError_t decimate_launch(const float *x, float *y, long long n_out, int osf, long long offset, long long n_in, hipStream_t s);
 hipError_t awgn_launch(const float *x, float *y, const float *sigma, unsigned long long seed, long long n_pairs, int F, hipStream_t s);
 
+// ---------------------------------------------------------------- frame synchronizer (N4, k_sync.hip)
+hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s);
+hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float *sofh_out, const float *cor_plsc, float *cv, float *corr,
+                              int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s);
+hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
+                              const int32_t *delay_f, int n, int nbuff2, hipStream_t s);
+
 }  // namespace dvbs2

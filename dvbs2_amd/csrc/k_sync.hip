@@ -1,0 +1,186 @@
+// N4 -- frame synchronizer, the data-parallel form of Synchronizer_frame_DVBS2_fast
+// (/root/reference src/common/Module/Synchronizer/Synchronizer_frame/Synchronizer_frame_DVBS2_fast.cpp):
+//   _synchronize1 (:132-150)  differential signal d[i] = x[i-1] conj(x[i]) and the two correlators
+//                             corr_SOF (25 real taps) / corr_PLSC (64 real taps), both Filter_FIR_ccr
+//   _synchronize2 (:222-299)  cor_SOF delayed by 64, |sum|^2 / |difference|^2 of the two correlations,
+//                             alpha-average per position across frames, arg max -> delay, and the
+//                             variable output delay (Variable_delay_cc_naive::_filter)
+// A call carries F PL frames that are consecutive in time = F calls of the reference with n_frames = 1.
+// Everything is a stream FIR or an element-wise map except three small recurrences across frames
+// (the average per position, the arg max per frame, the delay line), which run frame after frame on
+// device-resident state: no host round trip between the stages.
+#include "dvbs2hip_internal.h"
+
+namespace dvbs2 {
+
+// conj_SOF / conj_PLSC of Synchronizer_frame_DVBS2_fast.hpp:19-33
+__constant__ float c_conj_sof[25] = {1, -1, -1, 1, -1, 1, 1, -1, 1, 1, -1, -1, 1, -1, -1, -1, 1, -1, -1, -1, -1, 1, 1, 1, 1};
+__constant__ float c_conj_plsc[64] = {1, 0, 1, 0, -1, 0, -1, 0, 1, 0, -1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1, 0, 1, 0, -1, 0, -1, 0, 1, 0, 1, 0,
+                                      1, 0, 1, 0, -1, 0, -1, 0, -1, 0, -1, 0, -1, 0, 1, 0, 1, 0, -1, 0, 1, 0, 1, 0, 1, 0, -1, 0, -1, 0, 1, 0};
+
+constexpr int SY_T = 256;            // outputs per workgroup
+constexpr int SY_H = 64;             // samples of x a block needs before its first output (63 of d, one more of x)
+
+// ---- _synchronize1: x -> cor_SOF, cor_PLSC.  xh = the last 64 samples of the stream so far
+// (initially zeros with (1, 0) last: reg_channel, :19; the correlators start from empty memories).
+__global__ void __launch_bounds__(SY_T)
+sync_corr_kernel(const float2 *__restrict__ x, const float2 *__restrict__ xh, float2 *__restrict__ cor_sof, float2 *__restrict__ cor_plsc,
+                 long long n_total)
+{
+    __shared__ float2 xs[SY_T + SY_H];         // xs[k] = x[blk0 - 64 + k]
+    __shared__ float2 ds[SY_T + SY_H - 1];     // ds[k] = d[blk0 - 63 + k] = x[blk0 - 64 + k] conj(x[blk0 - 63 + k])
+    const long long blk0 = (long long)blockIdx.x * SY_T;
+    for (int k = threadIdx.x; k < SY_T + SY_H; k += SY_T) {
+        const long long g = blk0 - SY_H + k;
+        float2 v = make_float2(0.f, 0.f);
+        if (g < 0) v = xh[SY_H + g]; else if (g < n_total) v = x[g];
+        xs[k] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < SY_T + SY_H - 1; k += SY_T) {
+        const float2 a = xs[k], b = xs[k + 1];                     // :138-142 (a = previous sample)
+        ds[k] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    }
+    __syncthreads();
+    const long long i = blk0 + threadIdx.x;
+    if (i >= n_total) return;
+    // y[i] = sum_m b[m] d[i - m], oldest sample first (Filter_FIR_ccr.cpp:68-142)
+    float2 ap = make_float2(0.f, 0.f), as = make_float2(0.f, 0.f);
+    const int o = threadIdx.x + SY_H - 1;       // ds index of d[i]
+#pragma unroll 8
+    for (int m = 63; m >= 0; m--) {
+        const float2 v = ds[o - m];
+        const float b = c_conj_plsc[m];
+        ap.x = fmaf(b, v.x, ap.x); ap.y = fmaf(b, v.y, ap.y);
+    }
+#pragma unroll
+    for (int m = 24; m >= 0; m--) {
+        const float2 v = ds[o - m];
+        const float b = c_conj_sof[m];
+        as.x = fmaf(b, v.x, as.x); as.y = fmaf(b, v.y, as.y);
+    }
+    cor_plsc[i] = ap; cor_sof[i] = as;
+}
+
+// new history = last H samples of (old history ++ x)
+__global__ void sync_hist_kernel(const float2 *x, const float2 *hist_in, float2 *hist_out, int H, long long n_total)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H) return;
+    const long long gi = n_total - H + i;
+    hist_out[i] = gi >= 0 ? x[gi] : hist_in[H + gi];
+}
+
+// ---- _synchronize2, first half (:236-267, :278-285): one lane per position of the frame, frames in turn.
+// corr[f][i] = the averaged correlation the arg max of frame f sees; cv = corr_vec (carried between calls).
+__global__ void sync_metric_kernel(const float2 *__restrict__ cor_sof, const float2 *__restrict__ sofh, const float2 *__restrict__ cor_plsc,
+                                   float *__restrict__ cv, float *__restrict__ corr, int n, int F, float alpha, int end_vec)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float c = cv[i];
+    const float one_m = 1.0f - alpha;
+    for (int f = 0; f < F; f++) {
+        const long long g = (long long)f * n + i - 64;                 // SOF_PLSC_delay: 64 samples (:24, :236)
+        const float2 s = g >= 0 ? cor_sof[g] : sofh[64 + g];
+        const float2 p = cor_plsc[(long long)f * n + i];
+        const float sr = p.x + s.x, si = p.y + s.y, dr = s.x - p.x, di = s.y - p.y;
+        const float a2s = fmaf(sr, sr, si * si), a2d = fmaf(dr, dr, di * di);
+        const float m = sqrtf(fmaxf(a2s, a2d));
+        c = i < end_vec ? alpha * c + one_m * m : m;                    // the tail past the last full vector is not averaged (:284-285)
+        corr[(long long)f * n + i] = c;
+    }
+    cv[i] = c;
+}
+
+// ---- arg max of one frame (:269-276): the FIRST index of the largest value above 0; delay (:296)
+__global__ void __launch_bounds__(256)
+sync_argmax_kernel(const float *__restrict__ corr, int32_t *__restrict__ delay, float *__restrict__ metric, int32_t *__restrict__ flag, float trigger,
+                   int n, int n_sof, int n_plsc)
+{
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const float *c = corr + (long long)blockIdx.x * n;
+    float bv = 0.f;
+    int bi = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = c[i];
+        if (v > bv) { bv = v; bi = i; }          // ascending i per lane: keeps the first of equal values
+    }
+    sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float ov = sv[threadIdx.x + s];
+            const int oi = si[threadIdx.x + s];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // a lane that never saw a value above 0 reports index 0, as the reference's initial max_idx
+        const int idx = sv[0] > 0.f ? si[0] : 0;
+        delay[blockIdx.x] = (n + idx - n_sof - n_plsc) % n;
+        metric[blockIdx.x] = sv[0];                                  // TRI = get_metric(), Synchronizer_frame.hxx:181
+        if (flag) flag[blockIdx.x] = sv[0] > trigger ? 1 : 0;        // FLG = get_packet_flag(), .hpp:60
+    }
+}
+
+// ---- Variable_delay_cc_naive::_filter (Variable_delay_cc_naive.cpp:56-79) for ONE frame, literally: the
+// copies are applied in the reference's order (a later one overwrites an earlier one), what none of them
+// covers keeps the previous content of the output buffer.  st = {head2, first_time}.
+__global__ void sync_vdelay_kernel(const float *__restrict__ X, const float *__restrict__ Yprev, float *__restrict__ Y,
+                                   const float *__restrict__ buff_old, float *__restrict__ buff_new, const int *__restrict__ st_old,
+                                   int *__restrict__ st_new, const int32_t *__restrict__ delay_f, int n, int nbuff2)
+{
+    const int N = 2 * n;
+    const int dly = (n - delay_f[0]) % n;                   // set_delay((cplx_in_sz - delay) % cplx_in_sz), :298; always < size
+    const int D = 2 * dly, head2 = st_old[0], first = st_old[1];
+    const int start_Y = D > head2 ? D - head2 : 0;
+    const int start_buff = D < head2 ? head2 - D : 0;
+    int end_buff = start_buff + D;
+    end_buff = end_buff > nbuff2 ? nbuff2 : end_buff;
+    end_buff = (end_buff - start_buff > N - start_Y) ? end_buff - ((end_buff - start_buff) - (N - start_Y)) : end_buff;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < N) {
+        float v = Yprev[j];
+        if (j < start_Y) v = first ? 0.f : Yprev[N - start_Y + j];
+        if (j >= start_Y && j < start_Y + (end_buff - start_buff)) v = buff_old[start_buff + j - start_Y];
+        if (j >= D) v = X[j - D];
+        Y[j] = v;
+    }
+    if (j < nbuff2) buff_new[j] = j < D ? X[N - D + j] : buff_old[j];
+    if (j == 0) { st_new[0] = D; st_new[1] = 0; }
+}
+
+hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((n_total + SY_T - 1) / SY_T);
+    hipLaunchKernelGGL(sync_corr_kernel, dim3(grid), dim3(SY_T), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
+                       reinterpret_cast<float2 *>(cor_sof), reinterpret_cast<float2 *>(cor_plsc), n_total);
+    hipLaunchKernelGGL(sync_hist_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
+                       reinterpret_cast<float2 *>(xh_out), SY_H, n_total);
+    return hipGetLastError();
+}
+
+hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float *sofh_out, const float *cor_plsc, float *cv, float *corr,
+                              int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s)
+{
+    const int end_vec = (n / vec_width) * vec_width;
+    hipLaunchKernelGGL(sync_metric_kernel, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float2 *>(cor_sof),
+                       reinterpret_cast<const float2 *>(sofh_in), reinterpret_cast<const float2 *>(cor_plsc), cv, corr, n, F, alpha, end_vec);
+    hipLaunchKernelGGL(sync_hist_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float2 *>(cor_sof), reinterpret_cast<const float2 *>(sofh_in),
+                       reinterpret_cast<float2 *>(sofh_out), 64, (long long)n * F);
+    hipLaunchKernelGGL(sync_argmax_kernel, dim3(F), dim3(256), 0, s, corr, delay, metric, flag, trigger, n, 25, 64);
+    return hipGetLastError();
+}
+
+hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
+                              const int32_t *delay_f, int n, int nbuff2, hipStream_t s)
+{
+    const int tot = nbuff2 > 2 * n ? nbuff2 : 2 * n;
+    hipLaunchKernelGGL(sync_vdelay_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, X, Yprev, Y, buff_old, buff_new, st_old, st_new, delay_f, n, nbuff2);
+    return hipGetLastError();
+}
+
+}  // namespace dvbs2

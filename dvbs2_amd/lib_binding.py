@@ -51,6 +51,15 @@ ABI = {
     "dvbs2hip_last_error": (C.c_char_p, [_vp]),
     "dvbs2hip_ldpc_kernel_name": (C.c_char_p, [_vp]),
     "dvbs2hip_reset": (C.c_int, [_vp]),
+    "dvbs2hip_sync_frame_set_params": (C.c_int, [_vp, _f, _f, _i]),
+    "dvbs2hip_sync_frame_reset": (C.c_int, [_vp]),
+    "dvbs2hip_sync_frame_synchronize1": (C.c_int, [_vp, _vp, _vp, _vp, _i]),
+    "dvbs2hip_sync_frame_synchronize1_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i]),
+    "dvbs2hip_sync_frame_synchronize2": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "dvbs2hip_sync_frame_synchronize2_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "dvbs2hip_sync_frame_synchronize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "dvbs2hip_sync_frame_synchronize_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "dvbs2hip_sync_frame_get_metric": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "dvbs2hip_set_ldpc_params": (C.c_int, [_vp, _i, _f, _i]),
     "dvbs2hip_get_stream": (_vp, [_vp]),
     "dvbs2hip_synchronize": (C.c_int, [_vp]),

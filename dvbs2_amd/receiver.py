@@ -261,6 +261,41 @@ class Dvbs2Hip:
         self._chk(self.L.dvbs2hip_extract_dev(self.h, _ptr(X), _ptr(Y), n_cplx_out, osf, int(offset), n_frames))
 
     # ------------------------------------------------------------------ measurement
+    # ------------------------------------------------------------------ N4: frame synchronizer
+    def sync_frame_set_params(self, alpha=0.9, trigger=30.0, vec_width=8):
+        self._chk(self.L.dvbs2hip_sync_frame_set_params(self.h, float(alpha), float(trigger), int(vec_width)))
+
+    def sync_frame_reset(self):
+        self._chk(self.L.dvbs2hip_sync_frame_reset(self.h))
+
+    def sync_frame_synchronize1(self, X_N1):
+        X, F = self._frames(X_N1, 2 * self.pl_frame, np.float32)
+        cs, cp = np.empty_like(X), np.empty_like(X)
+        self._chk(self.L.dvbs2hip_sync_frame_synchronize1(self.h, _ptr(X), _ptr(cs), _ptr(cp), F))
+        return cs, cp
+
+    def sync_frame_synchronize2(self, X_N1, cor_sof, cor_plsc, with_flags=False):
+        X, F = self._frames(X_N1, 2 * self.pl_frame, np.float32)
+        cs, _ = self._frames(cor_sof, 2 * self.pl_frame, np.float32)
+        cp, _ = self._frames(cor_plsc, 2 * self.pl_frame, np.float32)
+        DEL, FLG, TRI, Y = np.empty(F, np.int32), np.empty(F, np.int32), np.empty(F, np.float32), np.empty_like(X)
+        self._chk(self.L.dvbs2hip_sync_frame_synchronize2(self.h, _ptr(X), _ptr(cs), _ptr(cp), _ptr(DEL), _ptr(FLG), _ptr(TRI), _ptr(Y), F))
+        return (DEL, FLG, TRI, Y) if with_flags else (DEL, Y)
+
+    def sync_frame_synchronize(self, X_N1, with_flags=False):
+        X, F = self._frames(X_N1, 2 * self.pl_frame, np.float32)
+        DEL, FLG, TRI, Y = np.empty(F, np.int32), np.empty(F, np.int32), np.empty(F, np.float32), np.empty_like(X)
+        self._chk(self.L.dvbs2hip_sync_frame_synchronize(self.h, _ptr(X), _ptr(DEL), _ptr(FLG), _ptr(TRI), _ptr(Y), F))
+        return (DEL, FLG, TRI, Y) if with_flags else (DEL, Y)
+
+    def sync_frame_synchronize_dev(self, X, DEL, FLG, TRI, Y, n_frames):
+        self._chk(self.L.dvbs2hip_sync_frame_synchronize_dev(self.h, X, DEL, FLG, TRI, Y, n_frames))
+
+    def sync_frame_metric(self):
+        m, fl = C.c_float(), C.c_int32()
+        self._chk(self.L.dvbs2hip_sync_frame_get_metric(self.h, C.byref(m), C.byref(fl)))
+        return m.value, bool(fl.value)
+
     def ldpc_kernel_name(self) -> str:
         return self.L.dvbs2hip_ldpc_kernel_name(self.h).decode()
 

@@ -3,7 +3,10 @@
 // (native-endian interleaved re/im float32, 2 * pl_frame values per frame:
 //  src/common/Module/Radio/Radio_user_binary/Radio_user_binary.cpp:55-100).
 //
-//   dvbs2_rx_bb --mod-cod QPSK-S_8/9 -F 8 --dec-ite 10 --in pl_frames.f32 --out info_bits.i32 [--src sent_bits.i32]
+//   dvbs2_rx_bb --mod-cod QPSK-S_8/9 -F 8 --dec-ite 10 --in pl_frames.f32 --out info_bits.i32 [--src sent_bits.i32] [--frame-sync]
+//
+// --frame-sync puts Synchronizer_frame_hip::synchronize in front, as the RX mains do
+// (src/mains/RX/main.cpp: sync_frame Y_N2 -> pl_scrambler Y_N1): the input may then start anywhere in a frame.
 //
 // It runs the SAME batch twice -- task by task through the ten sockets of the reference graph,
 // and through the fused Receiver_BB_hip task -- and fails if they differ; with --src it also
@@ -12,6 +15,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include "dvbs2hip_modules.hpp"
 
 using namespace aff3ct;
@@ -21,6 +25,7 @@ int main(int argc, char **argv)
     std::string modcod = "QPSK-S_8/9", in_path, out_path, src_path;
     int F = 1, n_ite = 50;
     float alpha = 1.0f;
+    bool frame_sync = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) { std::cerr << "missing value for " << a << "\n"; exit(2); } return argv[++i]; };
@@ -31,6 +36,7 @@ int main(int argc, char **argv)
         else if (a == "--in") in_path = next();
         else if (a == "--out") out_path = next();
         else if (a == "--src") src_path = next();
+        else if (a == "--frame-sync") frame_sync = true;
         else { std::cerr << "unknown argument " << a << "\n"; return 2; }
     }
     try {
@@ -66,6 +72,14 @@ int main(int argc, char **argv)
 
         std::vector<spu::runtime::Task *> order = {&pl_scrambler(), &framer(), &estimator(), &modem(), &itl_rx(),
                                                    &LDPC_decoder(), &BCH_decoder(), &bb_scrambler()};
+        std::unique_ptr<module::Synchronizer_frame_hip<>> sync_frame;
+        if (frame_sync) {
+            sync_frame.reset(new module::Synchronizer_frame_hip<>(ctx));
+            (*sync_frame)[sfm::sck::synchronize::X_N1] = pl_frames;
+            pl_scrambler[scr::sck::descramble::Y_N1] = (*sync_frame)[sfm::sck::synchronize::Y_N2];
+            receiver    [rcv::sck::receive::Y_N1   ] = (*sync_frame)[sfm::sck::synchronize::Y_N2];
+            order.insert(order.begin(), &(*sync_frame)[sfm::tsk::synchronize]);
+        }
         if (!src_path.empty()) order.push_back(&monitor());
         spu::runtime::Sequence seq(order);
 
@@ -91,6 +105,9 @@ int main(int argc, char **argv)
         monitor.get(fra, be, fe);
         std::printf("# %s F=%d ite=%d | batches %zu | task-graph vs fused mismatches %zu | FRA %llu BE %llu FE %llu\n", modcod.c_str(), F,
                     n_ite, batches, mismatch, (unsigned long long)fra, (unsigned long long)be, (unsigned long long)fe);
+        if (sync_frame)
+            std::printf("# frame-sync | DEL %d FLG %d TRI %.3f\n", (*sync_frame)[sfm::sck::synchronize::DEL].get_dataptr<int>()[F - 1],
+                        (*sync_frame)[sfm::sck::synchronize::FLG].get_dataptr<int>()[F - 1], (double)(*sync_frame)[sfm::sck::synchronize::TRI].get_dataptr<float>()[F - 1]);
         return mismatch ? 1 : 0;
     } catch (const std::exception &e) {
         std::cerr << e.what() << std::endl;

@@ -64,6 +64,11 @@ namespace scr { namespace sck { enum class descramble : size_t { Y_N1, Y_N2, sta
 namespace frm { namespace sck { enum class remove_plh : size_t { Y_N1, Y_N2, status }; } }
 namespace mnt { namespace sck { enum class check_errors : size_t { U, V, status }; } }
 namespace rcv { namespace sck { enum class receive : size_t { Y_N1, V_K, CWD_LDPC, CWD_BCH, status }; } }
+// Synchronizer_frame.hpp:15-24
+namespace sfm { enum class tsk : size_t { synchronize, synchronize1, synchronize2, SIZE };
+                namespace sck { enum class synchronize : size_t { X_N1, DEL, FLG, TRI, Y_N2, status };
+                                enum class synchronize1 : size_t { X_N1, cor_SOF, cor_PLSC, status };
+                                enum class synchronize2 : size_t { X_N1, cor_SOF, cor_PLSC, DEL, FLG, TRI, Y_N2, status }; } }
 
 // common shape: one task, sockets created in enum order, codelet forwards raw pointers
 class Module_hip : public spu::module::Stateful {
@@ -292,6 +297,73 @@ public:
     }
     void receive(const float *pl, B *V_K, int8_t *cwd_ldpc, int8_t *cwd_bch)
     { DVBS2HIP_CHK(ctx, dvbs2hip_rx_bb(ctx->h, pl, nullptr, (int32_t *)V_K, cwd_ldpc, cwd_bch, F())); }
+};
+
+// replaces Synchronizer_frame_DVBS2_fast<R> (Synchronizer_frame_DVBS2_fast.cpp; tasks and sockets of
+// Synchronizer_frame.hxx:40-98): three tasks on one module, state in the device context
+template <typename R = float>
+class Synchronizer_frame_hip : public Module_hip {
+public:
+    Synchronizer_frame_hip(std::shared_ptr<Context> c, R alpha = (R)0.9, R trigger = (R)30, int vec_width = 8)
+    : Module_hip(std::move(c), "Synchronizer_frame_hip")
+    {
+        DVBS2HIP_CHK(ctx, dvbs2hip_sync_frame_set_params(ctx->h, (float)alpha, (float)trigger, vec_width));
+        const size_t N = 2 * (size_t)ctx->sz.pl_frame_sym;
+        {
+            auto &t = create_task("synchronize");
+            auto sX = create_socket_in<R>(t, "X_N1", N);
+            auto sD = create_socket_out<int>(t, "DEL", 1);
+            auto sF = create_socket_out<int>(t, "FLG", 1);
+            auto sT = create_socket_out<R>(t, "TRI", 1);
+            auto sY = create_socket_out<R>(t, "Y_N2", N);
+            create_codelet(t, [sX, sD, sF, sT, sY](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+                static_cast<Synchronizer_frame_hip &>(m).synchronize(tk[sX].template get_dataptr<const R>(), tk[sD].template get_dataptr<int>(),
+                                                                     tk[sF].template get_dataptr<int>(), tk[sT].template get_dataptr<R>(),
+                                                                     tk[sY].template get_dataptr<R>());
+                return 0;
+            });
+        }
+        {
+            auto &t = create_task("synchronize1");
+            auto sX = create_socket_in<R>(t, "X_N1", N);
+            auto s1 = create_socket_out<R>(t, "cor_SOF", N);
+            auto s2 = create_socket_out<R>(t, "cor_PLSC", N);
+            create_codelet(t, [sX, s1, s2](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+                static_cast<Synchronizer_frame_hip &>(m).synchronize1(tk[sX].template get_dataptr<const R>(), tk[s1].template get_dataptr<R>(),
+                                                                      tk[s2].template get_dataptr<R>());
+                return 0;
+            });
+        }
+        {
+            auto &t = create_task("synchronize2");
+            auto sX = create_socket_in<R>(t, "X_N1", N);
+            auto s1 = create_socket_in<R>(t, "cor_SOF", N);
+            auto s2 = create_socket_in<R>(t, "cor_PLSC", N);
+            auto sD = create_socket_out<int>(t, "DEL", 1);
+            auto sF = create_socket_out<int>(t, "FLG", 1);
+            auto sT = create_socket_out<R>(t, "TRI", 1);
+            auto sY = create_socket_out<R>(t, "Y_N2", N);
+            create_codelet(t, [sX, s1, s2, sD, sF, sT, sY](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+                static_cast<Synchronizer_frame_hip &>(m).synchronize2(tk[sX].template get_dataptr<const R>(), tk[s1].template get_dataptr<const R>(),
+                                                                      tk[s2].template get_dataptr<const R>(), tk[sD].template get_dataptr<int>(),
+                                                                      tk[sF].template get_dataptr<int>(), tk[sT].template get_dataptr<R>(),
+                                                                      tk[sY].template get_dataptr<R>());
+                return 0;
+            });
+        }
+    }
+    spu::runtime::Task &operator[](sfm::tsk t) { return *tasks[(size_t)t]; }
+    spu::runtime::Socket &operator[](sfm::sck::synchronize s) { return (*tasks[(size_t)sfm::tsk::synchronize])[(size_t)s]; }
+    spu::runtime::Socket &operator[](sfm::sck::synchronize1 s) { return (*tasks[(size_t)sfm::tsk::synchronize1])[(size_t)s]; }
+    spu::runtime::Socket &operator[](sfm::sck::synchronize2 s) { return (*tasks[(size_t)sfm::tsk::synchronize2])[(size_t)s]; }
+    void synchronize(const R *X_N1, int *DEL, int *FLG, R *TRI, R *Y_N2)
+    { DVBS2HIP_CHK(ctx, dvbs2hip_sync_frame_synchronize(ctx->h, X_N1, (int32_t *)DEL, (int32_t *)FLG, TRI, Y_N2, F())); }
+    void synchronize1(const R *X_N1, R *cor_SOF, R *cor_PLSC) { DVBS2HIP_CHK(ctx, dvbs2hip_sync_frame_synchronize1(ctx->h, X_N1, cor_SOF, cor_PLSC, F())); }
+    void synchronize2(const R *X_N1, const R *cor_SOF, const R *cor_PLSC, int *DEL, int *FLG, R *TRI, R *Y_N2)
+    { DVBS2HIP_CHK(ctx, dvbs2hip_sync_frame_synchronize2(ctx->h, X_N1, cor_SOF, cor_PLSC, (int32_t *)DEL, (int32_t *)FLG, TRI, Y_N2, F())); }
+    void reset() { DVBS2HIP_CHK(ctx, dvbs2hip_sync_frame_reset(ctx->h)); }                        // Interface_reset
+    R get_metric() { float m; int32_t f; DVBS2HIP_CHK(ctx, dvbs2hip_sync_frame_get_metric(ctx->h, &m, &f)); return (R)m; }
+    bool get_packet_flag() { float m; int32_t f; DVBS2HIP_CHK(ctx, dvbs2hip_sync_frame_get_metric(ctx->h, &m, &f)); return f != 0; }
 };
 
 }  // namespace module

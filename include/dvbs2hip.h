@@ -245,6 +245,35 @@ int dvbs2hip_add_noise_dev(dvbs2hip_t *h, const float *CP, const float *X_N, flo
  * Y[i] = X[offset + i*osf] for i < n_frames*n_cplx_out; samples outside the batch read as zero.      */
 int dvbs2hip_extract_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx_out, int32_t osf, int64_t offset, int32_t n_frames);
 
+/* ------------------------------------------------------------------ N4: frame synchronizer
+ * replaces: Synchronizer_frame_DVBS2_fast<R> (type "FAST", the factory default,
+ * src/common/Factory/Module/Synchronizer_frame/Synchronizer_frame.cpp:71-72, .hpp:26-30) --
+ * src/common/Module/Synchronizer/Synchronizer_frame/Synchronizer_frame_DVBS2_fast.cpp:
+ *   synchronize1 (:132-150)  differential signal, correlators corr_SOF (25 taps) / corr_PLSC (64 taps)
+ *   synchronize2 (:222-299)  cor_SOF delayed by 64, correlation metric, alpha-average, arg max -> delay,
+ *                            variable output delay (Filter/Variable_delay/Variable_delay_cc_naive.cpp:56-79)
+ *   synchronize  (:46-128)   both in one task
+ * A call carries n_frames PL frames that are consecutive in time and behaves as n_frames calls of the
+ * reference task with its n_frames = 1 (the reference's delay line re-reads its own output socket, so
+ * its multi-frame form depends on what the socket held before; that case is not reproduced).  State
+ * (correlator memories, reg_channel, corr_vec, delay lines, previous output frame) lives in the handle.
+ *   X_N1: float[n_frames * 2*pl_frame]; cor_SOF, cor_PLSC, Y_N2: same size; DEL (delay), FLG (packet flag, may be
+ *   NULL): int32_t[n_frames]; TRI (metric, may be NULL): float[n_frames] -- the sockets of Synchronizer_frame.hxx:40-81
+ * set_params: alpha / trigger (defaults 0.9 / 30) and vec_width = mipp::N<float>() of the reference build
+ * (default 8 = AVX2): the samples past the last full vector of a frame are not alpha-averaged (:284-285).
+ * get_metric: _get_metric / _get_packet_flag (.hpp:59-60) after the last frame processed.            */
+int dvbs2hip_sync_frame_set_params(dvbs2hip_t *h, float alpha, float trigger, int32_t vec_width);
+int dvbs2hip_sync_frame_reset(dvbs2hip_t *h);
+int dvbs2hip_sync_frame_synchronize1(dvbs2hip_t *h, const float *X_N1, float *cor_SOF, float *cor_PLSC, int32_t n_frames);
+int dvbs2hip_sync_frame_synchronize1_dev(dvbs2hip_t *h, const float *X_N1, float *cor_SOF, float *cor_PLSC, int32_t n_frames);
+int dvbs2hip_sync_frame_synchronize2(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, const float *cor_PLSC, int32_t *DEL, int32_t *FLG,
+                                     float *TRI, float *Y_N2, int32_t n_frames);
+int dvbs2hip_sync_frame_synchronize2_dev(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, const float *cor_PLSC, int32_t *DEL, int32_t *FLG,
+                                         float *TRI, float *Y_N2, int32_t n_frames);
+int dvbs2hip_sync_frame_synchronize(dvbs2hip_t *h, const float *X_N1, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t n_frames);
+int dvbs2hip_sync_frame_synchronize_dev(dvbs2hip_t *h, const float *X_N1, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t n_frames);
+int dvbs2hip_sync_frame_get_metric(dvbs2hip_t *h, float *max_corr, int32_t *packet_flag);
+
 /* ------------------------------------------------------------------ measurement
  * Per-kernel device time, measured with hipEvents recorded on the handle's stream around
  * each launch while timing is enabled (the equivalent of `--sim-stats`,

@@ -700,3 +700,134 @@ void orc_upfir(const float *taps, int T, int osf, float *hist, const float *x, f
     orc_fir(taps, T, hist, up, y, n_in * osf);
     free(up);
 }
+
+/* ================================================================ frame synchronizer (row N4) */
+/* Variable_delay_cc_naive: ctor Variable_delay_cc_naive.cpp:11-24, `_filter` :56-79 */
+struct orc_vdelay { int N, delay, size, head2, first_time, nbuff2; float *buff2; };
+
+orc_vdelay *orc_vdelay_create(int N, int delay, int max_delay)
+{
+    orc_vdelay *d = (orc_vdelay *)calloc(1, sizeof *d);
+    d->N = N; d->delay = delay; d->size = max_delay + 1; d->head2 = 0; d->first_time = 1;
+    d->nbuff2 = 4 * (max_delay + 1);
+    d->buff2 = (float *)calloc((size_t)d->nbuff2, sizeof(float));
+    return d;
+}
+void orc_vdelay_destroy(orc_vdelay *d) { if (d) { free(d->buff2); free(d); } }
+void orc_vdelay_set_delay(orc_vdelay *d, int delay) { d->delay = delay < d->size ? delay : d->size - 1; }   /* .cpp:91-95 */
+void orc_vdelay_reset(orc_vdelay *d)       /* Variable_delay_cc_naive.cpp reset(): buffers to zero, heads to 0 */
+{
+    memset(d->buff2, 0, sizeof(float) * (size_t)d->nbuff2);
+    d->head2 = 0; d->first_time = 1;
+}
+void orc_vdelay_filter(orc_vdelay *d, const float *X, float *Y)
+{
+    const int N = d->N, D = 2 * d->delay;
+    int start_Y = (D > d->head2) ? D - d->head2 : 0;
+    int start_buff = (D < d->head2) ? d->head2 - D : 0;
+    int end_buff = start_buff + D;
+    end_buff = end_buff > d->nbuff2 ? d->nbuff2 : end_buff;
+    end_buff = (end_buff - start_buff > N - start_Y) ? end_buff - ((end_buff - start_buff) - (N - start_Y)) : end_buff;
+    if (start_Y && !d->first_time) memmove(Y, Y + N - start_Y, sizeof(float) * (size_t)start_Y);
+    else memset(Y, 0, sizeof(float) * (size_t)start_Y);
+    memcpy(Y + start_Y, d->buff2 + start_buff, sizeof(float) * (size_t)(end_buff - start_buff));
+    memcpy(Y + D, X, sizeof(float) * (size_t)(N - D));
+    memcpy(d->buff2, X + N - D, sizeof(float) * (size_t)D);
+    d->first_time = 0;
+    d->head2 = D;
+}
+
+static const float ORC_CONJ_SOF[25] = {1, -1, -1, 1, -1, 1, 1, -1, 1, 1, -1, -1, 1, -1, -1, -1, 1, -1, -1, -1, -1, 1, 1, 1, 1};
+static const float ORC_CONJ_PLSC[64] = {1, 0, 1, 0, -1, 0, -1, 0, 1, 0, -1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1, 0, 1, 0, -1, 0, -1, 0, 1, 0, 1, 0,
+                                        1, 0, 1, 0, -1, 0, -1, 0, -1, 0, -1, 0, -1, 0, 1, 0, 1, 0, -1, 0, 1, 0, 1, 0, 1, 0, -1, 0, -1, 0, 1, 0};
+void orc_sfm_taps(const float **sof, int *n_sof, const float **plsc, int *n_plsc)
+{
+    *sof = ORC_CONJ_SOF; *n_sof = 25; *plsc = ORC_CONJ_PLSC; *n_plsc = 64;
+}
+
+struct orc_sfm {
+    int n;                       /* complex samples per frame */
+    float alpha, trigger, max_corr;
+    int vecw, delay;
+    float reg_re, reg_im;        /* reg_channel */
+    float *corr_vec;             /* [n] */
+    float *hist_sof, *hist_plsc; /* FIR memories of corr_SOF (24) / corr_PLSC (63) */
+    orc_vdelay *output_delay, *sof_plsc_delay;
+    float *diff, *cor_sof, *cor_sof_delayed, *cor_plsc;
+};
+
+orc_sfm *orc_sfm_create(int n_cplx, float alpha, float trigger, int vec_width)
+{
+    orc_sfm *s = (orc_sfm *)calloc(1, sizeof *s);
+    const int N = 2 * n_cplx;
+    s->n = n_cplx; s->alpha = alpha; s->trigger = trigger; s->vecw = vec_width > 0 ? vec_width : 1;
+    s->reg_re = 1.f; s->reg_im = 0.f;                                             /* .cpp:19 */
+    s->corr_vec = (float *)calloc((size_t)n_cplx, sizeof(float));                 /* .cpp:20 */
+    s->hist_sof = (float *)calloc(2 * 24, sizeof(float)); s->hist_plsc = (float *)calloc(2 * 63, sizeof(float));
+    s->output_delay = orc_vdelay_create(N, N / 2, N / 2);                         /* .cpp:21 */
+    s->sof_plsc_delay = orc_vdelay_create(N, 64, 64);                             /* .cpp:24 */
+    s->diff = (float *)calloc((size_t)N, sizeof(float)); s->cor_sof = (float *)calloc((size_t)N, sizeof(float));
+    s->cor_sof_delayed = (float *)calloc((size_t)N, sizeof(float)); s->cor_plsc = (float *)calloc((size_t)N, sizeof(float));
+    return s;
+}
+void orc_sfm_destroy(orc_sfm *s)
+{
+    if (!s) return;
+    free(s->corr_vec); free(s->hist_sof); free(s->hist_plsc); orc_vdelay_destroy(s->output_delay); orc_vdelay_destroy(s->sof_plsc_delay);
+    free(s->diff); free(s->cor_sof); free(s->cor_sof_delayed); free(s->cor_plsc); free(s);
+}
+void orc_sfm_reset(orc_sfm *s)        /* .cpp:304-318 (SOF_PLSC_delay is not reset there) */
+{
+    orc_vdelay_reset(s->output_delay); orc_vdelay_set_delay(s->output_delay, 0);
+    s->reg_re = 1.f; s->reg_im = 0.f;
+    memset(s->corr_vec, 0, sizeof(float) * (size_t)s->n);
+    memset(s->hist_sof, 0, sizeof(float) * 2 * 24); memset(s->hist_plsc, 0, sizeof(float) * 2 * 63);
+}
+float orc_sfm_metric(const orc_sfm *s) { return s->max_corr; }
+int orc_sfm_packet_flag(const orc_sfm *s) { return s->max_corr > s->trigger; }
+
+void orc_sfm_synchronize1(orc_sfm *s, const float *X, float *cor_SOF, float *cor_PLSC)
+{
+    const int n = s->n;
+    float *d = s->diff;
+    d[0] = s->reg_re * X[0] + s->reg_im * X[1];                                   /* .cpp:136-137 */
+    d[1] = s->reg_im * X[0] - s->reg_re * X[1];
+    for (int i = 1; i < n; i++) {                                                 /* .cpp:138-142 */
+        d[2 * i] = X[2 * i - 2] * X[2 * i] + X[2 * i - 1] * X[2 * i + 1];
+        d[2 * i + 1] = X[2 * i - 1] * X[2 * i] - X[2 * i - 2] * X[2 * i + 1];
+    }
+    orc_fir(ORC_CONJ_SOF, 25, s->hist_sof, d, cor_SOF, n);                        /* .cpp:144 */
+    orc_fir(ORC_CONJ_PLSC, 64, s->hist_plsc, d, cor_PLSC, n);                     /* .cpp:145 */
+}
+
+int orc_sfm_synchronize2(orc_sfm *s, const float *X, const float *cor_SOF, const float *cor_PLSC, float *Y)
+{
+    const int n = s->n;
+    orc_vdelay_filter(s->sof_plsc_delay, cor_SOF, s->cor_sof_delayed);            /* .cpp:236 */
+    float max_corr = 0.f;
+    int max_idx = 0;
+    const int end_vec = (n / s->vecw) * s->vecw;
+    const float *cs = s->cor_sof_delayed;
+    for (int i = 0; i < n; i++) {
+        const float sr = cor_PLSC[2 * i] + cs[2 * i], si = cor_PLSC[2 * i + 1] + cs[2 * i + 1];
+        const float dr = cs[2 * i] - cor_PLSC[2 * i], di = cs[2 * i + 1] - cor_PLSC[2 * i + 1];
+        const float a2s = fmaf(sr, sr, si * si), a2d = fmaf(dr, dr, di * di);      /* mipp::fmadd, .cpp:253-261 */
+        const float m = sqrtf(a2s > a2d ? a2s : a2d);
+        if (i < end_vec) s->corr_vec[i] = s->alpha * s->corr_vec[i] + (1.f - s->alpha) * m;   /* .cpp:263-267 */
+        else s->corr_vec[i] = m;                                                  /* the second assignment wins, .cpp:284-285 */
+        if (s->corr_vec[i] > max_corr) { max_corr = s->corr_vec[i]; max_idx = i; } /* .cpp:269-276, :287-291 */
+    }
+    s->max_corr = max_corr;
+    s->reg_re = X[2 * n - 2]; s->reg_im = X[2 * n - 1];                            /* .cpp:294 */
+    const int delay = (n + max_idx - 25 - 64) % n;                                /* .cpp:296 */
+    s->delay = delay;
+    orc_vdelay_set_delay(s->output_delay, (n - delay) % n);                       /* .cpp:298 */
+    orc_vdelay_filter(s->output_delay, X, Y);                                     /* .cpp:299 */
+    return delay;
+}
+
+int orc_sfm_synchronize(orc_sfm *s, const float *X, float *Y)                     /* .cpp:46-128: the same two steps in one task */
+{
+    orc_sfm_synchronize1(s, X, s->cor_sof, s->cor_plsc);
+    return orc_sfm_synchronize2(s, X, s->cor_sof, s->cor_plsc, Y);
+}

@@ -102,6 +102,32 @@ void orc_fir(const float *taps, int T, float *hist, const float *x, float *y, in
 /* Filter_UPFIR_ccr_naive.cpp:52-66 (row N2): zero-stuff by osf then FIR */
 void orc_upfir(const float *taps, int T, int osf, float *hist, const float *x, float *y, int n_in);
 
+/* ---------------------------------------------------------------- frame synchronizer (row N4) */
+/* Variable_delay_cc_naive (Filter/Variable_delay/Variable_delay_cc_naive.cpp:14-69): the block form
+ * `_filter`, including what it does while the delay changes (it re-reads the output buffer of the
+ * previous call, which the caller therefore has to pass again). N floats per call. */
+typedef struct orc_vdelay orc_vdelay;
+orc_vdelay *orc_vdelay_create(int N, int delay, int max_delay);
+void        orc_vdelay_destroy(orc_vdelay *d);
+void        orc_vdelay_set_delay(orc_vdelay *d, int delay);
+void        orc_vdelay_reset(orc_vdelay *d);
+void        orc_vdelay_filter(orc_vdelay *d, const float *X, float *Y);
+/* Synchronizer_frame_DVBS2_fast (Synchronizer_frame_DVBS2_fast.cpp/.hpp), n_frames = 1 per call.
+ * n_cplx = PL frame length in symbols (the factory passes N = 2 * pl_frame, Synchronizer_frame.cpp:72);
+ * vec_width = mipp::N<float>() of the reference build (8 on AVX2, 16 on AVX-512, 4 on SSE/NEON): the
+ * samples past the last full vector skip the alpha-averaging (.cpp:113-114 / :284-285). */
+typedef struct orc_sfm orc_sfm;
+orc_sfm *orc_sfm_create(int n_cplx, float alpha, float trigger, int vec_width);
+void     orc_sfm_destroy(orc_sfm *s);
+void     orc_sfm_reset(orc_sfm *s);                                                        /* .cpp:304-318 */
+void     orc_sfm_synchronize1(orc_sfm *s, const float *X, float *cor_SOF, float *cor_PLSC); /* .cpp:132-150 */
+/* .cpp:222-299; Y is read as well as written (see orc_vdelay_filter); returns the delay */
+int      orc_sfm_synchronize2(orc_sfm *s, const float *X, const float *cor_SOF, const float *cor_PLSC, float *Y);
+int      orc_sfm_synchronize(orc_sfm *s, const float *X, float *Y);                        /* .cpp:46-128 */
+float    orc_sfm_metric(const orc_sfm *s);                                                 /* _get_metric, .hpp:59 */
+int      orc_sfm_packet_flag(const orc_sfm *s);                                            /* _get_packet_flag, .hpp:60 */
+void     orc_sfm_taps(const float **sof, int *n_sof, const float **plsc, int *n_plsc);     /* conj_SOF / conj_PLSC, .hpp:19-33 */
+
 /* ---------------------------------------------------------------- CPU baseline leg of bench.py */
 /* decode F frames with `threads` threads (frames sharded); returns seconds */
 double orc_ldpc_decode_batch(const orc_ldpc *c, const float *llr, int F, int sched, int n_ite,

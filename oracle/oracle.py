@@ -68,6 +68,23 @@ def lib():
         L.orc_rrc_taps.argtypes = [cf, ci, ci, vp]
         L.orc_fir.argtypes = [vp, ci, vp, vp, vp, ci]
         L.orc_upfir.argtypes = [vp, ci, ci, vp, vp, vp, ci]
+        L.orc_vdelay_create.restype = vp
+        L.orc_vdelay_create.argtypes = [ci, ci, ci]
+        L.orc_vdelay_destroy.argtypes = [vp]
+        L.orc_vdelay_set_delay.argtypes = [vp, ci]
+        L.orc_vdelay_reset.argtypes = [vp]
+        L.orc_vdelay_filter.argtypes = [vp, vp, vp]
+        L.orc_sfm_create.restype = vp
+        L.orc_sfm_create.argtypes = [ci, cf, cf, ci]
+        L.orc_sfm_destroy.argtypes = [vp]
+        L.orc_sfm_reset.argtypes = [vp]
+        L.orc_sfm_synchronize1.argtypes = [vp, vp, vp, vp]
+        L.orc_sfm_synchronize2.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_sfm_synchronize.argtypes = [vp, vp, vp]
+        L.orc_sfm_metric.restype = cf
+        L.orc_sfm_metric.argtypes = [vp]
+        L.orc_sfm_packet_flag.argtypes = [vp]
+        L.orc_sfm_taps.argtypes = [vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -287,6 +304,83 @@ def upfir(taps, osf, hist, x):
     y = np.empty(x.size * osf, dtype=np.float32)
     lib().orc_upfir(_p(taps), taps.size, osf, _p(hist), _p(x), _p(y), x.size // 2)
     return y
+
+
+class VariableDelay:
+    """Variable_delay_cc_naive, block form (row N4).  The output buffer is kept between calls, as the
+    reference's socket buffer is."""
+
+    def __init__(self, N, delay, max_delay):
+        self.N = N
+        self.h = lib().orc_vdelay_create(N, delay, max_delay)
+        self.Y = np.zeros(N, dtype=np.float32)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_vdelay_destroy(self.h)
+            self.h = None
+
+    def set_delay(self, d):
+        lib().orc_vdelay_set_delay(self.h, int(d))
+
+    def filter(self, X):
+        X = _f32(X).ravel()
+        assert X.size == self.N
+        lib().orc_vdelay_filter(self.h, _p(X), _p(self.Y))
+        return self.Y.copy()
+
+
+class SyncFrame:
+    """Synchronizer_frame_DVBS2_fast (row N4), one PL frame per call; the output frame is kept between
+    calls (the variable delay re-reads it while the delay grows)."""
+
+    def __init__(self, n_cplx, alpha=0.9, trigger=30.0, vec_width=8):
+        self.n = n_cplx
+        self.h = lib().orc_sfm_create(n_cplx, float(alpha), float(trigger), vec_width)
+        self.Y = np.zeros(2 * n_cplx, dtype=np.float32)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_sfm_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        lib().orc_sfm_reset(self.h)
+
+    def synchronize1(self, X):
+        X = _f32(X).ravel()
+        assert X.size == 2 * self.n
+        cs, cp = np.empty_like(X), np.empty_like(X)
+        lib().orc_sfm_synchronize1(self.h, _p(X), _p(cs), _p(cp))
+        return cs, cp
+
+    def synchronize2(self, X, cor_sof, cor_plsc):
+        X, cs, cp = _f32(X).ravel(), _f32(cor_sof).ravel(), _f32(cor_plsc).ravel()
+        d = lib().orc_sfm_synchronize2(self.h, _p(X), _p(cs), _p(cp), _p(self.Y))
+        return int(d), self.Y.copy()
+
+    def synchronize(self, X):
+        X = _f32(X).ravel()
+        assert X.size == 2 * self.n
+        d = lib().orc_sfm_synchronize(self.h, _p(X), _p(self.Y))
+        return int(d), self.Y.copy()
+
+    @property
+    def metric(self):
+        return float(lib().orc_sfm_metric(self.h))
+
+    @property
+    def packet_flag(self):
+        return bool(lib().orc_sfm_packet_flag(self.h))
+
+
+def sync_frame_taps():
+    a, b = C.c_void_p(), C.c_void_p()
+    na, nb = C.c_int(), C.c_int()
+    lib().orc_sfm_taps(C.byref(a), C.byref(na), C.byref(b), C.byref(nb))
+    sof = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_float)), (na.value,)).copy()
+    plsc = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_float)), (nb.value,)).copy()
+    return sof, plsc
 
 
 # ---------------------------------------------------------------- convenience: full TX / RX chains

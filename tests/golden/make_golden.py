@@ -9,6 +9,7 @@
                          only regression oracle: BER/FER traces, SPA 50 ite)
   src_K_14232.npy        conf/src/K_14232.src fixed payload (data file), packed bits
   kat_*.npz              known-answer vectors produced by the CPU oracle (seeded), small frames
+                         (`python make_golden.py sync` remakes only kat_sync_frame_32apsk.npz)
 """
 import json, os, re, sys
 import numpy as np
@@ -90,7 +91,29 @@ def kats():
     y1 = O.fir(taps, hist, x1); y2 = O.fir(taps, hist, x2)
     np.savez_compressed(os.path.join(HERE, "kat_fir_rrc81.npz"), taps=taps, x1=x1, x2=x2, y1=y1, y2=y2)
 
+def kat_sync():
+    """Frame synchronizer (row N4): a noise-free 32APSK-S_3/4 PL stream that starts 321 symbols late."""
+    from oracle import oracle as O
+    from helpers import chain
+    ch = chain(O, "32APSK-S_3/4")
+    rng = np.random.default_rng(104)
+    F, off = 6, 321
+    pl = np.stack([ch.tx(rng.integers(0, 2, ch.mc.K_bch).astype(np.int32))[0] for _ in range(F)])
+    n = pl.shape[1] // 2
+    stream = np.concatenate([np.zeros(2 * off, np.float32), pl.reshape(-1)])[:F * 2 * n].reshape(F, 2 * n)
+    sf = O.SyncFrame(n, alpha=0.9, trigger=30.0, vec_width=8)
+    dels, tris, flgs, ys = [], [], [], []
+    for f in range(F):
+        d, Y = sf.synchronize(stream[f])
+        dels.append(d); tris.append(sf.metric); flgs.append(int(sf.packet_flag)); ys.append(Y)
+    assert dels[-1] == off and np.array_equal(ys[-1], pl[F - 2])
+    np.savez_compressed(os.path.join(HERE, "kat_sync_frame_32apsk.npz"), stream=stream, DEL=np.array(dels, np.int32), TRI=np.array(tris, np.float32),
+                        FLG=np.array(flgs, np.int32), Y=np.stack(ys), alpha=0.9, trigger=30.0, vec_width=8)
+
 if __name__ == "__main__":
-    pl_seq(); refs(); src(); kats()
+    if len(sys.argv) > 1 and sys.argv[1] == "sync":
+        kat_sync()
+    else:
+        pl_seq(); refs(); src(); kats(); kat_sync()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

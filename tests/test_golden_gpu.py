@@ -53,6 +53,18 @@ def test_fir_golden(Rx):
     rx.close()
 
 
+def test_sync_frame_golden(Rx):
+    k = np.load(os.path.join(GOLD, "kat_sync_frame_32apsk.npz"))
+    rx = Rx("32APSK-S_3/4", max_frames=3)
+    rx.sync_frame_set_params(float(k["alpha"]), float(k["trigger"]), int(k["vec_width"]))
+    for f0 in (0, 3):
+        DEL, FLG, TRI, Y = rx.sync_frame_synchronize(k["stream"][f0:f0 + 3], with_flags=True)
+        assert np.array_equal(DEL, k["DEL"][f0:f0 + 3]) and np.array_equal(FLG, k["FLG"][f0:f0 + 3])
+        assert np.all(np.abs(TRI - k["TRI"][f0:f0 + 3]) <= 2e-4 * np.maximum(1.0, k["TRI"][f0:f0 + 3]))
+        assert np.array_equal(Y, k["Y"][f0:f0 + 3])
+    rx.close()
+
+
 def test_reference_fixed_payload_roundtrip(Rx, O):
     """conf/src/K_14232.src (the reference's Source_user pattern) through oracle TX -> GPU RX."""
     from helpers import chain, sigma_for

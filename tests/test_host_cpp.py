@@ -48,6 +48,25 @@ def test_host_rx_graph_on_gpu(O, tmp_path, modcod, ebn0):
 
 
 @pytest.mark.gpu
+def test_host_frame_sync_task_in_front_of_the_graph(O, tmp_path):
+    """Synchronizer_frame_hip::synchronize in front of the RX graph (as src/mains/RX/main.cpp binds it): a stream
+    that starts in the middle of a frame is aligned and decoded; frame k of the output is payload k-1."""
+    exe = build()
+    modcod, n_fr, off = "QPSK-S_8/9", 10, 2500
+    info, pl, _, _ = make_pl_frames(O, modcod, n_fr, 6.0, seed=62)
+    n = pl.shape[1] // 2
+    stream = np.concatenate([np.zeros(2 * off, np.float32), pl.reshape(-1)])[:n_fr * 2 * n]
+    pin, pout = str(tmp_path / "pl.f32"), str(tmp_path / "out.i32")
+    stream.astype(np.float32).tofile(pin)
+    r = subprocess.run([exe, "--mod-cod", modcod, "-F", "1", "--dec-ite", "10", "--frame-sync", "--in", pin, "--out", pout], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches 0" in r.stdout and "DEL %d " % off in r.stdout
+    out = np.fromfile(pout, dtype=np.int32).reshape(n_fr, -1)
+    for f in range(4, n_fr):
+        assert np.array_equal(out[f], info[f - 1]), f
+
+
+@pytest.mark.gpu
 def test_cpp_tx_rx_bb_reproduces_a_reference_row():
     """The C++ work-alike of dvbs2_tx_rx_bb (C ABI only) on one row of refs/TX_RX_BB/QPSK_8_9.txt."""
     import json

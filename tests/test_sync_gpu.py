@@ -1,0 +1,84 @@
+"""Row N4 parity on the GPU: frame synchronizer vs the CPU oracle's restatement of
+Synchronizer_frame_DVBS2_fast (correlations within 1e-4 of unit-power signals, the delay exact, the
+aligned output bit-exact since it only copies samples)."""
+import numpy as np
+import pytest
+
+from helpers import make_pl_frames
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4        # sums of up to 64 products of unit-power samples, accumulated in a different order
+
+
+@pytest.fixture(scope="module")
+def Rx():
+    from dvbs2_amd.receiver import Dvbs2Hip
+    return Dvbs2Hip
+
+
+@pytest.mark.parametrize("modcod,batch", [("QPSK-S_8/9", 1), ("QPSK-S_8/9", 3), ("16APSK-S_8/9", 2), ("32APSK-S_3/4", 4)])
+def test_synchronize_matches_oracle_frame_by_frame(O, Rx, modcod, batch):
+    F, off = 12, 777
+    _, pl, _, _ = make_pl_frames(O, modcod, F, 8.0, seed=4)
+    n = pl.shape[1] // 2
+    stream = np.concatenate([np.zeros(2 * off, np.float32), pl.reshape(-1)])[:F * 2 * n].reshape(F, 2 * n)
+    sf = O.SyncFrame(n, alpha=0.9, trigger=30.0, vec_width=8)
+    rx = Rx(modcod, max_frames=batch)
+    for f0 in range(0, F, batch):
+        x = stream[f0:f0 + batch]
+        d, flg, tri, Y = rx.sync_frame_synchronize(x, with_flags=True)
+        for k in range(batch):
+            do, Yo = sf.synchronize(x[k])
+            assert d[k] == do, (f0 + k, d[k], do)
+            assert np.array_equal(Y[k], Yo), f0 + k
+            assert abs(tri[k] - sf.metric) <= TOL * max(1.0, sf.metric) and bool(flg[k]) == sf.packet_flag     # TRI / FLG sockets
+        m, flag = rx.sync_frame_metric()
+        assert abs(m - sf.metric) <= TOL * max(1.0, sf.metric) and flag == sf.packet_flag
+    assert d[-1] == off
+    rx.close()
+
+
+def test_two_task_form_and_correlations(O, Rx):
+    modcod = "8PSK-S_3/5"
+    F = 5
+    _, pl, _, _ = make_pl_frames(O, modcod, F, 6.0, seed=5)
+    n = pl.shape[1] // 2
+    sf = O.SyncFrame(n)
+    rx = Rx(modcod, max_frames=F)
+    # synchronize1 on the whole batch at once = the stream form of the two correlators; the reference runs
+    # the two tasks alternately per frame (synchronize2 is what moves reg_channel on, .cpp:294)
+    cs, cp = rx.sync_frame_synchronize1(pl)
+    d, Y = rx.sync_frame_synchronize2(pl, cs, cp)
+    for f in range(F):
+        c1, c2 = sf.synchronize1(pl[f])
+        do, Yo = sf.synchronize2(pl[f], c1, c2)
+        assert np.max(np.abs(cs[f] - c1)) <= TOL * 25 and np.max(np.abs(cp[f] - c2)) <= TOL * 32
+        assert d[f] == do and np.array_equal(Y[f], Yo)
+    rx.close()
+
+
+def test_reset_parameters_and_delay_changes(O, Rx):
+    modcod = "QPSK-S_8/9"
+    _, pl, _, _ = make_pl_frames(O, modcod, 10, 9.0, seed=6)
+    n = pl.shape[1] // 2
+    flat = pl.reshape(-1)
+    rx = Rx(modcod, max_frames=2)
+    rx.sync_frame_set_params(alpha=0.5, trigger=10.0, vec_width=16)
+    sf = O.SyncFrame(n, alpha=0.5, trigger=10.0, vec_width=16)
+    # the offset of the stream changes twice: the delay line goes through its transitional branches
+    offs = [100, 100, 100, 4000, 4000, 4000, 50, 50]
+    pos = 0
+    for f, off in enumerate(offs):
+        x = np.roll(flat, 2 * off)[pos:pos + 2 * n].copy()
+        pos += 2 * n
+        d, Y = rx.sync_frame_synchronize(x)
+        do, Yo = sf.synchronize(x)
+        assert d[0] == do and np.array_equal(Y[0], Yo), f
+    m, flag = rx.sync_frame_metric()
+    assert flag == sf.packet_flag
+    rx.sync_frame_reset(); sf.reset()
+    x = flat[:2 * n]
+    d, Y = rx.sync_frame_synchronize(x)
+    do, Yo = sf.synchronize(x)
+    assert d[0] == do and np.array_equal(Y[0], Yo)
+    rx.close()
