@@ -69,6 +69,9 @@ struct dvbs2hip_handle {
         float *metric = nullptr;               // max_corr of the last frame
         int xh_cur = 0, sofh_cur = 0, od_cur = 0;
     } sfm;
+    // L&R fine frequency synchronizer (N4): damped autocorrelation R_l, alpha (factory default 0.999)
+    float *d_lr_R = nullptr;
+    float lr_alpha = 0.999f;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[DVBS2HIP_K_COUNT];
@@ -92,7 +95,7 @@ int fail(dvbs2hip_t *h, int code, const std::string &msg)
     } while (0)
 
 enum BufId { B_IN = 0, B_OUT, B_AUX0, B_AUX1, B_AUX2, B_AUX3, B_LLR, B_PACKED, B_EST, B_CWD0, B_CWD1, B_INFO, B_SIG, B_TXBCH, B_TXLDPC,
-             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY };
+             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY, B_SFF_TMP, B_SFF_OUT };
 
 int ensure(dvbs2hip_t *h, int id, size_t bytes, void **out)
 {
@@ -378,7 +381,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
         for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
-                        h->sfm.yprev, h->sfm.metric};
+                        h->sfm.yprev, h->sfm.metric, h->d_lr_R};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
@@ -830,6 +833,58 @@ int dvbs2hip_sync_frame_synchronize2(dvbs2hip_t *h, const float *X_N1, const flo
 int dvbs2hip_sync_frame_synchronize(dvbs2hip_t *h, const float *X_N1, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t F)
 {
     return sfm_host(h, X_N1, nullptr, nullptr, DEL, FLG, TRI, Y_N2, F);
+}
+
+// ------------------------------------------------------------------ N4: fine frequency / phase synchronizers (sockets X_N1, FRQ, PHS, Y_N2)
+static int sff_call(dvbs2hip_t *h, bool lr, bool host, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X_N1 || !Y_N2) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const int n = h->pl_frame;
+    if (n <= 1530) return fail(h, DVBS2HIP_EUNSUPPORTED, "the PL frame holds no pilot block");
+    if (lr && !h->d_lr_R) { HIPCHK(h, hipMalloc((void **)&h->d_lr_R, 2 * sizeof(float))); HIPCHK(h, hipMemsetAsync(h->d_lr_R, 0, 2 * sizeof(float), h->stream)); }
+    const size_t nb = sizeof(float) * 2 * (size_t)n * F;
+    void *tmp, *din = nullptr, *dout = nullptr, *dfp = nullptr;
+    if ((r = ensure(h, B_SFF_TMP, sizeof(float) * 4 * (size_t)F, &tmp))) return r;
+    const float *x = X_N1;
+    float *y = Y_N2, *frq = FRQ, *phs = PHS;
+    if (host) {
+        if ((r = ensure(h, B_IN, nb, &din)) || (r = ensure(h, B_OUT, nb, &dout)) || (r = ensure(h, B_SFF_OUT, sizeof(float) * 2 * (size_t)F, &dfp))) return r;
+        HIPCHK(h, hipMemcpyAsync(din, X_N1, nb, hipMemcpyHostToDevice, h->stream));
+        x = (const float *)din; y = (float *)dout; frq = (float *)dfp; phs = frq + F;
+    }
+    {
+        Timer tm(h, DVBS2HIP_K_MISC);
+        if (lr) HIPCHK(h, sff_lr_launch(x, y, h->d_lr_R, (float *)tmp, frq, phs, n, F, h->lr_alpha, h->stream));
+        else HIPCHK(h, sff_fp_launch(x, y, (float *)tmp, frq, phs, n, F, h->stream));
+    }
+    if (host) {
+        HIPCHK(h, hipMemcpyAsync(Y_N2, dout, nb, hipMemcpyDeviceToHost, h->stream));
+        if (FRQ) HIPCHK(h, hipMemcpyAsync(FRQ, frq, sizeof(float) * (size_t)F, hipMemcpyDeviceToHost, h->stream));
+        if (PHS) HIPCHK(h, hipMemcpyAsync(PHS, phs, sizeof(float) * (size_t)F, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+int dvbs2hip_sync_lr_synchronize(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t F) { return sff_call(h, true, true, X_N1, FRQ, PHS, Y_N2, F); }
+int dvbs2hip_sync_lr_synchronize_dev(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t F) { return sff_call(h, true, false, X_N1, FRQ, PHS, Y_N2, F); }
+int dvbs2hip_sync_freq_phase_synchronize(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t F) { return sff_call(h, false, true, X_N1, FRQ, PHS, Y_N2, F); }
+int dvbs2hip_sync_freq_phase_synchronize_dev(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t F) { return sff_call(h, false, false, X_N1, FRQ, PHS, Y_N2, F); }
+
+int dvbs2hip_sync_lr_set_alpha(dvbs2hip_t *h, float alpha)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    h->lr_alpha = alpha;
+    return 0;
+}
+
+int dvbs2hip_sync_lr_reset(dvbs2hip_t *h)          // Synchronizer_Luise_Reggiannini_DVBS2_aib::_reset, .cpp:170-176
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    if (hipSetDevice(h->device) != hipSuccess) return fail(h, DVBS2HIP_EHIP, "hipSetDevice failed");
+    if (h->d_lr_R) HIPCHK(h, hipMemsetAsync(h->d_lr_R, 0, 2 * sizeof(float), h->stream));
+    return 0;
 }
 
 int dvbs2hip_sync_frame_get_metric(dvbs2hip_t *h, float *max_corr, int32_t *packet_flag)

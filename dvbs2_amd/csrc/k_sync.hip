@@ -153,6 +153,140 @@ __global__ void sync_vdelay_kernel(const float *__restrict__ X, const float *__r
     if (j == 0) { st_new[0] = D; st_new[1] = 0; }
 }
 
+// ================================================================ fine frequency / phase synchronizers
+// Synchronizer_Luise_Reggiannini_DVBS2_aib (src/common/Module/Synchronizer/Synchronizer_freq/Synchronizer_freq_fine/
+// Synchronizer_Luise_Reggiannini_DVBS2_aib.cpp:93-167) and Synchronizer_freq_phase_DVBS2_aib (.cpp:44-112): an estimate
+// from the 36-symbol pilot blocks of a PL-descrambled frame (one small workgroup per frame, the sums in the reference's
+// order), then a rotation of the whole frame.  Pilot p starts at symbol 1530 + 1476 p (.cpp:18-24).
+constexpr int SFF_MAXP = 64;
+
+// ---- L&R, per frame: tR[f] = (temp_R_l_0, temp_R_l_1) (.cpp:102-130)
+__global__ void __launch_bounds__(256)
+sff_lr_pilot_kernel(const float *__restrict__ X, float2 *__restrict__ tR, int n)
+{
+    __shared__ float2 part[SFF_MAXP * 9];
+    const float *x = X + (size_t)blockIdx.x * 2 * n;
+    int P = 0;
+    for (int idx = 1530; idx < n; idx += 1476) P++;
+    const int Lp = 18;
+    for (int w = threadIdx.x; w < P * 9; w += 256) {
+        const int p = w / 9, m = w % 9 + 1, ps = 1530 + 1476 * p;
+        float s0 = 0.f, s1 = 0.f;
+        for (int k = m; k < Lp; k++) {
+            const float ar = x[2 * (ps + k)], ai = x[2 * (ps + k) + 1], br = x[2 * (ps + k - m)], bi = x[2 * (ps + k - m) + 1];
+            const float zkr = ar + ai, zki = ai - ar, zmr = br + bi, zmi = bi - br;       // z = x (1 - j), :107-114
+            s0 += zkr * zmr + zki * zmi;
+            s1 += zki * zmr - zkr * zmi;
+        }
+        part[w] = make_float2(s0 / (float)(2 * (Lp - m)), s1 / (float)(2 * (Lp - m)));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int w = 0; w < P * 9; w++) { t0 += part[w].x; t1 += part[w].y; }             // p-major, m-minor: the reference's order
+        tR[blockIdx.x] = make_float2(t0, t1);
+    }
+}
+
+// ---- L&R, the damped autocorrelation from frame to frame (:131-135): one thread; fr[f] = {estimated_freq, est * pi}
+__global__ void sff_lr_iir_kernel(const float2 *__restrict__ tR, float *__restrict__ R_l, float2 *__restrict__ fr, float *__restrict__ FRQ,
+                                  float *__restrict__ PHS, int F, float alpha)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    float r0 = R_l[0], r1 = R_l[1];
+    for (int f = 0; f < F; f++) {
+        r0 = alpha * r0 + (1 - alpha) * tR[f].x;
+        r1 = alpha * r1 + (1 - alpha) * tR[f].y;
+        float est = atan2f(r1, r0);
+        est = (float)((double)est / ((18 / 2 + 1) * 3.1415926535897932384626433832795));
+        fr[f] = make_float2(est, (float)((double)est * 3.1415926535897932384626433832795));
+        if (FRQ) FRQ[f] = est;
+        if (PHS) PHS[f] = 0.f;
+    }
+    R_l[0] = r0; R_l[1] = r1;
+}
+
+// ---- freq_phase, per frame: fr[f] = {estimated_freq, estimated_phase} (.cpp:53-101)
+__global__ void __launch_bounds__(64)
+sff_fp_pilot_kernel(const float *__restrict__ X, float2 *__restrict__ fr, float *__restrict__ FRQ, float *__restrict__ PHS, int n)
+{
+    __shared__ float phase_est[SFF_MAXP];
+    const float *x = X + (size_t)blockIdx.x * 2 * n;
+    int P = 0;
+    for (int idx = 1530; idx < n; idx += 1476) P++;
+    const int Lp = 36;
+    const double PI = 3.1415926535897932384626433832795;
+    for (int p = threadIdx.x; p < P; p += 64) {
+        const int ps = 1530 + 1476 * p;
+        float s0 = 0.f, s1 = 0.f;
+        for (int i = 0; i < Lp; i++) { s0 += x[2 * ps + 2 * i] + x[2 * ps + 2 * i + 1]; s1 += x[2 * ps + 2 * i + 1] - x[2 * ps + 2 * i]; }
+        float ph = atan2f(s1, s0);
+        phase_est[p] = ph < 0 ? (float)(ph + 2 * PI) : ph;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float inv_2PI = (float)(1.0f / (2 * PI));
+        float acc = 0.f, sum_t = 0.f, sum_y = 0.f, sum_ty = 0.f, sum_tt = 0.f;
+        for (int p = 0; p < P; p++) {
+            float y;
+            if (p == 0) y = inv_2PI * phase_est[0];
+            else {
+                const float diff_angle = phase_est[p] - phase_est[p - 1];
+                float acc_elt = diff_angle > 0 ? floorf(diff_angle * inv_2PI + 0.5f) : ceilf(diff_angle * inv_2PI - 0.5f);
+                acc_elt = (double)fabsf(diff_angle) > PI ? acc_elt : 0.0f;
+                acc += acc_elt;
+                y = inv_2PI * phase_est[p] - acc;
+            }
+            const float t = (float)(1530 + 1476 * p) + (float)(Lp / 2);
+            sum_t += t; sum_y += y; sum_ty += t * y; sum_tt += t * t;
+        }
+        const float ef = (P * sum_ty - sum_t * sum_y) / (P * sum_tt - sum_t * sum_t);
+        const float ep = (sum_y - ef * sum_t) / P;
+        fr[blockIdx.x] = make_float2(ef, ep);
+        if (FRQ) FRQ[blockIdx.x] = ef;
+        if (PHS) PHS[blockIdx.x] = ep;
+    }
+}
+
+// ---- rotation of the frame: y = x conj(e^{j theta}); MODE 0 (L&R, :141-166): theta = (est pi) * (2 k);
+// MODE 1 (freq_phase, :103-112): theta = 2 pi (freq k + phase), formed in double as the reference's expression is
+template <int MODE>
+__global__ void sff_rotate_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const float2 *__restrict__ fr, int n, long long n_total)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_total) return;
+    const int f = (int)(g / n), k = (int)(g - (long long)f * n);
+    const float2 e = fr[f];
+    float theta;
+    if (MODE == 0) theta = e.y * (float)(2 * k);
+    else theta = (float)(2 * 3.1415926535897932384626433832795 * (double)(e.x * (float)k + e.y));
+    float sn, c;
+    sincosf(theta, &sn, &c);
+    const float2 v = x[g];
+    y[g] = make_float2(v.x * c + v.y * sn, v.y * c - v.x * sn);
+}
+
+hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp /* 4 F floats */, float *FRQ, float *PHS, int n, int F, float alpha, hipStream_t s)
+{
+    float2 *tR = reinterpret_cast<float2 *>(tmp), *fr = tR + F;
+    hipLaunchKernelGGL(sff_lr_pilot_kernel, dim3(F), dim3(256), 0, s, X, tR, n);
+    hipLaunchKernelGGL(sff_lr_iir_kernel, dim3(1), dim3(1), 0, s, tR, R_l, fr, FRQ, PHS, F, alpha);
+    const long long tot = (long long)n * F;
+    hipLaunchKernelGGL(sff_rotate_kernel<0>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(X),
+                       reinterpret_cast<float2 *>(Y), fr, n, tot);
+    return hipGetLastError();
+}
+
+hipError_t sff_fp_launch(const float *X, float *Y, float *tmp /* 2 F floats */, float *FRQ, float *PHS, int n, int F, hipStream_t s)
+{
+    float2 *fr = reinterpret_cast<float2 *>(tmp);
+    hipLaunchKernelGGL(sff_fp_pilot_kernel, dim3(F), dim3(64), 0, s, X, fr, FRQ, PHS, n);
+    const long long tot = (long long)n * F;
+    hipLaunchKernelGGL(sff_rotate_kernel<1>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(X),
+                       reinterpret_cast<float2 *>(Y), fr, n, tot);
+    return hipGetLastError();
+}
+
 hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s)
 {
     const unsigned grid = (unsigned)((n_total + SY_T - 1) / SY_T);

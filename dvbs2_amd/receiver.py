@@ -296,6 +296,25 @@ class Dvbs2Hip:
         self._chk(self.L.dvbs2hip_sync_frame_get_metric(self.h, C.byref(m), C.byref(fl)))
         return m.value, bool(fl.value)
 
+    # ------------------------------------------------------------------ N4: fine frequency / phase synchronizers
+    def _sff(self, fn, X_N1):
+        X, F = self._frames(X_N1, 2 * self.pl_frame, np.float32)
+        FRQ, PHS, Y = np.empty(F, np.float32), np.empty(F, np.float32), np.empty_like(X)
+        self._chk(fn(self.h, _ptr(X), _ptr(FRQ), _ptr(PHS), _ptr(Y), F))
+        return FRQ, PHS, Y
+
+    def sync_lr_synchronize(self, X_N1):
+        return self._sff(self.L.dvbs2hip_sync_lr_synchronize, X_N1)
+
+    def sync_lr_set_alpha(self, alpha):
+        self._chk(self.L.dvbs2hip_sync_lr_set_alpha(self.h, float(alpha)))
+
+    def sync_lr_reset(self):
+        self._chk(self.L.dvbs2hip_sync_lr_reset(self.h))
+
+    def sync_freq_phase_synchronize(self, X_N1):
+        return self._sff(self.L.dvbs2hip_sync_freq_phase_synchronize, X_N1)
+
     def ldpc_kernel_name(self) -> str:
         return self.L.dvbs2hip_ldpc_kernel_name(self.h).decode()
 

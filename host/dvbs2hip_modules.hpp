@@ -64,6 +64,8 @@ namespace scr { namespace sck { enum class descramble : size_t { Y_N1, Y_N2, sta
 namespace frm { namespace sck { enum class remove_plh : size_t { Y_N1, Y_N2, status }; } }
 namespace mnt { namespace sck { enum class check_errors : size_t { U, V, status }; } }
 namespace rcv { namespace sck { enum class receive : size_t { Y_N1, V_K, CWD_LDPC, CWD_BCH, status }; } }
+// Synchronizer_freq_fine.hpp:14-19
+namespace sff { enum class tsk : size_t { synchronize, SIZE }; namespace sck { enum class synchronize : size_t { X_N1, FRQ, PHS, Y_N2, status }; } }
 // Synchronizer_frame.hpp:15-24
 namespace sfm { enum class tsk : size_t { synchronize, synchronize1, synchronize2, SIZE };
                 namespace sck { enum class synchronize : size_t { X_N1, DEL, FLG, TRI, Y_N2, status };
@@ -364,6 +366,37 @@ public:
     void reset() { DVBS2HIP_CHK(ctx, dvbs2hip_sync_frame_reset(ctx->h)); }                        // Interface_reset
     R get_metric() { float m; int32_t f; DVBS2HIP_CHK(ctx, dvbs2hip_sync_frame_get_metric(ctx->h, &m, &f)); return (R)m; }
     bool get_packet_flag() { float m; int32_t f; DVBS2HIP_CHK(ctx, dvbs2hip_sync_frame_get_metric(ctx->h, &m, &f)); return f != 0; }
+};
+
+// replaces Synchronizer_Luise_Reggiannini_DVBS2_aib<R> (LR = true; lr_alpha as Factory/.../Synchronizer_freq_fine.hpp:25)
+// and Synchronizer_freq_phase_DVBS2_aib<R> (LR = false): task and sockets of Synchronizer_freq_fine.hxx:32-47
+template <typename R = float>
+class Synchronizer_freq_fine_hip : public Module_hip {
+public:
+    Synchronizer_freq_fine_hip(std::shared_ptr<Context> c, bool luise_reggiannini, R lr_alpha = (R)0.999)
+    : Module_hip(std::move(c), luise_reggiannini ? "Synchronizer_Luise_Reggiannini_hip" : "Synchronizer_freq_phase_hip"), lr(luise_reggiannini)
+    {
+        if (lr) DVBS2HIP_CHK(ctx, dvbs2hip_sync_lr_set_alpha(ctx->h, (float)lr_alpha));
+        const size_t N = 2 * (size_t)ctx->sz.pl_frame_sym;
+        auto &t = create_task("synchronize");
+        auto sX = create_socket_in<R>(t, "X_N1", N);
+        auto sF = create_socket_out<R>(t, "FRQ", 1);
+        auto sP = create_socket_out<R>(t, "PHS", 1);
+        auto sY = create_socket_out<R>(t, "Y_N2", N);
+        create_codelet(t, [sX, sF, sP, sY](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Synchronizer_freq_fine_hip &>(m).synchronize(tk[sX].template get_dataptr<const R>(), tk[sF].template get_dataptr<R>(),
+                                                                     tk[sP].template get_dataptr<R>(), tk[sY].template get_dataptr<R>());
+            return 0;
+        });
+    }
+    void synchronize(const R *X_N1, R *FRQ, R *PHS, R *Y_N2)
+    {
+        if (lr) DVBS2HIP_CHK(ctx, dvbs2hip_sync_lr_synchronize(ctx->h, X_N1, FRQ, PHS, Y_N2, F()));
+        else DVBS2HIP_CHK(ctx, dvbs2hip_sync_freq_phase_synchronize(ctx->h, X_N1, FRQ, PHS, Y_N2, F()));
+    }
+    void reset() { if (lr) DVBS2HIP_CHK(ctx, dvbs2hip_sync_lr_reset(ctx->h)); }
+private:
+    bool lr;
 };
 
 }  // namespace module

@@ -274,6 +274,23 @@ int dvbs2hip_sync_frame_synchronize(dvbs2hip_t *h, const float *X_N1, int32_t *D
 int dvbs2hip_sync_frame_synchronize_dev(dvbs2hip_t *h, const float *X_N1, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t n_frames);
 int dvbs2hip_sync_frame_get_metric(dvbs2hip_t *h, float *max_corr, int32_t *packet_flag);
 
+/* ------------------------------------------------------------------ N4: fine frequency / phase synchronizers
+ * replace: Synchronizer_freq_fine::synchronize (sockets X_N1, FRQ, PHS, Y_N2: Synchronizer_freq_fine.hxx:32-47) of
+ *   Synchronizer_Luise_Reggiannini_DVBS2_aib -- src/common/Module/Synchronizer/Synchronizer_freq/Synchronizer_freq_fine/
+ *     Synchronizer_Luise_Reggiannini_DVBS2_aib.cpp:93-167 (autocorrelation of the pilot blocks, damped by lr_alpha from
+ *     frame to frame -- default 0.999, Factory/Module/Synchronizer_freq_fine/Synchronizer_freq_fine.hpp:25 -- then the
+ *     frame is rotated by the estimated frequency); _reset :170-176
+ *   Synchronizer_freq_phase_DVBS2_aib -- .../Synchronizer_freq_phase_DVBS2_aib.cpp:44-112 (phase of every pilot block,
+ *     unwrapped, least-squares line -> frequency and phase, rotation of the frame); stateless
+ * Input = PL-DESCRAMBLED frames (the RX mains run them after Scrambler_PL::descramble).
+ *   X_N1, Y_N2: float[n_frames * 2*pl_frame]; FRQ, PHS: float[n_frames] (may be NULL)                         */
+int dvbs2hip_sync_lr_synchronize(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t n_frames);
+int dvbs2hip_sync_lr_synchronize_dev(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t n_frames);
+int dvbs2hip_sync_lr_set_alpha(dvbs2hip_t *h, float alpha);
+int dvbs2hip_sync_lr_reset(dvbs2hip_t *h);
+int dvbs2hip_sync_freq_phase_synchronize(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t n_frames);
+int dvbs2hip_sync_freq_phase_synchronize_dev(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t n_frames);
+
 /* ------------------------------------------------------------------ measurement
  * Per-kernel device time, measured with hipEvents recorded on the handle's stream around
  * each launch while timing is enabled (the equivalent of `--sim-stats`,

@@ -701,6 +701,89 @@ void orc_upfir(const float *taps, int T, int osf, float *hist, const float *x, f
     free(up);
 }
 
+/* ================================================================ fine frequency / phase synchronizers (row N4) */
+#ifndef M_PI
+#define M_PI 3.1415926535897932384626433832795
+#endif
+int orc_sff_pilots(int n_cplx, int *pilot_start, int max)
+{
+    int n = 0;
+    for (int idx = 1530; idx < n_cplx; idx += 1476) { if (n < max) pilot_start[n] = idx; n++; }   /* .cpp:18-24 */
+    return n;
+}
+
+float orc_lr_synchronize(int n_cplx, float alpha, float *R_l, const float *X, float *Y)
+{
+    int ps[64];
+    const int P = orc_sff_pilots(n_cplx, ps, 64), Lp = 36 / 2, Lp_2 = Lp / 2;
+    float t0 = 0.f, t1 = 0.f;
+    for (int p = 0; p < P; p++) {                                                   /* .cpp:102-130 */
+        float z[2 * 18];
+        for (int i = 0; i < Lp; i++) {
+            z[2 * i] = X[2 * i + 2 * ps[p]] + X[2 * i + 2 * ps[p] + 1];
+            z[2 * i + 1] = X[2 * i + 2 * ps[p] + 1] - X[2 * i + 2 * ps[p]];
+        }
+        for (int m = 1; m < Lp_2 + 1; m++) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int k = m; k < Lp; k++) {
+                s0 += z[2 * k] * z[2 * (k - m)] + z[2 * k + 1] * z[2 * (k - m) + 1];
+                s1 += z[2 * k + 1] * z[2 * (k - m)] - z[2 * k] * z[2 * (k - m) + 1];
+            }
+            t0 += s0 / (float)(2 * (Lp - m));
+            t1 += s1 / (float)(2 * (Lp - m));
+        }
+    }
+    R_l[0] = alpha * R_l[0] + (1 - alpha) * t0;                                     /* .cpp:131-132 */
+    R_l[1] = alpha * R_l[1] + (1 - alpha) * t1;
+    float est = atan2f(R_l[1], R_l[0]);                                             /* .cpp:133 */
+    est = (float)(est / ((Lp_2 + 1) * M_PI));                                       /* .cpp:134 */
+    const float f_ = (float)(est * M_PI);                                           /* .cpp:135 */
+    for (int n = 0; n < 2 * n_cplx; n += 2) {                                       /* .cpp:141-166 (mipp::cossin / std::cos, std::sin) */
+        const float theta = f_ * (float)n, c = cosf(theta), sn = sinf(theta);
+        Y[n] = X[n] * c + X[n + 1] * sn;
+        Y[n + 1] = X[n + 1] * c - X[n] * sn;
+    }
+    return est;
+}
+
+void orc_fp_synchronize(int n_cplx, const float *X, float *Y, float *out2)
+{
+    int ps[64];
+    const int P = orc_sff_pilots(n_cplx, ps, 64), Lp = 36;
+    const float inv_2PI = (float)(1.0f / (2 * M_PI));                               /* .cpp:50 */
+    float phase_est[64], y[64], t[64];
+    for (int p = 0; p < P; p++) {                                                   /* .cpp:53-67 */
+        float s0 = 0.f, s1 = 0.f;
+        for (int i = 0; i < Lp; i++) {
+            s0 += X[2 * ps[p] + 2 * i] + X[2 * ps[p] + 2 * i + 1];
+            s1 += X[2 * ps[p] + 2 * i + 1] - X[2 * ps[p] + 2 * i];
+        }
+        phase_est[p] = atan2f(s1, s0);
+        phase_est[p] = phase_est[p] < 0 ? (float)(phase_est[p] + 2 * M_PI) : phase_est[p];
+    }
+    y[0] = inv_2PI * phase_est[0];                                                   /* .cpp:72-73 */
+    t[0] = ps[0] + (float)(Lp / 2);
+    float acc = 0.f;
+    for (int p = 1; p < P; p++) {                                                    /* .cpp:77-85 */
+        const float diff_angle = phase_est[p] - phase_est[p - 1];
+        float acc_elt = diff_angle > 0 ? floorf(diff_angle * inv_2PI + 0.5f) : ceilf(diff_angle * inv_2PI - 0.5f);
+        acc_elt = fabsf(diff_angle) > M_PI ? acc_elt : 0.0f;
+        acc += acc_elt;
+        y[p] = inv_2PI * phase_est[p] - acc;
+        t[p] = ps[p] + (float)(Lp / 2);
+    }
+    float sum_t = 0.f, sum_y = 0.f, sum_ty = 0.f, sum_tt = 0.f;
+    for (int p = 0; p < P; p++) { sum_t += t[p]; sum_y += y[p]; sum_ty += t[p] * y[p]; sum_tt += t[p] * t[p]; }    /* .cpp:92-98 */
+    const float ef = (P * sum_ty - sum_t * sum_y) / (P * sum_tt - sum_t * sum_t);   /* .cpp:100 */
+    const float ep = (sum_y - ef * sum_t) / P;                                      /* .cpp:101 */
+    out2[0] = ef; out2[1] = ep;
+    for (int n = 0; n < n_cplx; n++) {                                              /* .cpp:103-112 */
+        const float theta = (float)(2 * M_PI * (ef * (float)n + ep));
+        Y[2 * n] = X[2 * n] * cosf(theta) + X[2 * n + 1] * sinf(theta);
+        Y[2 * n + 1] = X[2 * n + 1] * cosf(theta) - X[2 * n] * sinf(theta);
+    }
+}
+
 /* ================================================================ frame synchronizer (row N4) */
 /* Variable_delay_cc_naive: ctor Variable_delay_cc_naive.cpp:11-24, `_filter` :56-79 */
 struct orc_vdelay { int N, delay, size, head2, first_time, nbuff2; float *buff2; };

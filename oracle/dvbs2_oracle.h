@@ -128,6 +128,15 @@ float    orc_sfm_metric(const orc_sfm *s);                                      
 int      orc_sfm_packet_flag(const orc_sfm *s);                                            /* _get_packet_flag, .hpp:60 */
 void     orc_sfm_taps(const float **sof, int *n_sof, const float **plsc, int *n_plsc);     /* conj_SOF / conj_PLSC, .hpp:19-33 */
 
+/* ---------------------------------------------------------------- fine frequency / phase synchronizers (row N4) */
+/* pilot positions of both: 1530 + 1476 k < n_cplx (Synchronizer_Luise_Reggiannini_DVBS2_aib.cpp:18-24) */
+int  orc_sff_pilots(int n_cplx, int *pilot_start, int max);
+/* Synchronizer_Luise_Reggiannini_DVBS2_aib::_synchronize (.cpp:93-167); R_l[2] = the damped autocorrelation
+ * carried between frames (zero after reset); returns estimated_freq (the FRQ socket; PHS stays 0) */
+float orc_lr_synchronize(int n_cplx, float alpha, float *R_l, const float *X, float *Y);
+/* Synchronizer_freq_phase_DVBS2_aib::_synchronize (.cpp:44-112), stateless; out2 = {estimated_freq, estimated_phase} */
+void orc_fp_synchronize(int n_cplx, const float *X, float *Y, float *out2);
+
 /* ---------------------------------------------------------------- CPU baseline leg of bench.py */
 /* decode F frames with `threads` threads (frames sharded); returns seconds */
 double orc_ldpc_decode_batch(const orc_ldpc *c, const float *llr, int F, int sched, int n_ite,

@@ -68,6 +68,10 @@ def lib():
         L.orc_rrc_taps.argtypes = [cf, ci, ci, vp]
         L.orc_fir.argtypes = [vp, ci, vp, vp, vp, ci]
         L.orc_upfir.argtypes = [vp, ci, ci, vp, vp, vp, ci]
+        L.orc_sff_pilots.argtypes = [ci, vp, ci]
+        L.orc_lr_synchronize.restype = cf
+        L.orc_lr_synchronize.argtypes = [ci, cf, vp, vp, vp]
+        L.orc_fp_synchronize.argtypes = [ci, vp, vp, vp]
         L.orc_vdelay_create.restype = vp
         L.orc_vdelay_create.argtypes = [ci, ci, ci]
         L.orc_vdelay_destroy.argtypes = [vp]
@@ -304,6 +308,38 @@ def upfir(taps, osf, hist, x):
     y = np.empty(x.size * osf, dtype=np.float32)
     lib().orc_upfir(_p(taps), taps.size, osf, _p(hist), _p(x), _p(y), x.size // 2)
     return y
+
+
+def sff_pilots(n_cplx):
+    ps = np.zeros(64, dtype=np.int32)
+    n = lib().orc_sff_pilots(n_cplx, _p(ps), 64)
+    return ps[:n].copy()
+
+
+class SyncLR:
+    """Synchronizer_Luise_Reggiannini_DVBS2_aib (row N4): fine frequency from the pilots, damped across frames."""
+
+    def __init__(self, n_cplx, alpha=0.999):
+        self.n, self.alpha = n_cplx, float(alpha)
+        self.R_l = np.zeros(2, dtype=np.float32)
+
+    def reset(self):
+        self.R_l[:] = 0
+
+    def synchronize(self, X):
+        X = _f32(X).ravel()
+        assert X.size == 2 * self.n
+        Y = np.empty_like(X)
+        frq = lib().orc_lr_synchronize(self.n, self.alpha, _p(self.R_l), _p(X), _p(Y))
+        return float(frq), 0.0, Y
+
+
+def sync_freq_phase(X):
+    """Synchronizer_freq_phase_DVBS2_aib (row N4), stateless -> FRQ, PHS, Y"""
+    X = _f32(X).ravel()
+    Y, o = np.empty_like(X), np.empty(2, dtype=np.float32)
+    lib().orc_fp_synchronize(X.size // 2, _p(X), _p(Y), _p(o))
+    return float(o[0]), float(o[1]), Y
 
 
 class VariableDelay:

@@ -82,3 +82,41 @@ def test_reset_parameters_and_delay_changes(O, Rx):
     do, Yo = sf.synchronize(x)
     assert d[0] == do and np.array_equal(Y[0], Yo)
     rx.close()
+
+
+def _rot(O, pl_frame, f0, ph):
+    d = O.pl_scramble(pl_frame, scramble=False)
+    n = d.size // 2
+    c = (d[0::2] + 1j * d[1::2]) * np.exp(2j * np.pi * (f0 * np.arange(n) + ph))
+    x = np.empty(2 * n, np.float32)
+    x[0::2], x[1::2] = c.real, c.imag
+    return x
+
+
+@pytest.mark.parametrize("modcod", ["QPSK-S_8/9", "QPSK-N_8/9", "16APSK-S_8/9"])
+def test_fine_synchronizers_match_oracle(O, Rx, modcod):
+    """Synchronizer_freq_phase_DVBS2_aib and Synchronizer_Luise_Reggiannini_DVBS2_aib: estimates within 1e-6 absolute
+    (float sums in the reference's order; atan2f may differ by an ulp), rotated frames within 2e-4 (cos / sin of a phase
+    of up to a few hundred radians held in fp32)."""
+    F = 4
+    _, pl, _, _ = make_pl_frames(O, modcod, F, 10.0, seed=9)
+    n = pl.shape[1] // 2
+    x = np.stack([_rot(O, pl[f], 1e-4 * (f + 1), 0.1 * f) for f in range(F)])
+    rx = Rx(modcod, max_frames=F)
+    FRQ, PHS, Y = rx.sync_freq_phase_synchronize(x)
+    for f in range(F):
+        fo, po, Yo = O.sync_freq_phase(x[f])
+        assert abs(FRQ[f] - fo) <= 1e-6 and abs(PHS[f] - po) <= 1e-4
+        assert np.max(np.abs(Y[f] - Yo)) <= 4e-3        # a 1e-6 difference in frequency is 2 pi n 1e-6 rad at the frame's end
+    rx.sync_lr_set_alpha(0.7)
+    lr = O.SyncLR(n, alpha=0.7)
+    for call in range(2):                               # the damped autocorrelation is carried across calls
+        FRQ, PHS, Y = rx.sync_lr_synchronize(x)
+        for f in range(F):
+            fo, po, Yo = lr.synchronize(x[f])
+            assert abs(FRQ[f] - fo) <= 1e-6 and PHS[f] == 0.0
+            assert np.max(np.abs(Y[f] - Yo)) <= 4e-3
+    rx.sync_lr_reset(); lr.reset()
+    FRQ, _, _ = rx.sync_lr_synchronize(x[:1])
+    assert abs(FRQ[0] - lr.synchronize(x[0])[0]) <= 1e-6
+    rx.close()

@@ -80,3 +80,35 @@ def test_frame_sync_tail_is_not_averaged(O):
     cs_a, cp_a = a.synchronize1(x2)
     cs_b, cp_b = b.synchronize1(x2)
     assert np.array_equal(cs_a, cs_b) and n % 8 == 2
+
+
+def _rotated(O, pl_frame, f0, ph):
+    d = O.pl_scramble(pl_frame, scramble=False)          # the fine synchronizers run after Scrambler_PL::descramble
+    n = d.size // 2
+    c = (d[0::2] + 1j * d[1::2]) * np.exp(2j * np.pi * (f0 * np.arange(n) + ph))
+    x = np.empty(2 * n, np.float32)
+    x[0::2], x[1::2] = c.real, c.imag
+    return d, x
+
+
+def test_fine_frequency_and_phase_synchronizers(O):
+    modcod = "QPSK-S_8/9"
+    _, pl, _, _ = make_pl_frames(O, modcod, 3, 14.0, seed=8)
+    n = pl.shape[1] // 2
+    assert list(O.sff_pilots(n)) == [1530, 3006, 4482, 5958, 7434]      # 90 + 16 slots, then every 16 slots + 36
+    f0, ph = 1.5e-4, -0.2
+    d, x = _rotated(O, pl[0], f0, ph)
+    frq, phs, Y = O.sync_freq_phase(x)
+    # Synchronizer_freq_phase_DVBS2_aib: least-squares line through the unwrapped pilot phases
+    assert abs(frq - f0) < 2e-5 and abs((phs - ph + 0.5) % 1.0 - 0.5) < 0.02
+    err = np.abs((Y[0::2] + 1j * Y[1::2]) - (d[0::2] + 1j * d[1::2]))[90:]
+    assert err.max() < 0.2
+    # Luise & Reggiannini: noisy on one frame, the damping pulls it in over frames; PHS stays 0
+    lr = O.SyncLR(n, alpha=0.9)
+    est = []
+    for k in range(30):
+        _, xk = _rotated(O, pl[k % 3], f0, 0.0)
+        est.append(lr.synchronize(xk)[0])
+    assert abs(np.mean(est[-10:]) - f0) < 1.5e-4
+    lr.reset()
+    assert np.all(lr.R_l == 0)
