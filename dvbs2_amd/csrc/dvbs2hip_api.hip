@@ -263,7 +263,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
     }
     lp.grid_max = ldpc_blocks_per_cu(lp) * h->n_cus;
     if (const char *ev = getenv("DVBS2HIP_LDPC_GRID_MAX")) { const int g = atoi(ev); if (g >= 1 && g < lp.grid_max) lp.grid_max = g; }   // scaling experiments
-    if (lp.gwork_words > 0) CREATE_HIP(hipMalloc((void **)&h->d_gwork, (size_t)lp.grid_max * (lp.fast ? lp.fast_nf * lp.fast_wf : 1) * lp.gwork_words * sizeof(float)));
+    if (lp.gwork_words > 0) CREATE_HIP(hipMalloc((void **)&h->d_gwork, (size_t)lp.grid_max * (lp.fast ? lp.fast_wf : 1) * lp.gwork_words * sizeof(float)));
 
     // ---- BCH
     e = bch_build_plan(h->bch, cfg->bch_m, cfg->bch_prim, cfg->bch_t, cfg->K_ldpc, cfg->K_bch);
@@ -399,10 +399,9 @@ const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
         const LdpcPlan &pl = h->ldpc;
         char buf[96];
         if (!pl.fast) snprintf(buf, sizeof buf, "ldpc_layered_nms_kernel<%d,%s,%s>", pl.ent_stride, pl.hybrid ? "true" : "false", pl.c2v_lds ? "true" : "false");
-        else if (pl.spa) snprintf(buf, sizeof buf, "ldpc_fast2_kernel<%d,%d,false,true>", pl.fast_deg, pl.fast_mode);
+        else if (pl.spa) snprintf(buf, sizeof buf, "ldpc_fast2_kernel<%d,%d,true>", pl.fast_deg, pl.fast_mode);
         else if (pl.fast_wg8) snprintf(buf, sizeof buf, "ldpc_wg8_kernel<%d,%d>", pl.fast_deg, pl.fast_mode);
-        else if (pl.fast_wf == 2) snprintf(buf, sizeof buf, "ldpc_fast2_kernel<%d,%d,%s,false>", pl.fast_deg, pl.fast_mode, pl.fast_pipe ? "true" : "false");
-        else snprintf(buf, sizeof buf, "ldpc_fast_kernel<%d,%d,%d>", pl.fast_deg, pl.fast_mode, pl.fast_nf);
+        else snprintf(buf, sizeof buf, "ldpc_fast2_kernel<%d,%d,false>", pl.fast_deg, pl.fast_mode);
         const_cast<dvbs2hip_t *>(h)->ldpc_name = buf;
     }
     return h->ldpc_name.c_str();

@@ -48,7 +48,6 @@ struct LdpcKParams {
     int32_t n_frames, n_ite, early_stop;
     float alpha;
     int32_t inf_row;           // fast path: byte offset of the +inf row (padded layers) or -1
-    int32_t pipe;              // fast path: software-pipelined layers (table sorted early-first, T[29] = n_early)
     const uint32_t *fast_tab;  // regular-code fast path: [q][LDPC_FAST_STRIDE] (see k_ldpc_fast.hip)
     uint32_t *cu_ctr;          // 8-wave workgroups: per-CU arrival counter (zeroed before the launch) or null
     struct {                   // k_ldpc_wg8.hip
@@ -82,10 +81,8 @@ struct LdpcPlan {             // host-side description, built once per handle
     int fast_deg = 0;             // slots per layer in the unrolled kernel (11, 13 or 27)
     bool fast_pad = false;        // layers padded with NULL slots (irregular code)
     int fast_inf_row = -1;        // byte offset of the +inf row the NULL slots read, or -1
-    int fast_mode = 0;            // 0: all posteriors in LDS, 1: all in the global workspace
-    int fast_nf = 1;              // frames per LANE (2 only in global mode; measured slower, opt-in)
-    bool fast_pipe = false;       // software-pipelined iteration: bit-exact but measured SLOWER (opt-in: DVBS2HIP_LDPC_PIPE=1)
-    int fast_wf = 1;              // frames per WORKGROUP: 2 = 12-wave workgroups, one frame per half (balanced SIMDs)
+    int fast_mode = 0;            // posterior image -- 0: in LDS, 1: in the workgroup's global slot, 3: static hybrid (k_ldpc.hip plan)
+    int fast_wf = 1;              // workspace slots per workgroup: 2 for the 12-wave two-frame kernel (k_ldpc_fast.hip), 1 for k_ldpc_wg8.hip
     bool fast_wg8 = false;        // one frame per 8-wave workgroup, SIMD-aware roles, two independent workgroups per CU (k_ldpc_wg8.hip)
     bool w8_dups_in_lds = false;  // static hybrid: every bit-group with two edges in one layer is LDS-resident
     std::vector<uint32_t> w8_tab, w8_rows;

@@ -19,18 +19,18 @@
 //
 // This file holds (1) the host-side PLAN: layer tables, storage policy and the choice between the
 // kernels, and (2) the GENERIC table-driven kernel (per-slot flags, hybrid LDS/global image), which is
-// the fallback for codes the fast path (k_ldpc_fast.hip) rejects -- check degree above 27 or more than
-// 16 duplicate edges per layer -- and the subject of `DVBS2HIP_LDPC_PATH=generic` experiments.  Every
-// DVB-S2 code shipped here runs on the fast path.
+// the fallback for codes the fast kernels reject -- check degree above 27 or more than 16 duplicate
+// edges per layer -- and the subject of `DVBS2HIP_LDPC_PATH=generic` experiments.  Every DVB-S2 code
+// shipped here runs on k_ldpc_wg8.hip (NMS / MS) or k_ldpc_fast.hip (SPA).
 //
 // Schedule and arithmetic are restated in oracle/dvbs2_oracle.c (ORC_SCHED_QC) and the two
 // must agree bit for bit: tests/test_ldpc_gpu.py.
 //
 // Tuning / experiment knobs (environment, read when a handle is created):
 //   DVBS2HIP_LDPC_PATH=generic        force the generic kernel
-//   DVBS2HIP_LDPC_FAST_MODE=lds|global|static|hybrid   posterior image of the fast path (static = default for N = 64800)
-//   DVBS2HIP_LDPC_WF=1                6-wave one-frame workgroups instead of 12-wave two-frame ones
-//   DVBS2HIP_LDPC_NF=2, DVBS2HIP_LDPC_PIPE=1    two frames per lane / software-pipelined layers (slower)
+//   DVBS2HIP_LDPC_WG=12               the two-frames-per-12-wave-workgroup NMS kernel of k_ldpc_fast.hip instead of k_ldpc_wg8.hip
+//   DVBS2HIP_LDPC_FAST_MODE=lds|global|static   posterior image of the fast kernels (default: lds for N = 16200, static hybrid for N = 64800)
+//   DVBS2HIP_LDPC_LOCK_DUPS=0         static hybrid without forcing the duplicate-edge bit-groups into LDS (then the 12-wave kernel runs)
 //   DVBS2HIP_LDPC_C2V=lds|global, DVBS2HIP_LDPC_LDS_GROUPS=n   generic kernel storage policy
 //   DVBS2HIP_LDPC_BLOCKS_PER_CU, DVBS2HIP_LDPC_GRID_MAX, DVBS2HIP_LDS_LIMIT   occupancy / scaling experiments
 #include "dvbs2hip_internal.h"
@@ -136,27 +136,12 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             pl.fast_deg = (uniform && pl.deg_max == 11) ? 11 : (uniform && pl.deg_max == 27) ? 27 : pl.deg_max <= 13 ? 13 : 27;
             pl.fast_pad = !(uniform && pl.deg_max == pl.fast_deg);
             const int xrows = pl.fast_pad ? 1 : 0;        // the +inf row
+            // posterior image: LDS when a CU holds two frames of it (N = 16200), else the workgroup's global slot,
+            // upgraded below to the static hybrid where the code allows.  DVBS2HIP_LDPC_FAST_MODE=lds|global|static forces one.
             const char *env_mode = getenv("DVBS2HIP_LDPC_FAST_MODE");
-            // short frames: the whole posterior image (N fp32 + one dummy row) fits LDS twice per CU
             pl.fast_mode = ((size_t)(pl.n_groups + 1 + xrows) * grp_bytes * 2 <= lds_limit + 1024) ? 0 : 1;
-            if (env_mode) pl.fast_mode = !strcmp(env_mode, "lds") ? 0 : 1;
-            if (pl.fast_mode == 0 && (size_t)(pl.n_groups + 1 + xrows) * grp_bytes > lds_limit) pl.fast_mode = 1;
-            const char *env_nf = getenv("DVBS2HIP_LDPC_NF");
-            pl.fast_nf = 1;      // two frames per lane (DVBS2HIP_LDPC_NF=2) measured slower: 235 VGPRs halve the occupancy
-            if (env_nf && pl.fast_mode == 1 && !spa) pl.fast_nf = atoi(env_nf) == 2 ? 2 : 1;
-            // mode 2 (hybrid, opt-in: DVBS2HIP_LDPC_FAST_MODE=hybrid): the most-touched bit-groups in LDS
-            // (+ a zero row and a junk row), the rest compactly in the workspace.  Measured SLOWER than the
-            // all-global image on MI355X (20.9 vs 12.6 ms / 4096 frames): the kernel is VALU-issue bound, not
-            // bandwidth bound, and the dual-issue costs instructions.
-            if (env_mode && !strcmp(env_mode, "hybrid") && !spa) pl.fast_mode = 2;
-            if (pl.fast_mode == 2) pl.fast_nf = 1;
-            {   // 12-wave workgroups (one frame per half) unless a variant that does not support them is forced
-                const char *env_wf = getenv("DVBS2HIP_LDPC_WF");
-                pl.fast_wf = (pl.fast_mode != 2 && pl.fast_nf == 1) ? 2 : 1;
-                if (env_wf && atoi(env_wf) == 1 && !spa) pl.fast_wf = 1;
-                if (spa) { pl.fast_nf = 1; pl.fast_wf = 2; }       // the SPA kernel exists in the two-frame-workgroup form only
-                if (pl.fast_wf == 2 && pl.fast_mode == 0 && 2 * (size_t)(pl.n_groups + 1 + xrows) * grp_bytes > lds_limit) pl.fast_wf = 1;
-            }
+            if (env_mode && strcmp(env_mode, "static")) pl.fast_mode = (!strcmp(env_mode, "lds") && pl.fast_mode == 0) ? 0 : 1;
+            pl.fast_wf = 2;      // k_ldpc_fast.hip: two frames per 12-wave workgroup
             std::vector<uint32_t> gbase(pl.n_groups), glds(pl.n_groups, 0u);
             int n_l = 0, n_g = 0;
             // mode 3 (STATIC hybrid, normal frames): pick the LDS-resident bit-groups so that EVERY layer has
@@ -165,9 +150,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             std::vector<char> in_lds(pl.n_groups, 0);
             {
                 const int NL = 9;
-                const char *ewf = getenv("DVBS2HIP_LDPC_WF"), *enf = getenv("DVBS2HIP_LDPC_NF");
-                const bool env_wf_is_1 = ewf && atoi(ewf) == 1, env_nf_is_2 = enf && atoi(enf) == 2;
-                const bool want = (env_mode && !strcmp(env_mode, "static")) || (!env_mode && pl.fast_mode == 1 && !env_wf_is_1 && !env_nf_is_2 && !pl.fast_pipe);
+                const bool want = (env_mode && !strcmp(env_mode, "static")) || (!env_mode && pl.fast_mode == 1);
                 if (want && !spa && pl.fast_deg == 27 && !pl.fast_pad) {
                     const int cap = (int)(lds_limit / 2 / grp_bytes) - 1;            // two frames per CU, one junk row each
                     std::vector<std::vector<int>> mult(pl.n_groups, std::vector<int>(q, 0));
@@ -218,22 +201,13 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                         if (ok && (c1 <= c0 || rnd() % 500 == 0)) c0 = c1;
                         else { if (ok && g_in >= 0) add(g_in, -1); if (g_out >= 0) add(g_out, +1); }
                     }
-                    if (c0 == 0) { pl.fast_mode = 3; pl.fast_nf = 1; pl.fast_wf = 2; pl.fast_pipe = false; }
+                    if (c0 == 0) pl.fast_mode = 3;
                     else { std::fill(in_lds.begin(), in_lds.end(), 0); pl.w8_dups_in_lds = false; }
                 }
             }
             if (pl.fast_mode == 3) {
                 for (int g = 0; g < pl.n_groups; g++) {
                     if (in_lds[g]) { gbase[g] = (uint32_t)(n_l++ * LDPC_Z); glds[g] = 1u; }
-                    else gbase[g] = (uint32_t)(n_g++ * LDPC_Z);
-                }
-            } else if (pl.fast_mode == 2) {
-                int cap = (int)(lds_limit / grp_bytes) - 2;
-                if (env_grp) cap = std::min(cap, std::max(0, atoi(env_grp)));
-                cap = std::min(cap, pl.n_groups);
-                for (int i = 0; i < pl.n_groups; i++) {
-                    const int g = order[i];
-                    if (i < cap) { gbase[g] = (uint32_t)(n_l++ * LDPC_Z); glds[g] = 1u; }
                     else gbase[g] = (uint32_t)(n_g++ * LDPC_Z);
                 }
             } else
@@ -244,9 +218,8 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             const uint32_t inf_row_words = (uint32_t)((pl.n_groups + (pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z);
             auto pack = [&](const Slot &sl) {
                 if (sl.group < 0) return (inf_row_words * 4u) << 11;
-                return (uint32_t)(sl.t0 * 4) | ((gbase[sl.group] * 4u) << 11) | (pl.fast_mode >= 2 && glds[sl.group] ? (1u << 29) : 0u);
+                return (uint32_t)(sl.t0 * 4) | ((gbase[sl.group] * 4u) << 11) | (pl.fast_mode == 3 && glds[sl.group] ? (1u << 29) : 0u);
             };
-            if (const char *ev = getenv("DVBS2HIP_LDPC_PIPE")) pl.fast_pipe = atoi(ev) != 0 && !spa;
             // k_ldpc_wg8.hip: same slot order, its own image layout -- LDS: [rows | junk | +inf]; global: [junk | +inf | rows]
             pl.w8_tab.assign((size_t)q * LDPC_FAST_STRIDE, 0u);
             const int w8_lrows = pl.fast_mode == 0 ? pl.n_groups : pl.fast_mode == 3 ? n_l : 0;
@@ -319,20 +292,18 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + 3 * M;
             }
             // workspace of one workgroup: [posteriors kept in global memory | packed c->v state 3 M words]
-            pl.glb_post_words = pl.fast_mode == 1 ? (pl.n_groups + xrows) * LDPC_Z : pl.fast_mode >= 2 ? n_g * LDPC_Z : 0;
-            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1 + xrows) * LDPC_Z : pl.fast_mode == 2 ? (n_l + 2) * LDPC_Z
-                              : pl.fast_mode == 3 ? (n_l + 1) * LDPC_Z : 0;
+            pl.glb_post_words = pl.fast_mode == 1 ? (pl.n_groups + xrows) * LDPC_Z : pl.fast_mode == 3 ? n_g * LDPC_Z : 0;
+            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1 + xrows) * LDPC_Z : pl.fast_mode == 3 ? (n_l + 1) * LDPC_Z : 0;
             pl.fast_inf_row = pl.fast_pad ? (int)(inf_row_words * 4u) : -1;
-            if (pl.fast_pad && pl.fast_mode == 2) return "LDPC: hybrid mode does not support padded layers";
             pl.gwork_words = pl.glb_post_words + (spa ? pl.fast_deg * M : 3 * M);      // SPA: one fp32 message per edge slot
             pl.lds_bytes = (size_t)pl.lds_post_words * 4;
-            pl.hybrid = pl.fast_mode >= 2; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : n_l;
+            pl.hybrid = pl.fast_mode == 3; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : n_l;
             // production shape: one frame per 8-wave workgroup, two independent workgroups per CU (k_ldpc_fast.hip);
             // DVBS2HIP_LDPC_WG=12 keeps the two-frames-per-12-wave-workgroup kernel
             {
                 const char *env_wg = getenv("DVBS2HIP_LDPC_WG");
                 const bool w8_ok = pl.fast_mode == 0 || pl.fast_mode == 1 || (pl.fast_mode == 3 && pl.w8_dups_in_lds);
-                if (!spa && pl.fast_wf == 2 && pl.fast_nf == 1 && !pl.fast_pipe && w8_ok && (size_t)pl.w8_lds_bytes <= lds_limit + 512 &&
+                if (!spa && w8_ok && (size_t)pl.w8_lds_bytes <= lds_limit + 512 &&
                     !(env_wg && atoi(env_wg) == 12)) {
                     pl.fast_wg8 = true; pl.fast_wf = 1; pl.gwork_words = pl.w8_gwork_words;
                 }
