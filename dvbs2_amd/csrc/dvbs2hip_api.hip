@@ -70,6 +70,8 @@ struct dvbs2hip_handle {
         int xh_cur = 0, sofh_cur = 0, od_cur = 0;
     } sfm;
     // L&R fine frequency synchronizer (N4): damped autocorrelation R_l, alpha (factory default 0.999)
+    int ldpc_sched = DVBS2HIP_SCHED_QC;
+    float *d_nat_work = nullptr;       // natural-order LDPC: frame-interleaved image + state, ceil(max_frames / 64) groups
     float *d_lr_R = nullptr;
     float lr_alpha = 0.999f;
     // timing
@@ -381,7 +383,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
         for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
-                        h->sfm.yprev, h->sfm.metric, h->d_lr_R};
+                        h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
@@ -392,10 +394,21 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
 
 const char *dvbs2hip_last_error(const dvbs2hip_t *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+int dvbs2hip_set_ldpc_schedule(dvbs2hip_t *h, int32_t schedule)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    if (schedule != DVBS2HIP_SCHED_QC && schedule != DVBS2HIP_SCHED_NATURAL) return fail(h, DVBS2HIP_EINVAL, "unknown LDPC schedule");
+    if (schedule == DVBS2HIP_SCHED_NATURAL && (!h->ldpc.fast || h->ldpc.spa))
+        return fail(h, DVBS2HIP_EUNSUPPORTED, "the natural-order schedule is implemented for NMS / MS on codes with check degree <= 27");
+    h->ldpc_sched = schedule;
+    return 0;
+}
+
 const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
 {
     if (!h) return "";
-    if (h->ldpc_name.empty()) {
+    if (h->ldpc_sched == DVBS2HIP_SCHED_NATURAL) { const_cast<dvbs2hip_t *>(h)->ldpc_name = "ldpc_nat_kernel<" + std::to_string(h->ldpc.fast_deg) + ">"; return h->ldpc_name.c_str(); }
+    {
         const LdpcPlan &pl = h->ldpc;
         char buf[96];
         if (!pl.fast) snprintf(buf, sizeof buf, "ldpc_layered_nms_kernel<%d,%s,%s>", pl.ent_stride, pl.hybrid ? "true" : "false", pl.c2v_lds ? "true" : "false");
@@ -448,6 +461,18 @@ static int ldpc_dev(dvbs2hip_t *h, const float *Y, int8_t *CWD, int32_t *V, uint
     memset(&p, 0, sizeof p);
     p.llr = Y; p.bits = V; p.packed = packed; p.cwd = CWD; p.post = post; p.ites = ites; p.gwork = h->d_gwork;
     p.n_frames = F; p.n_ite = h->n_ite; p.early_stop = h->early_stop; p.alpha = h->alpha;
+    if (h->ldpc_sched == DVBS2HIP_SCHED_NATURAL) {
+        LdpcPlan &pl = h->ldpc;
+        if (!h->d_nat_work) {
+            const size_t groups = ((size_t)h->max_frames + 63) / 64;
+            if (hipMalloc((void **)&h->d_nat_work, groups * ldpc_nat_group_words(pl) * sizeof(float)) != hipSuccess)
+                return fail(h, DVBS2HIP_ENOMEM, "natural-order LDPC: workspace of " + std::to_string(groups * ldpc_nat_group_words(pl) * 4) + " bytes does not fit");
+            if (upload(h, &pl.d_nat_tab, pl.nat_tab.data(), pl.nat_tab.size()) || upload(h, &pl.d_nat_haz, pl.nat_haz.data(), pl.nat_haz.size())) return DVBS2HIP_EHIP;
+        }
+        Timer tm(h, DVBS2HIP_K_LDPC);
+        HIPCHK(h, ldpc_nat_launch(pl, p, h->d_nat_work, h->stream));
+        return 0;
+    }
     Timer tm(h, DVBS2HIP_K_LDPC);
     HIPCHK(h, ldpc_launch(h->ldpc, p, h->stream));
     return 0;

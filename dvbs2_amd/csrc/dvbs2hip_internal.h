@@ -83,6 +83,8 @@ struct LdpcPlan {             // host-side description, built once per handle
     int fast_inf_row = -1;        // byte offset of the +inf row the NULL slots read, or -1
     int fast_mode = 0;            // posterior image -- 0: in LDS, 1: in the workgroup's global slot, 3: static hybrid (k_ldpc.hip plan)
     int fast_wf = 1;              // workspace slots per workgroup: 2 for the 12-wave two-frame kernel (k_ldpc_fast.hip), 1 for k_ldpc_wg8.hip
+    std::vector<uint32_t> nat_tab, nat_haz;   // k_ldpc_nat.hip: natural-row-order tables
+    uint32_t *d_nat_tab = nullptr, *d_nat_haz = nullptr;
     bool fast_wg8 = false;        // one frame per 8-wave workgroup, SIMD-aware roles, two independent workgroups per CU (k_ldpc_wg8.hip)
     bool w8_dups_in_lds = false;  // static hybrid: every bit-group with two edges in one layer is LDS-resident
     std::vector<uint32_t> w8_tab, w8_rows;
@@ -99,6 +101,8 @@ constexpr int LDPC_FAST_STRIDE = 64;   // dwords per layer: 27 entries | prim ma
 constexpr int LDPC_FAST_MAXC = 16;
 hipError_t ldpc_fast_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
 int ldpc_fast_blocks_per_cu(const LdpcPlan &pl);
+hipError_t ldpc_nat_launch(const LdpcPlan &pl, const LdpcKParams &kp, float *work, hipStream_t s);
+size_t ldpc_nat_group_words(const LdpcPlan &pl);
 hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
 int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl);
 

@@ -298,6 +298,44 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             pl.gwork_words = pl.glb_post_words + (spa ? pl.fast_deg * M : 3 * M);      // SPA: one fp32 message per edge slot
             pl.lds_bytes = (size_t)pl.lds_post_words * 4;
             pl.hybrid = pl.fast_mode == 3; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : n_l;
+            {   // k_ldpc_nat.hip (natural row order, one lane per frame): per layer the info slots (NULL-padded), then p_c, then p_{c-1}
+                pl.nat_tab.assign((size_t)q * pl.fast_deg * 2, 0u);
+                for (int r = 0; r < q; r++) {
+                    uint32_t *T = &pl.nat_tab[(size_t)r * pl.fast_deg * 2];
+                    const std::vector<Slot> &ls = layers[r];           // table order: info edges, p_c, p_{c-1}
+                    const int n_real = (int)ls.size(), n_null = pl.fast_deg - n_real;
+                    int j = 0;
+                    auto put = [&](const Slot &sl) {
+                        const bool par = sl.group >= pl.n_info;
+                        T[2 * j] = (uint32_t)sl.t0 | (par ? 1u << 16 : 0u);
+                        T[2 * j + 1] = par ? (uint32_t)(K + (sl.group - pl.n_info)) : (uint32_t)(sl.group * LDPC_Z);
+                        j++;
+                    };
+                    for (int i = 0; i < n_real - 2; i++) put(ls[i]);
+                    for (int i = 0; i < n_null; i++) { T[2 * j] = 1u << 17; T[2 * j + 1] = 0u; j++; }
+                    put(ls[n_real - 2]); put(ls[n_real - 1]);
+                    if (ls[n_real - 2].group != pl.n_info + r || !(ls[n_real - 1].group >= pl.n_info)) return "LDPC: internal: parity slots are not last";
+                }
+                // consecutive checks (cyclically) that share a bit other than the forwarded p_{c-1}
+                pl.nat_haz.assign((size_t)(M + 31) / 32, 0u);
+                auto vars_of = [&](int c, std::vector<int> &out) {
+                    out.clear();
+                    const int r = c % q, t = c / q;
+                    for (const Slot &sl : layers[r]) {
+                        if (sl.mask0 && c == 0) continue;
+                        const int e = ((t - sl.t0) % LDPC_Z + LDPC_Z) % LDPC_Z;
+                        out.push_back(sl.group < pl.n_info ? sl.group * LDPC_Z + e : K + q * e + (sl.group - pl.n_info));
+                    }
+                };
+                std::vector<int> a, b;
+                for (int c = 0; c < M; c++) {
+                    vars_of(c, a); vars_of((c + M - 1) % M, b);
+                    const int fwd_bit = c > 0 ? K + c - 1 : -1;
+                    bool hz = false;
+                    for (int x : a) if (x != fwd_bit && std::find(b.begin(), b.end(), x) != b.end()) hz = true;
+                    if (hz) pl.nat_haz[c >> 5] |= 1u << (c & 31);
+                }
+            }
             // production shape: one frame per 8-wave workgroup, two independent workgroups per CU (k_ldpc_fast.hip);
             // DVBS2HIP_LDPC_WG=12 keeps the two-frames-per-12-wave-workgroup kernel
             {

@@ -42,6 +42,7 @@ class Sizes(C.Structure):
 
 # name -> (restype, argtypes).  Every symbol of include/dvbs2hip.h; tests/test_abi.py checks
 # the list against the header and against the built .so.
+SCHED_QC, SCHED_NATURAL = 0, 1
 _vp, _i, _f = C.c_void_p, C.c_int32, C.c_float
 _SOCK2 = [_vp, _vp, _vp, _i]
 ABI = {
@@ -50,6 +51,7 @@ ABI = {
     "dvbs2hip_destroy": (None, [_vp]),
     "dvbs2hip_last_error": (C.c_char_p, [_vp]),
     "dvbs2hip_ldpc_kernel_name": (C.c_char_p, [_vp]),
+    "dvbs2hip_set_ldpc_schedule": (C.c_int, [_vp, _i]),
     "dvbs2hip_reset": (C.c_int, [_vp]),
     "dvbs2hip_sync_lr_synchronize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_sync_lr_synchronize_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i]),

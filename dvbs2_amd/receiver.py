@@ -315,6 +315,10 @@ class Dvbs2Hip:
     def sync_freq_phase_synchronize(self, X_N1):
         return self._sff(self.L.dvbs2hip_sync_freq_phase_synchronize, X_N1)
 
+    def set_ldpc_schedule(self, schedule):
+        """B.SCHED_QC (default) or B.SCHED_NATURAL (the reference's row order, one lane per frame)"""
+        self._chk(self.L.dvbs2hip_set_ldpc_schedule(self.h, int(schedule)))
+
     def ldpc_kernel_name(self) -> str:
         return self.L.dvbs2hip_ldpc_kernel_name(self.h).decode()
 

@@ -44,6 +44,9 @@ typedef struct dvbs2hip_handle dvbs2hip_t;
 
 /* LDPC check-node rule (--dec-implem, DVBS2.cpp:117-149; the reference's default is SPA) */
 enum { DVBS2HIP_IMPLEM_NMS = 0, DVBS2HIP_IMPLEM_MS = 1, DVBS2HIP_IMPLEM_SPA = 2 };
+/* Order in which the layered decoder visits the checks of a frame (dvbs2hip_set_ldpc_schedule) */
+enum { DVBS2HIP_SCHED_QC = 0,        /* quasi-cyclic layers of 360 independent checks: the throughput path */
+       DVBS2HIP_SCHED_NATURAL = 1 }; /* natural row order of H, what AFF3CT's BP_HORIZONTAL_LAYERED runs: one lane per frame */
 /* Interleaver read order (DVBS2.cpp:300-317) */
 enum { DVBS2HIP_ITL_TOP_LEFT = 0, DVBS2HIP_ITL_TOP_RIGHT = 1 };
 
@@ -103,6 +106,11 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out);
 void dvbs2hip_destroy(dvbs2hip_t *h);
 /* text of the last error on this handle (or of the last failed create when h == NULL) */
 const char *dvbs2hip_last_error(const dvbs2hip_t *h);
+/* selects the check order of ldpc_decode_siho / rx_bb on this handle (default DVBS2HIP_SCHED_QC).  NATURAL reproduces the
+ * reference's horizontal-layered sweep (checks 0 .. M-1 in row order) exactly as the oracle's ORC_SCHED_NATURAL does; it
+ * keeps 4 (N + 3 M) bytes of state per frame in HBM (22 MB per 64 normal frames, allocated on first use for max_frames)
+ * and only pays off on batches of tens of thousands of frames.  NMS / MS only: DVBS2HIP_EUNSUPPORTED otherwise. */
+int dvbs2hip_set_ldpc_schedule(dvbs2hip_t *h, int32_t schedule);
 /* name of the LDPC kernel instantiation the plan selected for this MODCOD (diagnostics, bench.py's roofline line) */
 const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h);
 /* Interface_reset: clears the filter state and the monitor counters */

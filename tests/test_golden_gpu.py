@@ -22,6 +22,12 @@ def test_ldpc_golden(Rx):
     assert np.array_equal(np.packbits(V.astype(np.uint8), axis=1), k["bits_qc"])
     assert np.array_equal(CWD, k["cwd_qc"])
     assert np.max(np.abs(post - k["post_qc"])) <= 1e-4 and np.array_equal(post, k["post_qc"])
+    # the reference's natural row order (dvbs2hip_set_ldpc_schedule): the fixture holds the oracle's NATURAL results too
+    from dvbs2_amd import lib_binding as B
+    rx.set_ldpc_schedule(B.SCHED_NATURAL)
+    V, CWD, post, _ = rx.decode_siho(k["llr"], with_post=True)
+    assert np.array_equal(np.packbits(V.astype(np.uint8), axis=1), k["bits_nat"]) and np.array_equal(CWD, k["cwd_nat"])
+    assert np.array_equal(post, k["post_nat"])
     rx.close()
 
 

@@ -174,3 +174,47 @@ def test_ldpc_spa_matches_oracle(O, Rx, modcod, ebn0):
     assert np.array_equal(V[conv], Vo[conv]) and np.all(np.abs(ites[conv] - iteso[conv]) <= 1)
     assert np.array_equal(V[conv], cw[conv][:, :ch.mc.K_ldpc])
     rx.close()
+
+
+NAT_CASES = [("QPSK-S_8/9", 4.4, 5), ("QPSK-S_8/9", 3.2, 70), ("QPSK-S_3/5", 1.2, 3), ("32APSK-S_3/4", 3.4, 4), ("QPSK-N_8/9", 3.6, 2)]
+
+
+@pytest.mark.parametrize("modcod,ebn0,F", NAT_CASES)
+@pytest.mark.parametrize("early", [False, True])
+def test_ldpc_natural_order_matches_oracle(O, Rx, modcod, ebn0, F, early):
+    """dvbs2hip_set_ldpc_schedule(NATURAL): the reference's sweep order (checks in row order, one lane per frame)
+    against the oracle's ORC_SCHED_NATURAL -- hard decisions, iteration counts and posteriors bit for bit; more
+    than 64 frames = more than one wave, a ragged last group."""
+    from dvbs2_amd import lib_binding as B
+    ch = chain(O, modcod)
+    _, llr, cw = make_llrs(O, modcod, F, ebn0, seed=21)
+    rx = Rx(modcod, max_frames=F, n_ite=8, alpha=0.875, early_stop=early)
+    rx.set_ldpc_schedule(B.SCHED_NATURAL)
+    assert rx.ldpc_kernel_name().startswith("ldpc_nat_kernel")
+    V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+    Vo, posto, cwdo, iteso = ch.ldpc.decode(llr, n_ite=8, alpha=0.875, sched=O.NATURAL, early_stop=early)
+    assert np.array_equal(V, Vo), "hard decisions differ: %d bits" % int((V != Vo).sum())
+    assert np.array_equal(CWD, cwdo) and np.array_equal(ites, iteso)
+    assert np.array_equal(post, posto), "posteriors are expected to be bit-identical (max diff %g)" % float(np.max(np.abs(post - posto)))
+    # and back: the same handle on the QC schedule
+    rx.set_ldpc_schedule(B.SCHED_QC)
+    V2, _, _, _ = rx.decode_siho(llr, with_post=True)
+    Vq, _, _, _ = ch.ldpc.decode(llr, n_ite=8, alpha=0.875, sched=O.QC, early_stop=early)
+    assert np.array_equal(V2, Vq)
+    rx.close()
+
+
+def test_natural_order_in_the_fused_chain(O, Rx):
+    from dvbs2_amd import lib_binding as B
+    from helpers import make_pl_frames
+    modcod = "16APSK-S_8/9"
+    info, pl, _, sigma = make_pl_frames(O, modcod, 3, 8.6, seed=22)
+    rx = Rx(modcod, max_frames=3, n_ite=10, alpha=1.0, early_stop=True)
+    rx.set_ldpc_schedule(B.SCHED_NATURAL)
+    out, c0, c1 = rx.rx_bb(pl, sigma=np.float32(sigma))
+    ch = chain(O, modcod)
+    for f in range(3):
+        r = ch.rx(pl[f], sigma=np.float32(sigma), n_ite=10, alpha=1.0, sched=O.NATURAL, early_stop=True)
+        assert np.array_equal(out[f], r["info"])
+    assert np.array_equal(out, info)
+    rx.close()
