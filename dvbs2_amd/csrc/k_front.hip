@@ -16,6 +16,7 @@
 // arithmetic folded into the load and the store, and the only HBM write is the LLR frame the
 // LDPC kernel consumes.
 #include "dvbs2hip_internal.h"
+#include <cstdlib>
 
 namespace dvbs2 {
 
@@ -161,6 +162,85 @@ front_kernel(const FrontKParams p)
     }
 }
 
+// ---- the fused front end for QPSK / 8PSK with the frame held in REGISTERS between its two sweeps: 1024 lanes per frame,
+// SPT symbols per lane, so the PL frame crosses the fabric once (the moments of a6 need the whole frame before the
+// first LLR of a3 can be formed; the two-sweep kernel above re-reads it from L2 / Infinity Cache), the loads of a lane
+// are all in flight together, and QPSK LLR pairs leave as one 8-byte store per lane.
+constexpr int FRONT_WIDE = 1024;
+typedef float front_f2 __attribute__((ext_vector_type(2)));      // a type the non-temporal builtins accept
+template <int BPS, int SPT>
+__global__ void __launch_bounds__(FRONT_WIDE)
+front_reg_kernel(const FrontKParams p)
+{
+    __shared__ float cs[2 * (1 << BPS)];
+    __shared__ float red[2][FRONT_WIDE / 64];
+    const int tid = threadIdx.x, f = blockIdx.x;
+    if (tid < 2 * (1 << BPS)) cs[tid] = p.cstl[tid];
+    const int n_sym = p.n_sym, n_pil = n_sym / (PL_SLOTS * PL_M);
+    const float2 *in = reinterpret_cast<const float2 *>(p.in + (size_t)f * 2 * (size_t)p.pl_frame);
+    float2 y[SPT];
+    // 32-bit offsets through buffer descriptors (a 64-bit address per load in flight would not fit the register budget);
+    // an offset past the frame returns zero, which is what the padding lanes have to hold
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(in), 0, 8 * p.pl_frame, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.pl_seq), 0, p.pl_frame, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+        const int k = tid + i * FRONT_WIDE;
+        const int pi = k < n_sym ? pl_index(k, n_pil) : p.pl_frame;
+        const front_f2 v = __builtin_bit_cast(front_f2, __builtin_amdgcn_raw_buffer_load_b64(rin, 8 * pi, 0, 2));      // nt: read once
+        y[i] = make_float2(v.x, v.y);
+    }
+    float sigma;
+    if (p.sigma_in == nullptr) {
+        float m2 = 0.f, m4 = 0.f;                  // |y| is invariant under the PL derotation; padding lanes hold zeros
+#pragma unroll
+        for (int i = 0; i < SPT; i++) { const float e = y[i].x * y[i].x + y[i].y * y[i].y; m2 += e; m4 += e * e; }
+        for (int o = 32; o > 0; o >>= 1) { m2 += __shfl_xor(m2, o); m4 += __shfl_xor(m4, o); }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = m2; red[1][tid >> 6] = m4; }
+        __syncthreads();
+        m2 = 0.f; m4 = 0.f;
+        for (int i = 0; i < FRONT_WIDE / 64; i++) { m2 += red[0][i]; m4 += red[1][i]; }
+        float ebn0, esn0;
+        m2m4_finish(m2, m4, n_sym, p.code_rate, p.bps, sigma, ebn0, esn0);
+        if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = ebn0; p.est[3 * f + 2] = esn0; }
+    } else {
+        __syncthreads();                           // the constellation is in LDS
+        sigma = p.sigma_in[f];
+        if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = 0.f; p.est[3 * f + 2] = 0.f; }
+    }
+    const float inv2s2 = 1.0f / (2.0f * sigma * sigma);
+    float *llr = p.llr + (size_t)f * n_sym * BPS;
+    const int n_rows = (n_sym * BPS) / (p.itl_cols > 1 ? p.itl_cols : 1);
+    const bool pairs = BPS == 2 && p.itl_cols <= 1;
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+        const int k = tid + i * FRONT_WIDE;
+        asm volatile("" ::: "memory");             // one symbol at a time: nothing of the next one is hoisted into registers
+        if (k >= n_sym) continue;
+        float out[BPS];
+        const int R = (int)__builtin_amdgcn_raw_buffer_load_b8(rsq, pl_index(k, n_pil) - PL_M, 0, 0);      // L2-resident table
+        demap_symbol<BPS>(pl_derotate(y[i], R), inv2s2, cs, out);
+        if (pairs) { front_f2 v; v.x = out[0]; v.y = out[BPS - 1]; __builtin_nontemporal_store(v, reinterpret_cast<front_f2 *>(llr) + k); }
+        else {
+#pragma unroll
+            for (int b = 0; b < BPS; b++) llr[deitl_index(k, b, BPS, p.itl_cols, p.itl_order, n_rows)] = out[b];
+        }
+    }
+}
+
+static bool front_reg_try(const FrontKParams &p, hipStream_t s)
+{
+    if (getenv("DVBS2HIP_FRONT_TWO_SWEEP")) return false;
+    dim3 g(p.n_frames), b(FRONT_WIDE);
+    const bool small = p.n_sym <= 8 * FRONT_WIDE, big = p.n_sym <= 32 * FRONT_WIDE;
+    if (p.bps == 2 && small) hipLaunchKernelGGL((front_reg_kernel<2, 8>), g, b, 0, s, p);
+    else if (p.bps == 2 && big) hipLaunchKernelGGL((front_reg_kernel<2, 32>), g, b, 0, s, p);
+    else if (p.bps == 3 && small) hipLaunchKernelGGL((front_reg_kernel<3, 8>), g, b, 0, s, p);
+    else if (p.bps == 3 && big) hipLaunchKernelGGL((front_reg_kernel<3, 32>), g, b, 0, s, p);
+    else return false;
+    return true;
+}
+
 template <bool FROM_PL, bool DEITL>
 static hipError_t front_dispatch(const FrontKParams &p, hipStream_t s)
 {
@@ -176,7 +256,11 @@ static hipError_t front_dispatch(const FrontKParams &p, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t front_rx_launch(FrontKParams p, hipStream_t s) { return front_dispatch<true, true>(p, s); }
+hipError_t front_rx_launch(FrontKParams p, hipStream_t s)
+{
+    if (front_reg_try(p, s)) return hipGetLastError();
+    return front_dispatch<true, true>(p, s);
+}
 hipError_t demod_launch(FrontKParams p, bool deinterleave, hipStream_t s)
 {
     return deinterleave ? front_dispatch<false, true>(p, s) : front_dispatch<false, false>(p, s);
