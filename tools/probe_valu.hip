@@ -13,7 +13,7 @@ template <int OP>
 __global__ void __launch_bounds__(1024) probe(unsigned long long *out, int iters, float seed)
 {
     float a = seed + threadIdx.x, b = seed * 2.f, c = seed * 3.f, d = 0.5f;
-    unsigned u = threadIdx.x, v = 7u;
+    unsigned u = OP >= 20 ? __builtin_amdgcn_readfirstlane(threadIdx.x) : threadIdx.x, v = 7u;
     unsigned long long m = 0x5555555555555555ull;
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -38,6 +38,11 @@ __global__ void __launch_bounds__(1024) probe(unsigned long long *out, int iters
         if (OP == 17) asm volatile(REP64("v_bfe_i32 %0, %1, 3, 1\n") : "+v"(u) : "v"(v));
         if (OP == 18) asm volatile(REP64("v_addc_co_u32 %0, vcc, %1, %2, vcc\n") : "+v"(u) : "v"(v), "v"(v) : "vcc");
         if (OP == 19) asm volatile(REP64("v_max_f32 %0, %1, %2\n") : "+v"(a) : "v"(b), "v"(c));
+        if (OP == 20) asm volatile(REP64("s_bfe_u32 %0, %1, 0x12000b\n") : "+s"(v) : "s"(u) : "scc");
+        if (OP == 21) asm volatile(REP64("s_and_b32 %0, %1, 0x7ff\n") : "+s"(v) : "s"(u) : "scc");
+        if (OP == 22) asm volatile(REP64("s_nop 0\n"));
+        if (OP == 23) asm volatile(REP64("s_cselect_b32 %0, %1, %0\n") : "+s"(v) : "s"(u) : "scc");
+        if (OP == 24) asm volatile(REP8(REP8("v_add_f32 %0, %2, %3\n s_and_b32 %1, %1, 0x7ff\n")) : "+v"(a), "+s"(v) : "v"(b), "v"(c) : "scc");
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
@@ -70,5 +75,7 @@ int main()
     run<13>("v_cmp_eq_u32 -> sgpr"); run<7>("v_alignbit_b32"); run<8>("v_and_or_b32 (sgpr)"); run<9>("v_bitop3_b32 (sgpr)");
     run<10>("v_lshlrev_b32"); run<11>("v_min_u32"); run<14>("v_subrev_u32 (sgpr)"); run<15>("v_add_u32 literal"); run<16>("v_xor_b32");
     run<17>("v_bfe_i32"); run<18>("v_addc_co_u32");
+    printf("scalar unit (per instruction and SIMD as above; a CU-wide unit shows as a cost that does not fall with W):\n");
+    run<20>("s_bfe_u32"); run<21>("s_and_b32"); run<23>("s_cselect_b32"); run<22>("s_nop 0"); run<24>("v_add_f32 + s_and_b32 (pairs)");
     return 0;
 }
