@@ -176,14 +176,24 @@ static void chk_update_spa(const float *v2c, int d, float *out)
     for (int j = 0; j < d; j++) out[j] = boxplus(fw[j], bw[j]);
 }
 
-int orc_ldpc_decode(const orc_ldpc *c, const float *llr, int implem, int sched, int n_ite,
-                    float alpha, int early_stop, int32_t *bits_K, float *post, int8_t *cwd)
+/* work buffers of one decoder instance (a thread of the CPU baseline keeps its own across frames:
+ * allocating ~1 MB per frame from 256 threads at once serialises them in the allocator) */
+typedef struct { float *L, *msg, *v2c, *nw; } ldpc_ws;
+static void ldpc_ws_alloc(const orc_ldpc *c, ldpc_ws *w)
+{
+    w->L = (float *)malloc(sizeof(float) * c->N);
+    w->msg = (float *)malloc(sizeof(float) * c->E);
+    w->v2c = (float *)malloc(sizeof(float) * 360 * c->max_deg);
+    w->nw = (float *)malloc(sizeof(float) * 360 * c->max_deg);
+}
+static void ldpc_ws_free(ldpc_ws *w) { free(w->L); free(w->msg); free(w->v2c); free(w->nw); }
+
+static int ldpc_decode_ws(const orc_ldpc *c, const float *llr, int implem, int sched, int n_ite,
+                          float alpha, int early_stop, int32_t *bits_K, float *post, int8_t *cwd, ldpc_ws *ws)
 {
     const int N = c->N, M = c->M, q = c->q;
-    float *L = (float *)malloc(sizeof(float) * N);
-    float *msg = (float *)calloc(c->E, sizeof(float));      /* c->v, zero-initialised */
-    float *v2c = (float *)malloc(sizeof(float) * 360 * c->max_deg);
-    float *nw  = (float *)malloc(sizeof(float) * 360 * c->max_deg);
+    float *L = ws->L, *msg = ws->msg, *v2c = ws->v2c, *nw = ws->nw;
+    memset(msg, 0, sizeof(float) * c->E);                   /* c->v, zero-initialised */
     memcpy(L, llr, sizeof(float) * N);
     int ite = 0;
     int max_lvl = 0;
@@ -235,7 +245,16 @@ int orc_ldpc_decode(const orc_ldpc *c, const float *llr, int implem, int sched, 
     if (cwd) *cwd = (int8_t)soft_syndrome_ok(c, L);
     if (bits_K) for (int i = 0; i < c->K; i++) bits_K[i] = L[i] < 0.0f;
     if (post) memcpy(post, L, sizeof(float) * N);
-    free(L); free(msg); free(v2c); free(nw);
+    return ite;
+}
+
+int orc_ldpc_decode(const orc_ldpc *c, const float *llr, int implem, int sched, int n_ite,
+                    float alpha, int early_stop, int32_t *bits_K, float *post, int8_t *cwd)
+{
+    ldpc_ws ws;
+    ldpc_ws_alloc(c, &ws);
+    const int ite = ldpc_decode_ws(c, llr, implem, sched, n_ite, alpha, early_stop, bits_K, post, cwd, &ws);
+    ldpc_ws_free(&ws);
     return ite;
 }
 
@@ -245,11 +264,19 @@ double orc_ldpc_decode_batch(const orc_ldpc *c, const float *llr, int F, int sch
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+#pragma omp parallel num_threads(threads)
 #endif
-    for (int f = 0; f < F; f++)
-        orc_ldpc_decode(c, llr + (size_t)f * c->N, ORC_NMS, sched, n_ite, alpha, 0,
-                        bits ? bits + (size_t)f * c->K : NULL, NULL, NULL);
+    {
+        ldpc_ws ws;
+        ldpc_ws_alloc(c, &ws);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int f = 0; f < F; f++)
+            ldpc_decode_ws(c, llr + (size_t)f * c->N, ORC_NMS, sched, n_ite, alpha, 0,
+                           bits ? bits + (size_t)f * c->K : NULL, NULL, NULL, &ws);
+        ldpc_ws_free(&ws);
+    }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     (void)threads;
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
@@ -261,12 +288,19 @@ double orc_ldpc_decode_batch(const orc_ldpc *c, const float *llr, int F, int sch
  * `omp simd` loops to AVX2 / AVX-512).  Natural row order, NMS, fixed n_ite.  Same arithmetic as
  * orc_ldpc_decode(.., ORC_NMS, ORC_SCHED_NATURAL, ..): results are bit-identical (tests). */
 #define ORC_W 16
-static void decode_inter_block(const orc_ldpc *c, const float *llr, int nf, int n_ite, float alpha, int32_t *bits)
+typedef struct { float *L, *msg, *v2c; } inter_ws;       /* one per thread, reused across blocks */
+static void inter_ws_alloc(const orc_ldpc *c, inter_ws *w)
 {
-    const int N = c->N, M = c->M, D = c->max_deg;
-    float *L = (float *)aligned_alloc(64, sizeof(float) * (size_t)N * ORC_W);
-    float *msg = (float *)aligned_alloc(64, sizeof(float) * (size_t)c->E * ORC_W);
-    float *v2c = (float *)aligned_alloc(64, sizeof(float) * (size_t)D * ORC_W);
+    w->L = (float *)aligned_alloc(64, sizeof(float) * (size_t)c->N * ORC_W);
+    w->msg = (float *)aligned_alloc(64, sizeof(float) * (size_t)c->E * ORC_W);
+    w->v2c = (float *)aligned_alloc(64, sizeof(float) * (size_t)c->max_deg * ORC_W);
+}
+static void inter_ws_free(inter_ws *w) { free(w->L); free(w->msg); free(w->v2c); }
+
+static void decode_inter_block(const orc_ldpc *c, const float *llr, int nf, int n_ite, float alpha, int32_t *bits, inter_ws *ws)
+{
+    const int N = c->N, M = c->M;
+    float *L = ws->L, *msg = ws->msg, *v2c = ws->v2c;
     memset(msg, 0, sizeof(float) * (size_t)c->E * ORC_W);
     for (int v = 0; v < N; v++)
         for (int w = 0; w < ORC_W; w++) L[(size_t)v * ORC_W + w] = w < nf ? llr[(size_t)w * N + v] : 1.0f;
@@ -312,7 +346,6 @@ static void decode_inter_block(const orc_ldpc *c, const float *llr, int nf, int 
     if (bits)
         for (int w = 0; w < nf; w++)
             for (int i = 0; i < c->K; i++) bits[(size_t)w * c->K + i] = L[(size_t)i * ORC_W + w] < 0.0f;
-    free(L); free(msg); free(v2c);
 }
 
 double orc_ldpc_decode_batch_inter(const orc_ldpc *c, const float *llr, int F, int n_ite, float alpha, int32_t *bits, int threads)
@@ -321,11 +354,19 @@ double orc_ldpc_decode_batch_inter(const orc_ldpc *c, const float *llr, int F, i
     clock_gettime(CLOCK_MONOTONIC, &t0);
     const int nb = (F + ORC_W - 1) / ORC_W;
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+#pragma omp parallel num_threads(threads)
 #endif
-    for (int blk = 0; blk < nb; blk++) {
-        const int f0 = blk * ORC_W, nf = F - f0 < ORC_W ? F - f0 : ORC_W;
-        decode_inter_block(c, llr + (size_t)f0 * c->N, nf, n_ite, alpha, bits ? bits + (size_t)f0 * c->K : NULL);
+    {
+        inter_ws ws;
+        inter_ws_alloc(c, &ws);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int blk = 0; blk < nb; blk++) {
+            const int f0 = blk * ORC_W, nf = F - f0 < ORC_W ? F - f0 : ORC_W;
+            decode_inter_block(c, llr + (size_t)f0 * c->N, nf, n_ite, alpha, bits ? bits + (size_t)f0 * c->K : NULL, &ws);
+        }
+        inter_ws_free(&ws);
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     (void)threads;
@@ -751,7 +792,8 @@ void orc_fp_synchronize(int n_cplx, const float *X, float *Y, float *out2)
     int ps[64];
     const int P = orc_sff_pilots(n_cplx, ps, 64), Lp = 36;
     const float inv_2PI = (float)(1.0f / (2 * M_PI));                               /* .cpp:50 */
-    float phase_est[64], y[64], t[64];
+    float phase_est[64] = {0}, y[64], t[64];
+    if (P < 1 || P > 64) { memcpy(Y, X, sizeof(float) * 2 * (size_t)n_cplx); out2[0] = out2[1] = 0.f; return; }   /* no pilot block: the reference would divide by zero */
     for (int p = 0; p < P; p++) {                                                   /* .cpp:53-67 */
         float s0 = 0.f, s1 = 0.f;
         for (int i = 0; i < Lp; i++) {
