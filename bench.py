@@ -191,23 +191,33 @@ def cpu_baseline(mc, llr, target_s):
     from dvbs2_amd import params as P
     rp, ad = P.load_ldpc_table(mc.ldpc_table)
     code = O.Ldpc(mc.N_ldpc, mc.K_ldpc, rp, ad)
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
     res = {}
-    for kind, fn, quantum in (("scalar", lambda x: code.decode_batch_timed(x, n_ite=N_ITE, alpha=1.0, sched=O.NATURAL, threads=cores), cores),
-                              ("inter16", lambda x: code.decode_batch_inter_timed(x, n_ite=N_ITE, alpha=1.0, threads=cores), 16 * cores)):
-        probe = llr[:min(llr.shape[0], quantum)].cpu().numpy()
-        _, sec = fn(probe)
-        per_round = max(sec, 1e-3)
-        rounds = int(max(1, min(64, 0.5 * target_s / per_round)))
-        n = min(llr.shape[0], probe.shape[0] * rounds)
-        _, sec = fn(llr[:n].cpu().numpy())
-        res[kind] = (n, sec)
+    for kind, quantum in (("scalar", 1), ("inter16", 16)):
+        def fn(x, thr):
+            if kind == "scalar":
+                return code.decode_batch_timed(x, n_ite=N_ITE, alpha=1.0, sched=O.NATURAL, threads=thr)
+            return code.decode_batch_inter_timed(x, n_ite=N_ITE, alpha=1.0, threads=thr)
+        # the box may give this job fewer cores than it shows (and SMT pairs share the 1 MB L2 a frame's 1.8 MB of
+        # state already overflows): probe a few thread counts on a small sample and keep the fastest
+        best_thr, best_rate = 1, 0.0
+        for thr in sorted({max(1, ncpu // 8), max(1, ncpu // 4), max(1, ncpu // 2), ncpu}):
+            n = min(llr.shape[0], quantum * thr * 4)
+            _, sec = fn(llr[:n].cpu().numpy(), thr)
+            if n / sec > best_rate:
+                best_thr, best_rate = thr, n / sec
+        n = int(min(llr.shape[0], max(quantum * best_thr, 0.5 * target_s * best_rate)))
+        x = llr[:n].cpu().numpy()
+        rounds = int(max(1, min(32, round(0.5 * target_s * best_rate / n))))       # the batch again and again up to ~target_s / 2
+        sec = sum(fn(x, best_thr)[1] for _ in range(rounds))
+        res[kind] = (n * rounds, sec, best_thr)
     best = max(res, key=lambda k: res[k][0] / res[k][1])
-    n, sec = res[best]
+    n, sec, cores = res[best]
     return {"value": n * mc.K_bch / sec, "unit": "bit/s", "fec_frames_per_s": n / sec, "cores": cores, "kind": "port",
             "sample": "%d frames of the same batch, oracle layered NMS (natural row order, fp32, 10 ite, %s flavour, frames "
-                      "sharded over %d threads), %.1f s" % (n, best, cores, sec),
-            "flavours_frames_per_s": {k: v[0] / v[1] for k, v in res.items()}}
+                      "sharded over %d threads -- the fastest of %d/8, /4, /2 and all %d hardware threads), %.1f s"
+                      % (n, best, cores, ncpu, ncpu, sec),
+            "flavours_frames_per_s": {k: v[0] / v[1] for k, v in res.items()}, "flavours_threads": {k: v[2] for k, v in res.items()}}
 
 
 if __name__ == "__main__":
