@@ -70,6 +70,11 @@ struct dvbs2hip_handle {
         int xh_cur = 0, sofh_cur = 0, od_cur = 0;
     } sfm;
     // L&R fine frequency synchronizer (N4): damped autocorrelation R_l, alpha (factory default 0.999)
+    // host sockets the integrator has pinned (dvbs2hip_host_register): base address -> bytes; copy streams + events of
+    // the chunked host-form pipeline (H2D of chunk i+1 | kernels of chunk i | D2H of chunk i-1)
+    std::map<uintptr_t, size_t> pinned;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<hipEvent_t> ev_pipe;
     int ldpc_sched = DVBS2HIP_SCHED_QC;
     float *d_nat_work = nullptr;       // natural-order LDPC: frame-interleaved image + state, ceil(max_frames / 64) groups
     float *d_lr_R = nullptr;
@@ -121,6 +126,51 @@ int check_frames(dvbs2hip_t *h, int n_frames)
                                             ", 'max_frames' = " + std::to_string(h->max_frames) + ").");
     return 0;
 }
+
+// ---- host-socket pipeline for PINNED sockets: the batch goes through in chunks, copies on two copy streams (the two DMA
+// directions run together), kernels on the handle's stream, so a call costs about max(H2D, D2H) instead of H2D + kernels + D2H
+struct HostCopy { const void *src; void *dst; size_t bytes_per_frame; };       // H2D: src = host, dst = device; D2H: src = device, dst = host
+
+static bool host_is_pinned(const dvbs2hip_t *h, const void *p, size_t bytes)
+{
+    if (!p || h->pinned.empty()) return false;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    auto it = h->pinned.upper_bound(a);
+    if (it == h->pinned.begin()) return false;
+    --it;
+    return a >= it->first && a + bytes <= it->first + it->second;
+}
+
+template <typename Fn>
+static int host_pipeline(dvbs2hip_t *h, int F, const std::vector<HostCopy> &ins, const std::vector<HostCopy> &outs, Fn dev_call)
+{
+    const int n_chunks = F >= 1024 ? 8 : F >= 128 ? 4 : 1;
+    const int chunk = (F + n_chunks - 1) / n_chunks;
+    if (!h->s_in) { HIPCHK(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking)); HIPCHK(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking)); }
+    while ((int)h->ev_pipe.size() < 2 * n_chunks) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_pipe.push_back(e); }
+    HIPCHK(h, hipStreamSynchronize(h->stream));             // what the handle's stream still does with the staging buffers
+    int c = 0;
+    for (int f0 = 0; f0 < F; f0 += chunk, c++) {
+        const int nf = F - f0 < chunk ? F - f0 : chunk;
+        for (const HostCopy &x : ins)
+            HIPCHK(h, hipMemcpyAsync((char *)x.dst + (size_t)f0 * x.bytes_per_frame, (const char *)x.src + (size_t)f0 * x.bytes_per_frame,
+                                     (size_t)nf * x.bytes_per_frame, hipMemcpyHostToDevice, h->s_in));
+        HIPCHK(h, hipEventRecord(h->ev_pipe[2 * c], h->s_in));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_pipe[2 * c], 0));
+        int r = dev_call(f0, nf);
+        if (r) { (void)hipStreamSynchronize(h->s_in); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->s_out); return r; }
+        HIPCHK(h, hipEventRecord(h->ev_pipe[2 * c + 1], h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->s_out, h->ev_pipe[2 * c + 1], 0));
+        for (const HostCopy &x : outs)
+            if (x.dst)
+                HIPCHK(h, hipMemcpyAsync((char *)x.dst + (size_t)f0 * x.bytes_per_frame, (const char *)x.src + (size_t)f0 * x.bytes_per_frame,
+                                         (size_t)nf * x.bytes_per_frame, hipMemcpyDeviceToHost, h->s_out));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->s_out));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 
 struct Timer {      // RAII: events around one kernel launch when timing is on
     dvbs2hip_t *h; int k; hipEvent_t a = nullptr, b = nullptr;
@@ -382,6 +432,10 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     for (auto &kv : h->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
         for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &kv : h->pinned) (void)hipHostUnregister(reinterpret_cast<void *>(kv.first));
+    for (hipEvent_t e : h->ev_pipe) (void)hipEventDestroy(e);
+    if (h->s_in) (void)hipStreamDestroy(h->s_in);
+    if (h->s_out) (void)hipStreamDestroy(h->s_out);
     void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
                         h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
@@ -494,6 +548,12 @@ int dvbs2hip_ldpc_decode_siho_post(dvbs2hip_t *h, const float *Y_N, int8_t *CWD,
     if ((r = ensure(h, B_IN, nin, &din)) || (r = ensure(h, B_OUT, nout, &dout)) || (r = ensure(h, B_CWD0, F, &dcwd))) return r;
     if (post && (r = ensure(h, B_AUX0, nin, &dpost))) return r;
     if (ites && (r = ensure(h, B_AUX1, (size_t)F * 4, &dit))) return r;
+    if (!post && !ites && host_is_pinned(h, Y_N, nin) && host_is_pinned(h, V_K, nout) && (!CWD || host_is_pinned(h, CWD, (size_t)F))) {
+        const size_t N = (size_t)h->N_ldpc, K = (size_t)h->K_ldpc;
+        return host_pipeline(h, F, {{Y_N, din, N * 4}}, {{dout, V_K, K * 4}, {dcwd, CWD, 1}}, [&](int f0, int nf) {
+            return ldpc_dev(h, (const float *)din + (size_t)f0 * N, (int8_t *)dcwd + f0, (int32_t *)dout + (size_t)f0 * K, nullptr, nullptr, nullptr, nf);
+        });
+    }
     HIPCHK(h, hipMemcpyAsync(din, Y_N, nin, hipMemcpyHostToDevice, h->stream));
     if ((r = ldpc_dev(h, (const float *)din, (int8_t *)dcwd, (int32_t *)dout, nullptr, (float *)dpost, (int32_t *)dit, F))) return r;
     HIPCHK(h, hipMemcpyAsync(V_K, dout, nout, hipMemcpyDeviceToHost, h->stream));
@@ -611,6 +671,29 @@ static int host_wrap(dvbs2hip_t *h, const Tin *in, size_t nin_el, Tout *out, siz
 }
 
 extern "C" {
+
+int dvbs2hip_host_register(dvbs2hip_t *h, void *ptr, size_t bytes)
+{
+    if (!h || !ptr || !bytes) return DVBS2HIP_EINVAL;
+    if (hipSetDevice(h->device) != hipSuccess) return fail(h, DVBS2HIP_EHIP, "hipSetDevice failed");
+    if (host_is_pinned(h, ptr, bytes)) return 0;
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) return fail(h, DVBS2HIP_EHIP, std::string("hipHostRegister: ") + hipGetErrorString(e));
+    h->pinned[reinterpret_cast<uintptr_t>(ptr)] = bytes;
+    return 0;
+}
+
+int dvbs2hip_host_unregister(dvbs2hip_t *h, void *ptr)
+{
+    if (!h || !ptr) return DVBS2HIP_EINVAL;
+    auto it = h->pinned.find(reinterpret_cast<uintptr_t>(ptr));
+    if (it == h->pinned.end()) return fail(h, DVBS2HIP_EINVAL, "this address was not registered");
+    if (hipSetDevice(h->device) != hipSuccess) return fail(h, DVBS2HIP_EHIP, "hipSetDevice failed");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipHostUnregister(ptr);
+    h->pinned.erase(it);
+    return 0;
+}
 
 int dvbs2hip_deinterleave(dvbs2hip_t *h, const float *itl, float *nat, int32_t F)
 {
@@ -1061,6 +1144,14 @@ int dvbs2hip_rx_bb(dvbs2hip_t *h, const float *pl, const float *sigma, int32_t *
     if (sigma) {
         if ((r = ensure(h, B_SIG, (size_t)F * 4, &dsig))) return r;
         HIPCHK(h, hipMemcpyAsync(dsig, sigma, (size_t)F * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    if (host_is_pinned(h, pl, nin) && host_is_pinned(h, info, nout) && (!cwd_l || host_is_pinned(h, cwd_l, (size_t)F)) &&
+        (!cwd_b || host_is_pinned(h, cwd_b, (size_t)F))) {
+        const size_t P2 = (size_t)2 * h->pl_frame, K = (size_t)h->K_bch;
+        return host_pipeline(h, F, {{pl, din, P2 * 4}}, {{dout, info, K * 4}, {dc0, cwd_l, 1}, {dc1, cwd_b, 1}}, [&](int f0, int nf) {
+            return dvbs2hip_rx_bb_dev(h, (const float *)din + (size_t)f0 * P2, dsig ? (const float *)dsig + f0 : nullptr, (int32_t *)dout + (size_t)f0 * K,
+                                      (int8_t *)dc0 + f0, (int8_t *)dc1 + f0, nf);
+        });
     }
     HIPCHK(h, hipMemcpyAsync(din, pl, nin, hipMemcpyHostToDevice, h->stream));
     if ((r = dvbs2hip_rx_bb_dev(h, (const float *)din, (const float *)dsig, (int32_t *)dout, (int8_t *)dc0, (int8_t *)dc1, F))) return r;

@@ -52,6 +52,8 @@ ABI = {
     "dvbs2hip_last_error": (C.c_char_p, [_vp]),
     "dvbs2hip_ldpc_kernel_name": (C.c_char_p, [_vp]),
     "dvbs2hip_set_ldpc_schedule": (C.c_int, [_vp, _i]),
+    "dvbs2hip_host_register": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "dvbs2hip_host_unregister": (C.c_int, [_vp, _vp]),
     "dvbs2hip_reset": (C.c_int, [_vp]),
     "dvbs2hip_sync_lr_synchronize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_sync_lr_synchronize_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i]),

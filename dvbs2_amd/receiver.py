@@ -100,10 +100,22 @@ class Dvbs2Hip:
         self._chk(self.L.dvbs2hip_set_ldpc_params(self.h, int(n_ite), float(alpha), 1 if early_stop else 0))
 
     # ------------------------------------------------------------------ a1
-    def decode_siho(self, Y_N, with_post=False):
+    def host_register(self, arr):
+        """pins a host socket buffer (numpy array) for the handle's lifetime: see dvbs2hip_host_register"""
+        self._chk(self.L.dvbs2hip_host_register(self.h, _ptr(arr), arr.nbytes))
+
+    def host_unregister(self, arr):
+        self._chk(self.L.dvbs2hip_host_unregister(self.h, _ptr(arr)))
+
+    def decode_siho(self, Y_N, with_post=False, out=None):
+        """out = (V_K int32[F,K_ldpc], CWD int8[F]) reuses the caller's socket buffers (e.g. pinned ones)"""
         Y, F = self._frames(Y_N, self.N_ldpc, np.float32)
-        V = np.empty((F, self.K_ldpc), dtype=np.int32)
-        CWD = np.zeros(F, dtype=np.int8)
+        if out is not None:
+            V, CWD = out
+            assert V.dtype == np.int32 and V.size == F * self.K_ldpc and CWD.dtype == np.int8 and CWD.size == F and V.flags.c_contiguous
+        else:
+            V = np.empty((F, self.K_ldpc), dtype=np.int32)
+            CWD = np.zeros(F, dtype=np.int8)
         if not with_post:
             self._chk(self.L.dvbs2hip_ldpc_decode_siho(self.h, _ptr(Y), _ptr(CWD), _ptr(V), F))
             return V, CWD
@@ -203,10 +215,15 @@ class Dvbs2Hip:
         self._chk(self.L.dvbs2hip_monitor_reset(self.h))
 
     # ------------------------------------------------------------------ fused chain
-    def rx_bb(self, pl_frames, sigma=None):
+    def rx_bb(self, pl_frames, sigma=None, out=None):
+        """out = (info int32[F,K_bch], cwd_ldpc int8[F], cwd_bch int8[F]) reuses the caller's socket buffers"""
         X, F = self._frames(pl_frames, 2 * self.pl_frame, np.float32)
-        info = np.empty((F, self.K_bch), dtype=np.int32)
-        c0, c1 = np.zeros(F, dtype=np.int8), np.zeros(F, dtype=np.int8)
+        if out is not None:
+            info, c0, c1 = out
+            assert info.dtype == np.int32 and info.size == F * self.K_bch and info.flags.c_contiguous and c0.dtype == np.int8 and c1.dtype == np.int8
+        else:
+            info = np.empty((F, self.K_bch), dtype=np.int32)
+            c0, c1 = np.zeros(F, dtype=np.int8), np.zeros(F, dtype=np.int8)
         sg = None
         if sigma is not None:
             sg = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, dtype=np.float32).ravel(), (F,)))

@@ -41,6 +41,7 @@ int main(int argc, char **argv)
     }
     try {
         auto ctx = std::make_shared<module::Context>(modcod, F, n_ite, alpha, true);
+        ctx->pin_sockets = true;            // the sockets below live until the modules go: pin them for overlapped PCIe copies
         module::Scrambler_PL_hip pl_scrambler(ctx);
         module::Framer_hip framer(ctx);
         module::Estimator_hip estimator(ctx);

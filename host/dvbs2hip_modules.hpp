@@ -39,6 +39,11 @@ public:
     dvbs2hip_t *h = nullptr;
     dvbs2hip_sizes sz{};
     int n_frames() const { return n_frames_; }
+    // Socket buffers live as long as their modules: with pin_sockets set, the decode_siho / receive codelets pin the
+    // buffers they are handed (once: dvbs2hip_host_register ignores a buffer it knows) and the C ABI then overlaps the
+    // PCIe copies with the kernels.  Leave it off if the graph is fed from short-lived buffers.
+    bool pin_sockets = false;
+    void pin(const void *p, size_t bytes) const { if (pin_sockets && p) (void)dvbs2hip_host_register(h, const_cast<void *>(p), bytes); }
 
 private:
     int n_frames_ = 1;
@@ -110,7 +115,10 @@ public:
         });
     }
     void decode_siho(const Q *Y_N, int8_t *CWD, B *V_K)
-    { DVBS2HIP_CHK(ctx, dvbs2hip_ldpc_decode_siho(ctx->h, (const float *)Y_N, CWD, (int32_t *)V_K, F())); }
+    {
+        ctx->pin(Y_N, sizeof(Q) * (size_t)ctx->sz.N_ldpc * F()); ctx->pin(V_K, sizeof(B) * (size_t)ctx->sz.K_ldpc * F()); ctx->pin(CWD, (size_t)F());
+        DVBS2HIP_CHK(ctx, dvbs2hip_ldpc_decode_siho(ctx->h, (const float *)Y_N, CWD, (int32_t *)V_K, F()));
+    }
 };
 
 // replaces Decoder_BCH_DVBS2<B,R> (Decoder_BCH_DVBS2.cpp:28-40; built DVBS2.cpp:406-416)
@@ -298,7 +306,11 @@ public:
         });
     }
     void receive(const float *pl, B *V_K, int8_t *cwd_ldpc, int8_t *cwd_bch)
-    { DVBS2HIP_CHK(ctx, dvbs2hip_rx_bb(ctx->h, pl, nullptr, (int32_t *)V_K, cwd_ldpc, cwd_bch, F())); }
+    {
+        ctx->pin(pl, sizeof(float) * 2 * (size_t)ctx->sz.pl_frame_sym * F()); ctx->pin(V_K, sizeof(B) * (size_t)ctx->sz.K_bch * F());
+        ctx->pin(cwd_ldpc, (size_t)F()); ctx->pin(cwd_bch, (size_t)F());
+        DVBS2HIP_CHK(ctx, dvbs2hip_rx_bb(ctx->h, pl, nullptr, (int32_t *)V_K, cwd_ldpc, cwd_bch, F()));
+    }
 };
 
 // replaces Synchronizer_frame_DVBS2_fast<R> (Synchronizer_frame_DVBS2_fast.cpp; tasks and sockets of

@@ -113,6 +113,13 @@ const char *dvbs2hip_last_error(const dvbs2hip_t *h);
 int dvbs2hip_set_ldpc_schedule(dvbs2hip_t *h, int32_t schedule);
 /* name of the LDPC kernel instantiation the plan selected for this MODCOD (diagnostics, bench.py's roofline line) */
 const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h);
+/* Pins a host socket buffer (hipHostRegister) for the lifetime of the handle or until _unregister.  With every socket of a
+ * call pinned, dvbs2hip_ldpc_decode_siho and dvbs2hip_rx_bb copy at PCIe speed and run the batch in chunks with the two copy
+ * directions and the kernels overlapped (host-form QPSK normal frames: 29 k -> ~150 k frames/s); unpinned sockets keep the plain
+ * copy -> kernels -> copy path.  StreamPU socket buffers live as long as their module, so an integration registers each once
+ * after binding.  The buffer must stay allocated while registered. */
+int dvbs2hip_host_register(dvbs2hip_t *h, void *ptr, size_t bytes);
+int dvbs2hip_host_unregister(dvbs2hip_t *h, void *ptr);
 /* Interface_reset: clears the filter state and the monitor counters */
 int dvbs2hip_reset(dvbs2hip_t *h);
 /* change --dec-ite / alpha / early-stop without rebuilding tables */

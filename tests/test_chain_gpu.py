@@ -97,3 +97,34 @@ def test_external_stream_reset_and_two_handles(O, Rx):
     assert rx.monitor_get() == (0, 0, 0)
     assert np.array_equal(rx.filter(x, 1), y1)                           # same output again: the filter memory was cleared
     other.close(); rx.close()
+
+
+def test_pinned_host_sockets_give_the_same_results(O, Rx):
+    """dvbs2hip_host_register: the chunked, overlapped host-form path (all sockets pinned) against the plain one,
+    on a batch that does not divide into the chunks evenly; unregistering falls back to the plain path."""
+    modcod, F = "QPSK-S_8/9", 333
+    info, pl, _, sigma = make_pl_frames(O, modcod, 9, 4.6, seed=31)
+    pl = np.ascontiguousarray(np.tile(pl, (37, 1)))[:F]
+    rx = Rx(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=True)
+    ref_info, ref_c0, ref_c1 = rx.rx_bb(pl, sigma=np.float32(sigma))
+    out = (np.empty((F, rx.K_bch), np.int32), np.zeros(F, np.int8), np.zeros(F, np.int8))
+    for a in (pl,) + out:
+        rx.host_register(a)
+    got = rx.rx_bb(pl, sigma=np.float32(sigma), out=out)
+    assert np.array_equal(got[0], ref_info) and np.array_equal(got[1], ref_c0) and np.array_equal(got[2], ref_c1)
+    assert np.array_equal(got[0][:9], info)
+    # LDPC task alone
+    llr = rx.demodulate(np.float32(sigma), rx.remove_plh(rx.pl_descramble(pl)), deinterleave=True)
+    V0, C0 = rx.decode_siho(llr)
+    llr = np.ascontiguousarray(llr)
+    outl = (np.empty((F, rx.K_ldpc), np.int32), np.zeros(F, np.int8))
+    for a in (llr,) + outl:
+        rx.host_register(a)
+    V1, C1 = rx.decode_siho(llr, out=outl)
+    assert np.array_equal(V0, V1) and np.array_equal(C0, C1)
+    rx.host_unregister(llr)
+    V2, C2 = rx.decode_siho(llr, out=outl)
+    assert np.array_equal(V0, V2)
+    with pytest.raises(Exception):
+        rx.host_unregister(llr)
+    rx.close()
