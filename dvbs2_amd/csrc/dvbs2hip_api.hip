@@ -654,8 +654,9 @@ int dvbs2hip_deinterleave_dev(dvbs2hip_t *h, const float *itl, float *nat, int32
 
 }  // extern "C"
 
-// generic "same-size or two-size elementwise" host wrapper
-template <typename Tin, typename Tout, typename Fn>
+// generic "same-size or two-size elementwise" host wrapper; dev_call(in, out, n_frames).  PER_FRAME: the task treats frames
+// independently or as one stream in order, so pinned sockets may go through in overlapped chunks
+template <bool PER_FRAME = false, typename Tin, typename Tout, typename Fn>
 static int host_wrap(dvbs2hip_t *h, const Tin *in, size_t nin_el, Tout *out, size_t nout_el, int F, Fn dev_call)
 {
     int r = check_frames(h, F); if (r) return r;
@@ -663,8 +664,11 @@ static int host_wrap(dvbs2hip_t *h, const Tin *in, size_t nin_el, Tout *out, siz
     const size_t nin = (size_t)F * nin_el * sizeof(Tin), nout = (size_t)F * nout_el * sizeof(Tout);
     void *din, *dout;
     if ((r = ensure(h, B_IN, nin, &din)) || (r = ensure(h, B_OUT, nout, &dout))) return r;
+    if (PER_FRAME && host_is_pinned(h, in, nin) && host_is_pinned(h, out, nout))
+        return host_pipeline(h, F, {{in, din, nin_el * sizeof(Tin)}}, {{dout, out, nout_el * sizeof(Tout)}},
+                             [&](int f0, int nf) { return dev_call((const Tin *)din + (size_t)f0 * nin_el, (Tout *)dout + (size_t)f0 * nout_el, nf); });
     HIPCHK(h, hipMemcpyAsync(din, in, nin, hipMemcpyHostToDevice, h->stream));
-    if ((r = dev_call((const Tin *)din, (Tout *)dout))) return r;
+    if ((r = dev_call((const Tin *)din, (Tout *)dout, F))) return r;
     HIPCHK(h, hipMemcpyAsync(out, dout, nout, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -697,8 +701,8 @@ int dvbs2hip_host_unregister(dvbs2hip_t *h, void *ptr)
 
 int dvbs2hip_deinterleave(dvbs2hip_t *h, const float *itl, float *nat, int32_t F)
 {
-    return host_wrap(h, itl, h ? h->N_ldpc : 0, nat, h ? h->N_ldpc : 0, F,
-                     [&](const float *a, float *b) { return dvbs2hip_deinterleave_dev(h, a, b, F); });
+    return host_wrap<true>(h, itl, h ? h->N_ldpc : 0, nat, h ? h->N_ldpc : 0, F,
+                           [&](const float *a, float *b, int nf) { return dvbs2hip_deinterleave_dev(h, a, b, nf); });
 }
 
 // ------------------------------------------------------------------ a5
@@ -717,8 +721,8 @@ int dvbs2hip_filter_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx,
 
 int dvbs2hip_filter(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx, int32_t F)
 {
-    return host_wrap(h, X, (size_t)2 * (n_cplx > 0 ? n_cplx : 0), Y, (size_t)2 * (n_cplx > 0 ? n_cplx : 0), F,
-                     [&](const float *a, float *b) { return dvbs2hip_filter_dev(h, a, b, n_cplx, F); });
+    return host_wrap<true>(h, X, (size_t)2 * (n_cplx > 0 ? n_cplx : 0), Y, (size_t)2 * (n_cplx > 0 ? n_cplx : 0), F,
+                           [&](const float *a, float *b, int nf) { return dvbs2hip_filter_dev(h, a, b, n_cplx, nf); });
 }
 
 int dvbs2hip_filter_reset(dvbs2hip_t *h)
@@ -749,7 +753,7 @@ int dvbs2hip_shape_filter_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n
 int dvbs2hip_shape_filter(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx, int32_t F)
 {
     const size_t n = (size_t)2 * (n_cplx > 0 ? n_cplx : 0);
-    return host_wrap(h, X, n, Y, n * (h ? h->fir_osf : 1), F, [&](const float *a, float *b) { return dvbs2hip_shape_filter_dev(h, a, b, n_cplx, F); });
+    return host_wrap(h, X, n, Y, n * (h ? h->fir_osf : 1), F, [&](const float *a, float *b, int nf) { return dvbs2hip_shape_filter_dev(h, a, b, n_cplx, nf); });
 }
 
 int dvbs2hip_add_noise_dev(dvbs2hip_t *h, const float *CP, const float *X, float *Y, uint64_t seed, int32_t n_elmts, int32_t F)
@@ -770,7 +774,7 @@ int dvbs2hip_add_noise(dvbs2hip_t *h, const float *CP, const float *X, float *Y,
     if ((r = ensure(h, B_SIG, (size_t)F * 4, &dsig))) return r;
     HIPCHK(h, hipMemcpyAsync(dsig, CP, (size_t)F * 4, hipMemcpyHostToDevice, h->stream));
     const size_t n = n_elmts > 0 ? (size_t)n_elmts : 0;
-    return host_wrap(h, X, n, Y, n, F, [&](const float *a, float *b) { return dvbs2hip_add_noise_dev(h, (const float *)dsig, a, b, seed, n_elmts, F); });
+    return host_wrap(h, X, n, Y, n, F, [&](const float *a, float *b, int nf) { return dvbs2hip_add_noise_dev(h, (const float *)dsig, a, b, seed, n_elmts, nf); });
 }
 
 int dvbs2hip_extract_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx_out, int32_t osf, int64_t offset, int32_t F)
@@ -1045,7 +1049,7 @@ int dvbs2hip_pl_descramble_dev(dvbs2hip_t *h, const float *a, float *b, int32_t 
 int dvbs2hip_pl_descramble(dvbs2hip_t *h, const float *a, float *b, int32_t F)
 {
     const size_t n = h ? (size_t)2 * h->pl_frame : 0;
-    return host_wrap(h, a, n, b, n, F, [&](const float *x, float *y) { return dvbs2hip_pl_descramble_dev(h, x, y, F); });
+    return host_wrap<true>(h, a, n, b, n, F, [&](const float *x, float *y, int nf) { return dvbs2hip_pl_descramble_dev(h, x, y, nf); });
 }
 int dvbs2hip_remove_plh_dev(dvbs2hip_t *h, const float *a, float *b, int32_t F)
 {
@@ -1057,8 +1061,8 @@ int dvbs2hip_remove_plh_dev(dvbs2hip_t *h, const float *a, float *b, int32_t F)
 }
 int dvbs2hip_remove_plh(dvbs2hip_t *h, const float *a, float *b, int32_t F)
 {
-    return host_wrap(h, a, h ? (size_t)2 * h->pl_frame : 0, b, h ? (size_t)2 * h->n_sym : 0, F,
-                     [&](const float *x, float *y) { return dvbs2hip_remove_plh_dev(h, x, y, F); });
+    return host_wrap<true>(h, a, h ? (size_t)2 * h->pl_frame : 0, b, h ? (size_t)2 * h->n_sym : 0, F,
+                           [&](const float *x, float *y, int nf) { return dvbs2hip_remove_plh_dev(h, x, y, nf); });
 }
 
 // ------------------------------------------------------------------ a8
@@ -1073,7 +1077,7 @@ int dvbs2hip_bb_descramble_dev(dvbs2hip_t *h, const int32_t *a, int32_t *b, int3
 int dvbs2hip_bb_descramble(dvbs2hip_t *h, const int32_t *a, int32_t *b, int32_t F)
 {
     const size_t n = h ? (size_t)h->K_bch : 0;
-    return host_wrap(h, a, n, b, n, F, [&](const int32_t *x, int32_t *y) { return dvbs2hip_bb_descramble_dev(h, x, y, F); });
+    return host_wrap<true>(h, a, n, b, n, F, [&](const int32_t *x, int32_t *y, int nf) { return dvbs2hip_bb_descramble_dev(h, x, y, nf); });
 }
 
 // ------------------------------------------------------------------ a9

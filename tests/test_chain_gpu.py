@@ -122,6 +122,19 @@ def test_pinned_host_sockets_give_the_same_results(O, Rx):
         rx.host_register(a)
     V1, C1 = rx.decode_siho(llr, out=outl)
     assert np.array_equal(V0, V1) and np.array_equal(C0, C1)
+    # the streaming tasks take the same path when their sockets are pinned (the receiver's Python wrappers allocate their
+    # outputs, so go through the ABI): PL descrambler, and the matched filter, whose memory has to chain through the chunks
+    import ctypes as C
+    y_ref = rx.pl_descramble(pl)
+    y = np.empty_like(pl)
+    rx.host_register(y)
+    assert rx.L.dvbs2hip_pl_descramble(rx.h, pl.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), F) == 0
+    assert np.array_equal(y, y_ref)
+    rx.filter_reset()
+    f_ref = rx.filter(pl, n_frames=F)
+    rx.filter_reset()
+    assert rx.L.dvbs2hip_filter(rx.h, pl.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), rx.pl_frame, F) == 0
+    assert np.array_equal(y.reshape(f_ref.shape), f_ref)
     rx.host_unregister(llr)
     V2, C2 = rx.decode_siho(llr, out=outl)
     assert np.array_equal(V0, V2)
