@@ -47,8 +47,12 @@ fir_ccr_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const float
     __syncthreads();
     const int s0 = tid * FIR_R;                   // window start inside the tile
     float2 acc[FIR_R], w[FIR_R];
+    // s0 is a multiple of 8, so fir_pad(s0 + j) = 9 tid + j + (j >> 3): one per-lane base, every further index a constant
+    // that goes into the immediate offset of the ds_read (no address arithmetic per tap)
+    const float2 *tp = tile + 9 * tid;
+    static_assert(FIR_R == 8, "the padded index is split on a window of 8");
 #pragma unroll
-    for (int r = 0; r < FIR_R; r++) { acc[r] = make_float2(0.f, 0.f); w[r] = tile[fir_pad(s0 + r)]; }
+    for (int r = 0; r < FIR_R; r++) { acc[r] = make_float2(0.f, 0.f); w[r] = tp[r]; }
     if (TS > 0) {
 #pragma unroll
         for (int k = 0; k < (TS > 0 ? TS : 1); k++) {
@@ -57,7 +61,7 @@ fir_ccr_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const float
             for (int r = 0; r < FIR_R; r++) { acc[r].x = fmaf(b, w[r].x, acc[r].x); acc[r].y = fmaf(b, w[r].y, acc[r].y); }
 #pragma unroll
             for (int r = 0; r + 1 < FIR_R; r++) w[r] = w[r + 1];
-            if (k + 1 < TS) w[FIR_R - 1] = tile[fir_pad(s0 + k + FIR_R)];
+            if (k + 1 < TS) w[FIR_R - 1] = tp[(k + FIR_R) + ((k + FIR_R) >> 3)];
         }
     } else {
         for (int k = 0; k < T; k++) {
