@@ -3,7 +3,8 @@
 // (bit-exact), rebuilt around what a per-phase cycle profile of that kernel showed on MI355X
 // (DESIGN.md section 6): 30 % of its time was frame I/O issued as ~180 dependent HBM round trips,
 // 12 % the replay of same-layer duplicate edges through global memory, and the layer loop itself
-// was VALU-issue bound (~610 VALU per layer and wave).
+// a long per-wave instruction stream (~610 VALU + ~250 scalar per layer; one wave issues one instruction
+// every 4.4 cycles whatever its type, tools/probe_valu.hip).
 //
 //  * Workgroup shape.  The dispatcher deals the waves of a workgroup round-robin over the CU's four
 //    SIMDs (tools/probe_placement.hip): 6 waves sit 2+2+1+1, 8 waves 2+2+2+2.  Every wave reads its
