@@ -62,10 +62,38 @@ __device__ __forceinline__ void demap_symbol(float2 y, float inv2s2, const float
 {
     constexpr int P = 1 << BPS;
     float met[P];
+    float mall = -INFINITY;
 #pragma unroll
     for (int s = 0; s < P; s++) {
         const float dr = y.x - cs[2 * s], di = y.y - cs[2 * s + 1];
         met[s] = -(dr * dr + di * di) * inv2s2;
+        mall = fmaxf(mall, met[s]);
+    }
+    if (BPS >= 3) {
+        // One exponential per constellation point instead of one per point AND bit: e_s = exp(met_s - max over all points),
+        // L_b = log(sum of e_s over the bit-0 subset) - log(sum over the bit-1 subset) -- the same quantity, as long as the
+        // largest term of every subset is still a normal number, i.e. no subset maximum lies more than ~80 below the overall
+        // one (|L_b| <= 80).  Symbols beyond that (very high SNR) take the per-subset form below.
+        float e[P], lo = mall;
+#pragma unroll
+        for (int b = 0; b < BPS; b++) {
+            float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < P; s++) { if (((s >> b) & 1) == 0) m0 = fmaxf(m0, met[s]); else m1 = fmaxf(m1, met[s]); }
+            lo = fminf(lo, fminf(m0, m1));
+        }
+        if (mall - lo <= 80.0f) {
+#pragma unroll
+            for (int s = 0; s < P; s++) e[s] = __expf(met[s] - mall);
+#pragma unroll
+            for (int b = 0; b < BPS; b++) {
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int s = 0; s < P; s++) { if (((s >> b) & 1) == 0) s0 += e[s]; else s1 += e[s]; }
+                out[b] = __logf(s0) - __logf(s1);
+            }
+            return;
+        }
     }
 #pragma unroll
     for (int b = 0; b < BPS; b++) {

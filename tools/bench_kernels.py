@@ -27,7 +27,10 @@ def chain_case(modcod, F, n_ite, ebn0):
     sent = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev); got = torch.empty_like(sent)
     sig = torch.full((F,), sigma, dtype=torch.float32, device=dev)
     rx.tx_bb_dev(None, 1, sig.data_ptr(), sent.data_ptr(), pl.data_ptr(), F); rx.synchronize()
-    f = lambda: rx.rx_bb_dev(pl.data_ptr(), None, got.data_ptr(), None, None, F)
+    # the M2M4 estimator (Estimator_DVBS2.hxx:31-58) assumes a constant-modulus constellation; like the reference's own APSK
+    # trace (refs/TX_RX_BB/16APSK_8_9.txt: --est-type PERFECT) the APSK cases are given the true sigma
+    sig_in = sig.data_ptr() if mc.bps >= 4 else None
+    f = lambda: rx.rx_bb_dev(pl.data_ptr(), sig_in, got.data_ptr(), None, None, F)
     out = {}
     for name, kid in (("front(a7+a6+a3+a4)", B.K_FRONT), ("ldpc(a1)", B.K_LDPC), ("bch+bb(a2+a8)", B.K_BCH)):
         out[name] = timed(rx, kid, f)
