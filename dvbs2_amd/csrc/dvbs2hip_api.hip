@@ -466,8 +466,8 @@ const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
         const LdpcPlan &pl = h->ldpc;
         char buf[96];
         if (!pl.fast) snprintf(buf, sizeof buf, "ldpc_layered_nms_kernel<%d,%s,%s>", pl.ent_stride, pl.hybrid ? "true" : "false", pl.c2v_lds ? "true" : "false");
+        else if (pl.fast_wg8) snprintf(buf, sizeof buf, pl.spa ? "ldpc_wg8_kernel<%d,%d,true>" : "ldpc_wg8_kernel<%d,%d>", pl.fast_deg, pl.fast_mode);
         else if (pl.spa) snprintf(buf, sizeof buf, "ldpc_fast2_kernel<%d,%d,true>", pl.fast_deg, pl.fast_mode);
-        else if (pl.fast_wg8) snprintf(buf, sizeof buf, "ldpc_wg8_kernel<%d,%d>", pl.fast_deg, pl.fast_mode);
         else snprintf(buf, sizeof buf, "ldpc_fast2_kernel<%d,%d,false>", pl.fast_deg, pl.fast_mode);
         const_cast<dvbs2hip_t *>(h)->ldpc_name = buf;
     }

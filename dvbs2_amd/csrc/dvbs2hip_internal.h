@@ -9,6 +9,15 @@
 
 namespace dvbs2 {
 
+// e^x and ln x on the hardware transcendental units, ONE v_exp_f32 / v_log_f32 plus a multiply each.  HIP's __expf / __logf
+// wrap the same instructions in a range check and a rescale for denormal results (8 instructions instead of 2); the
+// arguments here (exp of a non-positive number, log of a sum >= 1 or of a sum of such exponentials) do not need that:
+// a result below the smallest normal number flushes to zero, which is what the formulas treat it as.
+#if defined(__HIPCC__)
+__device__ __forceinline__ float hw_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float hw_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+#endif
+
 // ---------------------------------------------------------------- LDPC (a1)
 // One slot of a QC layer = one circulant: variable = group element (t - t0) mod 360.
 // Packed in ONE dword so a whole layer (<= 27 entries) is preloaded into SGPRs by a few wide

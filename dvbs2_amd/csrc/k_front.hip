@@ -84,13 +84,13 @@ __device__ __forceinline__ void demap_symbol(float2 y, float inv2s2, const float
         }
         if (mall - lo <= 80.0f) {
 #pragma unroll
-            for (int s = 0; s < P; s++) e[s] = __expf(met[s] - mall);
+            for (int s = 0; s < P; s++) e[s] = hw_exp(met[s] - mall);
 #pragma unroll
             for (int b = 0; b < BPS; b++) {
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                 for (int s = 0; s < P; s++) { if (((s >> b) & 1) == 0) s0 += e[s]; else s1 += e[s]; }
-                out[b] = __logf(s0) - __logf(s1);
+                out[b] = hw_log(s0) - hw_log(s1);
             }
             return;
         }
@@ -105,9 +105,9 @@ __device__ __forceinline__ void demap_symbol(float2 y, float inv2s2, const float
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int s = 0; s < P; s++) {
-            if (((s >> b) & 1) == 0) s0 += __expf(met[s] - m0); else s1 += __expf(met[s] - m1);
+            if (((s >> b) & 1) == 0) s0 += hw_exp(met[s] - m0); else s1 += hw_exp(met[s] - m1);
         }
-        out[b] = (m0 - m1) + (__logf(s0) - __logf(s1));
+        out[b] = (m0 - m1) + (hw_log(s0) - hw_log(s1));
     }
 }
 

@@ -151,7 +151,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             {
                 const int NL = 9;
                 const bool want = (env_mode && !strcmp(env_mode, "static")) || (!env_mode && pl.fast_mode == 1);
-                if (want && !spa && pl.fast_deg == 27 && !pl.fast_pad) {
+                if (want && pl.fast_deg == 27 && !pl.fast_pad) {
                     const int cap = (int)(lds_limit / 2 / grp_bytes) - 1;            // two frames per CU, one junk row each
                     std::vector<std::vector<int>> mult(pl.n_groups, std::vector<int>(q, 0));
                     for (int r = 0; r < q; r++) for (const Slot &sl : layers[r]) mult[sl.group][r]++;
@@ -289,7 +289,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 pl.w8_lds_junk = (uint32_t)(pl.w8_nl * LDPC_Z * 4);
                 pl.w8_lds_bytes = (pl.w8_nl + 1 + (pl.fast_pad && pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z * 4 + 64;
                 pl.w8_st_base = (uint32_t)((2 + pl.w8_ng) * LDPC_Z * 4);
-                pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + 3 * M;
+                pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + (spa ? pl.fast_deg * M : 3 * M);      // SPA: one fp32 message per edge slot
             }
             // workspace of one workgroup: [posteriors kept in global memory | packed c->v state 3 M words]
             pl.glb_post_words = pl.fast_mode == 1 ? (pl.n_groups + xrows) * LDPC_Z : pl.fast_mode == 3 ? n_g * LDPC_Z : 0;
@@ -341,10 +341,11 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             {
                 const char *env_wg = getenv("DVBS2HIP_LDPC_WG");
                 const bool w8_ok = pl.fast_mode == 0 || pl.fast_mode == 1 || (pl.fast_mode == 3 && pl.w8_dups_in_lds);
-                if (!spa && w8_ok && (size_t)pl.w8_lds_bytes <= lds_limit + 512 &&
-                    !(env_wg && atoi(env_wg) == 12)) {
+                if (w8_ok && (size_t)pl.w8_lds_bytes <= lds_limit + 512 && !(env_wg && atoi(env_wg) == 12)) {
                     pl.fast_wg8 = true; pl.fast_wf = 1; pl.gwork_words = pl.w8_gwork_words;
                 }
+                // the SPA kernel of k_ldpc_fast.hip knows the LDS and the global image only
+                if (spa && !pl.fast_wg8 && pl.fast_mode == 3) return "LDPC: SPA on the 12-wave kernel needs DVBS2HIP_LDPC_FAST_MODE=global for this code";
             }
         }
     }

@@ -259,7 +259,7 @@ __device__ __forceinline__ float boxplus(float a, float b)
 {
     const float mn = fminf(fabsf(a), fabsf(b));
     const float sg = __uint_as_float(__float_as_uint(mn) | ((__float_as_uint(a) ^ __float_as_uint(b)) & 0x80000000u));
-    const float r = sg + (__logf(1.0f + __expf(-fabsf(a + b))) - __logf(1.0f + __expf(-fabsf(a - b))));
+    const float r = sg + (hw_log(1.0f + hw_exp(-fabsf(a + b))) - hw_log(1.0f + hw_exp(-fabsf(a - b))));
     return a == INFINITY ? b : (b == INFINITY ? a : r);
 }
 

@@ -63,7 +63,27 @@ __device__ __forceinline__ float w8_unpack(float c1, float c2, uint32_t pk, uint
     return and_or(pk << ((32u - DEG) + j), sb, mag);
 }
 
-template <int DEG, int MODE>      // MODE 0: image in LDS, 1: in the workgroup's global slot, 3: static hybrid
+// exact sum-product pairing (`--dec-implem SPA`, the reference's default), as the oracle's chk_update_spa:
+//     a [+] b = sign(a) sign(b) min(|a|,|b|) + log(1 + e^-|a+b|) - log(1 + e^-|a-b|)
+// on the hardware exp2 / log2 units.  +inf is the neutral element (absent / NULL slots carry it).
+// CHECKED = false: at most one operand is +inf (regular codes: only the absent edge of lane 0 carries it), for which the
+// formula itself returns the other operand (e^-inf = 0); CHECKED = true (padded layers, several +inf slots in a row): the
+// inf - inf of two neutral elements is caught by selects.
+template <bool CHECKED>
+__device__ __forceinline__ float w8_boxplus(float a, float b)
+{
+    const float e1 = __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(a + b)), e2 = __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(a - b));
+    const float l = (__builtin_amdgcn_logf(1.0f + e1) - __builtin_amdgcn_logf(1.0f + e2)) * 0.693147180559945309f;
+    const float mn = fminf(fabsf(a), fabsf(b));
+    const float sg = __uint_as_float((__float_as_uint(mn) & 0x7FFFFFFFu) | ((__float_as_uint(a) ^ __float_as_uint(b)) & 0x80000000u));
+    const float r = sg + l;
+    if (!CHECKED) return r;
+    return a == INFINITY ? b : (b == INFINITY ? a : r);
+}
+
+// SPA = false: normalised min-sum with the packed per-check state.  SPA = true: sum-product check node, the c->v
+// messages kept per edge (fp32, [layer][slot][360] after the image in the workgroup's global slot).
+template <int DEG, int MODE, bool SPA = false>      // MODE 0: image in LDS, 1: in the workgroup's global slot, 3: static hybrid
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 ldpc_wg8_kernel(const LdpcKParams p)
 {
@@ -149,7 +169,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #pragma unroll
                 for (int k = 0; k < W8_IO; k++) if (l0 + k < ng) gst(t4, grow0 + (uint32_t)(l0 + k) * W8_ROW, v[k]);
             }
-            for (int r = 0; r < q; r++) { gst(t4, st_off(0, r), 0.f); gst(t4, st_off(1, r), 0.f); gst(t4, st_off(2, r), 0.f); }
+            if (SPA) { for (int e = 0; e < q * DEG; e++) gst(t4, st_base + (uint32_t)e * W8_ROW, 0.f); }
+            else for (int r = 0; r < q; r++) { gst(t4, st_off(0, r), 0.f); gst(t4, st_off(1, r), 0.f); gst(t4, st_off(2, r), 0.f); }
             if (p.w8.pad) { if (MODE == 0) lst(ljunk + W8_ROW + t4, INFINITY); else gst(t4, W8_ROW, INFINITY); }     // what NULL slots read
         }
         if (p.packed && role >= 0) {
@@ -175,6 +196,77 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 const uint32_t prim = TE[27], cinfo = TE[28], ce0 = TE[29], ce1 = TE[30];
                 const int ncf = (int)(cinfo & 0xFFu);
                 const bool mask0 = (r == 0) && (t == 0);        // p_{c-1} of check 0 does not exist
+                if (SPA) {
+                    // ================= sum-product layer =================
+                    const uint32_t mrow = st_base + (uint32_t)(r * DEG) * W8_ROW;       // messages of this layer: [slot][360]
+                    auto woff = [&](int j) { const uint32_t d = t4 - (E[j] & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
+                    float x[DEG], nw[DEG], dl[DEG];         // v->c, new c->v, new - old (what a duplicate edge adds)
+                    if (act) {
+#pragma unroll
+                        for (int j = 0; j < DEG; j++) {
+                            const uint32_t base = (E[j] >> 11) & 0x3FFFFu, wj = woff(j);
+                            x[j] = w8_slot_lds(MODE, j) ? lld(wj + base) : gld(wj, base);
+                            dl[j] = gld(t4, mrow + (uint32_t)j * W8_ROW);               // old message
+                        }
+#pragma unroll
+                        for (int j = 0; j < DEG; j++) {
+                            x[j] = x[j] - dl[j];
+                            if (j == DEG - 1 && mask0) x[j] = INFINITY;
+                        }
+                        // new_j = ([+] of the slots before j) [+] ([+] of the slots after j); the neutral +inf at the two ends is not paired
+                        constexpr bool CK = DEG == 13;            // the padded (irregular) instantiation
+                        float acc = x[0];
+                        nw[0] = INFINITY;
+#pragma unroll
+                        for (int j = 1; j < DEG; j++) { nw[j] = acc; if (j + 1 < DEG) acc = w8_boxplus<CK>(acc, x[j]); }
+                        acc = x[DEG - 1];
+#pragma unroll
+                        for (int j = DEG - 2; j >= 0; j--) { nw[j] = j == 0 ? acc : w8_boxplus<CK>(nw[j], acc); if (j > 0) acc = w8_boxplus<CK>(acc, x[j]); }
+#pragma unroll
+                        for (int j = 0; j < DEG; j++) dl[j] = nw[j] - dl[j];
+                    }
+                    if (ncf > 0) __syncthreads();         // every read of the layer precedes its writes
+                    if (act) {
+#pragma unroll
+                        for (int j = 0; j < DEG; j++) {
+                            const bool pr = ((prim >> j) & 1u) != 0u;
+                            const uint32_t base = (E[j] >> 11) & 0x3FFFFu, wj = woff(j);
+                            if (w8_slot_lds(MODE, j)) {
+                                uint32_t a = wj + (pr ? base : ljunk);
+                                if (j == DEG - 1 && mask0) a = ljunk;
+                                lst(a, x[j] + nw[j]);
+                            } else {
+                                const uint32_t sb = (MODE == 3 || pr) ? base : 0u;
+                                gst((j == DEG - 1 && mask0) ? W8_OOB : wj, sb, x[j] + nw[j]);
+                            }
+                            gst(t4, mrow + (uint32_t)j * W8_ROW, nw[j]);
+                        }
+                    }
+                    // duplicate edges: level by level, slot index wave-uniform -> a uniform branch picks the register
+                    uint32_t prev_lvl = 0u;
+                    for (int i = 0; i < ncf; i++) {
+                        const uint32_t e = i == 0 ? ce0 : i == 1 ? ce1 : T[32 + i];
+                        const uint32_t meta = i == 0 ? ((cinfo >> 8) & 31u) | (1u << 8) : i == 1 ? ((cinfo >> 16) & 31u) | (((cinfo >> 21) & 3u) << 8) : T[48 + i];
+                        const uint32_t jj = meta & 31u, lvl = meta >> 8;
+                        if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
+                        if (act) {
+                            float dv = 0.f;
+#pragma unroll
+                            for (int j = 0; j < DEG; j++) if ((uint32_t)j == jj) dv = dl[j];
+                            const uint32_t d = t4 - (e & 0x7FFu);
+                            const uint32_t off = min(d, d + (uint32_t)W8_ROW), base = (e >> 11) & 0x3FFFFu;
+                            if (MODE != 1) { const float Lv = lld(off + base); lst(off + base, Lv + dv); }
+                            else { const float Lv = gld(off, base); gst(off, base, Lv + dv); }
+                        }
+                    }
+                    {
+                        const const_u32 Tn = tab + (r + 1 < q ? r + 1 : 0) * LDPC_FAST_STRIDE;
+#pragma unroll
+                        for (int j = 0; j < 32; j++) TE[j] = Tn[j];
+                    }
+                    __syncthreads();
+                    continue;
+                }
                 float v[DEG];
                 uint32_t w[DEG];
                 const float c1o = nx1, c2o = nx2;
@@ -364,10 +456,10 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #endif
 }
 
-template <int DEG, int MODE>
+template <int DEG, int MODE, bool SPA = false>
 static hipError_t wg8_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
 {
-    auto kern = ldpc_wg8_kernel<DEG, MODE>;
+    auto kern = ldpc_wg8_kernel<DEG, MODE, SPA>;
     static size_t configured_dev[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -396,10 +488,10 @@ static hipError_t wg8_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t
     return hipGetLastError();
 }
 
-template <int DEG, int MODE>
+template <int DEG, int MODE, bool SPA = false>
 static int wg8_occ(const LdpcPlan &pl)
 {
-    auto kern = ldpc_wg8_kernel<DEG, MODE>;
+    auto kern = ldpc_wg8_kernel<DEG, MODE, SPA>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.w8_lds_bytes);
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 512, (size_t)pl.w8_lds_bytes) != hipSuccess) nb = 1;
@@ -413,7 +505,12 @@ static int wg8_occ(const LdpcPlan &pl)
      : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0>(__VA_ARGS__) : FN<13, 1>(__VA_ARGS__))                                           \
                          : (pl.fast_mode == 0 ? FN<11, 0>(__VA_ARGS__) : FN<11, 1>(__VA_ARGS__)))
 
-int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl) { return WG8_DISPATCH(wg8_occ, pl); }
+#define WG8_SPA_DISPATCH(FN, ...)                                                                                                                          \
+    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, true>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3, true>(__VA_ARGS__) : FN<27, 1, true>(__VA_ARGS__)) \
+     : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0, true>(__VA_ARGS__) : FN<13, 1, true>(__VA_ARGS__))                                                 \
+                         : (pl.fast_mode == 0 ? FN<11, 0, true>(__VA_ARGS__) : FN<11, 1, true>(__VA_ARGS__)))
+
+int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl) { return pl.spa ? WG8_SPA_DISPATCH(wg8_occ, pl) : WG8_DISPATCH(wg8_occ, pl); }
 
 hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
@@ -423,7 +520,7 @@ hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
     p.w8.nl_info = pl.w8_nl_info; p.w8.nl = pl.w8_nl; p.w8.ng_info = pl.w8_ng_info; p.w8.ng = pl.w8_ng;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.gwork_words = pl.w8_gwork_words;
-    return WG8_DISPATCH(wg8_inst, pl, p, s);
+    return pl.spa ? WG8_SPA_DISPATCH(wg8_inst, pl, p, s) : WG8_DISPATCH(wg8_inst, pl, p, s);
 }
 
 }  // namespace dvbs2
