@@ -186,9 +186,10 @@ tx_mod_kernel(const TxKParams p)
         const float sg = p.sigma[f];
         const uint4 r = philox4x32(make_uint4((uint32_t)i, (uint32_t)f, 1u, 0u), make_uint2(p.seed_lo, p.seed_hi));
         const float u1 = ((float)r.x + 1.0f) * 2.3283064365386963e-10f, u2 = (float)r.y * 2.3283064365386963e-10f;
-        const float rad = sqrtf(-2.0f * logf(u1));
-        float sn, cn;
-        sincosf(6.283185307179586f * u2, &sn, &cn);
+        // Box-Muller on the hardware units: v_log_f32, v_sqrt_f32, and v_sin_f32 / v_cos_f32, which take their argument in
+        // revolutions (u2 itself) -- the accurate libm forms cost ~10x the instructions and the noise needs none of it
+        const float rad = __builtin_amdgcn_sqrtf(-2.0f * hw_log(u1));
+        const float sn = __builtin_amdgcn_sinf(u2), cn = __builtin_amdgcn_cosf(u2);
         y.x += sg * rad * cn; y.y += sg * rad * sn;
     }
     reinterpret_cast<float2 *>(p.pl_out + (size_t)f * 2 * p.pl_frame)[i] = y;
@@ -203,9 +204,8 @@ __global__ void awgn_kernel(const float2 *x, float2 *y, const float *sigma, uint
     if (i >= n_pairs) return;
     const uint4 r = philox4x32(make_uint4((uint32_t)i, (uint32_t)f, 2u, (uint32_t)(i >> 32)), make_uint2(seed_lo, seed_hi));
     const float u1 = ((float)r.x + 1.0f) * 2.3283064365386963e-10f, u2 = (float)r.y * 2.3283064365386963e-10f;
-    const float rad = sigma[f] * sqrtf(-2.0f * logf(u1));
-    float sn, cn;
-    sincosf(6.283185307179586f * u2, &sn, &cn);
+    const float rad = sigma[f] * __builtin_amdgcn_sqrtf(-2.0f * hw_log(u1));
+    const float sn = __builtin_amdgcn_sinf(u2), cn = __builtin_amdgcn_cosf(u2);
     const float2 v = x[(size_t)f * n_pairs + i];
     y[(size_t)f * n_pairs + i] = make_float2(v.x + rad * cn, v.y + rad * sn);
 }
