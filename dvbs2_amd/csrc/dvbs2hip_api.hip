@@ -40,6 +40,7 @@ struct dvbs2hip_handle {
     float *d_cstl = nullptr;
     uint8_t *d_pl_seq = nullptr;
     float *d_taps_rev = nullptr;
+    uint16_t *d_fir_afrag = nullptr;       // Toeplitz fragments of the split taps for the matrix-core FIR (T <= 81)
     float *d_hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
     float *d_taps = nullptr;            // natural order (shaping filter)
@@ -76,6 +77,7 @@ struct dvbs2hip_handle {
     hipStream_t s_in = nullptr, s_out = nullptr;
     std::vector<hipEvent_t> ev_pipe;
     int ldpc_sched = DVBS2HIP_SCHED_QC;
+    int fir_kernel = DVBS2HIP_FIR_AUTO;
     float *d_nat_work = nullptr;       // natural-order LDPC: frame-interleaved image + state, ceil(max_frames / 64) groups
     float *d_lr_R = nullptr;
     float lr_alpha = 0.999f;
@@ -410,6 +412,10 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         std::vector<float> rev(h->fir_T);
         for (int i = 0; i < h->fir_T; i++) rev[i] = cfg->fir_taps[h->fir_T - 1 - i];
         if (upload(h, &h->d_taps_rev, rev.data(), rev.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+        if (h->fir_T <= 81) {
+            const std::vector<uint16_t> af = fir_mfma_afrag(rev.data(), h->fir_T);
+            if (upload(h, &h->d_fir_afrag, af.data(), af.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+        }
         const size_t hb = sizeof(float) * 2 * (size_t)(h->fir_T > 1 ? h->fir_T - 1 : 1);
         for (int i = 0; i < 2; i++) { CREATE_HIP(hipMalloc((void **)&h->d_hist[i], hb)); CREATE_HIP(hipMemset(h->d_hist[i], 0, hb)); }
         if (upload(h, &h->d_taps, cfg->fir_taps, (size_t)h->fir_T)) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
@@ -437,7 +443,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
     if (h->s_out) (void)hipStreamDestroy(h->s_out);
     void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
-                        h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz};
+                        h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
@@ -455,6 +461,15 @@ int dvbs2hip_set_ldpc_schedule(dvbs2hip_t *h, int32_t schedule)
     if (schedule == DVBS2HIP_SCHED_NATURAL && (!h->ldpc.fast || h->ldpc.spa))
         return fail(h, DVBS2HIP_EUNSUPPORTED, "the natural-order schedule is implemented for NMS / MS on codes with check degree <= 27");
     h->ldpc_sched = schedule;
+    return 0;
+}
+
+int dvbs2hip_set_filter_kernel(dvbs2hip_t *h, int32_t kernel)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    if (kernel != DVBS2HIP_FIR_AUTO && kernel != DVBS2HIP_FIR_VALU && kernel != DVBS2HIP_FIR_MFMA) return fail(h, DVBS2HIP_EINVAL, "unknown filter kernel");
+    if (kernel == DVBS2HIP_FIR_MFMA && !h->d_fir_afrag) return fail(h, DVBS2HIP_EUNSUPPORTED, "the matrix-core filter takes at most 81 taps");
+    h->fir_kernel = kernel;
     return 0;
 }
 
@@ -713,7 +728,7 @@ int dvbs2hip_filter_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx,
     if (h->fir_T <= 0) return fail(h, DVBS2HIP_EUNSUPPORTED, "handle was created without filter taps");
     if (n_cplx < 1) return fail(h, DVBS2HIP_EINVAL, "'n_cplx' has to be greater than 0");
     Timer tm(h, DVBS2HIP_K_FIR);
-    HIPCHK(h, fir_launch(X, Y, h->d_hist[h->hist_cur], h->d_hist[h->hist_cur ^ 1], h->d_taps_rev, h->fir_T,
+    HIPCHK(h, fir_launch(X, Y, h->d_hist[h->hist_cur], h->d_hist[h->hist_cur ^ 1], h->d_taps_rev, h->fir_kernel == DVBS2HIP_FIR_VALU ? nullptr : h->d_fir_afrag, h->fir_T,
                          (long long)n_cplx * F, h->stream));
     h->hist_cur ^= 1;
     return 0;

@@ -189,8 +189,12 @@ hipError_t tx_launch(const TxKParams &p, hipStream_t s);
 std::vector<uint8_t> bch_generator(const BchPlan &pl);
 
 // ---------------------------------------------------------------- FIR (a5)
-hipError_t fir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps_rev,
+hipError_t fir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps_rev, const uint16_t *afrag,
                       int T, long long n_total, hipStream_t s);
+// matrix-core form (k_fir_mfma.hip): bf16 x 3 split operands, fp32 accumulation
+std::vector<uint16_t> fir_mfma_afrag(const float *taps_rev, int T);
+bool fir_mfma_usable(const float *x, const float *y, int T, long long n_total);
+hipError_t fir_mfma_launch(const float *x, float *y, const float *hist_in, float *hist_out, const uint16_t *afrag, int T, long long n_total, hipStream_t s);
 
 hipError_t upfir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps, int T, int osf,
                         long long n_in, hipStream_t s);

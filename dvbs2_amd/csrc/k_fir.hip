@@ -14,8 +14,10 @@
 // once through LDS with a +1-per-8 pad that makes the stride-8 window reads conflict-free, and
 // the taps are wave-uniform scalars.  fp32 FMA like the reference's mipp::fmadd; the f32 MFMA
 // runs at the same rate as the vector FMA on gfx950 and a Toeplitz recast would waste flops on
-// the structural zeros, so there is no MFMA variant.
+// the structural zeros; the matrix-core form that does pay -- bf16 x 3 split operands -- is k_fir_mfma.hip, the default
+// for T <= 81, and this kernel serves longer filters, unaligned sockets and DVBS2HIP_FIR=valu.
 #include "dvbs2hip_internal.h"
+#include <cstdlib>
 
 namespace dvbs2 {
 
@@ -93,11 +95,16 @@ __global__ void fir_hist_kernel(const float2 *x, const float2 *hist_in, float2 *
     hist_out[i] = gi >= 0 ? x[gi] : hist_in[H + gi];
 }
 
-hipError_t fir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps_rev,
+// afrag != nullptr: the matrix-core form (k_fir_mfma.hip) when it applies (T <= 81, 16-byte aligned sockets);
+// dvbs2hip_set_filter_kernel(h, DVBS2HIP_FIR_VALU) (afrag == nullptr here) or DVBS2HIP_FIR=valu keep the vector kernel
+hipError_t fir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps_rev, const uint16_t *afrag,
                       int T, long long n_total, hipStream_t s)
 {
     if (T < 1 || T > FIR_TMAX) return hipErrorInvalidValue;
     const int H = T - 1;
+    static const bool force_valu = [] { const char *e = getenv("DVBS2HIP_FIR"); return e && e[0] == 'v'; }();
+    if (afrag && !force_valu && fir_mfma_usable(x, y, T, n_total))
+        return fir_mfma_launch(x, y, hist_in, hist_out, afrag, T, n_total, s);
     const size_t lds = sizeof(float2) * (size_t)(fir_pad(FIR_TILE + H) + 1);
     const unsigned grid = (unsigned)((n_total + FIR_TILE - 1) / FIR_TILE);
     const float2 *x2 = reinterpret_cast<const float2 *>(x);

@@ -43,6 +43,7 @@ class Sizes(C.Structure):
 # name -> (restype, argtypes).  Every symbol of include/dvbs2hip.h; tests/test_abi.py checks
 # the list against the header and against the built .so.
 SCHED_QC, SCHED_NATURAL = 0, 1
+FIR_AUTO, FIR_VALU, FIR_MFMA = 0, 1, 2
 _vp, _i, _f = C.c_void_p, C.c_int32, C.c_float
 _SOCK2 = [_vp, _vp, _vp, _i]
 ABI = {
@@ -52,6 +53,7 @@ ABI = {
     "dvbs2hip_last_error": (C.c_char_p, [_vp]),
     "dvbs2hip_ldpc_kernel_name": (C.c_char_p, [_vp]),
     "dvbs2hip_set_ldpc_schedule": (C.c_int, [_vp, _i]),
+    "dvbs2hip_set_filter_kernel": (C.c_int, [_vp, _i]),
     "dvbs2hip_host_register": (C.c_int, [_vp, _vp, C.c_size_t]),
     "dvbs2hip_host_unregister": (C.c_int, [_vp, _vp]),
     "dvbs2hip_reset": (C.c_int, [_vp]),

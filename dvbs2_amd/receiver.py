@@ -332,6 +332,10 @@ class Dvbs2Hip:
     def sync_freq_phase_synchronize(self, X_N1):
         return self._sff(self.L.dvbs2hip_sync_freq_phase_synchronize, X_N1)
 
+    def set_filter_kernel(self, kernel):
+        """B.FIR_AUTO (default: matrix cores for <= 81 taps), B.FIR_VALU or B.FIR_MFMA"""
+        self._chk(self.L.dvbs2hip_set_filter_kernel(self.h, int(kernel)))
+
     def set_ldpc_schedule(self, schedule):
         """B.SCHED_QC (default) or B.SCHED_NATURAL (the reference's row order, one lane per frame)"""
         self._chk(self.L.dvbs2hip_set_ldpc_schedule(self.h, int(schedule)))

@@ -193,6 +193,8 @@ public:
     }
     void filter(const float *X_N1, float *Y_N2) { DVBS2HIP_CHK(ctx, dvbs2hip_filter(ctx->h, X_N1, Y_N2, N / 2, F())); }
     void reset() { DVBS2HIP_CHK(ctx, dvbs2hip_filter_reset(ctx->h)); }
+    // DVBS2HIP_FIR_AUTO (matrix cores for <= 81 taps) | DVBS2HIP_FIR_VALU | DVBS2HIP_FIR_MFMA
+    void set_kernel(int kernel) { DVBS2HIP_CHK(ctx, dvbs2hip_set_filter_kernel(ctx->h, kernel)); }
 private:
     int N;
 };

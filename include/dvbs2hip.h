@@ -181,6 +181,12 @@ int dvbs2hip_demodulate_deinterleave_dev(dvbs2hip_t *h, const float *CP, const f
 int dvbs2hip_filter(dvbs2hip_t *h, const float *X_N1, float *Y_N2, int32_t n_cplx, int32_t n_frames);
 int dvbs2hip_filter_dev(dvbs2hip_t *h, const float *X_N1, float *Y_N2, int32_t n_cplx, int32_t n_frames);
 int dvbs2hip_filter_reset(dvbs2hip_t *h);
+/* Kernel behind dvbs2hip_filter[_dev] on this handle.  AUTO (default): the matrix-core form (bf16 x 3 split operands,
+ * fp32 accumulation, k_fir_mfma.hip) for filters of at most 81 taps on 16-byte aligned sockets, the fp32 vector kernel
+ * otherwise; VALU forces the vector kernel; MFMA returns DVBS2HIP_EUNSUPPORTED for a longer filter.  Both meet the same
+ * 1e-4 bar against Filter_FIR_ccr's fp32 FMA chain (neither reproduces its rounding order bit for bit). */
+enum { DVBS2HIP_FIR_AUTO = 0, DVBS2HIP_FIR_VALU = 1, DVBS2HIP_FIR_MFMA = 2 };
+int dvbs2hip_set_filter_kernel(dvbs2hip_t *h, int32_t kernel);
 
 /* ------------------------------------------------------------------ a6  noise estimator
  * replaces: Estimator<R>::estimate(X_N, SIG, Eb_N0, Es_N0) -> Estimator_DVBS2<R>::_estimate

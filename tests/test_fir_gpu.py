@@ -13,12 +13,16 @@ def Rx():
     return Dvbs2Hip
 
 
-def test_fir_matches_oracle_and_keeps_state(O, Rx, P):
+@pytest.mark.parametrize("kernel", ["auto", "valu", "mfma"])
+def test_fir_matches_oracle_and_keeps_state(O, Rx, P, kernel):
+    """both kernels behind dvbs2hip_filter: the fp32 vector FIR and the matrix-core FIR (bf16 x 3 split operands)"""
+    from dvbs2_amd import lib_binding as B
     taps = P.rrc_taps(0.2, 2, 20)
     assert taps.size == 81
     rng = np.random.default_rng(5)
     F, n = 3, 6804                       # 32APSK-S pl_frame 3402 * osf 2 (BASELINE config 5)
     rx = Rx("32APSK-S_3/4", max_frames=8)
+    rx.set_filter_kernel({"auto": B.FIR_AUTO, "valu": B.FIR_VALU, "mfma": B.FIR_MFMA}[kernel])
     hist = np.zeros(2 * 80, np.float32)
     for call in range(3):
         x = rng.standard_normal(F * 2 * n).astype(np.float32)
@@ -33,9 +37,12 @@ def test_fir_matches_oracle_and_keeps_state(O, Rx, P):
     rx.close()
 
 
-def test_fir_impulse_ragged_and_tiny(O, Rx, P):
-    taps = P.rrc_taps(0.35, 4, 5)        # 41 taps: run-time tap-count path
+@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+def test_fir_impulse_ragged_and_tiny(O, Rx, P, kernel):
+    from dvbs2_amd import lib_binding as B
+    taps = P.rrc_taps(0.35, 4, 5)        # 41 taps: run-time tap-count path (vector kernel), zero-padded band (matrix cores)
     rx = Rx("QPSK-S_8/9", max_frames=4, fir_taps=taps, fir_osf=4)
+    rx.set_filter_kernel(B.FIR_VALU if kernel == "valu" else B.FIR_MFMA)
     x = np.zeros(2 * 300, np.float32)
     x[0] = 1.0
     y = rx.filter(x, 1)
@@ -49,6 +56,49 @@ def test_fir_impulse_ragged_and_tiny(O, Rx, P):
         y = rx.filter(x, 1)
         yo = O.fir(taps, hist, x)
         assert np.max(np.abs(y - yo)) <= TOL, n
+    rx.close()
+
+
+def test_fir_mfma_large_stream_tile_carry_and_tail(O, Rx, P):
+    """several tiles per persistent workgroup (overlap carried in LDS), a ragged tail, state across calls; the two kernels
+    agree with each other far inside the 1e-4 bar; an unaligned device socket falls back to the vector kernel; a filter
+    longer than 81 taps refuses the matrix-core form"""
+    import torch
+    from dvbs2_amd import lib_binding as B
+    taps = P.rrc_taps(0.2, 2, 20)
+    rng = np.random.default_rng(21)
+    F, n = 37, 66564                                         # 2 462 868 samples = 1202.6 tiles of 2048: two tiles per workgroup
+    rx = Rx("QPSK-N_8/9", max_frames=F)
+    hist = np.zeros(2 * 80, np.float32)
+    x1 = rng.standard_normal(F * 2 * n).astype(np.float32)
+    out = {}
+    for kern in (B.FIR_MFMA, B.FIR_VALU):
+        rx.filter_reset(); rx.set_filter_kernel(kern)
+        ya = rx.filter(x1, n_frames=F)
+        out[kern] = ya
+    yo = O.fir(taps, hist, x1)
+    assert np.max(np.abs(out[B.FIR_MFMA] - yo)) <= TOL and np.max(np.abs(out[B.FIR_VALU] - yo)) <= TOL
+    assert np.max(np.abs(out[B.FIR_MFMA] - out[B.FIR_VALU])) <= 2e-5
+    # second call continues the stream (filter memory written by the matrix-core kernel itself), odd sample count
+    rx.filter_reset(); rx.set_filter_kernel(B.FIR_MFMA)
+    rx.filter(x1, n_frames=F)
+    m = 4099
+    x3 = rng.standard_normal(2 * m).astype(np.float32)
+    y3 = rx.filter(x3, 1)
+    assert np.max(np.abs(y3 - O.fir(taps, x1[-160:].copy(), x3))) <= TOL
+    # unaligned device sockets (8-byte offset): AUTO falls back to the vector kernel, results unchanged
+    rx.filter_reset(); rx.set_filter_kernel(B.FIR_AUTO)
+    dx = torch.zeros(2 * m + 2, dtype=torch.float32, device="cuda"); dy = torch.zeros_like(dx)
+    dx[2:] = torch.from_numpy(x3).cuda()
+    rx.filter_dev(dx.data_ptr() + 8, dy.data_ptr() + 8, m, 1); rx.synchronize()
+    assert np.max(np.abs(dy[2:].cpu().numpy() - O.fir(taps, np.zeros(160, np.float32), x3))) <= TOL
+    rx.close()
+    long_taps = P.rrc_taps(0.2, 4, 20)                       # 161 taps
+    rx = Rx("QPSK-S_8/9", max_frames=1, fir_taps=long_taps, fir_osf=4)
+    with pytest.raises(Exception):
+        rx.set_filter_kernel(B.FIR_MFMA)
+    x = rng.standard_normal(2 * 3000).astype(np.float32)
+    assert np.max(np.abs(rx.filter(x, 1) - O.fir(long_taps, np.zeros(320, np.float32), x))) <= TOL
     rx.close()
 
 
