@@ -77,6 +77,8 @@ struct dvbs2hip_handle {
     hipStream_t s_in = nullptr, s_out = nullptr;
     std::vector<hipEvent_t> ev_pipe;
     int ldpc_sched = DVBS2HIP_SCHED_QC;
+    int sep = 0, sep_ax[2] = {0, 0};       // separable 2-bit constellation: linear exact LLRs (k_front.hip, demap_sep2)
+    float sep_g[2] = {0.f, 0.f}, sep_h[2] = {0.f, 0.f};
     int fir_kernel = DVBS2HIP_FIR_AUTO;
     float *d_nat_work = nullptr;       // natural-order LDPC: frame-interleaved image + state, ceil(max_frames / 64) groups
     float *d_lr_R = nullptr;
@@ -401,6 +403,24 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
     if (!(sc > 0.f)) CREATE_FAIL(DVBS2HIP_EINVAL, "constellation has zero energy");
     for (int i = 0; i < 2 * P; i++) cs[i] = cfg->cstl[i] / sc;
     if (upload(h, &h->d_cstl, cs.data(), cs.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+    if (cfg->bps == 2 && !getenv("DVBS2HIP_DEMAP_GENERAL")) {
+        // bit b on one axis alone, two levels, the two bits on different axes => the four points are the product set
+        int ax[2] = {-1, -1};
+        float lv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        for (int b = 0; b < 2; b++)
+            for (int a = 0; a < 2 && ax[b] < 0; a++) {
+                float v[2] = {0.f, 0.f}; bool have[2] = {false, false}, ok = true;
+                for (int s = 0; s < 4 && ok; s++) {
+                    const int bit = (s >> b) & 1; const float c = cs[2 * s + a];
+                    if (!have[bit]) { v[bit] = c; have[bit] = true; } else if (fabsf(v[bit] - c) > 1e-6f) ok = false;
+                }
+                if (ok && fabsf(v[0] - v[1]) > 1e-3f) { ax[b] = a; lv[b][0] = v[0]; lv[b][1] = v[1]; }
+            }
+        if (ax[0] >= 0 && ax[1] >= 0 && ax[0] != ax[1]) {
+            h->sep = 1;
+            for (int b = 0; b < 2; b++) { h->sep_ax[b] = ax[b]; h->sep_g[b] = 2.0f * (lv[b][0] - lv[b][1]); h->sep_h[b] = lv[b][1] * lv[b][1] - lv[b][0] * lv[b][0]; }
+        }
+    }
     std::vector<uint8_t> seq;
     pl_sequence(seq);
     if (h->pl_frame - 90 > (int)seq.size()) CREATE_FAIL(DVBS2HIP_EINVAL, "PL frame longer than the scrambling sequence");
@@ -626,6 +646,7 @@ static FrontKParams front_params(dvbs2hip_t *h, const float *in, const float *si
     p.in = in; p.sigma_in = sigma; p.llr = llr; p.est = est; p.cstl = h->d_cstl; p.pl_seq = h->d_pl_seq;
     p.n_sym = h->n_sym; p.pl_frame = h->pl_frame; p.bps = h->bps; p.itl_cols = h->itl_cols; p.itl_order = h->itl_order;
     p.n_frames = F; p.code_rate = h->code_rate;
+    p.sep = h->sep; for (int b = 0; b < 2; b++) { p.sep_ax[b] = h->sep_ax[b]; p.sep_g[b] = h->sep_g[b]; p.sep_h[b] = h->sep_h[b]; }
     return p;
 }
 

@@ -155,6 +155,9 @@ struct FrontKParams {
     const uint8_t *pl_seq;  // PL scrambling sequence R(i), 66420 entries
     int32_t n_sym, pl_frame, bps, itl_cols, itl_order, n_frames;
     float code_rate;
+    // separable 2-bit constellation (plan time): L_b = c (y[sep_ax[b]] * sep_g[b] + sep_h[b]); sep = 0: general demapper
+    int32_t sep, sep_ax[2];
+    float sep_g[2], sep_h[2];
 };
 hipError_t front_rx_launch(FrontKParams p, hipStream_t s);                     // a7+a6+a3+a4 fused, in = pl frames
 hipError_t demod_launch(FrontKParams p, bool deinterleave, hipStream_t s);     // a3 (+a4), in = xfec frames, sigma_in required

@@ -52,62 +52,86 @@ __device__ __forceinline__ int deitl_index(int k, int b, int bps, int cols, int 
 
 // Exact log-sum-exp demapper:  L_b = max*_{s: bit_b(s)=0}(met_s) - max*_{s: bit_b(s)=1}(met_s),
 // met_s = -|y - s|^2 / (2 sigma^2).  The reference (Modem_generic_fast, MAX = max_star) folds
-// max*(a,b) = max(a,b) + log1p(exp(-|a-b|)) pairwise; the same quantity is evaluated here as
-// m + log(sum exp(met - m)) with m the maximum of the subset: 2^bps exp + 2 log per bit instead
-// of (2^bps - 2) exp AND log1p, every term relative to its own subset's maximum (the largest term
-// is exp(0) = 1, so nothing underflows at high SNR), on the hardware exp2/log2 units.
+// max*(a,b) = max(a,b) + log1p(exp(-|a-b|)) pairwise; the same quantity is evaluated here with far fewer
+// instructions (the kernel is bound by the vector ALU, not by HBM, once a frame has 8+ points per symbol):
+//  * |y|^2 is common to all points and drops out of every difference:  met_s = c (2 y.s - |s|^2) + const,
+//    c = 1 / (2 sigma^2).  In log2 units u_s = yr A_s + yi B_s + D_s with the per-FRAME table
+//    (A, B, D)_s = c log2(e) (2 re s, 2 im s, -|s|^2) in LDS: two FMAs per point, operands broadcast from LDS and
+//    shared by the U symbols a lane demaps together;
+//  * one exp2 per point relative to the overall maximum, shared by all bits;
+//  * the subset sums of all bits from one pairwise tree (bit b splits the level-b partial sums into even / odd):
+//    82 additions for 32 points instead of 150;
+//  * two log2 and one multiply per bit.
+// The exponentials are taken relative to 2^-120 of the overall maximum, so a subset sum is a normal number with full
+// relative precision unless the whole subset lies 2^-220 below the maximum (|LLR| beyond ~150: sum < 2^-100); such a
+// symbol takes the per-subset form, every term relative to its own subset's maximum.
 // |LLR error| vs the pairwise form stays below 1e-4 * max(1, |LLR|) (tests/test_front_gpu.py).
+constexpr float FRONT_LOG2E = 1.44269504088896341f, FRONT_LN2 = 0.693147180559945309f;
+
+// per-frame table of the constellation, thread s < 2^bps:  tab[s] = c log2(e) (2 re, 2 im, -|s|^2, 0)
+__device__ __forceinline__ float4 demap_table_entry(const float *cstl, int s, float inv2s2)
+{
+    const float k = inv2s2 * FRONT_LOG2E, sr = cstl[2 * s], si = cstl[2 * s + 1];
+    return make_float4(2.0f * k * sr, 2.0f * k * si, -k * (sr * sr + si * si), 0.f);
+}
+
 template <int BPS>
-__device__ __forceinline__ void demap_symbol(float2 y, float inv2s2, const float *cs, float *out)
+__device__ __forceinline__ void demap_symbol_far(float yr, float yi, const float4 *tab, float *out)
 {
     constexpr int P = 1 << BPS;
-    float met[P];
-    float mall = -INFINITY;
+    float u[P];
 #pragma unroll
     for (int s = 0; s < P; s++) {
-        const float dr = y.x - cs[2 * s], di = y.y - cs[2 * s + 1];
-        met[s] = -(dr * dr + di * di) * inv2s2;
-        mall = fmaxf(mall, met[s]);
-    }
-    if (BPS >= 3) {
-        // One exponential per constellation point instead of one per point AND bit: e_s = exp(met_s - max over all points),
-        // L_b = log(sum of e_s over the bit-0 subset) - log(sum over the bit-1 subset) -- the same quantity, as long as the
-        // largest term of every subset is still a normal number, i.e. no subset maximum lies more than ~80 below the overall
-        // one (|L_b| <= 80).  Symbols beyond that (very high SNR) take the per-subset form below.
-        float e[P], lo = mall;
-#pragma unroll
-        for (int b = 0; b < BPS; b++) {
-            float m0 = -INFINITY, m1 = -INFINITY;
-#pragma unroll
-            for (int s = 0; s < P; s++) { if (((s >> b) & 1) == 0) m0 = fmaxf(m0, met[s]); else m1 = fmaxf(m1, met[s]); }
-            lo = fminf(lo, fminf(m0, m1));
-        }
-        if (mall - lo <= 80.0f) {
-#pragma unroll
-            for (int s = 0; s < P; s++) e[s] = hw_exp(met[s] - mall);
-#pragma unroll
-            for (int b = 0; b < BPS; b++) {
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int s = 0; s < P; s++) { if (((s >> b) & 1) == 0) s0 += e[s]; else s1 += e[s]; }
-                out[b] = hw_log(s0) - hw_log(s1);
-            }
-            return;
-        }
+        if ((s & 7) == 0) asm volatile("" ::: "memory");          // at most 8 table rows in flight (registers)
+        const float4 t = tab[s]; u[s] = fmaf(yr, t.x, fmaf(yi, t.y, t.z));
     }
 #pragma unroll
     for (int b = 0; b < BPS; b++) {
         float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
-        for (int s = 0; s < P; s++) {
-            if (((s >> b) & 1) == 0) m0 = fmaxf(m0, met[s]); else m1 = fmaxf(m1, met[s]);
-        }
+        for (int s = 0; s < P; s++) { if (((s >> b) & 1) == 0) m0 = fmaxf(m0, u[s]); else m1 = fmaxf(m1, u[s]); }
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int s = 0; s < P; s++) {
-            if (((s >> b) & 1) == 0) s0 += hw_exp(met[s] - m0); else s1 += hw_exp(met[s] - m1);
+        for (int s = 0; s < P; s++) { if (((s >> b) & 1) == 0) s0 += __builtin_amdgcn_exp2f(u[s] - m0); else s1 += __builtin_amdgcn_exp2f(u[s] - m1); }
+        out[b] = FRONT_LN2 * ((m0 - m1) + (__builtin_amdgcn_logf(s0) - __builtin_amdgcn_logf(s1)));
+    }
+}
+
+template <int BPS, int U>
+__device__ __forceinline__ void demap_symbols(const float2 (&y)[U], const float4 *tab, float (&out)[U][BPS])
+{
+    constexpr int P = 1 << BPS;
+    float u[U][P], mx[U];
+#pragma unroll
+    for (int i = 0; i < U; i++) mx[i] = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+        if ((s & 7) == 0) asm volatile("" ::: "memory");          // at most 8 table rows in flight (registers)
+        const float4 t = tab[s];
+#pragma unroll
+        for (int i = 0; i < U; i++) { u[i][s] = fmaf(y[i].x, t.x, fmaf(y[i].y, t.y, t.z)); mx[i] = fmaxf(mx[i], u[i][s]); }
+    }
+#pragma unroll
+    for (int i = 0; i < U; i++) {
+        // relative to 2^-120 of the largest term: the sums stay below 2^(120 + BPS) < 2^128 and a subset keeps full relative
+        // precision down to 2^-220 of the overall maximum (|LLR| up to ~150) before the per-subset form is needed
+        const float ref = mx[i] - 120.0f;
+#pragma unroll
+        for (int s = 0; s < P; s++) u[i][s] = __builtin_amdgcn_exp2f(u[i][s] - ref);
+        float lo = 1.0f;
+#pragma unroll
+        for (int b = 0; b < BPS; b++) {
+            const int n = P >> b;                      // partial sums left at this level: index bit 0 is bit b of the point
+            float s0 = u[i][0], s1 = u[i][1];
+#pragma unroll
+            for (int j = 1; j < n / 2; j++) { s0 += u[i][2 * j]; s1 += u[i][2 * j + 1]; }
+            out[i][b] = FRONT_LN2 * (__builtin_amdgcn_logf(s0) - __builtin_amdgcn_logf(s1));
+            lo = fminf(lo, fminf(s0, s1));
+#pragma unroll
+            for (int j = 0; j < n / 2; j++) u[i][j] = u[i][2 * j] + u[i][2 * j + 1];
         }
-        out[b] = (m0 - m1) + (hw_log(s0) - hw_log(s1));
+        // wave-uniform test first: a real branch around the rare path (a per-lane condition alone is flattened into predicated code)
+        if (__builtin_amdgcn_ballot_w64(lo < 0x1p-100f) != 0ull) { if (lo < 0x1p-100f) demap_symbol_far<BPS>(y[i].x, y[i].y, tab, out[i]); }
     }
 }
 
@@ -136,17 +160,27 @@ __device__ __forceinline__ void m2m4_finish(float m2, float m4, int n_sym, float
     ebn0 = esn0 - 10.0f * log10f(code_rate * (float)bps);
 }
 
+// separable 2-bit constellation (every reference QPSK mapping): bit b is carried by one axis alone with two levels
+// (A0 for bit 0, A1 for bit 1), the other axis cancels out of the ratio and the exact LLR is linear,
+//     L_b = c (2 y_ax (A0 - A1) + A1^2 - A0^2),        c = 1 / (2 sigma^2)
+// (the pairwise max* form evaluates the same number through four exponentials).  Detected on the host at plan time.
+__device__ __forceinline__ void demap_sep2(float2 y, float c, const FrontKParams &p, float *out)
+{
+    out[0] = c * fmaf(p.sep_ax[0] ? y.y : y.x, p.sep_g[0], p.sep_h[0]);
+    out[1] = c * fmaf(p.sep_ax[1] ? y.y : y.x, p.sep_g[1], p.sep_h[1]);
+}
+
 // FROM_PL = true : in = PL frames, a7 folded in, sigma estimated unless sigma_in given
 // FROM_PL = false: in = XFEC frames, sigma_in required
 template <int BPS, bool FROM_PL, bool DEITL>
 __global__ void __launch_bounds__(FRONT_THREADS)
 front_kernel(const FrontKParams p)
 {
-    __shared__ float cs[2 * (1 << BPS)];
+    constexpr int U = BPS <= 3 ? 4 : 1;          // symbols a lane demaps per read of the constellation table
+    __shared__ float4 tab[1 << BPS];
     __shared__ float red[FRONT_THREADS / 64];
     __shared__ float s_sigma;
     const int tid = threadIdx.x, f = blockIdx.x;
-    if (tid < 2 * (1 << BPS)) cs[tid] = p.cstl[tid];
     const int n_sym = p.n_sym, n_pil = n_sym / (PL_SLOTS * PL_M);
     const size_t in_stride = FROM_PL ? 2 * (size_t)p.pl_frame : 2 * (size_t)n_sym;
     const float2 *in = reinterpret_cast<const float2 *>(p.in + (size_t)f * in_stride);
@@ -170,22 +204,47 @@ front_kernel(const FrontKParams p)
         sigma = s_sigma;
         if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = 0.f; p.est[3 * f + 2] = 0.f; }
     }
-    __syncthreads();
     const float inv2s2 = 1.0f / (2.0f * sigma * sigma);
+    if (tid < (1 << BPS)) tab[tid] = demap_table_entry(p.cstl, tid, inv2s2);
+    __syncthreads();
     float *llr = p.llr + (size_t)f * n_sym * BPS;
     const int n_rows = (n_sym * BPS) / (p.itl_cols > 1 ? p.itl_cols : 1);
-    for (int k = tid; k < n_sym; k += FRONT_THREADS) {
-        float2 y;
-        if (FROM_PL) {
-            const int pi = pl_index(k, n_pil);
-            y = pl_derotate(in[pi], p.pl_seq[pi - PL_M]);
-        } else y = in[k];
-        float out[BPS];
-        demap_symbol<BPS>(y, inv2s2, cs, out);
+    const bool sep = BPS == 2 && p.sep != 0;
+    // the symbols of iteration i + 1 are requested before those of iteration i are demapped (the arithmetic of one
+    // iteration is about as long as an HBM round trip, and a lane has nothing else to overlap it with)
+    float2 yn[U];
+    int Rn[U];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int b = 0; b < BPS; b++) {
-            const int dst = DEITL ? deitl_index(k, b, BPS, p.itl_cols, p.itl_order, n_rows) : k * BPS + b;
-            llr[dst] = out[b];
+        for (int i = 0; i < U; i++) {
+            const int k = k0 + i * FRONT_THREADS;
+            yn[i] = make_float2(0.f, 0.f); Rn[i] = 0;
+            if (k < n_sym) {
+                if (FROM_PL) { const int pi = pl_index(k, n_pil); yn[i] = in[pi]; Rn[i] = p.pl_seq[pi - PL_M]; }
+                else yn[i] = in[k];
+            }
+        }
+    };
+    fetch(tid);
+    for (int k0 = tid; k0 < n_sym; k0 += U * FRONT_THREADS) {
+        float2 y[U];
+#pragma unroll
+        for (int i = 0; i < U; i++) y[i] = FROM_PL ? pl_derotate(yn[i], Rn[i]) : yn[i];
+        fetch(k0 + U * FRONT_THREADS);
+        float out[U][BPS];
+        if (sep) {
+#pragma unroll
+            for (int i = 0; i < U; i++) demap_sep2(y[i], inv2s2, p, out[i]);
+        } else demap_symbols<BPS, U>(y, tab, out);
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            const int k = k0 + i * FRONT_THREADS;
+            if (k >= n_sym) continue;
+#pragma unroll
+            for (int b = 0; b < BPS; b++) {
+                const int dst = DEITL ? deitl_index(k, b, BPS, p.itl_cols, p.itl_order, n_rows) : k * BPS + b;
+                llr[dst] = out[i][b];
+            }
         }
     }
 }
@@ -196,14 +255,13 @@ front_kernel(const FrontKParams p)
 // are all in flight together, and QPSK LLR pairs leave as one 8-byte store per lane.
 constexpr int FRONT_WIDE = 1024;
 typedef float front_f2 __attribute__((ext_vector_type(2)));      // a type the non-temporal builtins accept
-template <int BPS, int SPT>
+template <int BPS, int SPT, bool SEP>            // SEP: separable 2-bit constellation, linear LLRs (no general demapper compiled in)
 __global__ void __launch_bounds__(FRONT_WIDE)
 front_reg_kernel(const FrontKParams p)
 {
-    __shared__ float cs[2 * (1 << BPS)];
+    __shared__ float4 tab[1 << BPS];
     __shared__ float red[2][FRONT_WIDE / 64];
     const int tid = threadIdx.x, f = blockIdx.x;
-    if (tid < 2 * (1 << BPS)) cs[tid] = p.cstl[tid];
     const int n_sym = p.n_sym, n_pil = n_sym / (PL_SLOTS * PL_M);
     const float2 *in = reinterpret_cast<const float2 *>(p.in + (size_t)f * 2 * (size_t)p.pl_frame);
     float2 y[SPT];
@@ -232,26 +290,45 @@ front_reg_kernel(const FrontKParams p)
         m2m4_finish(m2, m4, n_sym, p.code_rate, p.bps, sigma, ebn0, esn0);
         if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = ebn0; p.est[3 * f + 2] = esn0; }
     } else {
-        __syncthreads();                           // the constellation is in LDS
         sigma = p.sigma_in[f];
         if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = 0.f; p.est[3 * f + 2] = 0.f; }
     }
     const float inv2s2 = 1.0f / (2.0f * sigma * sigma);
+    if (!SEP) {
+        if (tid < (1 << BPS)) tab[tid] = demap_table_entry(p.cstl, tid, inv2s2);
+        __syncthreads();
+    }
     float *llr = p.llr + (size_t)f * n_sym * BPS;
     const int n_rows = (n_sym * BPS) / (p.itl_cols > 1 ? p.itl_cols : 1);
     const bool pairs = BPS == 2 && p.itl_cols <= 1;
+    constexpr bool sep = SEP;
+    constexpr int U = 1;                           // the frame itself fills the registers
+    static_assert(SPT % U == 0, "symbols per lane come in groups of U");
 #pragma unroll
-    for (int i = 0; i < SPT; i++) {
-        const int k = tid + i * FRONT_WIDE;
-        asm volatile("" ::: "memory");             // one symbol at a time: nothing of the next one is hoisted into registers
-        if (k >= n_sym) continue;
-        float out[BPS];
-        const int R = (int)__builtin_amdgcn_raw_buffer_load_b8(rsq, pl_index(k, n_pil) - PL_M, 0, 0);      // L2-resident table
-        demap_symbol<BPS>(pl_derotate(y[i], R), inv2s2, cs, out);
-        if (pairs) { front_f2 v; v.x = out[0]; v.y = out[BPS - 1]; __builtin_nontemporal_store(v, reinterpret_cast<front_f2 *>(llr) + k); }
-        else {
+    for (int i0 = 0; i0 < SPT; i0 += U) {
+        asm volatile("" ::: "memory");             // one group at a time: nothing of the next one is hoisted into registers
+        if (tid + i0 * FRONT_WIDE >= n_sym) continue;
+        float2 yy[U];
+        float out[U][BPS];
 #pragma unroll
-            for (int b = 0; b < BPS; b++) llr[deitl_index(k, b, BPS, p.itl_cols, p.itl_order, n_rows)] = out[b];
+        for (int i = 0; i < U; i++) {
+            const int k = tid + (i0 + i) * FRONT_WIDE;
+            const int R = (int)__builtin_amdgcn_raw_buffer_load_b8(rsq, (k < n_sym ? pl_index(k, n_pil) : PL_M) - PL_M, 0, 0);      // L2-resident table
+            yy[i] = pl_derotate(y[i0 + i], R);
+        }
+        if constexpr (sep) {
+#pragma unroll
+            for (int i = 0; i < U; i++) demap_sep2(yy[i], inv2s2, p, out[i]);
+        } else demap_symbols<BPS, U>(yy, tab, out);
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            const int k = tid + (i0 + i) * FRONT_WIDE;
+            if (k >= n_sym) continue;
+            if (pairs) { front_f2 v; v.x = out[i][0]; v.y = out[i][BPS - 1]; __builtin_nontemporal_store(v, reinterpret_cast<front_f2 *>(llr) + k); }
+            else {
+#pragma unroll
+                for (int b = 0; b < BPS; b++) llr[deitl_index(k, b, BPS, p.itl_cols, p.itl_order, n_rows)] = out[i][b];
+            }
         }
     }
 }
@@ -261,10 +338,12 @@ static bool front_reg_try(const FrontKParams &p, hipStream_t s)
     if (getenv("DVBS2HIP_FRONT_TWO_SWEEP")) return false;
     dim3 g(p.n_frames), b(FRONT_WIDE);
     const bool small = p.n_sym <= 8 * FRONT_WIDE, big = p.n_sym <= 32 * FRONT_WIDE;
-    if (p.bps == 2 && small) hipLaunchKernelGGL((front_reg_kernel<2, 8>), g, b, 0, s, p);
-    else if (p.bps == 2 && big) hipLaunchKernelGGL((front_reg_kernel<2, 32>), g, b, 0, s, p);
-    else if (p.bps == 3 && small) hipLaunchKernelGGL((front_reg_kernel<3, 8>), g, b, 0, s, p);
-    else if (p.bps == 3 && big) hipLaunchKernelGGL((front_reg_kernel<3, 32>), g, b, 0, s, p);
+    if (p.bps == 2 && p.sep && small) hipLaunchKernelGGL((front_reg_kernel<2, 8, true>), g, b, 0, s, p);
+    else if (p.bps == 2 && p.sep && big) hipLaunchKernelGGL((front_reg_kernel<2, 32, true>), g, b, 0, s, p);
+    else if (p.bps == 2 && small) hipLaunchKernelGGL((front_reg_kernel<2, 8, false>), g, b, 0, s, p);
+    else if (p.bps == 2 && big) hipLaunchKernelGGL((front_reg_kernel<2, 32, false>), g, b, 0, s, p);
+    else if (p.bps == 3 && small) hipLaunchKernelGGL((front_reg_kernel<3, 8, false>), g, b, 0, s, p);
+    else if (p.bps == 3 && big) hipLaunchKernelGGL((front_reg_kernel<3, 32, false>), g, b, 0, s, p);
     else return false;
     return true;
 }

@@ -51,8 +51,9 @@ def chain_case(modcod, F, n_ite, ebn0):
     rx.close()
     return r
 
-def fir_case(n_cplx, F, reps=20):
+def fir_case(n_cplx, F, reps=20, kernel=B.FIR_AUTO):
     rx = Dvbs2Hip("32APSK-S_3/4", max_frames=max(F, 1))
+    rx.set_filter_kernel(kernel)
     x = torch.randn((F, 2 * n_cplx), dtype=torch.float32, device=dev); y = torch.empty_like(x)
     ms = timed(rx, B.K_FIR, lambda: rx.filter_dev(x.data_ptr(), y.data_ptr(), n_cplx, F), reps)
     rx.synchronize(); t0 = time.perf_counter()
@@ -60,7 +61,8 @@ def fir_case(n_cplx, F, reps=20):
     rx.synchronize(); wall = (time.perf_counter() - t0) / reps * 1e3
     n = n_cplx * F
     rx.close()
-    return {"n_cplx": n_cplx, "frames": F, "kernel_ms": ms, "call_wall_ms": wall, "GFLOPs": 324 * n / (ms * 1e-3) / 1e9,
+    return {"kernel": "fir_ccr_kernel<81> (fp32 vector)" if kernel == B.FIR_VALU else "fir_mfma_kernel (bf16 x 3 split, matrix cores)",
+            "frac_hbm_8TBps": 16 * n / (ms * 1e-3) / 8e12, "n_cplx": n_cplx, "frames": F, "kernel_ms": ms, "call_wall_ms": wall, "GFLOPs": 324 * n / (ms * 1e-3) / 1e9,
             "GBps": 16 * n / (ms * 1e-3) / 1e9, "frac_fp32_peak_157TF": 324 * n / (ms * 1e-3) / 157.3e12}
 
 res["config3_QPSK-N_8/9_F4096_10ite"] = chain_case("QPSK-N_8/9", 4096, 10, 4.2)
@@ -87,6 +89,7 @@ res["latency_rx_bb_32APSK-S_3/4"] = [latency_case("32APSK-S_3/4", F) for F in (1
 res["latency_rx_bb_QPSK-S_8/9"] = [latency_case("QPSK-S_8/9", F) for F in (1, 8, 64)]
 res["fir_32APSK-S(6804 cplx/frame)"] = [fir_case(6804, F) for F in (1, 8, 64, 4096)]
 res["fir_QPSK-N(66564 cplx/frame)"] = [fir_case(66564, F) for F in (1, 8, 64, 1024)]
+res["fir_vector_kernel(for comparison)"] = [fir_case(6804, 4096, kernel=B.FIR_VALU), fir_case(66564, 1024, kernel=B.FIR_VALU)]
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "kernels.json")
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
