@@ -103,3 +103,30 @@ def test_sigma_per_frame_and_high_snr_signs(O, Rx):
         nato[ch.lut] = o
         assert np.all(np.abs(nat[f] - nato) <= 1e-4 * np.maximum(1.0, np.abs(nato)))
     rx.close()
+
+
+@pytest.mark.parametrize("modcod", ["QPSK-S_8/9", "QPSK-N_8/9"])
+def test_qpsk_general_demapper_equals_the_linear_form(O, Rx, modcod, monkeypatch):
+    """The reference's QPSK mapping is separable (one bit per axis), for which the library evaluates the exact LLR in its
+    linear closed form.  DVBS2HIP_DEMAP_GENERAL=1 (read at create) keeps the general log-sum-exp demapper for 2-bit
+    constellations: both must agree with the oracle's pairwise max* form, stand-alone and inside the fused front end."""
+    ch = chain(O, modcod)
+    mc = ch.mc
+    F = 2
+    info, pl, cw, sigma = make_pl_frames(O, modcod, F, 4.0, seed=77)
+    res = {}
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("DVBS2HIP_DEMAP_GENERAL", "1")
+        else:
+            monkeypatch.delenv("DVBS2HIP_DEMAP_GENERAL", raising=False)
+        rx = Rx(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=True)
+        x = rx.remove_plh(rx.pl_descramble(pl))
+        llr = rx.demodulate(np.full(F, sigma, np.float32), x)
+        llro = np.stack([O.demodulate(ch.cstl, mc.bps, np.float32(sigma), x[f]) for f in range(F)])
+        assert np.all(np.abs(llr - llro) <= 1e-4 * np.maximum(1.0, np.abs(llro)))
+        out, c0, c1 = rx.rx_bb(pl)                                   # estimated sigma: the register-resident fused kernel
+        assert np.array_equal(out, info)
+        res[general] = llr
+        rx.close()
+    assert np.all(np.abs(res[True] - res[False]) <= 1e-4 * np.maximum(1.0, np.abs(res[False])))
