@@ -131,7 +131,11 @@ bch_decode_kernel(const BchKParams p)
     const uint32_t n = (uint32_t)p.n;
     const int nw = (N + 31) / 32;
     uint16_t *stab = reinterpret_cast<uint16_t *>(words + nw);
-    for (int i = tid; i < 256 + 768 * t; i += BCH_THREADS) stab[i] = p.syn_tab[i];
+    {   // the tables, two entries per load (the entry count 256 + 768 t is even, both sides are 4-byte aligned)
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.syn_tab);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(stab);
+        for (int i = tid; i < (256 + 768 * t) / 2; i += BCH_THREADS) dst[i] = src[i];
+    }
     __syncthreads();
 
     for (int f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
@@ -257,6 +261,18 @@ bch_decode_kernel(const BchKParams p)
 
         // ---- 5. output the K systematic bits (optionally BB-descrambled, Scrambler_BB.hxx:51-72)
         int32_t *out = p.out_bits + (size_t)f * K;
+        if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+            // four bits per lane: one 16-byte non-temporal store (the socket is written once and read by another kernel)
+            typedef int32_t bch_i4 __attribute__((ext_vector_type(4)));
+            for (int k = 4 * tid; k < K; k += 4 * BCH_THREADS) {
+                uint32_t b = words[k >> 5];
+                if (p.prbs) b ^= p.prbs[k >> 5];
+                b >>= (k & 31);
+                bch_i4 v;
+                v.x = (int32_t)(b & 1u); v.y = (int32_t)((b >> 1) & 1u); v.z = (int32_t)((b >> 2) & 1u); v.w = (int32_t)((b >> 3) & 1u);
+                __builtin_nontemporal_store(v, reinterpret_cast<bch_i4 *>(out + k));
+            }
+        } else
         for (int k = tid; k < K; k += BCH_THREADS) {
             uint32_t b = (words[k >> 5] >> (k & 31)) & 1u;
             if (p.prbs) b ^= (p.prbs[k >> 5] >> (k & 31)) & 1u;
@@ -272,8 +288,9 @@ hipError_t bch_launch(const BchPlan &pl, BchKParams p, hipStream_t s)
     p.exp_ = pl.d_exp; p.log_ = pl.d_log; p.syn_tab = pl.d_syn_tab;
     p.N = pl.N; p.K = pl.K; p.m = pl.m; p.n = pl.n; p.t = pl.t;
     const size_t lds = (size_t)((pl.N + 31) / 32) * 4 + (256 + (size_t)768 * pl.t) * 2;
-    // persistent-ish grid: the tables are staged into LDS once per workgroup
-    const int grid = p.n_frames < 4096 ? p.n_frames : 4096;
+    // persistent grid (about the number of workgroups the chip holds at once): the tables are staged into LDS once per
+    // workgroup, not once per frame
+    const int grid = p.n_frames < 2048 ? p.n_frames : 2048;
     hipLaunchKernelGGL(bch_decode_kernel, dim3(grid), dim3(BCH_THREADS), lds, s, p);
     return hipGetLastError();
 }
