@@ -173,10 +173,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
             else for (int r = 0; r < q; r++) { gst(t4, st_off(0, r), 0.f); gst(t4, st_off(1, r), 0.f); gst(t4, st_off(2, r), 0.f); }
             if (p.w8.pad) { if (MODE == 0) lst(ljunk + W8_ROW + t4, INFINITY); else gst(t4, W8_ROW, INFINITY); }     // what NULL slots read
         }
-        if (p.packed && role >= 0) {
-            const int n_words = (p.K + 31) / 32;
-            for (int wd = t; wd < n_words; wd += LDPC_THREADS) p.packed[(size_t)f * n_words + wd] = 0u;
-        }
+        if (p.packed && threadIdx.x == 0 && (p.K & 31)) p.packed[(size_t)f * ((p.K + 31) / 32) + p.K / 32] = 0u;     // the bits behind K in the last word
         __syncthreads();
         PROF_MARK(8);
 
@@ -418,14 +415,12 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 } else if (p.post) p.post[(size_t)f * p.N + p.K + q * t + (g - p.n_info)] = Lv;
             }
             if (p.packed && role >= 0 && g < p.n_info) {
-                // 64 lanes = 64 consecutive info bits starting at bit o of the frame; o is a multiple of 8
+                // 64 lanes = 64 consecutive info bits starting at bit o = 360 g + 64 role of the frame: o is a multiple of 8, so the
+                // ballot is 8 whole bytes (5 for the last wave of a row) that no other wave or row touches -- plain byte stores,
+                // no atomics and no zeroing of the image
                 const unsigned long long m = __ballot(act && Lv < 0.f);
-                const int o = g * LDPC_Z + role * 64, sh = o & 31;
-                const unsigned long long lo = m << sh;
-                const uint32_t hi = sh ? (uint32_t)(m >> (64 - sh)) : 0u;
-                const uint32_t part = lane == 0 ? (uint32_t)lo : lane == 1 ? (uint32_t)(lo >> 32) : hi;
-                const int wd = (o >> 5) + lane;
-                if (lane < 3 && part && wd < n_words) atomicOr(&p.packed[(size_t)f * n_words + wd], part);
+                const int o8 = g * (LDPC_Z / 8) + role * 8, nb = role * 64 + 64 <= LDPC_Z ? 8 : (LDPC_Z - role * 64) / 8;
+                if (lane < nb) reinterpret_cast<uint8_t *>(p.packed + (size_t)f * n_words)[o8 + lane] = (uint8_t)(m >> (8 * lane));
             }
         };
         const int nl_out = p.post ? nl : nl_info, ng_out = p.post ? ng : ng_info;
