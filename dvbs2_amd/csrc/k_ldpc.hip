@@ -284,6 +284,13 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 pl.w8_rows.clear();
                 for (int g : lrow) pl.w8_rows.push_back((uint32_t)g);
                 for (int g : grow) pl.w8_rows.push_back((uint32_t)g);
+                // then, for the frame input of the parity part: where parity group r (bit-group n_info + r) lives --
+                // byte offset of its row in LDS, or bit 31 | byte offset inside the workgroup's global slot ([junk][+inf][rows])
+                for (int r = 0; r < q; r++) {
+                    const int g = pl.n_info + r;
+                    const bool in_lds = pl.fast_mode == 0 || (pl.fast_mode == 3 && glds[g]);
+                    pl.w8_rows.push_back(in_lds ? (uint32_t)gbase[g] * 4u : 0x80000000u | (uint32_t)((2 * LDPC_Z + (int)gbase[g]) * 4));
+                }
                 for (size_t i = 0; i < lrow.size(); i++) if ((int)gbase[lrow[i]] != (int)i * LDPC_Z) return "LDPC: internal: LDS row order";
                 for (size_t i = 0; i < grow.size(); i++) if ((int)gbase[grow[i]] != (int)i * LDPC_Z) return "LDPC: internal: global row order";
                 pl.w8_lds_junk = (uint32_t)(pl.w8_nl * LDPC_Z * 4);

@@ -142,33 +142,51 @@ ldpc_wg8_kernel(const LdpcKParams p)
 
     for (int f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
         // ---- channel LLRs -> posterior image, W8_IO independent loads per lane in flight; packed state := 0
+        const float *Y = p.llr + (size_t)f * p.N;
         if (act) {
-            const float *Y = p.llr + (size_t)f * p.N;
-            auto src_of = [&](int g) { return g < p.n_info ? g * LDPC_Z + t : p.K + q * t + (g - p.n_info); };
-            // info groups stream in once (coalesced rows): non-temporal; the parity groups are a stride-q
-            // gather of one 4 M-byte region that all q groups share: cached loads
-            for (int l0 = 0; l0 < nl; l0 += W8_IO) {
+            // info groups: coalesced rows of 360, streamed in once (non-temporal)
+            for (int l0 = 0; l0 < nl_info; l0 += W8_IO) {
                 float v[W8_IO];
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) {
-                    const int l = l0 + k < nl ? l0 + k : nl - 1;
-                    const int g = (int)rows[l];
-                    v[k] = l < nl_info ? __builtin_nontemporal_load(&Y[src_of(g)]) : Y[src_of(g)];
-                }
+                for (int k = 0; k < W8_IO; k++) v[k] = __builtin_nontemporal_load(&Y[(int)rows[l0 + k < nl_info ? l0 + k : nl_info - 1] * LDPC_Z + t]);
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) if (l0 + k < nl) lst((uint32_t)(l0 + k) * W8_ROW + t4, v[k]);
+                for (int k = 0; k < W8_IO; k++) if (l0 + k < nl_info) lst((uint32_t)(l0 + k) * W8_ROW + t4, v[k]);
             }
-            for (int l0 = 0; l0 < ng; l0 += W8_IO) {
+            for (int l0 = 0; l0 < ng_info; l0 += W8_IO) {
                 float v[W8_IO];
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) {
-                    const int l = l0 + k < ng ? l0 + k : ng - 1;
-                    const int g = (int)rows[nl + l];
-                    v[k] = l < ng_info ? __builtin_nontemporal_load(&Y[src_of(g)]) : Y[src_of(g)];
-                }
+                for (int k = 0; k < W8_IO; k++) v[k] = __builtin_nontemporal_load(&Y[(int)rows[nl + (l0 + k < ng_info ? l0 + k : ng_info - 1)] * LDPC_Z + t]);
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) if (l0 + k < ng) gst(t4, grow0 + (uint32_t)(l0 + k) * W8_ROW, v[k]);
+                for (int k = 0; k < W8_IO; k++) if (l0 + k < ng_info) gst(t4, grow0 + (uint32_t)(l0 + k) * W8_ROW, v[k]);
             }
+        }
+        if (role >= 0) {
+            // parity part: bit K + q t + r belongs to row n_info + r, element t -- a stride-q gather if read row by row (64
+            // cache lines per wave load).  Each wave instead reads the q * 64 consecutive LLRs of its 64 checks coalesced and
+            // scatters them into the rows (LDS, or the workgroup's cache-resident global slot).
+            const int tl0 = role * 64, cnt = (LDPC_Z - tl0 < 64 ? LDPC_Z - tl0 : 64) * q;
+            const float *Yp = Y + p.K + tl0 * q;
+            const const_u32 prow = rows + nl + ng;
+            // element e = 64 i + lane of the wave's region is (check tl = e / q, parity group r = e mod q): stepped, not divided
+            const int dq = 64 / q, dr = 64 - dq * q;
+            int tl = lane / q, r = lane - tl * q;
+            constexpr int PIO = 8;
+            for (int i0 = 0; i0 < q; i0 += PIO) {
+                float v[PIO];
+#pragma unroll
+                for (int k = 0; k < PIO; k++) { const int e = (i0 + k) * 64 + lane; v[k] = e < cnt ? Yp[e] : 0.f; }
+#pragma unroll
+                for (int k = 0; k < PIO; k++) {
+                    if ((i0 + k) * 64 + lane < cnt) {
+                        const uint32_t loc = prow[r], off = (loc & 0x7FFFFFFFu) + (uint32_t)(tl0 + tl) * 4u;
+                        if (loc >> 31) gst(off, 0u, v[k]); else lst(off, v[k]);
+                    }
+                    tl += dq; r += dr;
+                    if (r >= q) { r -= q; tl++; }
+                }
+            }
+        }
+        if (act) {
             if (SPA) { for (int e = 0; e < q * DEG; e++) gst(t4, st_base + (uint32_t)e * W8_ROW, 0.f); }
             else for (int r = 0; r < q; r++) { gst(t4, st_off(0, r), 0.f); gst(t4, st_off(1, r), 0.f); gst(t4, st_off(2, r), 0.f); }
             if (p.w8.pad) { if (MODE == 0) lst(ljunk + W8_ROW + t4, INFINITY); else gst(t4, W8_ROW, INFINITY); }     // what NULL slots read
