@@ -853,7 +853,7 @@ static int sfm_ready(dvbs2hip_t *h)
         HIPCHK(h, hipMalloc((void **)&S.xh[i], sizeof(float) * 2 * 64));
         HIPCHK(h, hipMalloc((void **)&S.sofh[i], sizeof(float) * 2 * 64));
         HIPCHK(h, hipMalloc((void **)&S.buff2[i], sizeof(float) * (size_t)S.nbuff2));
-        HIPCHK(h, hipMalloc((void **)&S.st[i], sizeof(int) * 2));
+        HIPCHK(h, hipMalloc((void **)&S.st[i], sizeof(int) * 4));
     }
     HIPCHK(h, hipMalloc((void **)&S.cv, sizeof(float) * (size_t)n));
     HIPCHK(h, hipMalloc((void **)&S.yprev, sizeof(float) * 2 * (size_t)n));
@@ -908,12 +908,10 @@ int dvbs2hip_sync_frame_synchronize2_dev(dvbs2hip_t *h, const float *X_N1, const
     HIPCHK(h, sync_metric_launch(cor_SOF, S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], cor_PLSC, S.cv, (float *)corr, delay, (float *)met, FLG, S.trigger,
                                  n, F, S.alpha, S.vec_width, h->stream));
     S.sofh_cur ^= 1;
-    for (int f = 0; f < F; f++) {           // the delay line is a recurrence from frame to frame; its state stays on the device
-        const float *yp = f == 0 ? S.yprev : Y_N2 + (size_t)2 * n * (f - 1);
-        HIPCHK(h, sync_vdelay_launch(X_N1 + (size_t)2 * n * f, yp, Y_N2 + (size_t)2 * n * f, S.buff2[S.od_cur], S.buff2[S.od_cur ^ 1], S.st[S.od_cur],
-                                     S.st[S.od_cur ^ 1], delay + f, n, S.nbuff2, h->stream));
-        S.od_cur ^= 1;
-    }
+    // the delay line is a recurrence from frame to frame made of copies only: resolved per output sample, one launch (k_sync.hip)
+    HIPCHK(h, sync_vdelay_launch(X_N1, S.yprev, Y_N2, S.buff2[S.od_cur], S.buff2[S.od_cur ^ 1], S.st[S.od_cur], S.st[S.od_cur ^ 1], delay,
+                                 S.st[S.od_cur ^ 1] + 2, n, S.nbuff2, F, h->stream));
+    S.od_cur ^= 1;
     HIPCHK(h, hipMemcpyAsync(S.yprev, Y_N2 + (size_t)2 * n * (F - 1), sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(S.metric, (float *)met + (F - 1), sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     return 0;

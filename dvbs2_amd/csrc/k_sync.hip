@@ -71,25 +71,41 @@ __global__ void sync_hist_kernel(const float2 *x, const float2 *hist_in, float2 
     hist_out[i] = gi >= 0 ? x[gi] : hist_in[H + gi];
 }
 
-// ---- _synchronize2, first half (:236-267, :278-285): one lane per position of the frame, frames in turn.
+// ---- _synchronize2, first half (:236-267, :278-285).  The instantaneous metric m[f][i] = max(|plsc + sof|, |sof - plsc|) of
+// every sample is independent work (sync_m_kernel, one lane per sample of the batch); the average over frames
+// corr_vec[i] = alpha corr_vec[i] + (1 - alpha) m[f][i] is a recurrence across frames and parallel across positions only
+// (sync_metric_kernel, one lane per position, frames in turn, the loads of 8 frames in flight ahead of the dependent
+// multiply-adds; same operations in the same order as the reference).
 // corr[f][i] = the averaged correlation the arg max of frame f sees; cv = corr_vec (carried between calls).
-__global__ void sync_metric_kernel(const float2 *__restrict__ cor_sof, const float2 *__restrict__ sofh, const float2 *__restrict__ cor_plsc,
-                                   float *__restrict__ cv, float *__restrict__ corr, int n, int F, float alpha, int end_vec)
+__global__ void sync_m_kernel(const float2 *__restrict__ cor_sof, const float2 *__restrict__ sofh, const float2 *__restrict__ cor_plsc,
+                              float *__restrict__ corr, long long n_total)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_total) return;
+    const float2 s = g >= 64 ? cor_sof[g - 64] : sofh[g];            // SOF_PLSC_delay: 64 samples (:24, :236)
+    const float2 p = cor_plsc[g];
+    const float sr = p.x + s.x, si = p.y + s.y, dr = s.x - p.x, di = s.y - p.y;
+    const float a2s = fmaf(sr, sr, si * si), a2d = fmaf(dr, dr, di * di);
+    corr[g] = sqrtf(fmaxf(a2s, a2d));
+}
+
+__global__ void sync_metric_kernel(float *__restrict__ cv, float *__restrict__ corr, int n, int F, float alpha, int end_vec)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float c = cv[i];
     const float one_m = 1.0f - alpha;
-    for (int f = 0; f < F; f++) {
-        const long long g = (long long)f * n + i - 64;                 // SOF_PLSC_delay: 64 samples (:24, :236)
-        const float2 s = g >= 0 ? cor_sof[g] : sofh[64 + g];
-        const float2 p = cor_plsc[(long long)f * n + i];
-        const float sr = p.x + s.x, si = p.y + s.y, dr = s.x - p.x, di = s.y - p.y;
-        const float a2s = fmaf(sr, sr, si * si), a2d = fmaf(dr, dr, di * di);
-        const float m = sqrtf(fmaxf(a2s, a2d));
-        c = i < end_vec ? alpha * c + one_m * m : m;                    // the tail past the last full vector is not averaged (:284-285)
-        corr[(long long)f * n + i] = c;
+    const bool avg = i < end_vec;                                      // the tail past the last full vector is not averaged (:284-285)
+    constexpr int UF = 8;
+    int f = 0;
+    for (; f + UF <= F; f += UF) {
+        float m[UF];
+#pragma unroll
+        for (int k = 0; k < UF; k++) m[k] = corr[(long long)(f + k) * n + i];
+#pragma unroll
+        for (int k = 0; k < UF; k++) { c = avg ? alpha * c + one_m * m[k] : m[k]; corr[(long long)(f + k) * n + i] = c; }
     }
+    for (; f < F; f++) { const float m = corr[(long long)f * n + i]; c = avg ? alpha * c + one_m * m : m; corr[(long long)f * n + i] = c; }
     cv[i] = c;
 }
 
@@ -126,31 +142,71 @@ sync_argmax_kernel(const float *__restrict__ corr, int32_t *__restrict__ delay, 
     }
 }
 
-// ---- Variable_delay_cc_naive::_filter (Variable_delay_cc_naive.cpp:56-79) for ONE frame, literally: the
-// copies are applied in the reference's order (a later one overwrites an earlier one), what none of them
-// covers keeps the previous content of the output buffer.  st = {head2, first_time}.
-__global__ void sync_vdelay_kernel(const float *__restrict__ X, const float *__restrict__ Yprev, float *__restrict__ Y,
-                                   const float *__restrict__ buff_old, float *__restrict__ buff_new, const int *__restrict__ st_old,
-                                   int *__restrict__ st_new, const int32_t *__restrict__ delay_f, int n, int nbuff2)
+// ---- Variable_delay_cc_naive::_filter (Variable_delay_cc_naive.cpp:56-79), the whole batch in ONE launch.
+// The reference runs frame after frame: output f is built by four copies (a later one overwrites an earlier one; what
+// none of them covers keeps the previous content of the output buffer) from input f, the delay line buff2 and output
+// f - 1, and buff2[0 .. D_f) := the tail of input f.  Every one of these is a COPY, so each output sample is one
+// particular earlier input sample (or a sample of the state the call started with, or the zero of first_time), and
+// which one follows from the delays alone:
+//   * buff2 after frame g holds, at index k, the tail of the LAST frame g' <= g whose D_g' exceeds k (vd_buff);
+//   * an output sample that the reference takes from output f - 1 is resolved by looking at frame f - 1 in turn (vd_source).
+// In lock (constant delay) neither walk takes a step; while the delay moves they take one or two.  One lane per output
+// sample, no frame-to-frame launches: the per-frame form cost 4 us per frame (a launch each) whatever the frame size.
+// st = {head2, first_time}; Dmax = the largest D of the call (vd_dmax_kernel), which bounds vd_buff's walk.
+__device__ __forceinline__ int vd_D(const int32_t *delay_f, int f, int n) { return 2 * ((n - delay_f[f]) % n); }   // set_delay((cplx_in_sz - delay) % cplx_in_sz), :298
+
+__device__ __forceinline__ float vd_buff(const float *__restrict__ X, const float *__restrict__ buff0, const int32_t *__restrict__ delay_f,
+                                         int g, int k, int n)
 {
     const int N = 2 * n;
-    const int dly = (n - delay_f[0]) % n;                   // set_delay((cplx_in_sz - delay) % cplx_in_sz), :298; always < size
-    const int D = 2 * dly, head2 = st_old[0], first = st_old[1];
-    const int start_Y = D > head2 ? D - head2 : 0;
-    const int start_buff = D < head2 ? head2 - D : 0;
-    int end_buff = start_buff + D;
-    end_buff = end_buff > nbuff2 ? nbuff2 : end_buff;
-    end_buff = (end_buff - start_buff > N - start_Y) ? end_buff - ((end_buff - start_buff) - (N - start_Y)) : end_buff;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < N) {
-        float v = Yprev[j];
-        if (j < start_Y) v = first ? 0.f : Yprev[N - start_Y + j];
-        if (j >= start_Y && j < start_Y + (end_buff - start_buff)) v = buff_old[start_buff + j - start_Y];
-        if (j >= D) v = X[j - D];
-        Y[j] = v;
+    for (; g >= 0; g--) {
+        const int Dg = vd_D(delay_f, g, n);
+        if (k < Dg) return X[(size_t)g * N + N - Dg + k];
     }
-    if (j < nbuff2) buff_new[j] = j < D ? X[N - D + j] : buff_old[j];
-    if (j == 0) { st_new[0] = D; st_new[1] = 0; }
+    return buff0[k];
+}
+
+__device__ __forceinline__ float vd_source(const float *__restrict__ X, const float *__restrict__ yprev0, const float *__restrict__ buff0,
+                                           const int *__restrict__ st0, const int32_t *__restrict__ delay_f, int f, int j, int n, int nbuff2)
+{
+    const int N = 2 * n;
+    for (;;) {
+        const int D = vd_D(delay_f, f, n), head2 = f == 0 ? st0[0] : vd_D(delay_f, f - 1, n), first = f == 0 ? st0[1] : 0;
+        if (j >= D) return X[(size_t)f * N + j - D];
+        const int start_Y = D > head2 ? D - head2 : 0, start_buff = D < head2 ? head2 - D : 0;
+        int end_buff = start_buff + D;
+        end_buff = end_buff > nbuff2 ? nbuff2 : end_buff;
+        end_buff = (end_buff - start_buff > N - start_Y) ? end_buff - ((end_buff - start_buff) - (N - start_Y)) : end_buff;
+        if (j >= start_Y && j < start_Y + (end_buff - start_buff)) return vd_buff(X, buff0, delay_f, f - 1, start_buff + j - start_Y, n);
+        if (j < start_Y) { if (first) return 0.f; j = N - start_Y + j; }
+        if (--f < 0) return yprev0[j];                      // the output buffer as the previous call left it
+    }
+}
+
+__global__ void vd_dmax_kernel(const int32_t *__restrict__ delay_f, int *__restrict__ dmax, int n, int F)
+{
+    __shared__ int red[256];
+    int m = 0;
+    for (int f = threadIdx.x; f < F; f += 256) { const int D = vd_D(delay_f, f, n); m = D > m ? D : m; }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) *dmax = red[0];
+}
+
+// blockIdx.y < F: output frame blockIdx.y; blockIdx.y == F: the delay line and {head2, first_time} after the last frame
+__global__ void sync_vdelay_batch_kernel(const float *__restrict__ X, const float *__restrict__ yprev0, float *__restrict__ Y,
+                                         const float *__restrict__ buff_old, float *__restrict__ buff_new, const int *__restrict__ st_old,
+                                         int *__restrict__ st_new, const int32_t *__restrict__ delay_f, const int *__restrict__ dmax, int n, int nbuff2, int F)
+{
+    const int N = 2 * n, f = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < F) {
+        if (j < N) Y[(size_t)f * N + j] = vd_source(X, yprev0, buff_old, st_old, delay_f, f, j, n, nbuff2);
+        return;
+    }
+    if (j < nbuff2) buff_new[j] = j < *dmax ? vd_buff(X, buff_old, delay_f, F - 1, j, n) : buff_old[j];
+    if (j == 0) { st_new[0] = vd_D(delay_f, F - 1, n); st_new[1] = 0; }
 }
 
 // ================================================================ fine frequency / phase synchronizers
@@ -188,22 +244,42 @@ sff_lr_pilot_kernel(const float *__restrict__ X, float2 *__restrict__ tR, int n)
     }
 }
 
-// ---- L&R, the damped autocorrelation from frame to frame (:131-135): one thread; fr[f] = {estimated_freq, est * pi}
-__global__ void sff_lr_iir_kernel(const float2 *__restrict__ tR, float *__restrict__ R_l, float2 *__restrict__ fr, float *__restrict__ FRQ,
-                                  float *__restrict__ PHS, int F, float alpha)
+// ---- L&R, the damped autocorrelation from frame to frame (:131-135); fr[f] = {estimated_freq, est * pi}.  One wave:
+// 64 frames at a time are staged in LDS, lane 0 runs the recurrence over them (two multiply-adds per frame, the only
+// serial part), then every lane forms the estimate of one frame (atan2 and the double-precision scaling, in parallel).
+__global__ void __launch_bounds__(64)
+sff_lr_iir_kernel(const float2 *__restrict__ tR, float *__restrict__ R_l, float2 *__restrict__ fr, float *__restrict__ FRQ,
+                  float *__restrict__ PHS, int F, float alpha)
 {
-    if (blockIdx.x || threadIdx.x) return;
-    float r0 = R_l[0], r1 = R_l[1];
-    for (int f = 0; f < F; f++) {
-        r0 = alpha * r0 + (1 - alpha) * tR[f].x;
-        r1 = alpha * r1 + (1 - alpha) * tR[f].y;
-        float est = atan2f(r1, r0);
-        est = (float)((double)est / ((18 / 2 + 1) * 3.1415926535897932384626433832795));
-        fr[f] = make_float2(est, (float)((double)est * 3.1415926535897932384626433832795));
-        if (FRQ) FRQ[f] = est;
-        if (PHS) PHS[f] = 0.f;
+    __shared__ float2 sh[64];
+    __shared__ float2 carry;
+    const int lane = threadIdx.x;
+    if (lane == 0) carry = make_float2(R_l[0], R_l[1]);
+    for (int f0 = 0; f0 < F; f0 += 64) {
+        const int f = f0 + lane, cnt = F - f0 < 64 ? F - f0 : 64;
+        if (f < F) sh[lane] = tR[f];
+        __syncthreads();
+        if (lane == 0) {
+            float r0 = carry.x, r1 = carry.y;
+            for (int k = 0; k < cnt; k++) {
+                const float2 t = sh[k];
+                r0 = alpha * r0 + (1 - alpha) * t.x;
+                r1 = alpha * r1 + (1 - alpha) * t.y;
+                sh[k] = make_float2(r0, r1);
+            }
+            carry = make_float2(r0, r1);
+        }
+        __syncthreads();
+        if (f < F) {
+            float est = atan2f(sh[lane].y, sh[lane].x);
+            est = (float)((double)est / ((18 / 2 + 1) * 3.1415926535897932384626433832795));
+            fr[f] = make_float2(est, (float)((double)est * 3.1415926535897932384626433832795));
+            if (FRQ) FRQ[f] = est;
+            if (PHS) PHS[f] = 0.f;
+        }
+        __syncthreads();
     }
-    R_l[0] = r0; R_l[1] = r1;
+    if (lane == 0) { R_l[0] = carry.x; R_l[1] = carry.y; }
 }
 
 // ---- freq_phase, per frame: fr[f] = {estimated_freq, estimated_phase} (.cpp:53-101)
@@ -270,7 +346,7 @@ hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp /* 4 F
 {
     float2 *tR = reinterpret_cast<float2 *>(tmp), *fr = tR + F;
     hipLaunchKernelGGL(sff_lr_pilot_kernel, dim3(F), dim3(256), 0, s, X, tR, n);
-    hipLaunchKernelGGL(sff_lr_iir_kernel, dim3(1), dim3(1), 0, s, tR, R_l, fr, FRQ, PHS, F, alpha);
+    hipLaunchKernelGGL(sff_lr_iir_kernel, dim3(1), dim3(64), 0, s, tR, R_l, fr, FRQ, PHS, F, alpha);
     const long long tot = (long long)n * F;
     hipLaunchKernelGGL(sff_rotate_kernel<0>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(X),
                        reinterpret_cast<float2 *>(Y), fr, n, tot);
@@ -301,19 +377,24 @@ hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float 
                               int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s)
 {
     const int end_vec = (n / vec_width) * vec_width;
-    hipLaunchKernelGGL(sync_metric_kernel, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float2 *>(cor_sof),
-                       reinterpret_cast<const float2 *>(sofh_in), reinterpret_cast<const float2 *>(cor_plsc), cv, corr, n, F, alpha, end_vec);
+    const long long tot = (long long)n * F;
+    hipLaunchKernelGGL(sync_m_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(cor_sof),
+                       reinterpret_cast<const float2 *>(sofh_in), reinterpret_cast<const float2 *>(cor_plsc), corr, tot);
+    hipLaunchKernelGGL(sync_metric_kernel, dim3((n + 63) / 64), dim3(64), 0, s, cv, corr, n, F, alpha, end_vec);
     hipLaunchKernelGGL(sync_hist_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float2 *>(cor_sof), reinterpret_cast<const float2 *>(sofh_in),
                        reinterpret_cast<float2 *>(sofh_out), 64, (long long)n * F);
     hipLaunchKernelGGL(sync_argmax_kernel, dim3(F), dim3(256), 0, s, corr, delay, metric, flag, trigger, n, 25, 64);
     return hipGetLastError();
 }
 
+// all F frames of a call; dmax = one int of device scratch
 hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
-                              const int32_t *delay_f, int n, int nbuff2, hipStream_t s)
+                              const int32_t *delay_f, int *dmax, int n, int nbuff2, int F, hipStream_t s)
 {
     const int tot = nbuff2 > 2 * n ? nbuff2 : 2 * n;
-    hipLaunchKernelGGL(sync_vdelay_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, X, Yprev, Y, buff_old, buff_new, st_old, st_new, delay_f, n, nbuff2);
+    hipLaunchKernelGGL(vd_dmax_kernel, dim3(1), dim3(256), 0, s, delay_f, dmax, n, F);
+    hipLaunchKernelGGL(sync_vdelay_batch_kernel, dim3((tot + 255) / 256, F + 1), dim3(256), 0, s, X, Yprev, Y, buff_old, buff_new, st_old, st_new, delay_f,
+                       dmax, n, nbuff2, F);
     return hipGetLastError();
 }
 

@@ -69,6 +69,28 @@ res["config3_QPSK-N_8/9_F4096_10ite"] = chain_case("QPSK-N_8/9", 4096, 10, 4.2)
 res["config1_QPSK-S_8/9_F8192_10ite"] = chain_case("QPSK-S_8/9", 8192, 10, 4.4)
 res["config4_16APSK-N_8/9_F4096_20ite"] = chain_case("16APSK-N_8/9", 4096, 20, 8.2)
 res["config5_32APSK-S_3/4_F4096_10ite"] = chain_case("32APSK-S_3/4", 4096, 10, 10.5)
+def sync_case(modcod, F, reps=10):
+    """row N4: frame synchronizer + the two pilot-aided fine synchronizers, device sockets, wall time per call"""
+    import ctypes
+    rx = Dvbs2Hip(modcod, max_frames=F)
+    n = rx.pl_frame
+    x = torch.randn((F, 2 * n), dtype=torch.float32, device=dev); y = torch.empty_like(x)
+    DEL = torch.empty(F, dtype=torch.int32, device=dev); FLG = torch.empty_like(DEL); TRI = torch.empty(F, dtype=torch.float32, device=dev)
+    FRQ = torch.empty(F, dtype=torch.float32, device=dev); PHS = torch.empty_like(FRQ)
+    vp = ctypes.c_void_p
+    calls = {"frame_sync(corr+metric+delay)": lambda: rx.sync_frame_synchronize_dev(vp(x.data_ptr()), vp(DEL.data_ptr()), vp(FLG.data_ptr()), vp(TRI.data_ptr()), vp(y.data_ptr()), F),
+             "luise_reggiannini": lambda: rx._chk(rx.L.dvbs2hip_sync_lr_synchronize_dev(rx.h, vp(x.data_ptr()), vp(FRQ.data_ptr()), vp(PHS.data_ptr()), vp(y.data_ptr()), F)),
+             "pilot_freq_phase": lambda: rx._chk(rx.L.dvbs2hip_sync_freq_phase_synchronize_dev(rx.h, vp(x.data_ptr()), vp(FRQ.data_ptr()), vp(PHS.data_ptr()), vp(y.data_ptr()), F))}
+    out = {"modcod": modcod, "frames": F, "samples": n * F}
+    for name, fn in calls.items():
+        fn(); rx.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps): fn()
+        rx.synchronize(); ms = (time.perf_counter() - t0) / reps * 1e3
+        # 8 B in + 8 B out per sample (the frame synchronizer also writes and re-reads two fp32 correlations per sample)
+        out[name] = {"call_ms": ms, "Msamples_per_s": n * F / ms / 1e3, "GBps_16B_per_sample": 16 * n * F / ms / 1e6}
+    rx.close()
+    return out
+
 def latency_case(modcod, F, reps=50):
     """small-batch latency of one fused-chain call (launch-bound regime, BASELINE config 5)"""
     mc = P.get_modcod(modcod)
@@ -89,6 +111,8 @@ res["latency_rx_bb_32APSK-S_3/4"] = [latency_case("32APSK-S_3/4", F) for F in (1
 res["latency_rx_bb_QPSK-S_8/9"] = [latency_case("QPSK-S_8/9", F) for F in (1, 8, 64)]
 res["fir_32APSK-S(6804 cplx/frame)"] = [fir_case(6804, F) for F in (1, 8, 64, 4096)]
 res["fir_QPSK-N(66564 cplx/frame)"] = [fir_case(66564, F) for F in (1, 8, 64, 1024)]
+res["sync_N4_QPSK-N_F1024"] = sync_case("QPSK-N_8/9", 1024)
+res["sync_N4_32APSK-S_F4096"] = sync_case("32APSK-S_3/4", 4096)
 res["fir_vector_kernel(for comparison)"] = [fir_case(6804, 4096, kernel=B.FIR_VALU), fir_case(66564, 1024, kernel=B.FIR_VALU)]
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "kernels.json")
 json.dump(res, open(out, "w"), indent=1)
