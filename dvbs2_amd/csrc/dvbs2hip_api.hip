@@ -40,7 +40,7 @@ struct dvbs2hip_handle {
     float *d_cstl = nullptr;
     uint8_t *d_pl_seq = nullptr;
     float *d_taps_rev = nullptr;
-    uint16_t *d_fir_afrag = nullptr;       // Toeplitz fragments of the split taps for the matrix-core FIR (T <= 81)
+    uint16_t *d_fir_afrag = nullptr, *d_upfir_afrag = nullptr;       // Toeplitz fragments of the split taps for the matrix-core FIR (T <= 81)
     float *d_hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
     float *d_taps = nullptr;            // natural order (shaping filter)
@@ -439,6 +439,10 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         const size_t hb = sizeof(float) * 2 * (size_t)(h->fir_T > 1 ? h->fir_T - 1 : 1);
         for (int i = 0; i < 2; i++) { CREATE_HIP(hipMalloc((void **)&h->d_hist[i], hb)); CREATE_HIP(hipMemset(h->d_hist[i], 0, hb)); }
         if (upload(h, &h->d_taps, cfg->fir_taps, (size_t)h->fir_T)) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+        if (h->fir_osf == 2) {
+            const std::vector<uint16_t> af2 = upfir_mfma_afrag(cfg->fir_taps, h->fir_T);
+            if (!af2.empty() && upload(h, &h->d_upfir_afrag, af2.data(), af2.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+        }
         for (int i = 0; i < 2; i++) { CREATE_HIP(hipMalloc((void **)&h->d_uphist[i], hb)); CREATE_HIP(hipMemset(h->d_uphist[i], 0, hb)); }
     }
     CREATE_HIP(hipMalloc((void **)&h->d_ctr, 3 * sizeof(unsigned long long)));
@@ -463,7 +467,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
     if (h->s_out) (void)hipStreamDestroy(h->s_out);
     void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
-                        h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag};
+                        h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
@@ -780,7 +784,7 @@ int dvbs2hip_shape_filter_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n
     if (h->fir_T <= 0) return fail(h, DVBS2HIP_EUNSUPPORTED, "handle was created without filter taps");
     if (n_cplx < 1) return fail(h, DVBS2HIP_EINVAL, "'n_cplx' has to be greater than 0");
     Timer tm(h, DVBS2HIP_K_FIR);
-    HIPCHK(h, upfir_launch(X, Y, h->d_uphist[h->uphist_cur], h->d_uphist[h->uphist_cur ^ 1], h->d_taps, h->fir_T, h->fir_osf,
+    HIPCHK(h, upfir_launch(X, Y, h->d_uphist[h->uphist_cur], h->d_uphist[h->uphist_cur ^ 1], h->d_taps, h->fir_kernel == DVBS2HIP_FIR_VALU ? nullptr : h->d_upfir_afrag, h->fir_T, h->fir_osf,
                            (long long)n_cplx * F, h->stream));
     h->uphist_cur ^= 1;
     return 0;

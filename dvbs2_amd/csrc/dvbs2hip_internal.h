@@ -199,8 +199,11 @@ std::vector<uint16_t> fir_mfma_afrag(const float *taps_rev, int T);
 bool fir_mfma_usable(const float *x, const float *y, int T, long long n_total);
 hipError_t fir_mfma_launch(const float *x, float *y, const float *hist_in, float *hist_out, const uint16_t *afrag, int T, long long n_total, hipStream_t s);
 
-hipError_t upfir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps, int T, int osf,
+hipError_t upfir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps, const uint16_t *afrag2, int T, int osf,
                         long long n_in, hipStream_t s);
+std::vector<uint16_t> upfir_mfma_afrag(const float *taps, int T);
+bool upfir_mfma_usable(const float *x, const float *y, int T, int osf, long long n_in);
+hipError_t upfir_mfma_launch(const float *x, float *y, const float *hist_in, float *hist_out, const uint16_t *afrag2, int T, long long n_in, hipStream_t s);
 hipError_t decimate_launch(const float *x, float *y, long long n_out, int osf, long long offset, long long n_in, hipStream_t s);
 hipError_t awgn_launch(const float *x, float *y, const float *sigma, unsigned long long seed, long long n_pairs, int F, hipStream_t s);
 

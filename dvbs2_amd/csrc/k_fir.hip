@@ -155,10 +155,12 @@ upfir_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const float2 
     y[i * osf + f] = acc;
 }
 
-hipError_t upfir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps, int T, int osf,
+// afrag2 != nullptr: the matrix-core form (k_fir_mfma.hip) when it applies (osf = 2, branches of at most 81 taps, aligned sockets)
+hipError_t upfir_launch(const float *x, float *y, const float *hist_in, float *hist_out, const float *taps, const uint16_t *afrag2, int T, int osf,
                         long long n_in, hipStream_t s)
 {
     if (T < 1 || T > FIR_TMAX || osf < 1 || osf > 16) return hipErrorInvalidValue;
+    if (afrag2 && upfir_mfma_usable(x, y, T, osf, n_in)) return upfir_mfma_launch(x, y, hist_in, hist_out, afrag2, T, n_in, s);
     const int Hin = (T - 1) / osf;                 // input samples of memory
     const int per_blk = UP_THREADS / osf;
     const size_t lds = sizeof(float2) * (size_t)(per_blk + Hin) + sizeof(float) * (size_t)T;

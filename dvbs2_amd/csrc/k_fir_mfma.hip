@@ -97,7 +97,11 @@ __device__ __forceinline__ float2 fm_fetch_edge(const float2 *__restrict__ x, co
 // stream is read from HBM exactly once.  The SAMPLES are the A operand (row = block of 16) and the Toeplitz band the B
 // operand (column = output inside the block): accumulator register r of lane (c, g) is output 16 (4 g + r) + c, so the
 // 16 lanes of a row write one whole 128-B line of interleaved (re, im) pairs.
-__global__ void __launch_bounds__(FM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// NPH = 1: the matched filter.  NPH = 2: the TX shaping filter (Filter_UPFIR_ccr_naive, osf = 2) -- two polyphase branches
+// of at most 81 taps over the SAME staged samples, branch ph in the band fragments afrag[ph]; output 2 i + ph of input i,
+// so a lane stores (re, im) of both branches as one 16-byte piece and 16 lanes a 256-byte run.  n_total counts INPUT samples.
+template <int NPH>
+__global__ void __launch_bounds__(FM_THREADS) __attribute__((amdgpu_waves_per_eu(NPH == 1 ? 4 : 3, NPH == 1 ? 4 : 3)))
 fir_mfma_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const float2 *__restrict__ hist_in, float2 *__restrict__ hist_out,
                 const uint4 *__restrict__ afrag, int T, long long n_total, int tiles_per_wg)
 {
@@ -128,11 +132,13 @@ fir_mfma_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const floa
         fm_stage(lds, 2 * tid, s0.x, s0.y, s1.x, s1.y);
     }
     // the Toeplitz fragments of the three tap parts (host-made, 9 KB, L2-resident)
-    fm_bf16x8 A[3][3];
+    fm_bf16x8 A[NPH][3][3];
 #pragma unroll
-    for (int p = 0; p < 3; p++)
+    for (int ph = 0; ph < NPH; ph++)
 #pragma unroll
-        for (int s = 0; s < 3; s++) A[p][s] = __builtin_bit_cast(fm_bf16x8, afrag[(p * 3 + s) * 64 + lane]);
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int s = 0; s < 3; s++) A[ph][p][s] = __builtin_bit_cast(fm_bf16x8, afrag[((ph * 3 + p) * 3 + s) * 64 + lane]);
     const int c = lane & 15, g = lane >> 4;
     // lane's share of the overlap that is carried from tile to tile inside LDS: 6 planes x 40 pairs
     const int ov_dst = (tid / (FM_H / 2)) * FM_PLANE + 2 * (tid % (FM_H / 2)), ov_src = ov_dst + FM_TILE;
@@ -158,7 +164,7 @@ fir_mfma_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const floa
             const int tt = wv + t2 * (FM_THREADS / 64);             // tile of 256 outputs inside the workgroup's 2048
             const long long o0 = blk0 + 256 * tt;
             if (o0 >= n_total) break;
-            fm_f32x4 acc[2];
+            fm_f32x4 acc[NPH][2];
 #pragma unroll
             for (int pl = 0; pl < 2; pl++) {
                 fm_bf16x8 B[3][3];
@@ -169,20 +175,29 @@ fir_mfma_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const floa
                         const int idx = 16 * (c + 2 * s + 16 * tt) + 8 * g;
                         B[p][s] = __builtin_bit_cast(fm_bf16x8, *reinterpret_cast<const uint4 *>(lds + (2 * p + pl) * FM_PLANE + idx));
                     }
-                fm_f32x4 d = {0.f, 0.f, 0.f, 0.f};
                 // (tap part, sample part), smallest products first
                 constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-                for (int q = 0; q < 6; q++)
+                for (int ph = 0; ph < NPH; ph++) {
+                    fm_f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s = 0; s < 3; s++) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[TB[q]][s], A[TA[q]][s], d, 0, 0, 0);
-                acc[pl] = d;
+                    for (int q = 0; q < 6; q++)
+#pragma unroll
+                        for (int s = 0; s < 3; s++) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[TB[q]][s], A[ph][TA[q]][s], d, 0, 0, 0);
+                    acc[ph][pl] = d;
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const long long o = o0 + 16 * (4 * g + r) + c;
-                fm_f32x2 w; w.x = acc[0][r]; w.y = acc[1][r];
-                if (o < n_total) __builtin_nontemporal_store(w, reinterpret_cast<fm_f32x2 *>(y + o));
+                if (o >= n_total) continue;
+                if (NPH == 1) {
+                    fm_f32x2 w; w.x = acc[0][0][r]; w.y = acc[0][1][r];
+                    __builtin_nontemporal_store(w, reinterpret_cast<fm_f32x2 *>(y + o));
+                } else {
+                    fm_f32x4 w; w.x = acc[0][0][r]; w.y = acc[0][1][r]; w.z = acc[NPH - 1][0][r]; w.w = acc[NPH - 1][1][r];
+                    __builtin_nontemporal_store(w, reinterpret_cast<fm_f32x4 *>(y + 2 * o));
+                }
             }
         }
         uint32_t carry = 0u;
@@ -232,9 +247,44 @@ hipError_t fir_mfma_launch(const float *x, float *y, const float *hist_in, float
     static const int max_wg = [] { const char *e = getenv("DVBS2HIP_FIR_WGS"); return e ? atoi(e) : 1024; }();      // 4 resident workgroups per CU
     const int tiles_per_wg = (int)((n_tiles + max_wg - 1) / max_wg);
     const unsigned grid = (unsigned)((n_tiles + tiles_per_wg - 1) / tiles_per_wg);
-    hipLaunchKernelGGL(fir_mfma_kernel, dim3(grid), dim3(FM_THREADS), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<float2 *>(y),
+    hipLaunchKernelGGL(fir_mfma_kernel<1>, dim3(grid), dim3(FM_THREADS), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<float2 *>(y),
                        reinterpret_cast<const float2 *>(hist_in), reinterpret_cast<float2 *>(hist_out), reinterpret_cast<const uint4 *>(afrag), T, n_total,
                        tiles_per_wg);
+    return hipGetLastError();
+}
+
+// ---- N2: the TX shaping filter (Filter_UPFIR_ccr_naive.cpp:52-66) with osf = 2 on the matrix cores: output i * 2 + ph =
+// sum_m H[ph + 2 m] x[i - m], i.e. two ordinary FIRs of Hin + 1 = (T - 1) / 2 + 1 taps over the input.  Band fragments of
+// both branches, [branch][part][K step][lane][8]:
+std::vector<uint16_t> upfir_mfma_afrag(const float *taps, int T)
+{
+    const int Hin = (T - 1) / 2, Tb = Hin + 1;
+    std::vector<uint16_t> out;
+    if (T < 1 || Tb > FM_H + 1) return out;
+    for (int ph = 0; ph < 2; ph++) {
+        std::vector<float> brev(Tb, 0.f);                      // brev[k] = h_ph[Tb - 1 - k], h_ph[m] = H[ph + 2 m]
+        for (int m = 0; m < Tb; m++) if (ph + 2 * m < T) brev[Tb - 1 - m] = taps[ph + 2 * m];
+        const std::vector<uint16_t> a = fir_mfma_afrag(brev.data(), Tb);
+        out.insert(out.end(), a.begin(), a.end());
+    }
+    return out;
+}
+
+bool upfir_mfma_usable(const float *x, const float *y, int T, int osf, long long n_in)
+{
+    return osf == 2 && T >= 1 && (T - 1) / 2 <= FM_H && n_in >= 2 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+}
+
+// hist = the last (T - 1) / 2 input samples
+hipError_t upfir_mfma_launch(const float *x, float *y, const float *hist_in, float *hist_out, const uint16_t *afrag2, int T, long long n_in, hipStream_t s)
+{
+    const long long n_tiles = (n_in + FM_TILE - 1) / FM_TILE;
+    const int max_wg = 768;                                                  // 3 resident workgroups per CU (168 VGPRs)
+    const int tiles_per_wg = (int)((n_tiles + max_wg - 1) / max_wg);
+    const unsigned grid = (unsigned)((n_tiles + tiles_per_wg - 1) / tiles_per_wg);
+    hipLaunchKernelGGL(fir_mfma_kernel<2>, dim3(grid), dim3(FM_THREADS), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<float2 *>(y),
+                       reinterpret_cast<const float2 *>(hist_in), reinterpret_cast<float2 *>(hist_out), reinterpret_cast<const uint4 *>(afrag2),
+                       (T - 1) / 2 + 1, n_in, tiles_per_wg);
     return hipGetLastError();
 }
 

@@ -117,13 +117,17 @@ def test_rrc_matched_pair_is_nyquist(O, Rx, P):
     rx.close()
 
 
-def test_shape_filter_matches_oracle_and_keeps_state(O, Rx, P):
-    """N2: polyphase up-sampling SRRC (Filter_UPFIR_ccr_naive.cpp:52-66) vs the oracle, 1e-4."""
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
+def test_shape_filter_matches_oracle_and_keeps_state(O, Rx, P, kernel):
+    """N2: polyphase up-sampling SRRC (Filter_UPFIR_ccr_naive.cpp:52-66) vs the oracle, 1e-4: the two branches on the
+    matrix cores (osf = 2) and the one-lane-per-output vector kernel."""
+    from dvbs2_amd import lib_binding as B
     taps = P.rrc_taps(0.2, 2, 20)
     rng = np.random.default_rng(15)
     rx = Rx("32APSK-S_3/4", max_frames=4)
+    rx.set_filter_kernel(B.FIR_MFMA if kernel == "mfma" else B.FIR_VALU)
     hist = np.zeros(2 * 80, np.float32)
-    for n, F in ((3402, 2), (7, 1), (1000, 3)):
+    for n, F in ((3402, 2), (7, 1), (1000, 3), (5000, 4)):
         x = rng.standard_normal(F * 2 * n).astype(np.float32)
         y = rx.shape_filter(x, n_frames=F, osf=2)
         yo = O.upfir(taps, 2, hist, x)

@@ -69,6 +69,18 @@ res["config3_QPSK-N_8/9_F4096_10ite"] = chain_case("QPSK-N_8/9", 4096, 10, 4.2)
 res["config1_QPSK-S_8/9_F8192_10ite"] = chain_case("QPSK-S_8/9", 8192, 10, 4.4)
 res["config4_16APSK-N_8/9_F4096_20ite"] = chain_case("16APSK-N_8/9", 4096, 20, 8.2)
 res["config5_32APSK-S_3/4_F4096_10ite"] = chain_case("32APSK-S_3/4", 4096, 10, 10.5)
+def upfir_case(n_in, F, reps=20):
+    """row N2: TX shaping filter (polyphase up-sampling SRRC, osf 2): 8 B in + 16 B out per input sample, 2 x 41 taps"""
+    rx = Dvbs2Hip("32APSK-S_3/4", max_frames=max(F, 1))
+    x = torch.randn((F, 2 * n_in), dtype=torch.float32, device=dev); y = torch.empty((F, 4 * n_in), dtype=torch.float32, device=dev)
+    f = lambda: rx.shape_filter_dev(x.data_ptr(), y.data_ptr(), n_in, F)
+    f(); rx.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): f()
+    rx.synchronize(); ms = (time.perf_counter() - t0) / reps * 1e3
+    rx.close()
+    return {"n_in_cplx": n_in, "frames": F, "call_ms": ms, "GBps_24B_per_input_sample": 24 * n_in * F / ms / 1e6, "frac_hbm_8TBps": 24 * n_in * F / ms / 1e6 / 8000}
+
+
 def sync_case(modcod, F, reps=10):
     """row N4: frame synchronizer + the two pilot-aided fine synchronizers, device sockets, wall time per call"""
     import ctypes
@@ -111,6 +123,7 @@ res["latency_rx_bb_32APSK-S_3/4"] = [latency_case("32APSK-S_3/4", F) for F in (1
 res["latency_rx_bb_QPSK-S_8/9"] = [latency_case("QPSK-S_8/9", F) for F in (1, 8, 64)]
 res["fir_32APSK-S(6804 cplx/frame)"] = [fir_case(6804, F) for F in (1, 8, 64, 4096)]
 res["fir_QPSK-N(66564 cplx/frame)"] = [fir_case(66564, F) for F in (1, 8, 64, 1024)]
+res["upfir_N2"] = [upfir_case(3402, 4096), upfir_case(33282, 1024)]
 res["sync_N4_QPSK-N_F1024"] = sync_case("QPSK-N_8/9", 1024)
 res["sync_N4_32APSK-S_F4096"] = sync_case("32APSK-S_3/4", 4096)
 res["fir_vector_kernel(for comparison)"] = [fir_case(6804, 4096, kernel=B.FIR_VALU), fir_case(66564, 1024, kernel=B.FIR_VALU)]
