@@ -53,7 +53,7 @@ struct dvbs2hip_handle {
     int32_t *d_enc_deg = nullptr;
     float *d_plh = nullptr;
     int enc_stride = 0;
-    unsigned long long *d_bch_tab = nullptr;
+    unsigned long long *d_bch_tab = nullptr, *d_bch_shift = nullptr;
     std::map<int, DevBuf> bufs;        // lazily grown staging / intermediate buffers
     // frame synchronizer (N4): device-resident state of Synchronizer_frame_DVBS2_fast
     struct {
@@ -368,6 +368,28 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
                 tab[3 * u] = s[0]; tab[3 * u + 1] = s[1]; tab[3 * u + 2] = s[2];
             }
             if (upload(h, &h->d_bch_tab, tab.data(), tab.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+            // segmented division (tx_bchpar_kernel): segment s of 16 is followed by after_s bytes; shift[s][b] = x^(b + 8 after_s) mod g
+            {
+                const int SEG = 16, nbytes = h->K_bch / 8, L = (nbytes + SEG - 1) / SEG;
+                std::vector<unsigned long long> sh((size_t)SEG * r * 3, 0ull);
+                std::vector<long long> base(SEG);
+                long long nmax = 0;
+                for (int sgm = 0; sgm < SEG; sgm++) {
+                    const int b1 = std::min(std::min(sgm * L, nbytes) + L, nbytes);
+                    base[sgm] = 8ll * (nbytes - b1); nmax = std::max(nmax, base[sgm] + r);
+                }
+                unsigned long long v[3] = {1ull, 0ull, 0ull};                       // x^n mod g, n = 0, 1, ..
+                for (long long n = 0; n < nmax; n++) {
+                    for (int sgm = 0; sgm < SEG; sgm++)
+                        if (n >= base[sgm] && n < base[sgm] + r) { unsigned long long *d = &sh[((size_t)sgm * r + (size_t)(n - base[sgm])) * 3]; d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; }
+                    const int top = r - 1;
+                    const bool fb = (v[top / 64] >> (top % 64)) & 1ull;
+                    v[2] = (v[2] << 1) | (v[1] >> 63); v[1] = (v[1] << 1) | (v[0] >> 63); v[0] <<= 1;
+                    for (int w = 0; w < 3; w++) { const int lo = 64 * w; if (r <= lo) v[w] = 0; else if (r < lo + 64) v[w] &= (1ull << (r - lo)) - 1ull; }
+                    if (fb) { v[0] ^= gl[0]; v[1] ^= gl[1]; v[2] ^= gl[2]; }
+                }
+                if (upload(h, &h->d_bch_shift, sh.data(), sh.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+            }
         }
         // PLHEADER = 26 SOF + 64 PLS symbols, pi/2-BPSK (Framer.hxx:97-196)
         static const int G[7][32] = {
@@ -467,7 +489,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
     if (h->s_out) (void)hipStreamDestroy(h->s_out);
     void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
-                        h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag};
+                        h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
@@ -1218,7 +1240,7 @@ int dvbs2hip_tx_bb_dev(dvbs2hip_t *h, const int32_t *info_in, uint64_t seed, con
     p.info_in = info_in; p.info_out = info_out; p.sigma = sigma; p.pl_out = pl;
     p.bch_cw = (uint32_t *)dbch; p.ldpc_cw = (uint32_t *)dldpc; p.prbs = h->bch.d_prbs;
     p.enc_tab = h->d_enc_tab; p.enc_deg = h->d_enc_deg; p.cstl = h->d_cstl; p.plh = h->d_plh; p.pl_seq = h->d_pl_seq;
-    p.bch_tab = h->d_bch_tab;
+    p.bch_tab = h->d_bch_tab; p.bch_shift = h->d_bch_shift;
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
     p.K_bch = h->K_bch; p.K_ldpc = h->K_ldpc; p.N_ldpc = h->N_ldpc; p.bps = h->bps; p.itl_cols = h->itl_cols; p.itl_order = h->itl_order;
     p.n_sym = h->n_sym; p.pl_frame = h->pl_frame; p.enc_stride = h->enc_stride; p.n_frames = F;

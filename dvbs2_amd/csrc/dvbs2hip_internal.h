@@ -184,6 +184,7 @@ struct TxKParams {
     const float *plh;           // 180 floats: PLHEADER
     const uint8_t *pl_seq;
     const unsigned long long *bch_tab;  // [256][3]: (u(x) x^r) mod g(x), byte-wise systematic encoder
+    const unsigned long long *bch_shift;   // [16 segments][r][3]: x^(b + 8 * bytes behind the segment) mod g (segmented division)
     uint32_t seed_lo, seed_hi;
     int32_t K_bch, K_ldpc, N_ldpc, bps, itl_cols, itl_order, n_sym, pl_frame, enc_stride, n_frames;
 };
