@@ -187,8 +187,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
             }
         }
         if (act) {
-            if (SPA) { for (int e = 0; e < q * DEG; e++) gst(t4, st_base + (uint32_t)e * W8_ROW, 0.f); }
-            else for (int r = 0; r < q; r++) { gst(t4, st_off(0, r), 0.f); gst(t4, st_off(1, r), 0.f); gst(t4, st_off(2, r), 0.f); }
+            // the c->v state is NOT zeroed: a layer's state is first read one iteration after it was first written, and the
+            // reads of the first iteration are replaced by zeros where they happen (nx* / dl[] below)
             if (p.w8.pad) { if (MODE == 0) lst(ljunk + W8_ROW + t4, INFINITY); else gst(t4, W8_ROW, INFINITY); }     // what NULL slots read
         }
         if (p.packed && threadIdx.x == 0 && (p.K & 31)) p.packed[(size_t)f * ((p.K + 31) / 32) + p.K / 32] = 0u;     // the bits behind K in the last word
@@ -221,7 +221,13 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         for (int j = 0; j < DEG; j++) {
                             const uint32_t base = (E[j] >> 11) & 0x3FFFFu, wj = woff(j);
                             x[j] = w8_slot_lds(MODE, j) ? lld(wj + base) : gld(wj, base);
-                            dl[j] = gld(t4, mrow + (uint32_t)j * W8_ROW);               // old message
+                        }
+                        if (it == 0) {
+#pragma unroll
+                            for (int j = 0; j < DEG; j++) dl[j] = 0.f;                      // no messages yet
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < DEG; j++) dl[j] = gld(t4, mrow + (uint32_t)j * W8_ROW);     // old message
                         }
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
@@ -298,7 +304,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         v[j] = w8_slot_lds(MODE, j) ? lld(w[j] + base) : gld(w[j], base);
                     }
                     const int rn = r + 1 < q ? r + 1 : 0;
-                    nx1 = gld(t4, st_off(0, rn)); nx2 = gld(t4, st_off(1, rn)); nxk = gld(t4, st_off(2, rn));
+                    if (it == 0 && r + 1 < q) { nx1 = 0.f; nx2 = 0.f; nxk = 0.f; }       // layer r + 1 has no messages yet in the first iteration
+                    else { nx1 = gld(t4, st_off(0, rn)); nx2 = gld(t4, st_off(1, rn)); nxk = gld(t4, st_off(2, rn)); }
                     PROF_MARK(0);
                     // ---- pass 1b: v->c = posterior - old c->v ; running min1 / min2 / signs
                     const uint32_t idxo = pko >> 27;
