@@ -309,6 +309,19 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     PROF_MARK(0);
                     // ---- pass 1b: v->c = posterior - old c->v ; running min1 / min2 / signs
                     const uint32_t idxo = pko >> 27;
+                    if (it == 0) {
+                        // first iteration: there are no messages yet, v->c is the posterior itself (4 VALU per edge less)
+#pragma unroll
+                        for (int j = 0; j < DEG; j++) {
+                            float x = v[j];
+                            if (j == DEG - 1 && mask0) x = INFINITY;
+                            v[j] = x;
+                            const float a = fabsf(x);
+                            mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);
+                            mn1 = fminf(mn1, a);
+                            sacc = __builtin_amdgcn_alignbit(sacc, __float_as_uint(x), 31);
+                        }
+                    } else
 #pragma unroll
                     for (int j = 0; j < DEG; j++) {
                         const float mag = (idxo == (uint32_t)j) ? c1o : c2o;
