@@ -37,3 +37,33 @@ def test_eof_without_auto_reset_aborts(tmp_path):
         RadioUserBinary(N, input_filename=str(tmp_path / "missing.bin"))
     with pytest.raises(RuntimeError, match="not open"):
         RadioUserBinary(N).receive()
+
+
+def test_ch_parser_matches_the_reference_command_line():
+    """host logic of the `dvbs2_ch` work-alike (README.md:151-169 workflow); the noise itself needs the GPU"""
+    from dvbs2_amd import ch
+    a = ch.build_parser().parse_args(["--rad-type", "USER_BIN", "--rad-rx-file-path", "after_TX.bin", "--rad-tx-file-path", "before_RX_4.5dB.bin",
+                                      "--rad-rx-no-loop", "-m", "4.5"])
+    assert a.ebn0 == 4.5 and a.rad_rx_no_loop and a.chn_type == "AWGN" and a.osf == 2 and a.n_frames == 1
+    with pytest.raises(SystemExit):
+        ch.build_parser().parse_args(["--rad-rx-file-path", "x", "--rad-tx-file-path", "y", "--chn-type", "SYNCHRO"])
+
+
+@pytest.mark.gpu
+def test_ch_adds_awgn_of_the_requested_variance(tmp_path):
+    import io
+    from dvbs2_amd import ch, params as P
+    mc = P.get_modcod("QPSK-S_8/9")
+    N = mc.pl_frame * 2
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((6, 2 * N)).astype(np.float32)
+    src, dst = str(tmp_path / "after_TX.bin"), str(tmp_path / "before_RX.bin")
+    RadioUserBinary(N, output_filename=src).send(x)
+    args = ch.build_parser().parse_args(["--rad-rx-file-path", src, "--rad-tx-file-path", dst, "--rad-rx-no-loop", "-m", "4.5", "-F", "2"])
+    log = io.StringIO()
+    assert ch.run(args, out=log) == 6 and "Channel AWGN" in log.getvalue()
+    y = RadioUserBinary(N, input_filename=dst, n_frames=6).receive()
+    sigma = P.esn0_to_sigma(P.ebn0_to_esn0(4.5, mc.K_bch / mc.N_ldpc, mc.bps))
+    n = (y - x).astype(np.float64)
+    assert abs(n.mean()) < 5e-3 and abs(n.std() - sigma) < 5e-3 * sigma + 2e-3
+    assert not np.array_equal(n[0], n[2])                      # a fresh noise block per sequence iteration
