@@ -1,0 +1,44 @@
+"""End to end through every built row on the GPU, no oracle in the loop: TX mirror (N1) -> a stream that starts mid-frame ->
+TX shaping filter (N2) -> AWGN -> matched filter (a5) -> perfect-timing extraction -> frame synchronizer (N4) -> pilot-aided
+phase synchronizer (N4) -> fused RX chain (a7 .. a8).  What comes out must be the payload that went in.  (The reference's
+dvbs2_rx has sample-serial timing / coarse-frequency loops in between, which are out of scope: timing is perfect here.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("modcod,ebn0", [("QPSK-S_8/9", 7.0), ("16APSK-S_8/9", 12.0)])
+def test_filtered_stream_with_unknown_frame_start_is_decoded(modcod, ebn0):
+    from dvbs2_amd.receiver import Dvbs2Hip
+    from dvbs2_amd import params as P
+    mc = P.get_modcod(modcod)
+    F, off = 12, 1234                                         # frames in the stream, symbols before the first SOF
+    rx = Dvbs2Hip(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=True)
+    n = rx.pl_frame
+    sent, pl = rx.tx_bb(F, seed=11)                           # noiseless PL frames [F, 2 n]
+    stream = np.concatenate([np.zeros(2 * off, np.float32), pl.reshape(-1)])[: F * 2 * n]
+    up = rx.shape_filter(stream, n_frames=F, osf=2)           # 2 samples per symbol
+    sigma = P.esn0_to_sigma(P.ebn0_to_esn0(ebn0, mc.K_bch / mc.N_ldpc, mc.bps)) * np.sqrt(2.0)   # matched filter of gain 1: per-sample noise at osf 2
+    noisy = rx.add_noise(np.float32(sigma), up, seed=5, n_frames=F)
+    mf = rx.filter(noisy, n_frames=F).reshape(-1, 2)
+    sym = np.zeros((F * n, 2), np.float32)
+    got = mf[80::2]                                           # two group delays of 40 samples; symbol phase known
+    sym[: got.shape[0]] = got[: F * n]
+    # frame synchronizer: finds the SOF, its output frames start on a PL header once locked
+    delay, aligned = rx.sync_frame_synchronize(sym.reshape(F, 2 * n))
+    assert (delay[3:] == delay[3]).all() and delay[3] == off % n
+    # pilot-aided phase / residual-frequency correction works on PL-descrambled frames (Synchronizer_freq_phase_DVBS2_aib)
+    desc = rx.pl_descramble(aligned)
+    _, _, fixed = rx.sync_freq_phase_synchronize(desc)
+    out, c0, c1 = rx.rx_bb(aligned)                           # the chain takes the PL-scrambled frames
+    # every output frame from the lock on is one of the transmitted payloads, in order
+    idx = []
+    for f in range(3, F):
+        m = [k for k in range(F) if np.array_equal(out[f], sent[k])]
+        assert len(m) == 1 and c1[f] == 1, f
+        idx.append(m[0])
+    assert idx == list(range(idx[0], idx[0] + len(idx)))
+    # the phase synchronizer leaves an unrotated (locked) stream essentially unrotated
+    assert np.max(np.abs(fixed[3:] - desc[3:])) < 0.3
+    rx.close()
