@@ -1,0 +1,59 @@
+"""`dvbs2_tx` work-alike (rows N1 + N2 + N3): source -> BB scramble -> BCH -> LDPC -> interleave -> modulate -> frame ->
+PL scramble -> shaping filter -> raw IQ file, every stage on the GPU (src/mains/TX/main.cpp of the reference; README.md:151-158).
+
+  python -m dvbs2_amd.tx --rad-tx-file-path out_tx.bin -F 8 --src-type USER --src-path K_14232.src --mod-cod QPSK-S_8/9 --n-frames 64
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+
+from . import params as P
+from .iqfile import RadioUserBinary
+from .srcfile import SourceUser
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="dvbs2_tx", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--mod-cod", default="QPSK-S_8/9")
+    ap.add_argument("-F", "--src-fra", type=int, default=1, dest="n_frames_batch")
+    ap.add_argument("--src-type", default="RAND", choices=["RAND", "USER"])
+    ap.add_argument("--src-path", default="")
+    ap.add_argument("--shp-osf", type=int, default=2, dest="osf", choices=[2], help="samples per symbol (the GPU shaping filter is built for 2)")
+    ap.add_argument("--rad-type", default="USER_BIN", choices=["USER_BIN"])
+    ap.add_argument("--rad-tx-file-path", required=True)
+    ap.add_argument("--n-frames", type=int, default=0, help="stop after this many frames")
+    ap.add_argument("--tx-time-limit", type=float, default=0.0, help="stop after this many milliseconds")
+    ap.add_argument("--sim-seed", type=int, default=0, dest="seed")
+    ap.add_argument("--device", type=int, default=0)
+    return ap
+
+
+def run(args, out=sys.stdout) -> int:
+    """-> number of frames written"""
+    from .receiver import Dvbs2Hip
+    mc = P.get_modcod(args.mod_cod)
+    if not args.n_frames and not args.tx_time_limit:
+        raise ValueError("one of --n-frames / --tx-time-limit is needed to end the transmission")
+    if args.src_type == "USER" and not args.src_path:
+        raise ValueError("--src-type USER needs --src-path")
+    F = args.n_frames_batch
+    src = SourceUser(args.src_path, mc.K_bch) if args.src_type == "USER" else None
+    rx = Dvbs2Hip(mc.name, max_frames=F, device=args.device)
+    snd = RadioUserBinary(mc.pl_frame * args.osf, output_filename=args.rad_tx_file_path, n_frames=F)
+    t0, frames, call = time.perf_counter(), 0, 0
+    try:
+        while (not args.n_frames or frames < args.n_frames) and (not args.tx_time_limit or (time.perf_counter() - t0) * 1e3 < args.tx_time_limit):
+            _, pl = rx.tx_bb(F, info=src.generate(F) if src else None, seed=(args.seed << 32) + call)
+            snd.send(rx.shape_filter(pl, n_frames=F, osf=args.osf))        # the filter memory carries over from call to call
+            frames += F
+            call += 1
+    finally:
+        rx.close(); snd.close()
+    print("(II) %d frames of %d complex samples written in '%s'" % (frames, mc.pl_frame * args.osf, args.rad_tx_file_path), file=out)
+    return frames
+
+
+if __name__ == "__main__":
+    run(build_parser().parse_args())
