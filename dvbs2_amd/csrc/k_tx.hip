@@ -168,6 +168,10 @@ tx_ldpc_kernel(const TxKParams p)
 // ---------------------------------------------------------------- interleave + modulate + frame + PL scramble + AWGN
 // One lane per PAIR of PL symbols: one Philox4x32-10 block (four words) is exactly the two Box-Muller pairs the two symbols
 // need, and the lane leaves with one 16-byte store.
+// BPS > 0: bits per symbol known at compile time (the bit gathers of a symbol are issued together, not one dependent load
+// after the other) and, with ITL, the column/row interleaver with as many columns as bits per symbol (every DVB-S2 one):
+// interleaved bit k bps + b sits at natural position col(b) * n_rows + k -- no division.  BPS == 0: any configuration.
+template <int BPS, bool ITL>
 __device__ __forceinline__ float2 tx_symbol(const TxKParams &p, const float *cs, const uint32_t *cw, int i, int n_pil)
 {
     if (i < 90) return make_float2(p.plh[2 * i], p.plh[2 * i + 1]);
@@ -180,6 +184,17 @@ __device__ __forceinline__ float2 tx_symbol(const TxKParams &p, const float *cs,
     if (k < 0) y = make_float2(0.70710678118654752440f, 0.70710678118654752440f);     // pilot (Framer.hxx:252-260)
     else {
         int idx = 0;
+        if (BPS > 0) {
+            const int n_rows = p.N_ldpc / BPS;
+            uint32_t wd[BPS > 0 ? BPS : 1];
+#pragma unroll
+            for (int b = 0; b < BPS; b++) {
+                const int nat = ITL ? (p.itl_order == 0 ? b : BPS - 1 - b) * n_rows + k : k * BPS + b;
+                wd[b] = cw[nat >> 5] >> (nat & 31);
+            }
+#pragma unroll
+            for (int b = 0; b < BPS; b++) idx |= (int)(wd[b] & 1u) << b;
+        } else
         for (int b = 0; b < p.bps; b++) {
             // interleaved bit k*bps+b comes from natural position col*n_rows + row (column/row interleaver)
             int nat = k * p.bps + b;
@@ -197,6 +212,8 @@ __device__ __forceinline__ float2 tx_symbol(const TxKParams &p, const float *cs,
     return y;
 }
 
+constexpr int TX_MOD_U = 4;                               // pairs of PL symbols per lane (independent: their loads overlap)
+template <int BPS, bool ITL>
 __global__ void __launch_bounds__(256)
 tx_mod_kernel(const TxKParams p)
 {
@@ -204,27 +221,30 @@ tx_mod_kernel(const TxKParams p)
     const int f = blockIdx.y;
     if (threadIdx.x < (2 << p.bps)) cs[threadIdx.x] = p.cstl[threadIdx.x];
     __syncthreads();
-    const int pr = blockIdx.x * blockDim.x + threadIdx.x;     // pair of PL symbols 2 pr, 2 pr + 1
-    const int i0 = 2 * pr;
-    if (i0 >= p.pl_frame) return;
-    const bool two = i0 + 1 < p.pl_frame;
     const int n_pil = p.n_sym / 1440;
     const uint32_t *cw = p.ldpc_cw + (size_t)f * ((p.N_ldpc + 31) / 32);
-    float2 y0 = tx_symbol(p, cs, cw, i0, n_pil), y1 = two ? tx_symbol(p, cs, cw, i0 + 1, n_pil) : make_float2(0.f, 0.f);
-    if (p.sigma) {
-        const float sg = p.sigma[f];
-        const uint4 r = philox4x32(make_uint4((uint32_t)pr, (uint32_t)f, 1u, 0u), make_uint2(p.seed_lo, p.seed_hi));
-        // Box-Muller on the hardware units: v_log_f32, v_sqrt_f32, and v_sin_f32 / v_cos_f32, which take their argument in
-        // revolutions (u2 itself) -- the accurate libm forms cost ~10x the instructions and the noise needs none of it
-        const float u1 = ((float)r.x + 1.0f) * 2.3283064365386963e-10f, u2 = (float)r.y * 2.3283064365386963e-10f;
-        const float u3 = ((float)r.z + 1.0f) * 2.3283064365386963e-10f, u4 = (float)r.w * 2.3283064365386963e-10f;
-        const float ra = sg * __builtin_amdgcn_sqrtf(-2.0f * hw_log(u1)), rb = sg * __builtin_amdgcn_sqrtf(-2.0f * hw_log(u3));
-        y0.x += ra * __builtin_amdgcn_cosf(u2); y0.y += ra * __builtin_amdgcn_sinf(u2);
-        y1.x += rb * __builtin_amdgcn_cosf(u4); y1.y += rb * __builtin_amdgcn_sinf(u4);
+    const float sg = p.sigma ? p.sigma[f] : 0.f;
+#pragma unroll
+    for (int u = 0; u < TX_MOD_U; u++) {
+        const int pr = (blockIdx.x * TX_MOD_U + u) * blockDim.x + threadIdx.x;     // pair of PL symbols 2 pr, 2 pr + 1
+        const int i0 = 2 * pr;
+        if (i0 >= p.pl_frame) continue;
+        const bool two = i0 + 1 < p.pl_frame;
+        float2 y0 = tx_symbol<BPS, ITL>(p, cs, cw, i0, n_pil), y1 = two ? tx_symbol<BPS, ITL>(p, cs, cw, i0 + 1, n_pil) : make_float2(0.f, 0.f);
+        if (p.sigma) {
+            const uint4 r = philox4x32(make_uint4((uint32_t)pr, (uint32_t)f, 1u, 0u), make_uint2(p.seed_lo, p.seed_hi));
+            // Box-Muller on the hardware units: v_log_f32, v_sqrt_f32, and v_sin_f32 / v_cos_f32, which take their argument in
+            // revolutions (u2 itself) -- the accurate libm forms cost ~10x the instructions and the noise needs none of it
+            const float u1 = ((float)r.x + 1.0f) * 2.3283064365386963e-10f, u2 = (float)r.y * 2.3283064365386963e-10f;
+            const float u3 = ((float)r.z + 1.0f) * 2.3283064365386963e-10f, u4 = (float)r.w * 2.3283064365386963e-10f;
+            const float ra = sg * __builtin_amdgcn_sqrtf(-2.0f * hw_log(u1)), rb = sg * __builtin_amdgcn_sqrtf(-2.0f * hw_log(u3));
+            y0.x += ra * __builtin_amdgcn_cosf(u2); y0.y += ra * __builtin_amdgcn_sinf(u2);
+            y1.x += rb * __builtin_amdgcn_cosf(u4); y1.y += rb * __builtin_amdgcn_sinf(u4);
+        }
+        float2 *out = reinterpret_cast<float2 *>(p.pl_out + (size_t)f * 2 * p.pl_frame) + i0;
+        if (two && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) *reinterpret_cast<float4 *>(out) = make_float4(y0.x, y0.y, y1.x, y1.y);
+        else { out[0] = y0; if (two) out[1] = y1; }
     }
-    float2 *out = reinterpret_cast<float2 *>(p.pl_out + (size_t)f * 2 * p.pl_frame) + i0;
-    if (two && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) *reinterpret_cast<float4 *>(out) = make_float4(y0.x, y0.y, y1.x, y1.y);
-    else { out[0] = y0; if (two) out[1] = y1; }
 }
 
 // Channel_AWGN::add_noise (DVBS2.cpp:593-613): Y = X + sigma[f] * n, n ~ N(0,1) per real value.
@@ -260,7 +280,17 @@ hipError_t tx_launch(const TxKParams &p, hipStream_t s)
     hipLaunchKernelGGL(tx_ldpc_kernel, dim3(p.n_frames), dim3(LDPC_THREADS), lds, s, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tx_mod_kernel, dim3(((p.pl_frame + 1) / 2 + 255) / 256, p.n_frames), dim3(256), 0, s, p);
+    const dim3 g(((p.pl_frame + 1) / 2 + 256 * TX_MOD_U - 1) / (256 * TX_MOD_U), p.n_frames), b(256);
+    const bool itl = p.itl_cols > 1;
+    if (itl && p.itl_cols != p.bps) hipLaunchKernelGGL((tx_mod_kernel<0, false>), g, b, 0, s, p);          // not a DVB-S2 interleaver: general form
+    else if (p.bps == 1) hipLaunchKernelGGL((tx_mod_kernel<1, false>), g, b, 0, s, p);
+    else if (p.bps == 2 && !itl) hipLaunchKernelGGL((tx_mod_kernel<2, false>), g, b, 0, s, p);
+    else if (p.bps == 2) hipLaunchKernelGGL((tx_mod_kernel<2, true>), g, b, 0, s, p);
+    else if (p.bps == 3 && !itl) hipLaunchKernelGGL((tx_mod_kernel<3, false>), g, b, 0, s, p);
+    else if (p.bps == 3) hipLaunchKernelGGL((tx_mod_kernel<3, true>), g, b, 0, s, p);
+    else if (p.bps == 4 && itl) hipLaunchKernelGGL((tx_mod_kernel<4, true>), g, b, 0, s, p);
+    else if (p.bps == 5 && itl) hipLaunchKernelGGL((tx_mod_kernel<5, true>), g, b, 0, s, p);
+    else hipLaunchKernelGGL((tx_mod_kernel<0, false>), g, b, 0, s, p);
     return hipGetLastError();
 }
 
