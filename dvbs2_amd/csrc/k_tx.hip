@@ -127,7 +127,11 @@ tx_ldpc_kernel(const TxKParams p)
     uint32_t *info = sm;                                     // nw_in words
     uint8_t *par = reinterpret_cast<uint8_t *>(sm + nw_in);  // [r][t], M bytes
     uint8_t *tot = par + M;                                  // 360 bytes
+    uint32_t *tab;
     const int t = threadIdx.x, f = blockIdx.x;
+    // the layer table (t0 | group << 9 per entry) in LDS: the inner loop then has no global round trip per entry
+    tab = sm + nw_in + (M + 512 + 3) / 4;
+    for (int w = t; w < q * p.enc_stride; w += LDPC_THREADS) tab[w] = p.enc_tab[w];
     const uint32_t *src = p.bch_cw + (size_t)f * nw_in;
     for (int w = t; w < nw_in; w += LDPC_THREADS) info[w] = src[w];
     __syncthreads();
@@ -136,13 +140,15 @@ tx_ldpc_kernel(const TxKParams p)
         for (int r = 0; r < q; r++) {
             uint32_t x = 0;
             const int deg = p.enc_deg[r];
+            const uint32_t *T = tab + r * p.enc_stride;
+#pragma unroll 4
             for (int j = 0; j < deg; j++) {
-                const uint32_t e = p.enc_tab[r * p.enc_stride + j];     // t0 | group << 9
+                const uint32_t e = T[j];                              // t0 | group << 9
                 int m = t - (int)(e & 0x1FFu); m += m < 0 ? LDPC_Z : 0;
                 const int idx = (int)(e >> 9) * LDPC_Z + m;
-                x ^= (info[idx >> 5] >> (idx & 31)) & 1u;
+                x ^= info[idx >> 5] >> (idx & 31);
             }
-            run ^= x;
+            run ^= x & 1u;
             par[r * LDPC_Z + t] = (uint8_t)run;               // prefix over r inside column t
         }
         tot[t] = (uint8_t)run;
@@ -153,13 +159,19 @@ tx_ldpc_kernel(const TxKParams p)
     uint32_t *dst = p.ldpc_cw + (size_t)f * nw_out;
     for (int w = t; w < nw_out; w += LDPC_THREADS) {
         uint32_t word = 0;
-        for (int b = 0; b < 32; b++) {
-            const int i = 32 * w + b;
-            if (i >= p.N_ldpc) break;
-            uint32_t bit;
-            if (i < K) bit = (info[i >> 5] >> (i & 31)) & 1u;
-            else { const int c = i - K, tt = c / q, r = c - tt * q; bit = (uint32_t)(par[r * LDPC_Z + tt] ^ tot[tt]) & 1u; }
-            word |= bit << b;
+        const int i0 = 32 * w;
+        if (i0 + 32 <= K) word = info[w];                     // systematic part, word-aligned
+        else {
+            // parity bit c = i - K sits at (r = c mod q, tt = c / q): stepped, one division per word
+            int c = i0 >= K ? i0 - K : 0, tt = c / q, r = c - tt * q;
+            for (int b = 0; b < 32; b++) {
+                const int i = i0 + b;
+                if (i >= p.N_ldpc) break;
+                uint32_t bit;
+                if (i < K) bit = (info[i >> 5] >> (i & 31)) & 1u;
+                else { bit = (uint32_t)(par[r * LDPC_Z + tt] ^ tot[tt]) & 1u; if (++r == q) { r = 0; tt++; } }
+                word |= bit << b;
+            }
         }
         dst[w] = word;
     }
@@ -276,7 +288,7 @@ hipError_t tx_launch(const TxKParams &p, hipStream_t s)
     hipLaunchKernelGGL(tx_bchpar_kernel, dim3((p.n_frames + 64 / TX_BCH_SEG - 1) / (64 / TX_BCH_SEG)), dim3(64), 0, s, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const size_t lds = (size_t)((p.K_ldpc + 31) / 32) * 4 + (size_t)(p.N_ldpc - p.K_ldpc) + 512;
+    const size_t lds = (size_t)((p.K_ldpc + 31) / 32) * 4 + (((size_t)(p.N_ldpc - p.K_ldpc) + 512 + 3) / 4) * 4 + (size_t)((p.N_ldpc - p.K_ldpc) / LDPC_Z) * p.enc_stride * 4;
     hipLaunchKernelGGL(tx_ldpc_kernel, dim3(p.n_frames), dim3(LDPC_THREADS), lds, s, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
