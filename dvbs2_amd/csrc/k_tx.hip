@@ -80,25 +80,50 @@ tx_bchpar_kernel(const TxKParams p)
     const unsigned long long m2 = r >= 192 ? ~0ull : r > 128 ? (1ull << (r - 128)) - 1ull : 0ull;
     const int nbytes = K / 8, L = (nbytes + TX_BCH_SEG - 1) / TX_BCH_SEG;
     const int b0 = min(seg * L, nbytes), b1 = min(b0 + L, nbytes);
-    uint32_t word = 0;
-    if (live)
-        for (int by = b0; by < b1; by++) {
-            if ((by & 3) == 0 || by == b0) word = cw[by >> 2];
-            const uint32_t raw = (word >> ((by & 3) * 8)) & 0xFFu;
-            const uint32_t top = (uint32_t)((tw == 0 ? s0 : tw == 1 ? s1 : s2) >> ts) & 0xFFu;
-            const uint32_t idx = top ^ brev[raw];
-            s2 = ((s2 << 8) | (s1 >> 56)) & m2; s1 = ((s1 << 8) | (s0 >> 56)) & m1; s0 <<= 8;
-            if (r <= 64) s0 &= (r == 64 ? ~0ull : (1ull << r) - 1ull);
-            s0 ^= T[idx][0]; s1 ^= T[idx][1]; s2 ^= T[idx][2];
+    if (live && b1 > b0) {
+        // the message words of the segment, 8 at a time and one batch ahead: the division is a dependent chain (table look-up
+        // -> XOR -> next look-up) and must not also wait for a global load every four bytes
+        constexpr int WB = 8;
+        const int w0 = b0 >> 2, w1 = (b1 - 1) >> 2;           // first / last word touched
+        uint32_t nxt[WB];
+#pragma unroll
+        for (int k = 0; k < WB; k++) nxt[k] = cw[min(w0 + k, w1)];
+        for (int wb = w0; wb <= w1; wb += WB) {
+            uint32_t cur[WB];
+#pragma unroll
+            for (int k = 0; k < WB; k++) cur[k] = nxt[k];
+#pragma unroll
+            for (int k = 0; k < WB; k++) nxt[k] = cw[min(wb + WB + k, w1)];
+#pragma unroll
+            for (int k = 0; k < WB; k++) {
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) {
+                    const int by = 4 * (wb + k) + bb;
+                    if (by < b0 || by >= b1) continue;
+                    const uint32_t raw = (cur[k] >> (bb * 8)) & 0xFFu;
+                    const uint32_t top = (uint32_t)((tw == 0 ? s0 : tw == 1 ? s1 : s2) >> ts) & 0xFFu;
+                    const uint32_t idx = top ^ brev[raw];
+                    s2 = ((s2 << 8) | (s1 >> 56)) & m2; s1 = ((s1 << 8) | (s0 >> 56)) & m1; s0 <<= 8;
+                    if (r <= 64) s0 &= (r == 64 ? ~0ull : (1ull << r) - 1ull);
+                    s0 ^= T[idx][0]; s1 ^= T[idx][1]; s2 ^= T[idx][2];
+                }
+            }
         }
+    }
     // to the segment's place: sum over the set bits b of the remainder of x^(b + 8 (nbytes - b1)) mod g
     if (b1 < nbytes) {
         const unsigned long long *P = p.bch_shift + (size_t)seg * r * 3;
         unsigned long long a0 = 0, a1 = 0, a2 = 0;
-        for (int b = 0; b < r; b++) {
-            const unsigned long long bit = b < 64 ? (s0 >> b) & 1ull : b < 128 ? (s1 >> (b - 64)) & 1ull : (s2 >> (b - 128)) & 1ull;
-            const unsigned long long m = 0ull - bit;
-            a0 ^= P[3 * b] & m; a1 ^= P[3 * b + 1] & m; a2 ^= P[3 * b + 2] & m;
+        for (int b0 = 0; b0 < r; b0 += 8) {               // r is a multiple of 8 (m t, m = 14 or 16); 24 table loads in flight
+            unsigned long long q0[8], q1[8], q2[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { q0[k] = P[3 * (b0 + k)]; q1[k] = P[3 * (b0 + k) + 1]; q2[k] = P[3 * (b0 + k) + 2]; }
+            const unsigned long long sw = b0 < 64 ? s0 >> b0 : b0 < 128 ? s1 >> (b0 - 64) : s2 >> (b0 - 128);      // 8 bits of the remainder (b0 is a multiple of 8)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const unsigned long long m = 0ull - ((sw >> k) & 1ull);
+                a0 ^= q0[k] & m; a1 ^= q1[k] & m; a2 ^= q2[k] & m;
+            }
         }
         s0 = a0; s1 = a1; s2 = a2;
     }
