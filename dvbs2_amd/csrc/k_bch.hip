@@ -264,7 +264,8 @@ bch_decode_kernel(const BchKParams p)
         if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
             // four bits per lane: one 16-byte non-temporal store (the socket is written once and read by another kernel)
             typedef int32_t bch_i4 __attribute__((ext_vector_type(4)));
-            for (int k = 4 * tid; k < K; k += 4 * BCH_THREADS) {
+#pragma unroll 8
+            for (int k = 4 * tid; k < K; k += 4 * BCH_THREADS) {          // unrolled: the PRBS words (global, cache-resident) of 8 iterations in flight
                 uint32_t b = words[k >> 5];
                 if (p.prbs) b ^= p.prbs[k >> 5];
                 b >>= (k & 31);
