@@ -105,7 +105,8 @@ struct LdpcPlan {             // host-side description, built once per handle
     uint32_t *d_cu_ctr = nullptr; // [LDPC_CU_CTR_WORDS]
 };
 constexpr int LDPC_PROF_WORDS = 1024 * 64;   // development aid (LDPC_PHASE_PROF builds): per-wave phase timers
-constexpr int LDPC_CU_CTR_WORDS = 4096;    // key = XCC_ID << 8 | SE_ID << 5 | SH_ID << 4 | CU_ID
+constexpr int LDPC_CU_CTR_WORDS = 4096 + 64;   // [0, 4096): arrivals per CU, key = XCC_ID << 8 | SE_ID << 5 | SH_ID << 4 | CU_ID; [4096]: frames handed out (work queue)
+constexpr int LDPC_FRAME_CTR = 4096;
 constexpr int LDPC_FAST_STRIDE = 64;   // dwords per layer: 27 entries | prim mask | n_conf | 16 conf entries | 16 conf meta
 constexpr int LDPC_FAST_MAXC = 16;
 hipError_t ldpc_fast_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);

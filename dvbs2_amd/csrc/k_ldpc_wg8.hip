@@ -140,7 +140,10 @@ ldpc_wg8_kernel(const LdpcKParams p)
     unsigned long long pt_ = prof_t0;
 #endif
 
-    for (int f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
+    // Frames are handed out through a counter (the first one of every workgroup is its block index): with the syndrome early
+    // stop frames take 1 .. n_ite iterations, and a fixed round-robin assignment left the workgroups with the slow frames running
+    // alone at the end of the launch.
+    for (int f = blockIdx.x; f < p.n_frames; ) {
         // ---- channel LLRs -> posterior image, W8_IO independent loads per lane in flight; packed state := 0
         const float *Y = p.llr + (size_t)f * p.N;
         if (act) {
@@ -478,7 +481,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 for (int k = 0; k < W8_IO; k++) if (l0 + k < ng_out) emit((int)rows[nl + l0 + k], v[k]);
             }
         }
+        if (threadIdx.x == 0) s_misc[9] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[LDPC_FRAME_CTR], 1u) + gridDim.x) : f + (int)gridDim.x;
         __syncthreads();     // the posterior image is reused by the next frame of this workgroup
+        f = s_misc[9];
         PROF_MARK(7);
     }
 #ifdef LDPC_PHASE_PROF

@@ -13,5 +13,9 @@ cp dvbs2_amd/lib/libdvbs2hip.so /tmp/lib_old.so
 cp /tmp/new_wg8.hip dvbs2_amd/csrc/k_ldpc_wg8.hip; cp /tmp/new_ldpc.hip dvbs2_amd/csrc/k_ldpc.hip
 for i in 1 2 3; do for v in old new; do
   cp /tmp/lib_$v.so dvbs2_amd/lib/libdvbs2hip.so
-  python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],3), d['ber']['BE'])"
+  if [ "${AB_MODE:-bench}" = sim ]; then     # early-stop workload: the Monte-Carlo simulator (SIM_THR column, Mb/s)
+    python -m dvbs2_amd.sim --mod-cod QPSK-N_8/9 -m 3.9 -M 4.11 -s 0.1 --dec-ite 10 -F 2048 --max-frames 400000 2>/dev/null | grep -E "^ +[0-9]" | awk -v v=$v '{printf "%s Eb/N0 %s  FE %s  %s Mb/s\n", v, $3, $9, $15}'
+  else
+    python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],3), d['ber']['BE'])"
+  fi
 done; done
