@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 namespace dvbs2 {
 
@@ -485,6 +486,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
         __syncthreads();     // the posterior image is reused by the next frame of this workgroup
         f = s_misc[9];
         PROF_MARK(7);
+#ifdef LDPC_PHASE_PROF
+        prof[9]++;                                            // frames this workgroup decoded
+#endif
     }
 #ifdef LDPC_PHASE_PROF
     if (lane == 0 && p.cu_ctr) {
@@ -518,8 +522,16 @@ static hipError_t wg8_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t
         (void)hipMemcpy(hbuf.data(), p.cu_ctr + LDPC_CU_CTR_WORDS, hbuf.size() * 4, hipMemcpyDeviceToHost);
         double acc[12] = {0}; int nw = 0;
         for (int w = 0; w < grid * 8; w++) { if (!hbuf[(size_t)w * 12 + 11]) continue; nw++; for (int i = 0; i < 12; i++) acc[i] += hbuf[(size_t)w * 12 + i]; }
-        static const char *nm[12] = {"1a issue", "1b", "mid barrier", "pass 2", "replay", "end barrier", "syndrome", "output", "input", "-", "-", "TOTAL"};
+        static const char *nm[12] = {"1a issue", "1b", "mid barrier", "pass 2", "replay", "end barrier", "syndrome", "output", "input", "-frames", "-", "TOTAL"};
         fprintf(stderr, "[ldpc phase prof] %d working waves\n", nw);
+        {   // frames per workgroup and busy time: how evenly the work queue feeds the persistent grid
+            std::vector<int> hist(64, 0); double tmin = 1e30, tmax = 0;
+            for (int w = 0; w < grid * 8; w++) { const uint32_t *q = &hbuf[(size_t)w * 12]; if (!q[11] || (w & 7) >= 1) continue; hist[q[9] < 63 ? q[9] : 63]++; }
+            for (int w = 0; w < grid * 8; w++) { const uint32_t *q = &hbuf[(size_t)w * 12]; if (!q[11]) continue; tmin = std::min(tmin, (double)q[11]); tmax = std::max(tmax, (double)q[11]); }
+            fprintf(stderr, "  frames per workgroup (wave 0 of each):");
+            for (int i = 0; i < 64; i++) if (hist[i]) fprintf(stderr, "  %d frames: %d WGs", i, hist[i]);
+            fprintf(stderr, "\n  busy ticks per wave: min %.0f max %.0f\n", tmin, tmax);
+        }
         for (int i = 0; i < 12; i++) if (nm[i][0] != '-') fprintf(stderr, "  %-12s %12.0f ticks/wave  %5.1f %%\n", nm[i], acc[i] / (nw ? nw : 1), 100.0 * acc[i] / (acc[11] > 0 ? acc[11] : 1));
     }
 #endif
