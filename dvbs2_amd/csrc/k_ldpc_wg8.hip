@@ -299,7 +299,10 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 float mn1 = INFINITY, mn2 = INFINITY, cst1 = 0.f, cst2 = 0.f;
                 uint32_t sacc = 0u, tot = 0u, pkn = 0u;
                 if (act) {
-                    // ---- pass 1a: every posterior load of the check in flight before any use
+                    // ---- pass 1a: every posterior load of the check in flight before any use.  Wave priorities (same-box A/B, tools/ab_kernel.sh):
+                    // 3 while the loads are issued, 0 while pass 1b waits for them, 2 in pass 2 (stores, and the way to the barrier) is
+                    // worth 2.5 %; (3, 0, 3) 1.8 %, (3, 1, 2) 1.4 %, load issue alone 1.2 %, the replay stretch on top nothing
+                    __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                     for (int j = 0; j < DEG; j++) {
                         const uint32_t d = t4 - (E[j] & 0x7FFu);
@@ -310,6 +313,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     const int rn = r + 1 < q ? r + 1 : 0;
                     if (it == 0 && r + 1 < q) { nx1 = 0.f; nx2 = 0.f; nxk = 0.f; }       // layer r + 1 has no messages yet in the first iteration
                     else { nx1 = gld(t4, st_off(0, rn)); nx2 = gld(t4, st_off(1, rn)); nxk = gld(t4, st_off(2, rn)); }
+                    __builtin_amdgcn_s_setprio(0);
                     PROF_MARK(0);
                     // ---- pass 1b: v->c = posterior - old c->v ; running min1 / min2 / signs
                     const uint32_t idxo = pko >> 27;
@@ -346,6 +350,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 if (ncf > 0) __syncthreads();         // every read of the layer precedes its writes
                 PROF_MARK(2);
                 if (act) {
+                    __builtin_amdgcn_s_setprio(2);
                     // ---- pass 2: new c->v ; posterior = v->c + new c->v.  Duplicate edges (not in `prim`) go to
                     //      the junk row (selected on the scalar unit), the absent edge of lane 0 is dropped.
                     uint32_t idxn = 0u;
@@ -376,6 +381,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     pkn |= idxn << 27;
                     gst(t4, st_off(0, r), cst1); gst(t4, st_off(1, r), cst2); gst(t4, st_off(2, r), __uint_as_float(pkn));
                     if (q == 1) { nx1 = cst1; nx2 = cst2; nxk = __uint_as_float(pkn); }
+                    __builtin_amdgcn_s_setprio(0);
                 }
                 PROF_MARK(3);
                 // ---- duplicate edges of a bit-group inside this layer: ordered delta updates, level by level.  The
