@@ -147,6 +147,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
     for (int f = blockIdx.x; f < p.n_frames; ) {
         // ---- channel LLRs -> posterior image, W8_IO independent loads per lane in flight; packed state := 0
         const float *Y = p.llr + (size_t)f * p.N;
+        __builtin_amdgcn_s_setprio(3);                       // frame I/O: short bursts of loads that the other workgroup's arithmetic should not delay
         if (act) {
             // info groups: coalesced rows of 360, streamed in once (non-temporal)
             for (int l0 = 0; l0 < nl_info; l0 += W8_IO) {
@@ -196,6 +197,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
             if (p.w8.pad) { if (MODE == 0) lst(ljunk + W8_ROW + t4, INFINITY); else gst(t4, W8_ROW, INFINITY); }     // what NULL slots read
         }
         if (p.packed && threadIdx.x == 0 && (p.K & 31)) p.packed[(size_t)f * ((p.K + 31) / 32) + p.K / 32] = 0u;     // the bits behind K in the last word
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         PROF_MARK(8);
 
