@@ -223,6 +223,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     auto woff = [&](int j) { const uint32_t d = t4 - (E[j] & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
                     float x[DEG], nw[DEG], dl[DEG];         // v->c, new c->v, new - old (what a duplicate edge adds)
                     if (act) {
+                        __builtin_amdgcn_s_setprio(3);            // as in the min-sum layer: load issue first, the long arithmetic last
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
                             const uint32_t base = (E[j] >> 11) & 0x3FFFFu, wj = woff(j);
@@ -235,6 +236,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #pragma unroll
                             for (int j = 0; j < DEG; j++) dl[j] = gld(t4, mrow + (uint32_t)j * W8_ROW);     // old message
                         }
+                        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
                             x[j] = x[j] - dl[j];
@@ -254,6 +256,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     }
                     if (ncf > 0) __syncthreads();         // every read of the layer precedes its writes
                     if (act) {
+                        __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
                             const bool pr = ((prim >> j) & 1u) != 0u;
@@ -268,6 +271,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             }
                             gst(t4, mrow + (uint32_t)j * W8_ROW, nw[j]);
                         }
+                        __builtin_amdgcn_s_setprio(0);
                     }
                     // duplicate edges: level by level, slot index wave-uniform -> a uniform branch picks the register
                     uint32_t prev_lvl = 0u;
