@@ -13,53 +13,67 @@
 
 namespace dvbs2 {
 
-// conj_SOF / conj_PLSC of Synchronizer_frame_DVBS2_fast.hpp:19-33
-__constant__ float c_conj_sof[25] = {1, -1, -1, 1, -1, 1, 1, -1, 1, 1, -1, -1, 1, -1, -1, -1, 1, -1, -1, -1, -1, 1, 1, 1, 1};
-__constant__ float c_conj_plsc[64] = {1, 0, 1, 0, -1, 0, -1, 0, 1, 0, -1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1, 0, 1, 0, -1, 0, -1, 0, 1, 0, 1, 0,
-                                      1, 0, 1, 0, -1, 0, -1, 0, -1, 0, -1, 0, -1, 0, 1, 0, 1, 0, -1, 0, 1, 0, 1, 0, 1, 0, -1, 0, -1, 0, 1, 0};
+// conj_SOF / conj_PLSC of Synchronizer_frame_DVBS2_fast.hpp:19-33 (compile-time: the taps are +-1 and, for the PLSC, every
+// other one is 0 -- fma(0, v, acc) is acc, so leaving those out changes nothing)
+constexpr float K_CONJ_SOF[25] = {1, -1, -1, 1, -1, 1, 1, -1, 1, 1, -1, -1, 1, -1, -1, -1, 1, -1, -1, -1, -1, 1, 1, 1, 1};
+constexpr float K_CONJ_PLSC[64] = {1, 0, 1, 0, -1, 0, -1, 0, 1, 0, -1, 0, 1, 0, -1, 0, 1, 0, -1, 0, -1, 0, 1, 0, -1, 0, -1, 0, 1, 0, 1, 0,
+                                   1, 0, 1, 0, -1, 0, -1, 0, -1, 0, -1, 0, -1, 0, 1, 0, 1, 0, -1, 0, 1, 0, 1, 0, 1, 0, -1, 0, -1, 0, 1, 0};
 
-constexpr int SY_T = 256;            // outputs per workgroup
-constexpr int SY_H = 64;             // samples of x a block needs before its first output (63 of d, one more of x)
+constexpr int SY_THREADS = 256;
+constexpr int SY_R = 4;                       // outputs per lane
+constexpr int SY_T = SY_THREADS * SY_R;       // outputs per workgroup
+constexpr int SY_H = 64;                      // samples of x a block needs before its first output (63 of d, one more of x)
+__device__ __forceinline__ int sy_pad(int i) { return i + (i >> 2); }     // one element of padding per 4: the lanes' stride-4 reads hit 32 different banks
 
 // ---- _synchronize1: x -> cor_SOF, cor_PLSC.  xh = the last 64 samples of the stream so far
 // (initially zeros with (1, 0) last: reg_channel, :19; the correlators start from empty memories).
-__global__ void __launch_bounds__(SY_T)
+// Each lane forms SY_R consecutive outputs from one pass over the 63 + SY_R differential samples they share (a value is read
+// from LDS once and used by up to SY_R x 2 taps; one output per lane read 89 values per output and was LDS-bound), every
+// output accumulating oldest sample first like Filter_FIR_ccr.cpp:68-142.
+__global__ void __launch_bounds__(SY_THREADS)
 sync_corr_kernel(const float2 *__restrict__ x, const float2 *__restrict__ xh, float2 *__restrict__ cor_sof, float2 *__restrict__ cor_plsc,
                  long long n_total)
 {
-    __shared__ float2 xs[SY_T + SY_H];         // xs[k] = x[blk0 - 64 + k]
-    __shared__ float2 ds[SY_T + SY_H - 1];     // ds[k] = d[blk0 - 63 + k] = x[blk0 - 64 + k] conj(x[blk0 - 63 + k])
+    __shared__ float2 xs[SY_T + SY_H];                               // xs[k] = x[blk0 - 64 + k]
+    __shared__ float2 ds[SY_T + SY_H + (SY_T + SY_H) / 4 + 4];       // ds[pad(k)] = d[blk0 - 63 + k] = x[blk0 - 64 + k] conj(x[blk0 - 63 + k])
     const long long blk0 = (long long)blockIdx.x * SY_T;
-    for (int k = threadIdx.x; k < SY_T + SY_H; k += SY_T) {
+    for (int k = threadIdx.x; k < SY_T + SY_H; k += SY_THREADS) {
         const long long g = blk0 - SY_H + k;
         float2 v = make_float2(0.f, 0.f);
         if (g < 0) v = xh[SY_H + g]; else if (g < n_total) v = x[g];
         xs[k] = v;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < SY_T + SY_H - 1; k += SY_T) {
+    for (int k = threadIdx.x; k < SY_T + SY_H - 1; k += SY_THREADS) {
         const float2 a = xs[k], b = xs[k + 1];                     // :138-142 (a = previous sample)
-        ds[k] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+        ds[sy_pad(k)] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
     }
     __syncthreads();
-    const long long i = blk0 + threadIdx.x;
-    if (i >= n_total) return;
-    // y[i] = sum_m b[m] d[i - m], oldest sample first (Filter_FIR_ccr.cpp:68-142)
-    float2 ap = make_float2(0.f, 0.f), as = make_float2(0.f, 0.f);
-    const int o = threadIdx.x + SY_H - 1;       // ds index of d[i]
-#pragma unroll 8
-    for (int m = 63; m >= 0; m--) {
-        const float2 v = ds[o - m];
-        const float b = c_conj_plsc[m];
-        ap.x = fmaf(b, v.x, ap.x); ap.y = fmaf(b, v.y, ap.y);
+    const int l0 = threadIdx.x * SY_R;                             // first output of the lane inside the block
+    const long long i0 = blk0 + l0;
+    if (i0 >= n_total) return;
+    // output l0 + r = sum_m b[m] d[i - m]; d[i - m] sits at ds index (l0 + r) + 63 - m
+    float2 ap[SY_R], as[SY_R];
+#pragma unroll
+    for (int r = 0; r < SY_R; r++) { ap[r] = make_float2(0.f, 0.f); as[r] = make_float2(0.f, 0.f); }
+#pragma unroll
+    for (int jj = 0; jj < 64 + SY_R - 1; jj++) {                   // ds index l0 + jj, oldest first
+        const float2 v = ds[sy_pad(l0 + jj)];
+#pragma unroll
+        for (int r = 0; r < SY_R; r++) {
+            const int m = 63 + r - jj;                             // tap that pairs this sample with output r
+            if (m >= 0 && m < 64 && K_CONJ_PLSC[m < 0 ? 0 : m > 63 ? 63 : m] != 0.f) {
+                const float b = K_CONJ_PLSC[m < 0 ? 0 : m > 63 ? 63 : m];
+                ap[r].x = fmaf(b, v.x, ap[r].x); ap[r].y = fmaf(b, v.y, ap[r].y);
+            }
+            if (m >= 0 && m < 25) {
+                const float b = K_CONJ_SOF[m < 0 ? 0 : m > 24 ? 24 : m];
+                as[r].x = fmaf(b, v.x, as[r].x); as[r].y = fmaf(b, v.y, as[r].y);
+            }
+        }
     }
 #pragma unroll
-    for (int m = 24; m >= 0; m--) {
-        const float2 v = ds[o - m];
-        const float b = c_conj_sof[m];
-        as.x = fmaf(b, v.x, as.x); as.y = fmaf(b, v.y, as.y);
-    }
-    cor_plsc[i] = ap; cor_sof[i] = as;
+    for (int r = 0; r < SY_R; r++) if (i0 + r < n_total) { cor_plsc[i0 + r] = ap[r]; cor_sof[i0 + r] = as[r]; }
 }
 
 // new history = last H samples of (old history ++ x)
@@ -366,7 +380,7 @@ hipError_t sff_fp_launch(const float *X, float *Y, float *tmp /* 2 F floats */, 
 hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s)
 {
     const unsigned grid = (unsigned)((n_total + SY_T - 1) / SY_T);
-    hipLaunchKernelGGL(sync_corr_kernel, dim3(grid), dim3(SY_T), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
+    hipLaunchKernelGGL(sync_corr_kernel, dim3(grid), dim3(SY_THREADS), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
                        reinterpret_cast<float2 *>(cor_sof), reinterpret_cast<float2 *>(cor_plsc), n_total);
     hipLaunchKernelGGL(sync_hist_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
                        reinterpret_cast<float2 *>(xh_out), SY_H, n_total);
