@@ -106,7 +106,7 @@ int fail(dvbs2hip_t *h, int code, const std::string &msg)
     } while (0)
 
 enum BufId { B_IN = 0, B_OUT, B_AUX0, B_AUX1, B_AUX2, B_AUX3, B_LLR, B_PACKED, B_EST, B_CWD0, B_CWD1, B_INFO, B_SIG, B_TXBCH, B_TXLDPC,
-             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY, B_SFF_TMP, B_SFF_OUT };
+             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY, B_SFM_DTAB, B_SFF_TMP, B_SFF_OUT };
 
 int ensure(dvbs2hip_t *h, int id, size_t bytes, void **out)
 {
@@ -928,7 +928,9 @@ int dvbs2hip_sync_frame_synchronize2_dev(dvbs2hip_t *h, const float *X_N1, const
     auto &S = h->sfm;
     const int n = h->pl_frame;
     void *corr, *met;
-    if ((r = ensure(h, B_SFM_CORR, sizeof(float) * (size_t)n * F, &corr)) || (r = ensure(h, B_SFM_MET, sizeof(float) * (size_t)F, &met))) return r;
+    void *dtab;
+    if ((r = ensure(h, B_SFM_CORR, sizeof(float) * (size_t)n * F, &corr)) || (r = ensure(h, B_SFM_MET, sizeof(float) * (size_t)F, &met)) ||
+        (r = ensure(h, B_SFM_DTAB, sizeof(int32_t) * (size_t)F, &dtab))) return r;
     Timer tm(h, DVBS2HIP_K_MISC);
     if (TRI) met = TRI;
     HIPCHK(h, sync_metric_launch(cor_SOF, S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], cor_PLSC, S.cv, (float *)corr, delay, (float *)met, FLG, S.trigger,
@@ -936,7 +938,7 @@ int dvbs2hip_sync_frame_synchronize2_dev(dvbs2hip_t *h, const float *X_N1, const
     S.sofh_cur ^= 1;
     // the delay line is a recurrence from frame to frame made of copies only: resolved per output sample, one launch (k_sync.hip)
     HIPCHK(h, sync_vdelay_launch(X_N1, S.yprev, Y_N2, S.buff2[S.od_cur], S.buff2[S.od_cur ^ 1], S.st[S.od_cur], S.st[S.od_cur ^ 1], delay,
-                                 S.st[S.od_cur ^ 1] + 2, n, S.nbuff2, F, h->stream));
+                                 (int32_t *)dtab, S.st[S.od_cur ^ 1] + 2, n, S.nbuff2, F, h->stream));
     S.od_cur ^= 1;
     HIPCHK(h, hipMemcpyAsync(S.yprev, Y_N2 + (size_t)2 * n * (F - 1), sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(S.metric, (float *)met + (F - 1), sizeof(float), hipMemcpyDeviceToDevice, h->stream));

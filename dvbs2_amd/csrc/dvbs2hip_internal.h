@@ -216,6 +216,6 @@ hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float 
 hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp, float *FRQ, float *PHS, int n, int F, float alpha, hipStream_t s);
 hipError_t sff_fp_launch(const float *X, float *Y, float *tmp, float *FRQ, float *PHS, int n, int F, hipStream_t s);
 hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
-                              const int32_t *delay_f, int *dmax, int n, int nbuff2, int F, hipStream_t s);
+                              const int32_t *delay_f, int32_t *Dtab, int *dmax, int n, int nbuff2, int F, hipStream_t s);
 
 }  // namespace dvbs2

@@ -167,7 +167,9 @@ sync_argmax_kernel(const float *__restrict__ corr, int32_t *__restrict__ delay, 
 // In lock (constant delay) neither walk takes a step; while the delay moves they take one or two.  One lane per output
 // sample, no frame-to-frame launches: the per-frame form cost 4 us per frame (a launch each) whatever the frame size.
 // st = {head2, first_time}; Dmax = the largest D of the call (vd_dmax_kernel), which bounds vd_buff's walk.
-__device__ __forceinline__ int vd_D(const int32_t *delay_f, int f, int n) { return 2 * ((n - delay_f[f]) % n); }   // set_delay((cplx_in_sz - delay) % cplx_in_sz), :298
+// D[f] = 2 * ((n - delay[f]) % n) (set_delay((cplx_in_sz - delay) % cplx_in_sz), :298), tabulated per frame by vd_dmax_kernel:
+// the walks below would otherwise pay two integer divisions per output sample
+__device__ __forceinline__ int vd_D(const int32_t *Dtab, int f, int) { return Dtab[f]; }
 
 __device__ __forceinline__ float vd_buff(const float *__restrict__ X, const float *__restrict__ buff0, const int32_t *__restrict__ delay_f,
                                          int g, int k, int n)
@@ -197,11 +199,11 @@ __device__ __forceinline__ float vd_source(const float *__restrict__ X, const fl
     }
 }
 
-__global__ void vd_dmax_kernel(const int32_t *__restrict__ delay_f, int *__restrict__ dmax, int n, int F)
+__global__ void vd_dmax_kernel(const int32_t *__restrict__ delay_f, int32_t *__restrict__ Dtab, int *__restrict__ dmax, int n, int F)
 {
     __shared__ int red[256];
     int m = 0;
-    for (int f = threadIdx.x; f < F; f += 256) { const int D = vd_D(delay_f, f, n); m = D > m ? D : m; }
+    for (int f = threadIdx.x; f < F; f += 256) { const int D = 2 * ((n - delay_f[f]) % n); Dtab[f] = D; m = D > m ? D : m; }
     red[threadIdx.x] = m;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s]; __syncthreads(); }
@@ -401,13 +403,13 @@ hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float 
     return hipGetLastError();
 }
 
-// all F frames of a call; dmax = one int of device scratch
+// all F frames of a call; dmax = one int, Dtab = F ints of device scratch
 hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
-                              const int32_t *delay_f, int *dmax, int n, int nbuff2, int F, hipStream_t s)
+                              const int32_t *delay_f, int32_t *Dtab /* F ints of scratch */, int *dmax, int n, int nbuff2, int F, hipStream_t s)
 {
     const int tot = nbuff2 > 2 * n ? nbuff2 : 2 * n;
-    hipLaunchKernelGGL(vd_dmax_kernel, dim3(1), dim3(256), 0, s, delay_f, dmax, n, F);
-    hipLaunchKernelGGL(sync_vdelay_batch_kernel, dim3((tot + 255) / 256, F + 1), dim3(256), 0, s, X, Yprev, Y, buff_old, buff_new, st_old, st_new, delay_f,
+    hipLaunchKernelGGL(vd_dmax_kernel, dim3(1), dim3(256), 0, s, delay_f, Dtab, dmax, n, F);
+    hipLaunchKernelGGL(sync_vdelay_batch_kernel, dim3((tot + 255) / 256, F + 1), dim3(256), 0, s, X, Yprev, Y, buff_old, buff_new, st_old, st_new, Dtab,
                        dmax, n, nbuff2, F);
     return hipGetLastError();
 }
