@@ -91,7 +91,7 @@ __device__ __forceinline__ float2 fm_fetch_edge(const float2 *__restrict__ x, co
     return v;
 }
 
-// Persistent workgroups, each filtering `tiles_per_wg` consecutive tiles of 2048 outputs.  The loads of tile i + 1 (one
+// Workgroups filter `tiles_per_wg` consecutive tiles of 2048 outputs each (chunks of 4 on long streams: see fir_mfma_launch).  The loads of tile i + 1 (one
 // contiguous KB per wave instruction) are in flight -- in registers, no branch between them and their use -- while tile i
 // goes through the matrix cores; the 80-sample overlap with the previous tile is taken from LDS, already split, so the
 // stream is read from HBM exactly once.  The SAMPLES are the A operand (row = block of 16) and the Toeplitz band the B
@@ -244,8 +244,12 @@ bool fir_mfma_usable(const float *x, const float *y, int T, long long n_total)
 hipError_t fir_mfma_launch(const float *x, float *y, const float *hist_in, float *hist_out, const uint16_t *afrag, int T, long long n_total, hipStream_t s)
 {
     const long long n_tiles = (n_total + FM_TILE - 1) / FM_TILE;
-    static const int max_wg = [] { const char *e = getenv("DVBS2HIP_FIR_WGS"); return e ? atoi(e) : 1024; }();      // 4 resident workgroups per CU
-    const int tiles_per_wg = (int)((n_tiles + max_wg - 1) / max_wg);
+    // Chunks of 4 tiles, handed to the CUs by the hardware dispatcher as workgroups retire: resident workgroups do not run at
+    // the same speed (the arbiter favours the older waves), and one persistent workgroup per slot with an equal share of the
+    // stream waited for the slowest -- same-box sweep at 68 M samples: 1024 workgroups (33 tiles each) 0.222 ms, 8192 (5 tiles)
+    // 0.207 ms, 16384 0.211 ms.  Short streams still get one workgroup per tile.  DVBS2HIP_FIR_WGS caps the grid instead.
+    static const int max_wg = [] { const char *e = getenv("DVBS2HIP_FIR_WGS"); return e ? atoi(e) : 0; }();
+    const int tiles_per_wg = max_wg > 0 ? (int)((n_tiles + max_wg - 1) / max_wg) : (n_tiles >= 4096 ? 4 : (int)((n_tiles + 1023) / 1024));
     const unsigned grid = (unsigned)((n_tiles + tiles_per_wg - 1) / tiles_per_wg);
     hipLaunchKernelGGL(fir_mfma_kernel<1>, dim3(grid), dim3(FM_THREADS), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<float2 *>(y),
                        reinterpret_cast<const float2 *>(hist_in), reinterpret_cast<float2 *>(hist_out), reinterpret_cast<const uint4 *>(afrag), T, n_total,
@@ -279,8 +283,7 @@ bool upfir_mfma_usable(const float *x, const float *y, int T, int osf, long long
 hipError_t upfir_mfma_launch(const float *x, float *y, const float *hist_in, float *hist_out, const uint16_t *afrag2, int T, long long n_in, hipStream_t s)
 {
     const long long n_tiles = (n_in + FM_TILE - 1) / FM_TILE;
-    const int max_wg = 768;                                                  // 3 resident workgroups per CU (168 VGPRs)
-    const int tiles_per_wg = (int)((n_tiles + max_wg - 1) / max_wg);
+    const int tiles_per_wg = n_tiles >= 4096 ? 4 : (int)((n_tiles + 1023) / 1024);       // as fir_mfma_launch
     const unsigned grid = (unsigned)((n_tiles + tiles_per_wg - 1) / tiles_per_wg);
     hipLaunchKernelGGL(fir_mfma_kernel<2>, dim3(grid), dim3(FM_THREADS), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<float2 *>(y),
                        reinterpret_cast<const float2 *>(hist_in), reinterpret_cast<float2 *>(hist_out), reinterpret_cast<const uint4 *>(afrag2),
