@@ -14,6 +14,7 @@
 // all lanes share the Chien search over the 2^m-1 field positions.
 // Integer work: results are bit-exact against oracle/dvbs2_oracle.c (orc_bch_decode).
 #include "dvbs2hip_internal.h"
+#include <cstdlib>
 
 namespace dvbs2 {
 
@@ -291,7 +292,8 @@ hipError_t bch_launch(const BchPlan &pl, BchKParams p, hipStream_t s)
     const size_t lds = (size_t)((pl.N + 31) / 32) * 4 + (256 + (size_t)768 * pl.t) * 2;
     // persistent grid (about the number of workgroups the chip holds at once): the tables are staged into LDS once per
     // workgroup, not once per frame
-    const int grid = p.n_frames < 2048 ? p.n_frames : 2048;
+    static const int cap = [] { const char *e = getenv("DVBS2HIP_BCH_GRID"); return e ? atoi(e) : 2048; }();
+    const int grid = p.n_frames < cap ? p.n_frames : cap;
     hipLaunchKernelGGL(bch_decode_kernel, dim3(grid), dim3(BCH_THREADS), lds, s, p);
     return hipGetLastError();
 }
