@@ -123,7 +123,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gwork, 0, p.gwork_words * 4, 0x00020000);
     const const_u32 tab = (const_u32)p.w8.tab;
     const const_u32 rows = (const_u32)p.w8.rows;
-    const uint32_t st_base = p.w8.st_base;                   // packed state: [c1][c2][pk], each [q][360]
+    const uint32_t st_base = p.w8.st_base;                   // packed state: [q][360] x {c1, c2, pk} (12 bytes per check, one access)
     const uint32_t ljunk = p.w8.lds_junk;                    // LDS junk row (write-only)
     uint32_t SB = 0x80000000u;
     asm volatile("" : "+s"(SB));                             // the sign mask as an SGPR operand (VOP3 takes no literal)
@@ -318,7 +318,11 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     }
                     const int rn = r + 1 < q ? r + 1 : 0;
                     if (it == 0 && r + 1 < q) { nx1 = 0.f; nx2 = 0.f; nxk = 0.f; }       // layer r + 1 has no messages yet in the first iteration
-                    else { nx1 = gld(t4, st_off(0, rn)); nx2 = gld(t4, st_off(1, rn)); nxk = gld(t4, st_off(2, rn)); }
+                    else {      // {c1, c2, pk} of a check are 12 consecutive bytes: one load
+                        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                        const u32x3 sv = __builtin_amdgcn_raw_buffer_load_b96(rs, t4 * 3u, st_base + (uint32_t)(rn * LDPC_Z) * 12u, 0);
+                        nx1 = __uint_as_float(sv.x); nx2 = __uint_as_float(sv.y); nxk = __uint_as_float(sv.z);
+                    }
                     __builtin_amdgcn_s_setprio(0);
                     PROF_MARK(0);
                     // ---- pass 1b: v->c = posterior - old c->v ; running min1 / min2 / signs
@@ -385,7 +389,11 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         }
                     }
                     pkn |= idxn << 27;
-                    gst(t4, st_off(0, r), cst1); gst(t4, st_off(1, r), cst2); gst(t4, st_off(2, r), __uint_as_float(pkn));
+                    {
+                        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                        u32x3 sv; sv.x = __float_as_uint(cst1); sv.y = __float_as_uint(cst2); sv.z = pkn;
+                        __builtin_amdgcn_raw_buffer_store_b96(sv, rs, t4 * 3u, st_base + (uint32_t)(r * LDPC_Z) * 12u, 0);
+                    }
                     if (q == 1) { nx1 = cst1; nx2 = cst2; nxk = __uint_as_float(pkn); }
                     __builtin_amdgcn_s_setprio(0);
                 }
