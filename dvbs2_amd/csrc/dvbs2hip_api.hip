@@ -2,6 +2,8 @@
 // The arithmetic is in k_ldpc.hip / k_bch.hip / k_front.hip / k_fir.hip.  No CPU fallback.
 #include "dvbs2hip_internal.h"
 #include "dvbs2_tables_gen.h"
+#include <dlfcn.h>
+#include <unistd.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +14,8 @@
 #include <utility>
 
 using namespace dvbs2;
+
+typedef struct { char internal[128]; } dvbs2hip_nccl_id;        // = ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value
 
 namespace {
 
@@ -83,6 +87,11 @@ struct dvbs2hip_handle {
     float *d_nat_work = nullptr;       // natural-order LDPC: frame-interleaved image + state, ceil(max_frames / 64) groups
     float *d_lr_R = nullptr;
     float lr_alpha = 0.999f;
+    float *d_hist_zero = nullptr, *d_hist_junk = nullptr;     // filter2: zero history in, discarded history out
+    // monitor reduction over RCCL (one process per GPU): communicator + the 3 x uint64 receive buffer
+    void *nccl_comm = nullptr;
+    unsigned long long *d_red = nullptr;
+    int red_rank = 0, red_world = 1;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[DVBS2HIP_K_COUNT];
@@ -106,7 +115,7 @@ int fail(dvbs2hip_t *h, int code, const std::string &msg)
     } while (0)
 
 enum BufId { B_IN = 0, B_OUT, B_AUX0, B_AUX1, B_AUX2, B_AUX3, B_LLR, B_PACKED, B_EST, B_CWD0, B_CWD1, B_INFO, B_SIG, B_TXBCH, B_TXLDPC,
-             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY, B_SFM_DTAB, B_SFF_TMP, B_SFF_OUT };
+             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY, B_SFM_DTAB, B_SFF_TMP, B_SFF_OUT, B_FLT2, B_MON_BE, B_MON_OUT };
 
 int ensure(dvbs2hip_t *h, int id, size_t bytes, void **out)
 {
@@ -121,10 +130,17 @@ int ensure(dvbs2hip_t *h, int id, size_t bytes, void **out)
     return 0;
 }
 
-int check_frames(dvbs2hip_t *h, int n_frames)
+// every entry point that touches HIP selects the handle's device first: a process may drive several GPUs, one handle each
+int enter(dvbs2hip_t *h)
 {
     if (!h) return DVBS2HIP_EINVAL;
     if (hipSetDevice(h->device) != hipSuccess) return fail(h, DVBS2HIP_EHIP, "hipSetDevice failed");
+    return 0;
+}
+
+int check_frames(dvbs2hip_t *h, int n_frames)
+{
+    int r0 = enter(h); if (r0) return r0;
     if (n_frames < 1 || n_frames > h->max_frames)
         return fail(h, DVBS2HIP_EINVAL, "'n_frames' has to be in [1, max_frames] ('n_frames' = " + std::to_string(n_frames) +
                                             ", 'max_frames' = " + std::to_string(h->max_frames) + ").");
@@ -242,7 +258,7 @@ int dvbs2hip_cfg_from_modcod(const char *modcod, dvbs2hip_cfg *cfg)
         memset(cfg, 0, sizeof *cfg);
         cfg->N_ldpc = r.N_ldpc; cfg->K_ldpc = r.K_ldpc; cfg->K_bch = r.K_bch;
         cfg->ldpc_n_rows = r.ldpc_n_rows; cfg->ldpc_row_ptr = r.rp; cfg->ldpc_addr = r.ad;
-        cfg->ldpc_n_ite = 50; cfg->ldpc_implem = DVBS2HIP_IMPLEM_NMS; cfg->ldpc_alpha = 1.0f; cfg->ldpc_early_stop = 1;
+        cfg->ldpc_n_ite = 50; cfg->ldpc_implem = DVBS2HIP_IMPLEM_SPA; cfg->ldpc_alpha = 1.0f; cfg->ldpc_early_stop = 1;
         cfg->bch_m = r.bch_m; cfg->bch_t = r.bch_t; cfg->bch_prim = r.prim;
         cfg->bps = r.bps; cfg->cstl = r.cstl;
         cfg->itl_cols = r.itl_cols; cfg->itl_order = r.itl_order;
@@ -481,6 +497,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)dvbs2hip_monitor_reduce_finalize(h);
     for (auto &kv : h->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
         for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -489,7 +506,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
     if (h->s_out) (void)hipStreamDestroy(h->s_out);
     void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
-                        h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift};
+                        h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift, h->d_hist_zero, h->d_hist_junk, h->d_red};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
@@ -556,7 +573,7 @@ void *dvbs2hip_get_stream(dvbs2hip_t *h) { return h ? (void *)h->stream : nullpt
 
 int dvbs2hip_synchronize(dvbs2hip_t *h)
 {
-    if (!h) return DVBS2HIP_EINVAL;
+    int r0 = enter(h); if (r0) return r0;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -578,11 +595,15 @@ static int ldpc_dev(dvbs2hip_t *h, const float *Y, int8_t *CWD, int32_t *V, uint
     p.n_frames = F; p.n_ite = h->n_ite; p.early_stop = h->early_stop; p.alpha = h->alpha;
     if (h->ldpc_sched == DVBS2HIP_SCHED_NATURAL) {
         LdpcPlan &pl = h->ldpc;
-        if (!h->d_nat_work) {
+        if (!h->d_nat_work || !pl.d_nat_tab || !pl.d_nat_haz) {
             const size_t groups = ((size_t)h->max_frames + 63) / 64;
-            if (hipMalloc((void **)&h->d_nat_work, groups * ldpc_nat_group_words(pl) * sizeof(float)) != hipSuccess)
+            if (!h->d_nat_work && hipMalloc((void **)&h->d_nat_work, groups * ldpc_nat_group_words(pl) * sizeof(float)) != hipSuccess) {
+                h->d_nat_work = nullptr;
                 return fail(h, DVBS2HIP_ENOMEM, "natural-order LDPC: workspace of " + std::to_string(groups * ldpc_nat_group_words(pl) * 4) + " bytes does not fit");
-            if (upload(h, &pl.d_nat_tab, pl.nat_tab.data(), pl.nat_tab.size()) || upload(h, &pl.d_nat_haz, pl.nat_haz.data(), pl.nat_haz.size())) return DVBS2HIP_EHIP;
+            }
+            // a failed upload leaves its pointer null (or is freed here), so the next call tries again instead of launching with null tables
+            if (!pl.d_nat_tab && upload(h, &pl.d_nat_tab, pl.nat_tab.data(), pl.nat_tab.size())) { if (pl.d_nat_tab) { (void)hipFree(pl.d_nat_tab); pl.d_nat_tab = nullptr; } return DVBS2HIP_EHIP; }
+            if (!pl.d_nat_haz && upload(h, &pl.d_nat_haz, pl.nat_haz.data(), pl.nat_haz.size())) { if (pl.d_nat_haz) { (void)hipFree(pl.d_nat_haz); pl.d_nat_haz = nullptr; } return DVBS2HIP_EHIP; }
         }
         Timer tm(h, DVBS2HIP_K_LDPC);
         HIPCHK(h, ldpc_nat_launch(pl, p, h->d_nat_work, h->stream));
@@ -787,9 +808,77 @@ int dvbs2hip_filter(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx, int
                            [&](const float *a, float *b, int nf) { return dvbs2hip_filter_dev(h, a, b, n_cplx, nf); });
 }
 
+// filter1 / filter2: the reference splits the matched filter over two pipeline stages (Filter_FIR_ccr.cpp:144-294; bound
+// RX/main_sched.cpp:199-201): filter1 produces the lower part of every frame and advances the state, filter2 copies Y_N2h and
+// produces the upper part from X_N1 alone.  Both are pure functions of their sockets here too (they may sit in different
+// pipeline stages, working on different batches at the same time).
+int dvbs2hip_filter_split(const dvbs2hip_t *h, int32_t n_cplx)
+{
+    if (!h || h->fir_T <= 0) return DVBS2HIP_EINVAL;
+    const int split = (n_cplx / 2) & ~3;                  // 32-byte aligned rows for the 2-D copies
+    return split >= h->fir_T - 1 && split < n_cplx ? split : DVBS2HIP_EINVAL;
+}
+
+int dvbs2hip_filter1_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx, int32_t F)
+{
+    if (h && dvbs2hip_filter_split(h, n_cplx) < 0) return fail(h, DVBS2HIP_EINVAL, "filter1 / filter2: half a frame has to hold the filter's memory (n_cplx / 2 >= n_taps - 1)");
+    // the lower part is all the reference defines for this socket; the upper part of Y_N2, which the reference leaves as it
+    // was, is filled too (one stream pass computes both, and filter2 overwrites it anyway)
+    return dvbs2hip_filter_dev(h, X, Y, n_cplx, F);
+}
+
+int dvbs2hip_filter2_dev(dvbs2hip_t *h, const float *X, const float *Yh, float *Y, int32_t n_cplx, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X || !Yh || !Y) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    if (h->fir_T <= 0) return fail(h, DVBS2HIP_EUNSUPPORTED, "handle was created without filter taps");
+    const int split = dvbs2hip_filter_split(h, n_cplx);
+    if (split < 0) return fail(h, DVBS2HIP_EINVAL, "filter1 / filter2: half a frame has to hold the filter's memory (n_cplx / 2 >= n_taps - 1)");
+    const size_t hb = sizeof(float) * 2 * (size_t)(h->fir_T > 1 ? h->fir_T - 1 : 1);
+    if (!h->d_hist_zero) {
+        HIPCHK(h, hipMalloc((void **)&h->d_hist_zero, hb)); HIPCHK(h, hipMalloc((void **)&h->d_hist_junk, hb));
+        HIPCHK(h, hipMemsetAsync(h->d_hist_zero, 0, hb, h->stream));
+    }
+    void *tmp;
+    const size_t row = sizeof(float) * 2 * (size_t)n_cplx;
+    if ((r = ensure(h, B_FLT2, row * F, &tmp))) return r;
+    {   // the upper part of a frame reads nothing before the frame (split >= n_taps - 1): the state is neither used nor advanced
+        Timer tm(h, DVBS2HIP_K_FIR);
+        HIPCHK(h, fir_launch(X, (float *)tmp, h->d_hist_zero, h->d_hist_junk, h->d_taps_rev, h->fir_kernel == DVBS2HIP_FIR_VALU ? nullptr : h->d_fir_afrag, h->fir_T,
+                             (long long)n_cplx * F, h->stream));
+    }
+    const size_t lo = sizeof(float) * 2 * (size_t)split;
+    if (Y != Yh) HIPCHK(h, hipMemcpy2DAsync(Y, row, Yh, row, lo, (size_t)F, hipMemcpyDeviceToDevice, h->stream));       // std::copy(Y_N2h, ..) :224
+    HIPCHK(h, hipMemcpy2DAsync((char *)Y + lo, row, (const char *)tmp + lo, row, row - lo, (size_t)F, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+int dvbs2hip_filter1(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx, int32_t F)
+{
+    if (h && dvbs2hip_filter_split(h, n_cplx) < 0) return fail(h, DVBS2HIP_EINVAL, "filter1 / filter2: half a frame has to hold the filter's memory (n_cplx / 2 >= n_taps - 1)");
+    return dvbs2hip_filter(h, X, Y, n_cplx, F);
+}
+
+int dvbs2hip_filter2(dvbs2hip_t *h, const float *X, const float *Yh, float *Y, int32_t n_cplx, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X || !Yh || !Y) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const int split = dvbs2hip_filter_split(h, n_cplx);
+    if (split < 0) return fail(h, DVBS2HIP_EINVAL, "filter1 / filter2: half a frame has to hold the filter's memory (n_cplx / 2 >= n_taps - 1)");
+    const size_t row = sizeof(float) * 2 * (size_t)n_cplx, lo = sizeof(float) * 2 * (size_t)split;
+    void *din, *dout;
+    if ((r = ensure(h, B_IN, row * F, &din)) || (r = ensure(h, B_OUT, row * F, &dout))) return r;
+    HIPCHK(h, hipMemcpyAsync(din, X, row * F, hipMemcpyHostToDevice, h->stream));
+    if ((r = dvbs2hip_filter2_dev(h, (const float *)din, (const float *)dout, (float *)dout, n_cplx, F))) return r;     // Yh == Y on the device: lower part untouched
+    if (Y != Yh) for (int f = 0; f < F; f++) memcpy((char *)Y + (size_t)f * row, (const char *)Yh + (size_t)f * row, lo);   // std::copy(Y_N2h, ..) :224, lower part
+    HIPCHK(h, hipMemcpy2DAsync((char *)Y + lo, row, (const char *)dout + lo, row, row - lo, (size_t)F, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int dvbs2hip_filter_reset(dvbs2hip_t *h)
 {
-    if (!h) return DVBS2HIP_EINVAL;
+    int r0 = enter(h); if (r0) return r0;
     if (h->fir_T > 1)
         for (int i = 0; i < 2; i++) {
             HIPCHK(h, hipMemsetAsync(h->d_hist[i], 0, sizeof(float) * 2 * (h->fir_T - 1), h->stream));
@@ -1164,9 +1253,136 @@ int dvbs2hip_monitor_check_errors(dvbs2hip_t *h, const int32_t *U, const int32_t
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
+// check_errors2: the counters after every frame of the call, as sockets (device pointers; any of the five may be NULL)
+int dvbs2hip_monitor_check_errors2_dev(dvbs2hip_t *h, const int32_t *U, const int32_t *V, int64_t *FRA, int32_t *BE, int32_t *FE, float *BER, float *FER, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!U || !V) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    void *tmp;
+    if ((r = ensure(h, B_MON_BE, (size_t)F * 4, &tmp))) return r;
+    Timer tm(h, DVBS2HIP_K_MISC);
+    HIPCHK(h, monitor2_launch(U, V, h->d_ctr, (int32_t *)tmp, (long long *)FRA, BE, FE, BER, FER, h->K_bch, F, h->stream));
+    return 0;
+}
+int dvbs2hip_monitor_check_errors2(dvbs2hip_t *h, const int32_t *U, const int32_t *V, int64_t *FRA, int32_t *BE, int32_t *FE, float *BER, float *FER, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!U || !V) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const size_t n = (size_t)F * h->K_bch * 4;
+    void *du, *dv, *dout;
+    if ((r = ensure(h, B_IN, n, &du)) || (r = ensure(h, B_OUT, n, &dv)) || (r = ensure(h, B_MON_OUT, (size_t)F * 24, &dout))) return r;
+    int64_t *dfra = (int64_t *)dout; int32_t *dbe = (int32_t *)(dfra + F), *dfe = dbe + F; float *dber = (float *)(dfe + F), *dfer = dber + F;
+    HIPCHK(h, hipMemcpyAsync(du, U, n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dv, V, n, hipMemcpyHostToDevice, h->stream));
+    if ((r = dvbs2hip_monitor_check_errors2_dev(h, (const int32_t *)du, (const int32_t *)dv, dfra, dbe, dfe, dber, dfer, F))) return r;
+    if (FRA) HIPCHK(h, hipMemcpyAsync(FRA, dfra, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream));
+    if (BE) HIPCHK(h, hipMemcpyAsync(BE, dbe, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
+    if (FE) HIPCHK(h, hipMemcpyAsync(FE, dfe, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
+    if (BER) HIPCHK(h, hipMemcpyAsync(BER, dber, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
+    if (FER) HIPCHK(h, hipMemcpyAsync(FER, dfer, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- Monitor_reduction across GPUs (TX_RX_BB/main.cpp:123-125,155-161): one process per GPU, ONE RCCL all-reduce of 3 x uint64.
+// librccl is opened at run time (the library itself does not link it: single-GPU users never load it).
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, dvbs2hip_nccl_id, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+const char *rccl_load()
+{
+    if (g_rccl.lib) return nullptr;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *l = nullptr;
+    for (const char *n : names) if ((l = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;          // the copy the process already has (torch ships one)
+    if (!l) for (const char *n : names) if ((l = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!l) return "librccl.so not found (dlopen)";
+    g_rccl.GetUniqueId = (int (*)(void *))dlsym(l, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void **, int, dvbs2hip_nccl_id, int))dlsym(l, "ncclCommInitRank");
+    g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(l, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(void *))dlsym(l, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(l, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) return "librccl.so lacks the nccl* entry points";
+    g_rccl.lib = l;
+    return nullptr;
+}
+std::string rccl_err(int e) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : ("rccl error " + std::to_string(e)); }
+}  // namespace
+
+int dvbs2hip_monitor_reduce_init(dvbs2hip_t *h, int32_t rank, int32_t world, const char *rendezvous, int32_t timeout_ms)
+{
+    int r0 = enter(h); if (r0) return r0;
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, DVBS2HIP_EINVAL, "'rank' has to be in [0, world_size)");
+    if (h->nccl_comm) return fail(h, DVBS2HIP_EINVAL, "the monitor reduction is already initialised on this handle");
+    if (world > 1 && (!rendezvous || !*rendezvous)) return fail(h, DVBS2HIP_EINVAL, "a rendezvous file path is needed for world_size > 1");
+    if (const char *e = rccl_load()) return fail(h, DVBS2HIP_EUNSUPPORTED, e);
+    dvbs2hip_nccl_id id;
+    memset(&id, 0, sizeof id);
+    if (rank == 0) {
+        int e = g_rccl.GetUniqueId(&id);
+        if (e) return fail(h, DVBS2HIP_EHIP, "ncclGetUniqueId: " + rccl_err(e));
+        if (world > 1) {                                    // publish atomically: write beside, then rename
+            const std::string tmp = std::string(rendezvous) + ".tmp";
+            FILE *f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(&id, sizeof id, 1, f) != 1) { if (f) fclose(f); return fail(h, DVBS2HIP_EINVAL, "cannot write the rendezvous file " + tmp); }
+            fclose(f);
+            if (rename(tmp.c_str(), rendezvous)) return fail(h, DVBS2HIP_EINVAL, std::string("cannot publish the rendezvous file ") + rendezvous);
+        }
+    } else {
+        const int step_ms = 20;
+        int waited = 0;
+        for (;;) {
+            FILE *f = fopen(rendezvous, "rb");
+            if (f) { const size_t n = fread(&id, 1, sizeof id, f); fclose(f); if (n == sizeof id) break; }
+            if (timeout_ms >= 0 && waited >= timeout_ms) return fail(h, DVBS2HIP_EHIP, std::string("timed out waiting for the rendezvous file ") + rendezvous);
+            usleep(step_ms * 1000); waited += step_ms;
+        }
+    }
+    void *comm = nullptr;
+    int e = g_rccl.CommInitRank(&comm, world, id, rank);
+    if (e) return fail(h, DVBS2HIP_EHIP, "ncclCommInitRank: " + rccl_err(e));
+    if (!h->d_red && hipMalloc((void **)&h->d_red, 3 * sizeof(unsigned long long)) != hipSuccess) { (void)g_rccl.CommDestroy(comm); return fail(h, DVBS2HIP_ENOMEM, "hipMalloc failed"); }
+    h->nccl_comm = comm; h->red_rank = rank; h->red_world = world;
+    return 0;
+}
+
+int dvbs2hip_monitor_reduce(dvbs2hip_t *h, uint64_t out[3])
+{
+    if (!h || !out) return DVBS2HIP_EINVAL;
+    if (!h->nccl_comm) return dvbs2hip_monitor_get(h, out);         // a single process: the local counters are the sum
+    int r0 = enter(h); if (r0) return r0;
+    const int e = g_rccl.AllReduce(h->d_ctr, h->d_red, 3, 5 /* ncclUint64 */, 0 /* ncclSum */, h->nccl_comm, h->stream);
+    if (e) return fail(h, DVBS2HIP_EHIP, "ncclAllReduce: " + rccl_err(e));
+    unsigned long long tmp[3];
+    HIPCHK(h, hipMemcpyAsync(tmp, h->d_red, sizeof tmp, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 3; i++) out[i] = tmp[i];
+    return 0;
+}
+
+int dvbs2hip_monitor_reduce_finalize(dvbs2hip_t *h)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    if (h->nccl_comm) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        (void)g_rccl.CommDestroy(h->nccl_comm);
+        h->nccl_comm = nullptr; h->red_world = 1; h->red_rank = 0;
+    }
+    return 0;
+}
+
 int dvbs2hip_monitor_get(dvbs2hip_t *h, uint64_t out[3])
 {
     if (!h || !out) return DVBS2HIP_EINVAL;
+    int r0 = enter(h); if (r0) return r0;
     unsigned long long tmp[3];
     HIPCHK(h, hipMemcpyAsync(tmp, h->d_ctr, sizeof tmp, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1175,7 +1391,7 @@ int dvbs2hip_monitor_get(dvbs2hip_t *h, uint64_t out[3])
 }
 int dvbs2hip_monitor_reset(dvbs2hip_t *h)
 {
-    if (!h) return DVBS2HIP_EINVAL;
+    int r0 = enter(h); if (r0) return r0;
     HIPCHK(h, hipMemsetAsync(h->d_ctr, 0, 3 * sizeof(unsigned long long), h->stream));
     return 0;
 }
@@ -1282,6 +1498,7 @@ int dvbs2hip_timing_reset(dvbs2hip_t *h)
 int dvbs2hip_timing_get(dvbs2hip_t *h, int32_t k, double *total_ms, int64_t *n)
 {
     if (!h || k < 0 || k >= DVBS2HIP_K_COUNT || !total_ms || !n) return DVBS2HIP_EINVAL;
+    int r0 = enter(h); if (r0) return r0;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     double tot = 0.0;
     for (auto &p : h->ev[k]) {
@@ -1295,20 +1512,21 @@ int dvbs2hip_timing_get(dvbs2hip_t *h, int32_t k, double *total_ms, int64_t *n)
 int dvbs2hip_malloc(dvbs2hip_t *h, void **d, size_t bytes)
 {
     if (!h || !d) return DVBS2HIP_EINVAL;
+    int r0 = enter(h); if (r0) return r0;
     if (hipMalloc(d, bytes) != hipSuccess) return fail(h, DVBS2HIP_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
     return 0;
 }
-int dvbs2hip_free(dvbs2hip_t *h, void *d) { if (!h) return DVBS2HIP_EINVAL; HIPCHK(h, hipFree(d)); return 0; }
+int dvbs2hip_free(dvbs2hip_t *h, void *d) { int r0 = enter(h); if (r0) return r0; HIPCHK(h, hipFree(d)); return 0; }
 int dvbs2hip_memcpy_h2d(dvbs2hip_t *h, void *dst, const void *src, size_t bytes)
 {
-    if (!h) return DVBS2HIP_EINVAL;
+    int r0 = enter(h); if (r0) return r0;
     HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 int dvbs2hip_memcpy_d2h(dvbs2hip_t *h, void *dst, const void *src, size_t bytes)
 {
-    if (!h) return DVBS2HIP_EINVAL;
+    int r0 = enter(h); if (r0) return r0;
     HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;

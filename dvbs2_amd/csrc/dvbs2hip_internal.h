@@ -169,6 +169,8 @@ hipError_t pl_descramble_launch(const float *in, float *out, const uint8_t *seq,
 hipError_t remove_plh_launch(const float *in, float *out, int n_sym, int pl_frame, int F, hipStream_t s);
 hipError_t bb_descramble_launch(const int32_t *in, int32_t *out, const uint32_t *prbs, int K, int F, hipStream_t s);
 hipError_t monitor_launch(const int32_t *U, const int32_t *V, unsigned long long *ctr, int K, int F, hipStream_t s);
+hipError_t monitor2_launch(const int32_t *U, const int32_t *V, unsigned long long *ctr, int32_t *be_tmp, long long *FRA, int32_t *BE, int32_t *FE, float *BER,
+                           float *FER, int K, int F, hipStream_t s);
 
 // ---------------------------------------------------------------- TX mirror + AWGN (N1)
 struct TxKParams {

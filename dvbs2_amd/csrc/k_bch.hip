@@ -20,7 +20,9 @@ namespace dvbs2 {
 
 std::string bch_build_plan(BchPlan &pl, int m, const int32_t *prim, int t, int N, int K)
 {
-    if (m < 3 || m > 16) return "BCH: need 3 <= m <= 16";
+    // the syndrome kernel splits remainders into a low byte and m - 8 high bits (k_bch.hip, bch_decode_kernel): m < 8 would shift
+    // by a negative amount.  DVB-S2 uses m = 14 (short) and 16 (normal).
+    if (m < 8 || m > 16) return "BCH: need 8 <= m <= 16 (DVB-S2: 14 or 16)";
     if (t < 1 || t > 12) return "BCH: need 1 <= t <= 12";
     const int n = (1 << m) - 1;
     if (N > n || K >= N || K <= 0) return "BCH: need 0 < K < N <= 2^m-1";

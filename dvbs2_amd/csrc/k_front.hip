@@ -491,4 +491,64 @@ hipError_t monitor_launch(const int32_t *U, const int32_t *V, unsigned long long
     return hipGetLastError();
 }
 
+// check_errors2 (aff3ct Monitor_BFER, task bound at RX/main_sched.cpp:222-223,244-247): the counters AFTER every frame of the
+// call leave through per-frame sockets.  Pass 1: bit errors of every frame (one workgroup per frame, no atomics); pass 2: one
+// workgroup scans them from the counters the call started with, writes the five sockets and the new counters.
+__global__ void __launch_bounds__(FRONT_THREADS)
+monitor_be_kernel(const int32_t *U, const int32_t *V, int32_t *be_out, int K)
+{
+    __shared__ int red[FRONT_THREADS / 64];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    int be = 0;
+    for (int k = tid; k < K; k += FRONT_THREADS) be += (U[(size_t)f * K + k] != V[(size_t)f * K + k]) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) be += __shfl_xor(be, o);
+    if ((tid & 63) == 0) red[tid >> 6] = be;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int i = 0; i < FRONT_THREADS / 64; i++) tot += red[i];
+        be_out[f] = tot;
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+monitor_scan_kernel(const int32_t *be_f, unsigned long long *ctr, long long *FRA, int32_t *BE, int32_t *FE, float *BER, float *FER, int K, int F)
+{
+    __shared__ unsigned long long s_be[1024];
+    __shared__ unsigned int s_fe[1024];
+    const int tid = threadIdx.x;
+    const int per = (F + 1023) / 1024, f0 = tid * per, f1 = min(F, f0 + per);
+    unsigned long long be = 0; unsigned int fe = 0;
+    for (int f = f0; f < f1; f++) { be += (unsigned)be_f[f]; fe += be_f[f] != 0; }
+    s_be[tid] = be; s_fe[tid] = fe;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                    // inclusive scan over the 1024 segments
+        unsigned long long b = tid >= o ? s_be[tid - o] : 0ull; unsigned int e = tid >= o ? s_fe[tid - o] : 0u;
+        __syncthreads();
+        s_be[tid] += b; s_fe[tid] += e;
+        __syncthreads();
+    }
+    const unsigned long long fra0 = ctr[0], be0 = ctr[1], fe0 = ctr[2];
+    unsigned long long cb = be0 + (tid ? s_be[tid - 1] : 0ull), ce = fe0 + (tid ? s_fe[tid - 1] : 0u);
+    for (int f = f0; f < f1; f++) {
+        cb += (unsigned)be_f[f]; ce += be_f[f] != 0;
+        const unsigned long long fra = fra0 + f + 1;
+        if (FRA) FRA[f] = (long long)fra;
+        if (BE) BE[f] = (int32_t)cb;
+        if (FE) FE[f] = (int32_t)ce;
+        // Monitor_BFER::get_ber / get_fer (aff3ct): with no error yet they report the bound 1 / n_fra [/ K], not zero
+        if (FER) FER[f] = cb ? (float)ce / (float)fra : 1.f / (float)fra;
+        if (BER) BER[f] = cb ? (float)cb / (float)fra / (float)K : 1.f / (float)fra / (float)K;
+    }
+    __syncthreads();
+    if (tid == 1023) { ctr[0] = fra0 + F; ctr[1] = be0 + s_be[1023]; ctr[2] = fe0 + s_fe[1023]; }
+}
+hipError_t monitor2_launch(const int32_t *U, const int32_t *V, unsigned long long *ctr, int32_t *be_tmp, long long *FRA, int32_t *BE, int32_t *FE, float *BER,
+                           float *FER, int K, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(monitor_be_kernel, dim3(F), dim3(FRONT_THREADS), 0, s, U, V, be_tmp, K);
+    hipLaunchKernelGGL(monitor_scan_kernel, dim3(1), dim3(1024), 0, s, be_tmp, ctr, FRA, BE, FE, BER, FER, K, F);
+    return hipGetLastError();
+}
+
 }  // namespace dvbs2

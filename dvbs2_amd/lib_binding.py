@@ -90,6 +90,11 @@ ABI = {
     "dvbs2hip_filter": (C.c_int, [_vp, _vp, _vp, _i, _i]),
     "dvbs2hip_filter_dev": (C.c_int, [_vp, _vp, _vp, _i, _i]),
     "dvbs2hip_filter_reset": (C.c_int, [_vp]),
+    "dvbs2hip_filter_split": (C.c_int, [_vp, _i]),
+    "dvbs2hip_filter1": (C.c_int, [_vp, _vp, _vp, _i, _i]),
+    "dvbs2hip_filter1_dev": (C.c_int, [_vp, _vp, _vp, _i, _i]),
+    "dvbs2hip_filter2": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i]),
+    "dvbs2hip_filter2_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i]),
     "dvbs2hip_estimate": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_estimate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_pl_descramble": (C.c_int, [_vp, _vp, _vp, _i]),
@@ -102,6 +107,11 @@ ABI = {
     "dvbs2hip_monitor_check_errors_dev": (C.c_int, [_vp, _vp, _vp, _i]),
     "dvbs2hip_monitor_get": (C.c_int, [_vp, _vp]),
     "dvbs2hip_monitor_reset": (C.c_int, [_vp]),
+    "dvbs2hip_monitor_check_errors2": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "dvbs2hip_monitor_check_errors2_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "dvbs2hip_monitor_reduce_init": (C.c_int, [_vp, _i, _i, C.c_char_p, _i]),
+    "dvbs2hip_monitor_reduce": (C.c_int, [_vp, _vp]),
+    "dvbs2hip_monitor_reduce_finalize": (C.c_int, [_vp]),
     "dvbs2hip_rx_bb": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_rx_bb_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_tx_bb": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _i]),

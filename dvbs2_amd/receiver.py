@@ -168,6 +168,32 @@ class Dvbs2Hip:
     def filter_reset(self):
         self._chk(self.L.dvbs2hip_filter_reset(self.h))
 
+    def filter_split(self, n_cplx):
+        """first complex sample of a frame that filter2 (and not filter1) produces"""
+        r = self.L.dvbs2hip_filter_split(self.h, n_cplx)
+        if r < 0:
+            raise ValueError("half a frame has to hold the filter's memory")
+        return r
+
+    def filter1(self, X_N1, n_frames=1):
+        """Filter<R>::filter1 (Filter_FIR_ccr.cpp:144-218): lower part of every frame, state advanced"""
+        X = np.ascontiguousarray(X_N1, dtype=np.float32).ravel()
+        if X.size % (2 * n_frames):
+            raise ValueError("filter socket size must be a multiple of 2 * n_frames")
+        out = np.zeros_like(X)
+        self._chk(self.L.dvbs2hip_filter1(self.h, _ptr(X), _ptr(out), X.size // (2 * n_frames), n_frames))
+        return out
+
+    def filter2(self, X_N1, Y_N2h, n_frames=1):
+        """Filter<R>::filter2 (Filter_FIR_ccr.cpp:220-294): Y_N2h copied, upper part of every frame from X_N1 alone"""
+        X = np.ascontiguousarray(X_N1, dtype=np.float32).ravel()
+        Yh = np.ascontiguousarray(Y_N2h, dtype=np.float32).ravel()
+        if X.size % (2 * n_frames) or Yh.size != X.size:
+            raise ValueError("filter2 sockets must have the same size, a multiple of 2 * n_frames")
+        out = np.empty_like(X)
+        self._chk(self.L.dvbs2hip_filter2(self.h, _ptr(X), _ptr(Yh), _ptr(out), X.size // (2 * n_frames), n_frames))
+        return out
+
     # ------------------------------------------------------------------ a6
     def estimate(self, X_N):
         X, F = self._frames(X_N, 2 * self.N_xfec, np.float32)
@@ -213,6 +239,29 @@ class Dvbs2Hip:
 
     def monitor_reset(self):
         self._chk(self.L.dvbs2hip_monitor_reset(self.h))
+
+    def check_errors2(self, U, V):
+        """Monitor_BFER::check_errors2: -> FRA int64[F], BE int32[F], FE int32[F], BER f32[F], FER f32[F] (counters after each frame)"""
+        Ua, F = self._frames(U, self.K_bch, np.int32)
+        Va, F2 = self._frames(V, self.K_bch, np.int32)
+        if F != F2:
+            raise ValueError("U and V hold a different number of frames")
+        fra = np.empty(F, np.int64); be = np.empty(F, np.int32); fe = np.empty(F, np.int32)
+        ber = np.empty(F, np.float32); fer = np.empty(F, np.float32)
+        self._chk(self.L.dvbs2hip_monitor_check_errors2(self.h, _ptr(Ua), _ptr(Va), _ptr(fra), _ptr(be), _ptr(fe), _ptr(ber), _ptr(fer), F))
+        return fra, be, fe, ber, fer
+
+    def monitor_reduce_init(self, rank, world_size, rendezvous_path=None, timeout_ms=60000):
+        self._chk(self.L.dvbs2hip_monitor_reduce_init(self.h, rank, world_size, rendezvous_path.encode() if rendezvous_path else None, timeout_ms))
+
+    def monitor_reduce(self):
+        """tools::Monitor_reduction across one-process-per-GPU ranks: RCCL sum of {FRA, BE, FE} (collective)"""
+        out = np.zeros(3, dtype=np.uint64)
+        self._chk(self.L.dvbs2hip_monitor_reduce(self.h, _ptr(out)))
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def monitor_reduce_finalize(self):
+        self._chk(self.L.dvbs2hip_monitor_reduce_finalize(self.h))
 
     # ------------------------------------------------------------------ fused chain
     def rx_bb(self, pl_frames, sigma=None, out=None):

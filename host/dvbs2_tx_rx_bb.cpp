@@ -3,9 +3,17 @@
 // written against the C ABI only (include/dvbs2hip.h): device buffers from dvbs2hip_malloc, the
 // `_dev` entry points chained on the handle's stream, one 24-byte counter read per batch.
 // Same flags where they apply to this path (src/common/Factory/DVBS2/DVBS2.cpp:117-149), same table
-// as refs/TX_RX_BB/*.txt.  (Multi-GPU runs use the Python twin, dvbs2_amd/sim.py, under torchrun.)
+// as refs/TX_RX_BB/*.txt.
 //
 //   dvbs2_tx_rx_bb --mod-cod QPSK-S_8/9 -m 3.6 -M 3.81 -s 0.1 --dec-implem SPA --dec-ite 50 -F 2048
+//
+// Multi-GPU: ONE PROCESS PER GPU.  Start N copies with --world N --rank r --rendezvous /path/to/file (or with the
+// environment a torchrun-style launcher sets: WORLD_SIZE, RANK, LOCAL_RANK; the file then defaults to
+// /tmp/dvbs2hip_rdv_$MASTER_PORT).  Rank r uses GPU LOCAL_RANK (default r) and its own noise / payload stream
+// (seed = base + rank, like the reference's per-clone seeds, main.cpp:118-120); the monitors are reduced by
+// dvbs2hip_monitor_reduce = one RCCL all-reduce of {FRA, BE, FE} per batch, which is what tools::Monitor_reduction does
+// across the reference's threads (main.cpp:123-125,155-161); every rank stops on the REDUCED frame-error count; rank 0
+// prints the table.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -24,6 +32,9 @@ int main(int argc, char **argv)
     int F = 512, n_ite = 50, max_fe = 100;                 // DVBS2.cpp:135-142 (implem SPA, 50 ite, 100 frame errors)
     long long max_frames = 10000000;
     float alpha = 1.0f;
+    auto env_int = [](const char *n, int d) { const char *v = std::getenv(n); return v && *v ? std::atoi(v) : d; };
+    int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0), local_rank = env_int("LOCAL_RANK", -1);
+    std::string rendezvous = std::getenv("MASTER_PORT") ? std::string("/tmp/dvbs2hip_rdv_") + std::getenv("MASTER_PORT") : "";
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -38,31 +49,38 @@ int main(int argc, char **argv)
         else if (a == "--dec-alpha") alpha = (float)std::atof(next());
         else if (a == "--est-type") est = next();
         else if (a == "--max-frames") max_frames = std::atoll(next());
+        else if (a == "--world") world = std::atoi(next());
+        else if (a == "--rank") rank = std::atoi(next());
+        else if (a == "--local-rank") local_rank = std::atoi(next());
+        else if (a == "--rendezvous") rendezvous = next();
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     dvbs2hip_t *h = nullptr;
     dvbs2hip_cfg cfg;
     if (dvbs2hip_cfg_from_modcod(modcod.c_str(), &cfg)) { std::fprintf(stderr, "%s\n", dvbs2hip_last_error(nullptr)); return 3; }
     cfg.max_frames = F; cfg.ldpc_n_ite = n_ite; cfg.ldpc_alpha = alpha; cfg.ldpc_early_stop = 1;
+    cfg.device = local_rank >= 0 ? local_rank : rank;
     cfg.ldpc_implem = implem == "SPA" ? DVBS2HIP_IMPLEM_SPA : implem == "MS" ? DVBS2HIP_IMPLEM_MS : DVBS2HIP_IMPLEM_NMS;
     if (implem != "SPA" && implem != "MS" && implem != "NMS") { std::fprintf(stderr, "--dec-implem has to be SPA, MS or NMS\n"); return 2; }
     if (dvbs2hip_create(&cfg, &h)) { std::fprintf(stderr, "%s\n", dvbs2hip_last_error(nullptr)); return 3; }
     dvbs2hip_sizes sz;
     CHK(dvbs2hip_get_sizes(h, &sz));
+    if (world > 1 || std::getenv("DVBS2HIP_FORCE_RCCL")) CHK(dvbs2hip_monitor_reduce_init(h, rank, world, rendezvous.c_str(), 120000));
+    const bool chief = rank == 0;
     void *d_pl, *d_sent, *d_got, *d_sig;
     CHK(dvbs2hip_malloc(h, &d_pl, (size_t)F * 2 * sz.pl_frame_sym * sizeof(float)));
     CHK(dvbs2hip_malloc(h, &d_sent, (size_t)F * sz.K_bch * sizeof(int32_t)));
     CHK(dvbs2hip_malloc(h, &d_got, (size_t)F * sz.K_bch * sizeof(int32_t)));
     CHK(dvbs2hip_malloc(h, &d_sig, (size_t)F * sizeof(float)));
 
-    std::printf("# * DVB-S2 (HIP) ------------------------------------\n#    ** Modulation and coding = %s\n#    ** LDPC implem           = %s\n"
-                "#    ** LDPC n iterations     = %d\n#    ** Frames per batch (-F)  = %d\n", modcod.c_str(), implem.c_str(), n_ite, F);
-    std::printf("# ----------|----------||----------|----------|----------|----------|----------||----------|----------\n"
+    if (chief) std::printf("# * DVB-S2 (HIP) ------------------------------------\n#    ** Modulation and coding = %s\n#    ** LDPC implem           = %s\n"
+                "#    ** LDPC n iterations     = %d\n#    ** Frames per batch (-F)  = %d\n#    ** Processes (1 per GPU)  = %d\n", modcod.c_str(), implem.c_str(), n_ite, F, world);
+    if (chief) std::printf("# ----------|----------||----------|----------|----------|----------|----------||----------|----------\n"
                 "#     Es/N0 |    Eb/N0 ||      FRA |       BE |       FE |      BER |      FER ||  SIM_THR |    ET/RT\n"
                 "#      (dB) |     (dB) ||          |          |          |          |          ||   (Mb/s) | (hhmmss)\n"
                 "# ----------|----------||----------|----------|----------|----------|----------||----------|----------\n");
     const double R = (double)sz.K_bch / sz.N_ldpc;                       // main.cpp:142
-    unsigned long long batch = 0;
+    unsigned long long batch = (unsigned long long)rank << 40;            // disjoint Philox key ranges per rank
     for (double ebn0 = ebn0_min; ebn0 < ebn0_max - 1e-9; ebn0 += step) {
         const double esn0 = ebn0 + 10.0 * std::log10(R * sz.bps);         // main.cpp:143-146
         const float sigma = (float)std::sqrt(1.0 / (2.0 * std::pow(10.0, esn0 / 10.0)));
@@ -75,16 +93,17 @@ int main(int argc, char **argv)
             CHK(dvbs2hip_tx_bb_dev(h, nullptr, (batch++ << 8), (const float *)d_sig, (int32_t *)d_sent, (float *)d_pl, F));
             CHK(dvbs2hip_rx_bb_dev(h, (const float *)d_pl, est == "PERFECT" ? (const float *)d_sig : nullptr, (int32_t *)d_got, nullptr, nullptr, F));
             CHK(dvbs2hip_monitor_check_errors_dev(h, (const int32_t *)d_sent, (const int32_t *)d_got, F));
-            CHK(dvbs2hip_monitor_get(h, c));
+            CHK(dvbs2hip_monitor_reduce(h, c));                               // Monitor_reduction::is_done_all: every rank sees the same sum
         }
         const double et = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const int hh = (int)(et / 3600), mm = (int)(et / 60) % 60, ss = (int)et % 60;
-        std::printf("  %9.2f | %8.2f || %8llu | %8llu | %8llu | %8.2e | %8.2e || %8.3f | %02dh%02d'%02d\n", esn0, ebn0, (unsigned long long)c[0],
+        if (chief) std::printf("  %9.2f | %8.2f || %8llu | %8llu | %8llu | %8.2e | %8.2e || %8.3f | %02dh%02d'%02d\n", esn0, ebn0, (unsigned long long)c[0],
                     (unsigned long long)c[1], (unsigned long long)c[2], (double)c[1] / ((double)c[0] * sz.K_bch), (double)c[2] / (double)c[0],
                     (double)c[0] * sz.K_bch / et / 1e6, hh, mm, ss);
         std::fflush(stdout);
     }
-    std::printf("# End of the simulation\n");
+    if (chief) std::printf("# End of the simulation\n");
+    if (chief && world > 1 && !rendezvous.empty()) std::remove(rendezvous.c_str());
     dvbs2hip_free(h, d_pl); dvbs2hip_free(h, d_sent); dvbs2hip_free(h, d_got); dvbs2hip_free(h, d_sig);
     dvbs2hip_destroy(h);
     return 0;

@@ -1,7 +1,11 @@
 // dvbs2hip_modules.hpp -- StreamPU-style modules whose codelets call libdvbs2hip.so (the C ABI
 // of include/dvbs2hip.h).  Task and socket names are the reference's, so the socket graph of
-// /root/reference src/mains/TX_RX_BB/main.cpp:83-94 and src/mains/RX/main_sched.cpp:197-241 binds
-// unchanged; each module replaces the aff3ct / dvbs2 module named in its comment.
+// /root/reference src/mains/TX_RX_BB/main.cpp:83-94 binds unchanged, and so do the lines of src/mains/RX/main_sched.cpp:197-247
+// that touch the modules built here (matched filter filter1 / filter2 with Y_N2h, frame synchronizer synchronize1 / 2, the two
+// fine synchronizers, PL descrambler .. BB descrambler, monitor check_errors2 with its BE / FE / BER / FER sockets); host/
+// dvbs2_rx_bb.cpp holds those lines literally and tests/test_host_cpp.py builds and runs them.  The sample-serial loops of
+// dvbs2_rx (AGC, coarse frequency PLL, Gardner timing) are out of scope and have no module here.  Each module replaces the
+// aff3ct / dvbs2 module named in its comment.
 //
 // One GPU = one Context (dvbs2hip handle) shared by the modules of a chain; -F (n_frames) is the
 // grid width on the device, so ONE module instance per GPU replaces the 28-40 thread clones of
@@ -19,12 +23,16 @@ namespace module {
 
 class Context {     // RAII owner of the dvbs2hip handle
 public:
+    // defaults = the reference's (DVBS2.cpp:135-138: --dec-implem SPA, --dec-ite 50); ldpc_implem: "SPA" | "NMS" | "MS"
     Context(const std::string &modcod, int n_frames, int ldpc_n_ite = 50, float ldpc_alpha = 1.0f, bool early_stop = true,
-            int device = 0)
+            int device = 0, const std::string &ldpc_implem = "SPA")
     {
         dvbs2hip_cfg cfg;
         if (dvbs2hip_cfg_from_modcod(modcod.c_str(), &cfg) != DVBS2HIP_OK)
             throw spu::tools::invalid_argument(__FILE__, __LINE__, __func__, dvbs2hip_last_error(nullptr));   // DVBS2.cpp:319
+        if (ldpc_implem != "SPA" && ldpc_implem != "NMS" && ldpc_implem != "MS")
+            throw spu::tools::invalid_argument(__FILE__, __LINE__, __func__, "'ldpc_implem' has to be SPA, NMS or MS");
+        cfg.ldpc_implem = ldpc_implem == "SPA" ? DVBS2HIP_IMPLEM_SPA : ldpc_implem == "MS" ? DVBS2HIP_IMPLEM_MS : DVBS2HIP_IMPLEM_NMS;
         cfg.max_frames = n_frames; cfg.ldpc_n_ite = ldpc_n_ite; cfg.ldpc_alpha = ldpc_alpha;
         cfg.ldpc_early_stop = early_stop ? 1 : 0; cfg.device = device;
         const int rc = dvbs2hip_create(&cfg, &h);
@@ -63,11 +71,17 @@ namespace dec { enum class tsk : size_t { decode_siho = 0, decode_hiho = 0 };
                 namespace sck { enum class decode_siho : size_t { Y_N, CWD, V_K, status }; enum class decode_hiho : size_t { Y_N, CWD, V_K, status }; } }
 namespace mdm { namespace sck { enum class demodulate : size_t { CP, Y_N1, Y_N2, status }; } }
 namespace itl { namespace sck { enum class deinterleave : size_t { itl, nat, status }; } }
-namespace flt { namespace sck { enum class filter : size_t { X_N1, Y_N2, status }; } }
+// Filter.hpp:22-29
+namespace flt { enum class tsk : size_t { filter, filter1, filter2, SIZE };
+                namespace sck { enum class filter : size_t { X_N1, Y_N2, status }; enum class filter1 : size_t { X_N1, Y_N2, status };
+                                enum class filter2 : size_t { X_N1, Y_N2h, Y_N2, status }; } }
 namespace est { namespace sck { enum class estimate : size_t { X_N, SIG, Eb_N0, Es_N0, status }; } }
 namespace scr { namespace sck { enum class descramble : size_t { Y_N1, Y_N2, status }; } }
 namespace frm { namespace sck { enum class remove_plh : size_t { Y_N1, Y_N2, status }; } }
-namespace mnt { namespace sck { enum class check_errors : size_t { U, V, status }; } }
+// aff3ct Monitor_BFER (absent submodule): tasks check_errors and check_errors2, the latter bound by the RX mains (main_sched.cpp:222-223,244-247)
+namespace mnt { enum class tsk : size_t { check_errors, check_errors2, SIZE };
+                namespace sck { enum class check_errors : size_t { U, V, status };
+                                enum class check_errors2 : size_t { U, V, FRA, BE, FE, BER, FER, status }; } }
 namespace rcv { namespace sck { enum class receive : size_t { Y_N1, V_K, CWD_LDPC, CWD_BCH, status }; } }
 // Synchronizer_freq_fine.hpp:14-19
 namespace sff { enum class tsk : size_t { synchronize, SIZE }; namespace sck { enum class synchronize : size_t { X_N1, FRQ, PHS, Y_N2, status }; } }
@@ -177,21 +191,51 @@ public:
     void deinterleave(const float *itl, float *nat) { DVBS2HIP_CHK(ctx, dvbs2hip_deinterleave(ctx->h, itl, nat, F())); }
 };
 
-// replaces Filter_RRC_ccr_naive / Filter_FIR_ccr::filter (Filter_FIR_ccr.cpp:68-142; bound main_sched.cpp:199-201)
+// replaces Filter_RRC_ccr_naive / Filter_FIR_ccr: tasks filter, filter1, filter2 (Filter.hpp:22-29, codelets Filter.hxx:56-96, bodies
+// Filter_FIR_ccr.cpp:68-294); the RX mains bind filter1 / filter2 with the Y_N2h socket in between (main_sched.cpp:199-201)
 class Filter_FIR_hip : public Module_hip {
 public:
     Filter_FIR_hip(std::shared_ptr<Context> c, int N) : Module_hip(std::move(c), "Filter_FIR_hip"), N(N)
     {
         if (N <= 0 || N % 2) throw spu::tools::invalid_argument(__FILE__, __LINE__, __func__, "'N' has to be a positive even number of floats");
-        auto &t = create_task("filter");
-        auto s1 = create_socket_in<float>(t, "X_N1", N);
-        auto s2 = create_socket_out<float>(t, "Y_N2", N);
-        create_codelet(t, [s1, s2](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
-            static_cast<Filter_FIR_hip &>(m).filter(tk[s1].template get_dataptr<const float>(), tk[s2].template get_dataptr<float>());
-            return 0;
-        });
+        {
+            auto &t = create_task("filter");
+            auto s1 = create_socket_in<float>(t, "X_N1", N);
+            auto s2 = create_socket_out<float>(t, "Y_N2", N);
+            create_codelet(t, [s1, s2](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+                static_cast<Filter_FIR_hip &>(m).filter(tk[s1].template get_dataptr<const float>(), tk[s2].template get_dataptr<float>());
+                return 0;
+            });
+        }
+        {
+            auto &t = create_task("filter1");
+            auto s1 = create_socket_in<float>(t, "X_N1", N);
+            auto s2 = create_socket_out<float>(t, "Y_N2", N);
+            create_codelet(t, [s1, s2](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+                static_cast<Filter_FIR_hip &>(m).filter1(tk[s1].template get_dataptr<const float>(), tk[s2].template get_dataptr<float>());
+                return 0;
+            });
+        }
+        {
+            auto &t = create_task("filter2");
+            auto s1 = create_socket_in<float>(t, "X_N1", N);
+            auto sh = create_socket_in<float>(t, "Y_N2h", N);
+            auto s2 = create_socket_out<float>(t, "Y_N2", N);
+            create_codelet(t, [s1, sh, s2](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+                static_cast<Filter_FIR_hip &>(m).filter2(tk[s1].template get_dataptr<const float>(), tk[sh].template get_dataptr<const float>(),
+                                                         tk[s2].template get_dataptr<float>());
+                return 0;
+            });
+        }
     }
+    spu::runtime::Task &operator[](flt::tsk t) { return *tasks[(size_t)t]; }
+    spu::runtime::Socket &operator[](flt::sck::filter s) { return (*tasks[(size_t)flt::tsk::filter])[(size_t)s]; }
+    spu::runtime::Socket &operator[](flt::sck::filter1 s) { return (*tasks[(size_t)flt::tsk::filter1])[(size_t)s]; }
+    spu::runtime::Socket &operator[](flt::sck::filter2 s) { return (*tasks[(size_t)flt::tsk::filter2])[(size_t)s]; }
+    int get_N() const { return N; }
     void filter(const float *X_N1, float *Y_N2) { DVBS2HIP_CHK(ctx, dvbs2hip_filter(ctx->h, X_N1, Y_N2, N / 2, F())); }
+    void filter1(const float *X_N1, float *Y_N2) { DVBS2HIP_CHK(ctx, dvbs2hip_filter1(ctx->h, X_N1, Y_N2, N / 2, F())); }
+    void filter2(const float *X_N1, const float *Y_N2h, float *Y_N2) { DVBS2HIP_CHK(ctx, dvbs2hip_filter2(ctx->h, X_N1, Y_N2h, Y_N2, N / 2, F())); }
     void reset() { DVBS2HIP_CHK(ctx, dvbs2hip_filter_reset(ctx->h)); }
     // DVBS2HIP_FIR_AUTO (matrix cores for <= 81 taps) | DVBS2HIP_FIR_VALU | DVBS2HIP_FIR_MFMA
     void set_kernel(int kernel) { DVBS2HIP_CHK(ctx, dvbs2hip_set_filter_kernel(ctx->h, kernel)); }
@@ -268,23 +312,53 @@ public:
     void descramble(const B *Y_N1, B *Y_N2) { DVBS2HIP_CHK(ctx, dvbs2hip_bb_descramble(ctx->h, (const int32_t *)Y_N1, (int32_t *)Y_N2, F())); }
 };
 
-// replaces Monitor_BFER<B>::check_errors (DVBS2.cpp:575-591; bound main.cpp:93-94)
+// replaces Monitor_BFER<B> (built DVBS2.cpp:575-591): check_errors (bound TX_RX_BB/main.cpp:93-94) and check_errors2 (bound
+// RX/main_sched.cpp:222-223, its BE / FE / BER / FER sockets feeding probes :244-247)
 template <typename B = int>
 class Monitor_BFER_hip : public Module_hip {
 public:
     Monitor_BFER_hip(std::shared_ptr<Context> c, unsigned max_fe = 100) : Module_hip(std::move(c), "Monitor_BFER_hip"), max_fe(max_fe)
     {
-        auto &t = create_task("check_errors");
-        auto sU = create_socket_in<B>(t, "U", ctx->sz.K_bch);
-        auto sV = create_socket_in<B>(t, "V", ctx->sz.K_bch);
-        create_codelet(t, [sU, sV](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
-            static_cast<Monitor_BFER_hip &>(m).check_errors(tk[sU].template get_dataptr<const B>(), tk[sV].template get_dataptr<const B>());
-            return 0;
-        });
+        {
+            auto &t = create_task("check_errors");
+            auto sU = create_socket_in<B>(t, "U", ctx->sz.K_bch);
+            auto sV = create_socket_in<B>(t, "V", ctx->sz.K_bch);
+            create_codelet(t, [sU, sV](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+                static_cast<Monitor_BFER_hip &>(m).check_errors(tk[sU].template get_dataptr<const B>(), tk[sV].template get_dataptr<const B>());
+                return 0;
+            });
+        }
+        {
+            auto &t = create_task("check_errors2");
+            auto sU = create_socket_in<B>(t, "U", ctx->sz.K_bch);
+            auto sV = create_socket_in<B>(t, "V", ctx->sz.K_bch);
+            auto sFRA = create_socket_out<int64_t>(t, "FRA", 1);
+            auto sBE = create_socket_out<int32_t>(t, "BE", 1);
+            auto sFE = create_socket_out<int32_t>(t, "FE", 1);
+            auto sBER = create_socket_out<float>(t, "BER", 1);
+            auto sFER = create_socket_out<float>(t, "FER", 1);
+            create_codelet(t, [sU, sV, sFRA, sBE, sFE, sBER, sFER](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+                static_cast<Monitor_BFER_hip &>(m).check_errors2(tk[sU].template get_dataptr<const B>(), tk[sV].template get_dataptr<const B>(),
+                                                                 tk[sFRA].template get_dataptr<int64_t>(), tk[sBE].template get_dataptr<int32_t>(),
+                                                                 tk[sFE].template get_dataptr<int32_t>(), tk[sBER].template get_dataptr<float>(),
+                                                                 tk[sFER].template get_dataptr<float>());
+                return 0;
+            });
+        }
     }
+    spu::runtime::Task &operator[](mnt::tsk t) { return *tasks[(size_t)t]; }
+    spu::runtime::Socket &operator[](mnt::sck::check_errors s) { return (*tasks[(size_t)mnt::tsk::check_errors])[(size_t)s]; }
+    spu::runtime::Socket &operator[](mnt::sck::check_errors2 s) { return (*tasks[(size_t)mnt::tsk::check_errors2])[(size_t)s]; }
     void check_errors(const B *U, const B *V) { DVBS2HIP_CHK(ctx, dvbs2hip_monitor_check_errors(ctx->h, (const int32_t *)U, (const int32_t *)V, F())); }
+    void check_errors2(const B *U, const B *V, int64_t *FRA, int32_t *BE, int32_t *FE, float *BER, float *FER)
+    { DVBS2HIP_CHK(ctx, dvbs2hip_monitor_check_errors2(ctx->h, (const int32_t *)U, (const int32_t *)V, FRA, BE, FE, BER, FER, F())); }
     void get(uint64_t &fra, uint64_t &be, uint64_t &fe) { uint64_t c[3]; DVBS2HIP_CHK(ctx, dvbs2hip_monitor_get(ctx->h, c)); fra = c[0]; be = c[1]; fe = c[2]; }
+    // tools::Monitor_reduction for one process per GPU (TX_RX_BB/main.cpp:123-125,155-161): RCCL sum over the ranks, collective
+    void reduce_init(int rank, int world_size, const std::string &rendezvous_path, int timeout_ms = 60000)
+    { DVBS2HIP_CHK(ctx, dvbs2hip_monitor_reduce_init(ctx->h, rank, world_size, rendezvous_path.c_str(), timeout_ms)); }
+    void get_reduced(uint64_t &fra, uint64_t &be, uint64_t &fe) { uint64_t c[3]; DVBS2HIP_CHK(ctx, dvbs2hip_monitor_reduce(ctx->h, c)); fra = c[0]; be = c[1]; fe = c[2]; }
     bool is_done() { uint64_t a, b, c; get(a, b, c); return c >= max_fe; }      // stop at max_fe (DVBS2.cpp:136)
+    bool is_done_all() { uint64_t a, b, c; get_reduced(a, b, c); return c >= max_fe; }   // Monitor_reduction::is_done_all
     void reset() { DVBS2HIP_CHK(ctx, dvbs2hip_monitor_reset(ctx->h)); }
 private:
     unsigned max_fe;

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DVBS2HIP_VERSION 100
+#define DVBS2HIP_VERSION 101
 
 typedef enum {
     DVBS2HIP_OK           = 0,
@@ -99,7 +99,7 @@ typedef struct dvbs2hip_cfg {
  * rows "QPSK-N_8/9", "8PSK-N_8/9", "16APSK-N_8/9", "32APSK-S_3/4".  Unknown name:
  * DVBS2HIP_EINVAL (the reference throws invalid_argument, DVBS2.cpp:319).  Fills code
  * sizes, tables, constellation, interleaver and the 81-tap SRRC (Shaping_filter.hpp:24-28);
- * n_ite = 50, alpha = 1, early_stop = 1, max_frames = 1 (the reference's defaults,
+ * implem = SPA, n_ite = 50, alpha = 1, early_stop = 1, max_frames = 1 (the reference's defaults,
  * DVBS2.cpp:135-142). */
 int dvbs2hip_cfg_from_modcod(const char *modcod, dvbs2hip_cfg *cfg);
 int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out);
@@ -181,6 +181,24 @@ int dvbs2hip_demodulate_deinterleave_dev(dvbs2hip_t *h, const float *CP, const f
 int dvbs2hip_filter(dvbs2hip_t *h, const float *X_N1, float *Y_N2, int32_t n_cplx, int32_t n_frames);
 int dvbs2hip_filter_dev(dvbs2hip_t *h, const float *X_N1, float *Y_N2, int32_t n_cplx, int32_t n_frames);
 int dvbs2hip_filter_reset(dvbs2hip_t *h);
+/* replaces: Filter<R>::filter1(X_N1, Y_N2) and ::filter2(X_N1, Y_N2h, Y_N2) -> Filter_FIR_ccr<R>::_filter1 / _filter2
+ * -- Filter_FIR_ccr.cpp:144-218 and :220-294; tasks and sockets flt::tsk::{filter1,filter2}, flt::sck::filter1::{X_N1,Y_N2},
+ * flt::sck::filter2::{X_N1,Y_N2h,Y_N2} (Filter.hpp:22-29, codelets Filter.hxx:69-96); bound RX/main_sched.cpp:199-201 and split
+ * over two pipeline stages in main_13-sta.cpp:274-282.  The reference's filter1 writes the outputs below about half a frame and
+ * advances the filter state; its filter2 copies Y_N2h and computes the rest from X_N1 alone.  Same here, as pure functions of
+ * the sockets (the two tasks may run in different pipeline stages on different batches):
+ *   filter1: Y_N2[f][0 .. split) = the filtered frame, state advanced exactly as dvbs2hip_filter does.  (The samples from
+ *            `split` on, which the reference leaves as they were, are filled as well -- nothing may depend on them.)
+ *   filter2: Y_N2[f][0 .. split) = Y_N2h[f][0 .. split);  Y_N2[f][split .. n_cplx) computed from X_N1[f] only; no state read
+ *            or written.  filter2(X, filter1(X)) == filter(X) bit for bit.
+ * split = dvbs2hip_filter_split(h, n_cplx) complex samples (n_cplx / 2 rounded down to a multiple of 4; the reference's own
+ * split depends on its SIMD width).  Half a frame has to hold the filter's memory: n_cplx / 2 >= n_taps - 1, else EINVAL
+ * (the reference reads out of bounds in that case).   X_N1, Y_N2h, Y_N2 : float[n_frames * 2 * n_cplx]                  */
+int dvbs2hip_filter_split(const dvbs2hip_t *h, int32_t n_cplx);
+int dvbs2hip_filter1(dvbs2hip_t *h, const float *X_N1, float *Y_N2, int32_t n_cplx, int32_t n_frames);
+int dvbs2hip_filter1_dev(dvbs2hip_t *h, const float *X_N1, float *Y_N2, int32_t n_cplx, int32_t n_frames);
+int dvbs2hip_filter2(dvbs2hip_t *h, const float *X_N1, const float *Y_N2h, float *Y_N2, int32_t n_cplx, int32_t n_frames);
+int dvbs2hip_filter2_dev(dvbs2hip_t *h, const float *X_N1, const float *Y_N2h, float *Y_N2, int32_t n_cplx, int32_t n_frames);
 /* Kernel behind dvbs2hip_filter[_dev] on this handle.  AUTO (default): the matrix-core form (bf16 x 3 split operands,
  * fp32 accumulation, k_fir_mfma.hip) for filters of at most 81 taps on 16-byte aligned sockets, the fp32 vector kernel
  * otherwise; VALU forces the vector kernel; MFMA returns DVBS2HIP_EUNSUPPORTED for a longer filter.  Both meet the same
@@ -222,6 +240,28 @@ int dvbs2hip_monitor_check_errors(dvbs2hip_t *h, const int32_t *U, const int32_t
 int dvbs2hip_monitor_check_errors_dev(dvbs2hip_t *h, const int32_t *U, const int32_t *V, int32_t n_frames);
 int dvbs2hip_monitor_get(dvbs2hip_t *h, uint64_t fra_be_fe[3]);
 int dvbs2hip_monitor_reset(dvbs2hip_t *h);
+/* replaces: module::Monitor_BFER<B>::check_errors2(U, V, FRA, BE, FE, BER, FER) -- the task the RX mains bind
+ * (RX/main_sched.cpp:222-223 U / V, :244-247 BE / FE / BER / FER into probes; aff3ct, absent: sockets
+ * mnt::sck::check_errors2::{U,V,FRA,BE,FE,BER,FER}).  Counts like check_errors AND writes the monitor's counters as they
+ * stand after each frame of the call (frame f of the socket = state after frames 0..f): FRA int64, BE / FE int32,
+ * BER = BE / FRA / K_bch and FER = FE / FRA as float, with Monitor_BFER's convention that before the first bit error they
+ * report the bound 1 / FRA [/ K_bch] instead of 0.  Any of the five output pointers may be NULL.
+ *   U, V : int32_t[n_frames * K_bch];  FRA : int64_t[n_frames];  BE, FE : int32_t[n_frames];  BER, FER : float[n_frames]   */
+int dvbs2hip_monitor_check_errors2(dvbs2hip_t *h, const int32_t *U, const int32_t *V, int64_t *FRA, int32_t *BE, int32_t *FE,
+                                   float *BER, float *FER, int32_t n_frames);
+int dvbs2hip_monitor_check_errors2_dev(dvbs2hip_t *h, const int32_t *U, const int32_t *V, int64_t *FRA, int32_t *BE, int32_t *FE,
+                                       float *BER, float *FER, int32_t n_frames);
+/* replaces: tools::Monitor_reduction over the per-thread monitors (TX_RX_BB/main.cpp:123-125 construction + 500 ms period,
+ * :155-161 is_done_all / final reduction) for ONE PROCESS PER GPU: the sum of {FRA, BE, FE} over the ranks, one RCCL
+ * all-reduce of 3 x uint64 on the handle's stream (over xGMI inside a node).  COLLECTIVE: every rank calls _reduce the same
+ * number of times (call it once per batch, as is_done_all is).  librccl.so is opened at run time on the first _init.
+ *   init    : rank 0 creates the communicator id and publishes it in the file `rendezvous_path` (written beside, then
+ *             renamed); the others poll for it for at most timeout_ms (< 0: for ever).  world_size 1 needs no file.
+ *   reduce  : the reduced counters; on a handle without _init it is dvbs2hip_monitor_get (a single process).
+ *   finalize: destroys the communicator (also done by dvbs2hip_destroy).                                              */
+int dvbs2hip_monitor_reduce_init(dvbs2hip_t *h, int32_t rank, int32_t world_size, const char *rendezvous_path, int32_t timeout_ms);
+int dvbs2hip_monitor_reduce(dvbs2hip_t *h, uint64_t fra_be_fe[3]);
+int dvbs2hip_monitor_reduce_finalize(dvbs2hip_t *h);
 
 /* ------------------------------------------------------------------ fused RX baseband chain (a7 -> a8)
  * One call = the RX half of TX_RX_BB/main.cpp:83-92:

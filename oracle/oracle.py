@@ -303,6 +303,47 @@ def fir(taps, hist, x):
     return y
 
 
+def fir_split(n_floats, n_taps, simd_width=8):
+    """Where Filter_FIR_ccr::_filter1 stops and ::_filter2 starts, in FLOATS of one frame of n_floats (Filter_FIR_ccr.cpp:
+    rest = N - P*M with M = mipp::N<R>() and P = (N - 2(T-1)) / M, .cpp:17-18,152; filter1 runs i = rest .. N/2 step M (:183),
+    filter2 from up_half = N/2 + ((N/2 - rest) % M) (:243-245)).  -> (end of what filter1 wrote, up_half): the first exceeds or
+    equals the second, so together they cover the frame."""
+    M = simd_width
+    P = (n_floats - 2 * (n_taps - 1)) // M
+    rest = n_floats - P * M
+    last = rest + ((n_floats // 2 - 1 - rest) // M) * M          # last i < N/2 of filter1's vector loop
+    up_half = n_floats // 2 + ((n_floats // 2 - rest) % M)
+    return last + M, up_half
+
+
+def fir1(taps, hist, x, n_frames=1, simd_width=8):
+    """Filter<R>::filter1 over n_frames consecutive frames (Filter.hxx:149-160 loops _filter1 over the frames;
+    Filter_FIR_ccr.cpp:144-218): every frame's outputs below the split, the rest of Y_N2 untouched (zeros here);
+    the state (hist) advances by whole frames exactly as in fir()."""
+    taps, x = _f32(taps), _f32(x).ravel()
+    n = x.size // n_frames
+    y = np.zeros_like(x)
+    full = fir(taps, hist, x)
+    end1, _ = fir_split(n, taps.size, simd_width)
+    for f in range(n_frames):
+        y[f * n: f * n + end1] = full[f * n: f * n + end1]
+    return y
+
+
+def fir2(taps, x, yh, n_frames=1, simd_width=8):
+    """Filter<R>::filter2 (Filter_FIR_ccr.cpp:220-294): Y_N2 = Y_N2h, then the outputs from up_half on, computed from X_N1
+    alone (they read nothing before the frame: up_half >= 2 (T-1)); no state."""
+    taps, x, yh = _f32(taps), _f32(x).ravel(), _f32(yh).ravel()
+    n = x.size // n_frames
+    y = yh.copy()
+    _, up = fir_split(n, taps.size, simd_width)
+    assert up >= 2 * (taps.size - 1)
+    for f in range(n_frames):
+        full = fir(taps, np.zeros(2 * (taps.size - 1), np.float32), x[f * n:(f + 1) * n])
+        y[f * n + up:(f + 1) * n] = full[up:]
+    return y
+
+
 def upfir(taps, osf, hist, x):
     taps, x = _f32(taps), _f32(x).ravel()
     y = np.empty(x.size * osf, dtype=np.float32)

@@ -166,3 +166,46 @@ def test_filtered_loop_awgn_extract(O, Rx, P):
     assert np.array_equal(out.reshape(-1, 2)[: F * n - 40], got) and not out.reshape(-1, 2)[F * n - 40:].any()
     L.dvbs2hip_free(rx.h, din); L.dvbs2hip_free(rx.h, dout)
     rx.close()
+
+
+@pytest.mark.parametrize("kernel", ["auto", "valu"])
+def test_filter1_filter2_split_matches_the_reference_tasks(O, Rx, P, kernel):
+    """flt::tsk::filter1 / filter2 (Filter_FIR_ccr.cpp:144-294, bound RX/main_sched.cpp:199-201): filter2(X, filter1(X)) is the
+    whole filter; each half agrees with the oracle's restatement of the reference's halves where both define the output; filter2 is
+    a pure function of its sockets (garbage in the upper part of Y_N2h does not leak, no state is read or advanced)."""
+    from dvbs2_amd import lib_binding as B
+    taps = P.rrc_taps(0.2, 2, 20)
+    rng = np.random.default_rng(15)
+    F, n = 3, 6804
+    rx = Rx("32APSK-S_3/4", max_frames=8)
+    rx.set_filter_kernel({"auto": B.FIR_AUTO, "valu": B.FIR_VALU}[kernel])
+    ref = Rx("32APSK-S_3/4", max_frames=8)
+    ref.set_filter_kernel({"auto": B.FIR_AUTO, "valu": B.FIR_VALU}[kernel])
+    split = rx.filter_split(n)
+    assert split % 4 == 0 and 80 <= split <= n // 2
+    end1, up = O.fir_split(2 * n, 81)
+    assert end1 >= up                                         # the reference's halves overlap or meet
+    hist = np.zeros(2 * 80, np.float32)
+    for call in range(3):
+        x = rng.standard_normal(F * 2 * n).astype(np.float32)
+        y1 = rx.filter1(x, n_frames=F)
+        y2 = rx.filter2(x, y1, n_frames=F)
+        yw = ref.filter(x, n_frames=F)                        # the one-task filter on a twin handle with the same history
+        assert np.array_equal(y2, yw)                         # bit for bit: same kernel, same stream
+        h2 = hist.copy()
+        o1 = O.fir1(taps, hist, x, n_frames=F)
+        o2 = O.fir2(taps, x, o1, n_frames=F)
+        assert np.max(np.abs(o2 - O.fir(taps, h2, x))) == 0.0           # the oracle's halves make the oracle's whole
+        lo = min(2 * split, end1)
+        for f in range(F):
+            a = slice(f * 2 * n, f * 2 * n + lo)
+            assert np.max(np.abs(y1[a] - o1[a])) <= TOL       # what both filter1s define
+        assert np.max(np.abs(y2 - o2)) <= TOL
+        # filter2 alone: Y_N2h arbitrary; its lower part is copied, its upper part ignored
+        yh = rng.standard_normal(F * 2 * n).astype(np.float32)
+        y3 = rx.filter2(x, yh, n_frames=F).reshape(F, 2 * n)
+        assert np.array_equal(y3[:, :2 * split], yh.reshape(F, 2 * n)[:, :2 * split])
+        assert np.array_equal(y3[:, 2 * split:], yw.reshape(F, 2 * n)[:, 2 * split:])
+    with pytest.raises(Exception):
+        rx.filter1(np.zeros(2 * 100, np.float32), 1)          # half a frame shorter than the filter's memory
+    rx.close(); ref.close()

@@ -85,6 +85,36 @@ def test_bb_descramble_and_monitor(O, Rx):
     rx.close()
 
 
+def test_monitor_check_errors2_sockets(O, Rx):
+    """Monitor_BFER::check_errors2 (bound RX/main_sched.cpp:222-223, sockets read by probes :244-247): the counters after
+    every frame of the call, BER / FER with Monitor_BFER's 1 / FRA bound before the first error."""
+    modcod = "QPSK-S_8/9"
+    K = chain(O, modcod).mc.K_bch
+    rng = np.random.default_rng(3)
+    F = 7
+    U = rng.integers(0, 2, (F, K)).astype(np.int32)
+    V = U.copy()
+    V[2, :5] ^= 1
+    V[3, 9] ^= 1
+    V[6, 1000:1003] ^= 1
+    rx = Rx(modcod, max_frames=F)
+    fra, be, fe, ber, fer = rx.check_errors2(U, V)
+    e = np.array([0, 0, 5, 1, 0, 0, 3])
+    cb, cf, n = np.cumsum(e), np.cumsum(e > 0), np.arange(1, F + 1)
+    assert fra.dtype == np.int64 and be.dtype == np.int32 and fer.dtype == np.float32
+    assert np.array_equal(fra, n) and np.array_equal(be, cb) and np.array_equal(fe, cf)
+    want_fer = np.where(cb > 0, cf / n, 1.0 / n).astype(np.float32)
+    want_ber = np.where(cb > 0, cb / n / K, 1.0 / n / K).astype(np.float32)
+    assert np.allclose(fer, want_fer, rtol=1e-6) and np.allclose(ber, want_ber, rtol=1e-6)
+    assert rx.monitor_get() == (7, 9, 3)
+    fra, be, fe, ber, fer = rx.check_errors2(U[:2], U[:2])          # the counters carry on across calls and tasks
+    assert fra.tolist() == [8, 9] and be.tolist() == [9, 9] and fe.tolist() == [3, 3]
+    rx.check_errors(U, V)
+    assert rx.monitor_get() == (16, 18, 6)
+    assert rx.monitor_reduce() == (16, 18, 6)                       # no communicator on this handle: the local counters
+    rx.close()
+
+
 def test_sigma_per_frame_and_high_snr_signs(O, Rx):
     """CP socket holds one sigma per frame; at high SNR the LLR sign is the hard decision."""
     modcod = "16APSK-S_8/9"

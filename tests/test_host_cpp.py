@@ -39,7 +39,7 @@ def test_host_rx_graph_on_gpu(O, tmp_path, modcod, ebn0):
     pin, psrc, pout = (str(tmp_path / n) for n in ("pl.f32", "src.i32", "out.i32"))
     pl.astype(np.float32).tofile(pin)
     info.astype(np.int32).tofile(psrc)
-    r = subprocess.run([exe, "--mod-cod", modcod, "-F", str(F), "--dec-ite", "10", "--in", pin, "--src", psrc, "--out", pout],
+    r = subprocess.run([exe, "--mod-cod", modcod, "-F", str(F), "--dec-implem", "NMS", "--dec-ite", "10", "--in", pin, "--src", psrc, "--out", pout],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "mismatches 0" in r.stdout and "FRA %d BE 0 FE 0" % (F * batches) in r.stdout
@@ -58,7 +58,7 @@ def test_host_frame_sync_task_in_front_of_the_graph(O, tmp_path):
     stream = np.concatenate([np.zeros(2 * off, np.float32), pl.reshape(-1)])[:n_fr * 2 * n]
     pin, pout = str(tmp_path / "pl.f32"), str(tmp_path / "out.i32")
     stream.astype(np.float32).tofile(pin)
-    r = subprocess.run([exe, "--mod-cod", modcod, "-F", "1", "--dec-ite", "10", "--frame-sync", "--in", pin, "--out", pout], capture_output=True, text=True)
+    r = subprocess.run([exe, "--mod-cod", modcod, "-F", "1", "--dec-implem", "NMS", "--dec-ite", "10", "--frame-sync", "--in", pin, "--out", pout], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "mismatches 0" in r.stdout and "DEL %d " % off in r.stdout
     out = np.fromfile(pout, dtype=np.int32).reshape(n_fr, -1)
@@ -81,3 +81,49 @@ def test_cpp_tx_rx_bb_reproduces_a_reference_row():
     ref = json.load(open(os.path.join(ROOT, "tests", "golden", "refs_tx_rx_bb.json")))["QPSK_8_9.txt"]["rows"][1]
     assert abs(float(f[0]) - ref["esn0"]) < 0.0051 and fe >= 100
     assert ref["fer"] / 2.5 <= fer <= ref["fer"] * 2.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("modcod,F", [("QPSK-S_8/9", 1), ("QPSK-S_8/9", 4), ("16APSK-S_8/9", 2)])
+def test_host_dvbs2_rx_graph_with_filter1_filter2_and_check_errors2(O, P, tmp_path, modcod, F):
+    """The dvbs2_rx graph from the matched filter to the monitor, bound with the reference's own lines
+    (src/mains/RX/main_sched.cpp:199-201 filter1 / filter2 / Y_N2h, :206-222 frame sync .. monitor check_errors2, :244-247 the
+    BE / FE / BER / FER sockets into probes) against the HIP modules: a shaped stream that starts mid-frame is filtered,
+    aligned, corrected and decoded; the monitor (source delayed by the frame synchronizer's one frame) counts no error."""
+    exe = build()
+    n_fr, off = 6 * F if F > 1 else 10, 1777
+    info, pl, _, _ = make_pl_frames(O, modcod, n_fr, 14.0, seed=63)
+    n = pl.shape[1] // 2
+    stream = np.concatenate([np.zeros(2 * off, np.float32), pl.reshape(-1)])[:n_fr * 2 * n]
+    taps = P.rrc_taps(0.2, 2, 20)
+    shaped = O.upfir(taps, 2, np.zeros(2 * 40, np.float32), stream)              # TX shaping filter, 2 samples per symbol
+    pin, psrc, pout = (str(tmp_path / x) for x in ("rx.f32", "src.i32", "out.i32"))
+    shaped.astype(np.float32).tofile(pin)
+    info.astype(np.int32).tofile(psrc)
+    skip = 4 if F == 1 else 2
+    r = subprocess.run([exe, "--matched-filter", "--mod-cod", modcod, "-F", str(F), "--dec-implem", "NMS", "--dec-ite", "10", "--in", pin, "--src", psrc,
+                        "--src-delay", "1", "--mon-skip", str(skip), "--out", pout], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    fra = n_fr - skip * F
+    assert "FRA %d BE 0 FE 0" % fra in r.stdout, r.stdout
+    assert "probes | BE 0 FE 0" in r.stdout and "DEL %d FLG 1" % ((off + 40) % n) in r.stdout, r.stdout      # 40 symbols = the two filters' group delays
+    out = np.fromfile(pout, dtype=np.int32).reshape(n_fr, -1)
+    for f in range(skip * F, n_fr):
+        assert np.array_equal(out[f], info[f - 1]), f
+
+
+@pytest.mark.gpu
+def test_cpp_tx_rx_bb_reduces_its_monitor_over_rccl(tmp_path):
+    """dvbs2hip_monitor_reduce = tools::Monitor_reduction for one process per GPU (TX_RX_BB/main.cpp:123-125,155-161): the C++
+    simulator with a 1-rank RCCL communicator forced on (this box has one GPU) stops on the REDUCED counters and prints the
+    same kind of row; the rendezvous through a file is exercised by rank 0 writing it."""
+    build()
+    exe = os.path.join(ROOT, "host", "dvbs2_tx_rx_bb")
+    env = dict(os.environ, DVBS2HIP_FORCE_RCCL="1")
+    r = subprocess.run([exe, "--mod-cod", "QPSK-S_8/9", "-m", "3.6", "-M", "3.61", "--dec-implem", "NMS", "--dec-ite", "10", "-F", "1024", "--world", "1", "--rank", "0",
+                        "--rendezvous", str(tmp_path / "rdv")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    row = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("#")][0]
+    f = [x.strip() for x in row.replace("||", "|").split("|")]
+    assert int(f[4]) >= 100 and int(f[2]) % 1024 == 0
+    assert "Processes (1 per GPU)  = 1" in r.stdout

@@ -15,7 +15,7 @@ for f in /tmp/ab_new/*; do cp $f dvbs2_amd/csrc/$(basename $f); done
 for i in 1 2 3; do for v in old new; do
   cp /tmp/lib_$v.so dvbs2_amd/lib/libdvbs2hip.so
   case "${AB_MODE:-bench}" in
-    sim) python -m dvbs2_amd.sim --mod-cod QPSK-N_8/9 -m 3.9 -M 4.11 -s 0.1 --dec-ite 10 -F 2048 --max-frames 400000 2>/dev/null | grep -E "^ +[0-9]" | awk -v v=$v '{printf "%s Eb/N0 %s  FE %s  %s Mb/s\n", v, $3, $9, $15}' ;;
+    sim) python -m dvbs2_amd.sim --mod-cod QPSK-N_8/9 -m 3.9 -M 4.11 -s 0.1 --dec-implem NMS --dec-ite 10 -F 2048 --max-frames 400000 2>/dev/null | grep -E "^ +[0-9]" | awk -v v=$v '{printf "%s Eb/N0 %s  FE %s  %s Mb/s\n", v, $3, $9, $15}' ;;
     cmd) echo -n "$v "; bash -c "$AB_CMD" 2>/dev/null | tail -1 ;;
     *)   python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],3), d['ber']['BE'])" ;;
   esac
