@@ -155,7 +155,9 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                     const int cap = (int)(lds_limit / 2 / grp_bytes) - 1;            // two frames per CU, one junk row each
                     std::vector<std::vector<int>> mult(pl.n_groups, std::vector<int>(q, 0));
                     for (int r = 0; r < q; r++) for (const Slot &sl : layers[r]) mult[sl.group][r]++;
-                    const int banned = n_rows + q - 1;                                // its layer-0 slot is the absent-for-check-0 one: keep it last
+                    // the parity groups stay out of LDS: table order then puts p_c and p_{c-1} at the last two (global) slots of every layer,
+                    // where k_ldpc_wg8.hip forwards the parity chain in a register; p_{c-1} of layer 0 is the absent-for-check-0 slot
+                    auto banned_g = [&](int g) { return g >= n_rows; };
                     std::vector<int> cnt(q, 0);
                     int size = 0;
                     auto fits = [&](int g) { for (int r = 0; r < q; r++) if (cnt[r] + mult[g][r] > NL) return false; return true; };
@@ -170,7 +172,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                         for (int g = 0; g < pl.n_groups && lock_ok; g++) {
                             bool d = false;
                             for (int r = 0; r < q; r++) d |= mult[g][r] > 1;
-                            if (d) { if (g == banned) lock_ok = false; dups.push_back(g); }
+                            if (d) { if (banned_g(g)) lock_ok = false; dups.push_back(g); }
                         }
                         for (int g : dups) { if (!lock_ok) break; if (fits(g) && size < cap) { add(g, +1); locked[g] = 1; } else lock_ok = false; }
                         if (!lock_ok) { for (int g = 0; g < pl.n_groups; g++) if (in_lds[g]) add(g, -1); std::fill(locked.begin(), locked.end(), 0); }
@@ -180,7 +182,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                         int best = 0, bg = -1;
                         for (int i = 0; i < pl.n_groups && size < cap; i++) {
                             const int g = order[i];
-                            if (in_lds[g] || g == banned || !fits(g)) continue;
+                            if (in_lds[g] || banned_g(g) || !fits(g)) continue;
                             if (touches[g] > best) { best = touches[g]; bg = g; }
                         }
                         if (bg < 0) break;
@@ -193,7 +195,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                     for (int it = 0; it < 400000 && c0 > 0; it++) {
                         int g_out = -1, g_in = -1;
                         if (rnd() & 1) { do { g_out = (int)(rnd() % pl.n_groups); } while (!in_lds[g_out]); if (locked[g_out]) g_out = -1; }
-                        if (rnd() % 10 != 0) { do { g_in = (int)(rnd() % pl.n_groups); } while (in_lds[g_in] || g_in == banned); }
+                        if (rnd() % 10 != 0) { do { g_in = (int)(rnd() % pl.n_groups); } while (in_lds[g_in] || banned_g(g_in)); }
                         if (g_out >= 0) add(g_out, -1);
                         bool ok = true;
                         if (g_in >= 0) { ok = fits(g_in) && size < cap; if (ok) add(g_in, +1); }
@@ -244,6 +246,9 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                     for (const Slot &sl : layers[r]) if (in_lds[sl.group]) ord.push_back(sl);
                     if ((int)ord.size() != 9) return "LDPC: internal: static hybrid balance broken";
                     for (const Slot &sl : layers[r]) if (!in_lds[sl.group]) ord.push_back(sl);
+                    const size_t nn = ord.size();
+                    if (nn < 2 || ord[nn - 2].group != n_rows + r || ord[nn - 1].group != n_rows + (r + q - 1) % q || ord[nn - 2].t0 != 0 || (r > 0 && ord[nn - 1].t0 != 0))
+                        return "LDPC: internal: static hybrid needs p_c and p_{c-1} at the last two slots (parity chain forwarding)";
                 } else {
                     for (const Slot &sl : layers[r]) if (!prev_touch[sl.group]) ord.push_back(sl);
                     n_early = (int)ord.size();

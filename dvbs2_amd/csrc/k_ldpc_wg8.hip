@@ -20,6 +20,11 @@
 //  * Static hybrid image (N = 64800): 9 of the 27 slots of every layer are LDS-resident, known at
 //    compile time, AND every bit-group with two edges in one layer is among them -- the duplicate-edge
 //    replay and the store redirection then never leave LDS, and stores to global memory need no select.
+//  * Parity chain in a register (static hybrid): parity bit q t + r joins only checks (r, t) and (r + 1, t) -- the same lane of two
+//    consecutive layers.  Its posterior after layer r is read by nobody but layer r + 1, so it travels in a VGPR: slot DEG-2 (p_c)
+//    is not stored by layer r < q-1 and slot DEG-1 (p_{c-1}) not loaded by layer r > 0 (layer 0 reads group q-1 shifted by one
+//    check: that one goes through memory).  19 loads and 19 stores of the 360 global posterior accesses of an iteration less; the
+//    same fp32 values in the same order, so still bit-exact.  The plan keeps the parity groups out of LDS and at the last two slots.
 //  * VALU per edge: byte-addressed LDS (one add per access), sign/magnitude merges as single
 //    v_and_or / v_bitop3 with the sign mask in an SGPR, store redirection selected on the scalar unit.
 #include "dvbs2hip_internal.h"
@@ -134,6 +139,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
     auto st_off = [&](int arr, int r) { return st_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u; };
     const int nl_info = p.w8.nl_info, nl = p.w8.nl, ng_info = p.w8.ng_info, ng = p.w8.ng;
     const uint32_t grow0 = 2u * W8_ROW;                      // global image: [junk row][+inf row][group rows ..]
+    constexpr bool FWD = MODE == 3 && !SPA;                  // parity chain forwarded in a register (plan: p_c at slot DEG-2, p_{c-1} at DEG-1, both global)
 #ifdef LDPC_PHASE_PROF
     uint32_t prof[12];
     for (int i = 0; i < 12; i++) prof[i] = 0u;
@@ -204,6 +210,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
         int it = 0;
         bool ok = false;
         float nx1 = 0.f, nx2 = 0.f, nxk = 0.f;           // packed state of the next layer (prefetched)
+        float pfw = 0.f;                                 // posterior of parity bit q t + r after layer r, on its way to layer r + 1
         // layer table of the NEXT layer, fetched under the end-of-layer barrier: 27 slots | prim | conflict info | 2 conflict entries
         uint32_t TE[32];
 #pragma unroll
@@ -314,7 +321,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         const uint32_t d = t4 - (E[j] & 0x7FFu);
                         const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
                         w[j] = min(d, d + (uint32_t)W8_ROW);
-                        v[j] = w8_slot_lds(MODE, j) ? lld(w[j] + base) : gld(w[j], base);
+                        if (FWD && j == DEG - 1) { if (r > 0) v[j] = pfw; else v[j] = gld(w[j], base); }      // p_{c-1}: handed over by layer r - 1
+                        else v[j] = w8_slot_lds(MODE, j) ? lld(w[j] + base) : gld(w[j], base);
                     }
                     const int rn = r + 1 < q ? r + 1 : 0;
                     if (it == 0 && r + 1 < q) { nx1 = 0.f; nx2 = 0.f; nxk = 0.f; }       // layer r + 1 has no messages yet in the first iteration
@@ -385,7 +393,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             // MODE 3: the duplicate edges all live in LDS, a global slot is always primary
                             const uint32_t sb = (MODE == 3 || pr) ? base : 0u;                // global junk row = row 0
                             const uint32_t vo = (j == DEG - 1 && mask0) ? W8_OOB : w[j];
-                            gst(vo, sb, x + nw);
+                            if (FWD && j == DEG - 2) { if (r + 1 < q) pfw = x + nw; else gst(vo, sb, x + nw); }      // p_c: kept for layer r + 1
+                            else gst(vo, sb, x + nw);
                         }
                     }
                     pkn |= idxn << 27;

@@ -30,6 +30,25 @@ def test_rx_bb_perfect_sigma_matches_oracle(O, Rx, modcod, ebn0):
     rx.close()
 
 
+@pytest.mark.parametrize("modcod,ebn0,n_ite", [("16APSK-N_8/9", 8.2, 20), ("16APSK-N_8/9", 7.0, 20), ("32APSK-S_3/4", 9.0, 10), ("32APSK-S_3/4", 7.4, 10)])
+def test_rx_bb_configs_3_and_4_match_oracle(O, Rx, modcod, ebn0, n_ite):
+    """BASELINE configs[3] (16APSK N = 64800, NMS 20 ite) and the baseband part of configs[4] (32APSK-S_3/4) through the FUSED chain,
+    frame by frame against the oracle chain: payload, both CWD flags; at a clean point (payload recovered) and in the waterfall
+    (some frames fail in LDPC and BCH: the failure path must agree too)."""
+    ch = chain(O, modcod)
+    F = 4
+    info, pl, cw, sigma = make_pl_frames(O, modcod, F, ebn0, seed=45)
+    rx = Rx(modcod, max_frames=F, n_ite=n_ite, alpha=1.0, early_stop=True)
+    out, c0, c1 = rx.rx_bb(pl, sigma=np.float32(sigma))
+    for f in range(F):
+        r = ch.rx(pl[f], sigma=np.float32(sigma), n_ite=n_ite, alpha=1.0, sched=O.QC, early_stop=True)
+        assert np.array_equal(out[f], r["info"]), f
+        assert c0[f] == r["ldpc_cwd"] and c1[f] == r["bch_cwd"], f
+    if ebn0 > 8.0:
+        assert np.array_equal(out, info)
+    rx.close()
+
+
 def test_rx_bb_estimated_sigma_recovers_payload(O, Rx):
     modcod = "QPSK-S_8/9"
     F = 8

@@ -218,3 +218,54 @@ def test_natural_order_in_the_fused_chain(O, Rx):
         assert np.array_equal(out[f], r["info"])
     assert np.array_equal(out, info)
     rx.close()
+
+
+def _big_batch(O, modcod, F, ebn0s, seed, n_cw=8):
+    """F channel-LLR frames (BPSK-equivalent) of n_cw oracle-encoded codewords, frame f at ebn0s[f % len]"""
+    ch = chain(O, modcod)
+    mc = ch.mc
+    rng = np.random.default_rng(seed)
+    info = rng.integers(0, 2, (n_cw, mc.K_bch)).astype(np.int32)
+    bch = ch.bch.encode(info)
+    cw = ch.ldpc.encode(bch)
+    idx = rng.integers(0, n_cw, F)
+    rate = mc.K_bch / mc.N_ldpc
+    eb = np.asarray(ebn0s, np.float64)[np.arange(F) % len(ebn0s)]
+    sigma = np.sqrt(1.0 / (2.0 * rate * 10.0 ** (eb / 10.0))).astype(np.float32)[:, None]
+    llr = np.empty((F, mc.N_ldpc), np.float32)
+    for s0 in range(0, F, 256):
+        e = min(F, s0 + 256)
+        y = (1.0 - 2.0 * cw[idx[s0:e]]).astype(np.float32) + sigma[s0:e] * rng.standard_normal((e - s0, mc.N_ldpc), dtype=np.float32)
+        llr[s0:e] = 2.0 * y / sigma[s0:e] ** 2
+    return ch, bch[idx], llr
+
+
+@pytest.mark.parametrize("n_ite,F", [(10, 2304), (20, 1536)])
+@pytest.mark.parametrize("ebn0s", [(3.0,), (3.0, 4.2)])
+def test_ldpc_headline_config_at_size_matches_oracle(O, Rx, n_ite, F, ebn0s):
+    """BASELINE configs[1] (N = 64800 8/9, 10 ite) and configs[3]'s 20 iterations AT SIZE: more frames than the persistent grid
+    holds (2 x 256 workgroups), so every workgroup decodes a 2nd .. 5th frame through the work queue on an image and a c->v state
+    that the previous frame left behind, at 3.0 dB where frames do NOT converge (stale state would show) and in a 3.0 / 4.2 dB mix
+    where frames of different length interleave under the early stop.  The LAST 8 frames and 8 random ones are compared with the
+    oracle: posterior bit patterns, hard decisions, CWD, iteration counts; fixed iterations and early stop."""
+    modcod = "QPSK-N_8/9"
+    ch, sent, llr = _big_batch(O, modcod, F, ebn0s, seed=1000 + n_ite + len(ebn0s))
+    rng = np.random.default_rng(5)
+    pick = np.unique(np.concatenate([np.arange(F - 8, F), rng.choice(F - 8, 8, replace=False)]))
+    for early in (False, True):
+        rx = Rx(modcod, max_frames=F, n_ite=n_ite, alpha=1.0, early_stop=early)
+        V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+        Vo, posto, cwdo, iteso = ch.ldpc.decode(llr[pick], n_ite=n_ite, alpha=1.0, sched=O.QC, early_stop=early)
+        assert np.array_equal(post[pick].view(np.uint32), posto.view(np.uint32)), (early, "posterior bit patterns")
+        assert np.array_equal(V[pick], Vo) and np.array_equal(CWD[pick], cwdo) and np.array_equal(ites[pick], iteso)
+        # size-independent properties over the whole batch: a detected codeword is the sent one; the easy half converges
+        okf = CWD == 1
+        assert np.array_equal(V[okf], sent[okf])
+        if len(ebn0s) == 2:
+            assert okf[1::2].mean() > 0.99 and (ites[1::2] < n_ite).mean() > (0.9 if early else -1)
+        if not early:
+            assert (ites == n_ite).all()
+            V2, CWD2 = rx.decode_siho(llr)                  # same launch again: nothing of the first one survives in the workspaces
+            assert np.array_equal(V, V2) and np.array_equal(CWD, CWD2)
+        rx.close()
+    assert (CWD[0::2] if len(ebn0s) == 2 else CWD).mean() < 0.5      # 3.0 dB: most frames fail, which is the point

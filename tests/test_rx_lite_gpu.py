@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("modcod,ebn0", [("QPSK-S_8/9", 7.0), ("16APSK-S_8/9", 12.0)])
+@pytest.mark.parametrize("modcod,ebn0", [("QPSK-S_8/9", 7.0), ("16APSK-S_8/9", 12.0), ("32APSK-S_3/4", 14.0)])      # the last one: BASELINE configs[4]
 def test_filtered_stream_with_unknown_frame_start_is_decoded(modcod, ebn0):
     from dvbs2_amd.receiver import Dvbs2Hip
     from dvbs2_amd import params as P

@@ -72,8 +72,18 @@ if pmc:
         lines.append("L2 hit rate = %.3f" % (pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])))
     cf, cw = (corr_f or 1.0), (corr_w or 1.0)
     lines.append("traffic (calibrated) = %.3f x FETCH + %.3f x WRITE = %.3f GB per launch" % (cf, cw, (cf * fetch_b + cw * write_b) / 1e9))
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import bench as _bench
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    except Exception:
+        head = None
     json.dump({"hbm_bytes_per_launch": cf * fetch_b + cw * write_b, "fetch_bytes_raw": fetch_b, "write_bytes_raw": write_b,
                "fetch_correction": cf, "write_correction": cw, "source": "profiles/%s_ldpc_rocprof.md" % tag,
+               "kernel_sha": _bench.kernel_sha(), "kernel_sources": list(_bench.KERNEL_SOURCES), "git_head": head,
+               "kernel": meta[0].replace("void ", "").split("(")[0].replace("dvbs2::", "").replace(", false>", ">").replace(", ", ","),
+               "frames": _bench.FRAMES_PER_GPU, "n_ite": _bench.N_ITE,
                "note": "fabric-side bytes (L2 misses + written-through stores), Infinity-Cache hits included; corrected by the factors "
                        "measured on a known dword-per-lane copy (tools/calibrate_fetch.py)"},
               open(os.path.join(PROF, "ldpc_pmc_traffic.json"), "w"), indent=1)
