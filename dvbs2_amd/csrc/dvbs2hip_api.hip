@@ -346,6 +346,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         CREATE_FAIL(DVBS2HIP_EHIP, h->err);
     std::vector<uint32_t> prbs;
     bb_prbs(cfg->K_bch, prbs);
+    prbs.resize((size_t)cfg->K_ldpc / 32 + 4, 0u);       // zero words behind bit K_bch: the LDPC kernel's fused output reads 64-bit stretches up to K_ldpc
     if (upload(h, &h->bch.d_prbs, prbs.data(), prbs.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
 
     // ---- TX mirror tables: encoder layer table, BCH generator, PLHEADER
@@ -587,11 +588,15 @@ int dvbs2hip_get_sizes(const dvbs2hip_t *h, dvbs2hip_sizes *o)
 }
 
 // ------------------------------------------------------------------ a1
-static int ldpc_dev(dvbs2hip_t *h, const float *Y, int8_t *CWD, int32_t *V, uint32_t *packed, float *post, int32_t *ites, int F)
+// the LDPC kernel can write the chain's output socket itself (descrambled info bits of a frame the BCH stage leaves alone)
+static bool ldpc_writes_info(const dvbs2hip_t *h) { return h->ldpc.fast_wg8 && h->ldpc_sched == DVBS2HIP_SCHED_QC && !getenv("DVBS2HIP_CHAIN_UNFUSED"); }
+
+static int ldpc_dev(dvbs2hip_t *h, const float *Y, int8_t *CWD, int32_t *V, uint32_t *packed, float *post, int32_t *ites, int F, int32_t *info_out = nullptr)
 {
     LdpcKParams p;
     memset(&p, 0, sizeof p);
     p.llr = Y; p.bits = V; p.packed = packed; p.cwd = CWD; p.post = post; p.ites = ites; p.gwork = h->d_gwork;
+    p.info_out = info_out; p.info_prbs = h->bch.d_prbs; p.K_info = h->K_bch;
     p.n_frames = F; p.n_ite = h->n_ite; p.early_stop = h->early_stop; p.alpha = h->alpha;
     if (h->ldpc_sched == DVBS2HIP_SCHED_NATURAL) {
         LdpcPlan &pl = h->ldpc;
@@ -652,11 +657,11 @@ int dvbs2hip_ldpc_decode_siho(dvbs2hip_t *h, const float *Y_N, int8_t *CWD, int3
 }
 
 // ------------------------------------------------------------------ a2
-static int bch_dev(dvbs2hip_t *h, const int32_t *Y, const uint32_t *packed, int8_t *CWD, int32_t *V, bool descramble, int F)
+static int bch_dev(dvbs2hip_t *h, const int32_t *Y, const uint32_t *packed, int8_t *CWD, int32_t *V, bool descramble, int F, bool patch_only = false)
 {
     BchKParams p;
     memset(&p, 0, sizeof p);
-    p.in_bits = Y; p.in_packed = packed; p.out_bits = V; p.cwd = CWD; p.n_frames = F;
+    p.in_bits = Y; p.in_packed = packed; p.out_bits = V; p.cwd = CWD; p.n_frames = F; p.patch_only = patch_only ? 1 : 0;
     p.prbs = descramble ? h->bch.d_prbs : nullptr;
     Timer tm(h, DVBS2HIP_K_BCH);
     HIPCHK(h, bch_launch(h->bch, p, h->stream));
@@ -1410,8 +1415,12 @@ int dvbs2hip_rx_bb_dev(dvbs2hip_t *h, const float *pl, const float *sigma, int32
         Timer tm(h, DVBS2HIP_K_FRONT);
         HIPCHK(h, front_rx_launch(front_params(h, pl, sigma, (float *)dllr, (float *)dest, F), h->stream));
     }
-    if ((r = ldpc_dev(h, (const float *)dllr, cwd_l, nullptr, (uint32_t *)dpk, nullptr, nullptr, F))) return r;
-    return bch_dev(h, nullptr, (const uint32_t *)dpk, cwd_b, info, true, F);
+    // the LDPC kernel writes the descrambled info bits of every frame straight into the output socket (what the BCH stage outputs for a
+    // frame it does not correct: nearly all of them behind a converged LDPC decoder); the BCH stage then only checks the syndromes of the
+    // packed hard decisions and flips the bits it corrects -- its 4 K_bch output bytes per frame were 90 % of its time
+    const bool fused_out = ldpc_writes_info(h);
+    if ((r = ldpc_dev(h, (const float *)dllr, cwd_l, nullptr, (uint32_t *)dpk, nullptr, nullptr, F, fused_out ? info : nullptr))) return r;
+    return bch_dev(h, nullptr, (const uint32_t *)dpk, cwd_b, info, true, F, fused_out);
 }
 
 int dvbs2hip_rx_bb(dvbs2hip_t *h, const float *pl, const float *sigma, int32_t *info, int8_t *cwd_l, int8_t *cwd_b, int32_t F)

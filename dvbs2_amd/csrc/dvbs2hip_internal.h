@@ -44,6 +44,11 @@ struct LdpcKParams {
     int8_t *cwd;             // [F]               (may be null)
     float *post;             // [F][N] natural    (may be null)
     int32_t *ites;           // [F]               (may be null)
+    // fused chain (k_ldpc_wg8.hip): the first K_info hard decisions XOR the BB descrambling sequence, one int32 per bit, straight
+    // into the chain's output socket -- what the BCH stage would write for a frame it does not have to correct
+    int32_t *info_out;       // [F][K_info]       (may be null)
+    const uint32_t *info_prbs;  // packed PRBS, padded with 3 zero words behind bit K (read as wave-uniform scalars)
+    int32_t K_info;
     float *gwork;            // [grid][gwork_words] per-workgroup global workspace
     const LdpcEntry *entries;  // [q][deg_max_padded]
     const int32_t *layer_deg;  // [q]
@@ -141,6 +146,7 @@ struct BchKParams {
     int8_t *cwd;                // [F] or null
     const uint16_t *exp_, *log_, *syn_tab;
     const uint32_t *prbs;       // packed K-bit BB descrambling sequence or null (no descramble)
+    int32_t patch_only;         // out_bits already holds the (descrambled) uncorrected bits: only flip what the decoder corrects
     int32_t N, K, m, n, t, n_frames;
 };
 std::string bch_build_plan(BchPlan &pl, int m, const int32_t *prim, int t, int N, int K);

@@ -255,7 +255,10 @@ bch_decode_kernel(const BchKParams p)
                 if (s_nroots == L) {
                     if (tid < L) {
                         const int pos = N - 1 - roots[tid];
-                        if (pos >= 0 && pos < K) atomicXor(&words[pos >> 5], 1u << (pos & 31));
+                        if (pos >= 0 && pos < K) {
+                            atomicXor(&words[pos >> 5], 1u << (pos & 31));
+                            if (p.patch_only) p.out_bits[(size_t)f * K + pos] ^= 1;          // the producer wrote the uncorrected (descrambled) bit
+                        }
                     }
                 } else if (tid == 0) s_status = 1;
                 __syncthreads();
@@ -264,7 +267,9 @@ bch_decode_kernel(const BchKParams p)
 
         // ---- 5. output the K systematic bits (optionally BB-descrambled, Scrambler_BB.hxx:51-72)
         int32_t *out = p.out_bits + (size_t)f * K;
-        if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        if (p.patch_only) {
+            // fused chain: the LDPC kernel has written the K descrambled bits of this frame already (k_ldpc_wg8.hip, `info_out`)
+        } else if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
             // four bits per lane: one 16-byte non-temporal store (the socket is written once and read by another kernel)
             typedef int32_t bch_i4 __attribute__((ext_vector_type(4)));
 #pragma unroll 8

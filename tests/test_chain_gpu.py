@@ -30,11 +30,13 @@ def test_rx_bb_perfect_sigma_matches_oracle(O, Rx, modcod, ebn0):
     rx.close()
 
 
-@pytest.mark.parametrize("modcod,ebn0,n_ite", [("16APSK-N_8/9", 8.2, 20), ("16APSK-N_8/9", 7.0, 20), ("32APSK-S_3/4", 9.0, 10), ("32APSK-S_3/4", 7.4, 10)])
+@pytest.mark.parametrize("modcod,ebn0,n_ite", [("16APSK-N_8/9", 8.2, 20), ("16APSK-N_8/9", 6.6, 20), ("32APSK-S_3/4", 9.0, 10), ("32APSK-S_3/4", 6.0, 10)])
 def test_rx_bb_configs_3_and_4_match_oracle(O, Rx, modcod, ebn0, n_ite):
     """BASELINE configs[3] (16APSK N = 64800, NMS 20 ite) and the baseband part of configs[4] (32APSK-S_3/4) through the FUSED chain,
-    frame by frame against the oracle chain: payload, both CWD flags; at a clean point (payload recovered) and in the waterfall
-    (some frames fail in LDPC and BCH: the failure path must agree too)."""
+    frame by frame against the oracle chain: payload and both CWD flags at a clean point (payload recovered); well below the
+    waterfall the failure path: the LDPC flags agree (nothing converges).  (The demapper meets the oracle to 1e-4, not bit for
+    bit, so the hard decisions of a frame that does NOT converge may differ: only converged frames are compared bit by bit.  The
+    decoder itself is compared on non-convergent frames in test_ldpc_headline_config_at_size_matches_oracle.)"""
     ch = chain(O, modcod)
     F = 4
     info, pl, cw, sigma = make_pl_frames(O, modcod, F, ebn0, seed=45)
@@ -42,10 +44,41 @@ def test_rx_bb_configs_3_and_4_match_oracle(O, Rx, modcod, ebn0, n_ite):
     out, c0, c1 = rx.rx_bb(pl, sigma=np.float32(sigma))
     for f in range(F):
         r = ch.rx(pl[f], sigma=np.float32(sigma), n_ite=n_ite, alpha=1.0, sched=O.QC, early_stop=True)
-        assert np.array_equal(out[f], r["info"]), f
-        assert c0[f] == r["ldpc_cwd"] and c1[f] == r["bch_cwd"], f
+        assert c0[f] == r["ldpc_cwd"], f
+        if r["ldpc_cwd"]:
+            assert np.array_equal(out[f], r["info"]) and c1[f] == r["bch_cwd"], f
     if ebn0 > 8.0:
-        assert np.array_equal(out, info)
+        assert np.array_equal(out, info) and (c0 == 1).all() and (c1 == 1).all()
+    else:
+        assert (c0 == 0).all()
+    rx.close()
+
+
+@pytest.mark.parametrize("modcod,ebn0,n_ite", [("QPSK-S_8/9", 5.2, 2), ("QPSK-N_8/9", 4.9, 2), ("16APSK-S_8/9", 8.4, 2), ("QPSK-S_8/9", 3.0, 4)])
+def test_rx_bb_bch_corrects_and_fails_behind_the_fused_output(O, Rx, monkeypatch, modcod, ebn0, n_ite):
+    """In the fused chain the LDPC kernel writes the descrambled info bits itself and the BCH stage only patches what it corrects.
+    Cut the LDPC decoder short (2-3 fixed iterations at a high SNR) so that frames reach the BCH stage with a few residual bit
+    errors: BCH must correct them in place (LDPC CWD 0, BCH CWD 1, payload exact).  At 3.0 dB everything fails: the output is the
+    uncorrected word.  Both ways the result equals the unfused chain's (BCH writing every bit: DVBS2HIP_CHAIN_UNFUSED) bit for bit."""
+    F = 24 if "-N_" in modcod else 64
+    info, pl, cw, sigma = make_pl_frames(O, modcod, F, ebn0, seed=46)
+    rx = Rx(modcod, max_frames=F, n_ite=n_ite, alpha=1.0, early_stop=False)
+    out, c0, c1 = rx.rx_bb(pl, sigma=np.float32(sigma))
+    monkeypatch.setenv("DVBS2HIP_CHAIN_UNFUSED", "1")
+    out_u, c0_u, c1_u = rx.rx_bb(pl, sigma=np.float32(sigma))
+    monkeypatch.delenv("DVBS2HIP_CHAIN_UNFUSED")
+    assert np.array_equal(out, out_u) and np.array_equal(c0, c0_u) and np.array_equal(c1, c1_u)
+    if ebn0 > 4.0:
+        fixed = (c0 == 0) & (c1 == 1)
+        assert fixed.sum() >= 3, (int(fixed.sum()), int(c0.sum()))                       # frames the BCH stage had to repair
+        assert np.array_equal(out[c1 == 1], info[c1 == 1])
+        # and against the oracle chain for the repaired frames
+        ch = chain(O, modcod)
+        for f in np.flatnonzero(fixed)[:3]:
+            r = ch.rx(pl[f], sigma=np.float32(sigma), n_ite=n_ite, alpha=1.0, sched=O.QC, early_stop=False)
+            assert r["bch_cwd"] == 1 and np.array_equal(out[f], r["info"])
+    else:
+        assert (c1 == 0).all() and (out != info).any(axis=1).all()
     rx.close()
 
 

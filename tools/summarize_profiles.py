@@ -17,7 +17,7 @@ def short(name):
     name = name.replace("void ", "")
     return name if len(name) < 100 else name[:97] + "..."
 
-lines = ["# rocprofv3 summary (%s) -- `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`" % tag, ""]
+lines = ["# rocprofv3 summary (%s) -- `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras`" % tag, ""]
 ks = first("prof_stats/*/*_kernel_stats.csv")
 if ks:
     lines += ["## --kernel-trace --stats (top kernels)", "", "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
