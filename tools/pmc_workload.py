@@ -1,0 +1,57 @@
+"""Workload for the rocprofv3 passes over the NON-LDPC kernels (tools/profile_kernels.sh): every stage of the RX inner path and
+the N4 synchronizers a few times each, at the sizes of BASELINE's configs.  GPU box only; prints nothing the profiler needs."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from dvbs2_amd.receiver import Dvbs2Hip
+from dvbs2_amd import params as P
+
+dev = torch.device("cuda", 0)
+REPS = 4
+vp = ctypes.c_void_p
+
+
+def chain(modcod, F, n_ite, ebn0):
+    mc = P.get_modcod(modcod)
+    rx = Dvbs2Hip(modcod, max_frames=F, n_ite=n_ite, alpha=1.0, early_stop=False)
+    sigma = P.esn0_to_sigma(P.ebn0_to_esn0(ebn0, mc.code_rate, mc.bps))
+    pl = torch.empty((F, 2 * rx.pl_frame), dtype=torch.float32, device=dev)
+    sent = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev); got = torch.empty_like(sent)
+    sig = torch.full((F,), sigma, dtype=torch.float32, device=dev)
+    rx.tx_bb_dev(None, 1, sig.data_ptr(), sent.data_ptr(), pl.data_ptr(), F); rx.synchronize()
+    for _ in range(REPS):
+        rx.rx_bb_dev(pl.data_ptr(), sig.data_ptr() if mc.bps >= 4 else None, got.data_ptr(), None, None, F)
+    rx.synchronize()
+    # stand-alone BCH task on int32 sockets (Decoder_BCH_DVBS2::decode_hiho), the received word = a codeword with 3 bit errors per frame
+    cwb = torch.zeros((F, rx.K_ldpc), dtype=torch.int32, device=dev)
+    cwb[:, 5] = 1; cwb[:, 77] = 1; cwb[:, 1234] = 1
+    out = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev); cwd = torch.empty(F, dtype=torch.int8, device=dev)
+    for _ in range(REPS):
+        rx.decode_hiho_dev(cwb.data_ptr(), cwd.data_ptr(), out.data_ptr(), F)
+    zero = torch.zeros_like(cwb)
+    for _ in range(REPS):
+        rx.decode_hiho_dev(zero.data_ptr(), cwd.data_ptr(), out.data_ptr(), F)
+    rx.synchronize(); rx.close()
+
+
+def sync(modcod, F):
+    rx = Dvbs2Hip(modcod, max_frames=F)
+    n = rx.pl_frame
+    x = torch.randn((F, 2 * n), dtype=torch.float32, device=dev); y = torch.empty_like(x)
+    DEL = torch.empty(F, dtype=torch.int32, device=dev); FLG = torch.empty_like(DEL); TRI = torch.empty(F, dtype=torch.float32, device=dev)
+    FRQ = torch.empty(F, dtype=torch.float32, device=dev); PHS = torch.empty_like(FRQ)
+    for _ in range(REPS):
+        rx.sync_frame_synchronize_dev(vp(x.data_ptr()), vp(DEL.data_ptr()), vp(FLG.data_ptr()), vp(TRI.data_ptr()), vp(y.data_ptr()), F)
+        rx._chk(rx.L.dvbs2hip_sync_lr_synchronize_dev(rx.h, vp(x.data_ptr()), vp(FRQ.data_ptr()), vp(PHS.data_ptr()), vp(y.data_ptr()), F))
+        rx._chk(rx.L.dvbs2hip_sync_freq_phase_synchronize_dev(rx.h, vp(x.data_ptr()), vp(FRQ.data_ptr()), vp(PHS.data_ptr()), vp(y.data_ptr()), F))
+    rx.synchronize(); rx.close()
+
+
+chain("QPSK-N_8/9", 4096, 10, 4.2)
+chain("QPSK-S_8/9", 8192, 10, 4.4)
+chain("16APSK-N_8/9", 4096, 20, 8.2)
+chain("32APSK-S_3/4", 4096, 10, 10.5)
+sync("QPSK-N_8/9", 1024)
+sync("32APSK-S_3/4", 4096)
+print("pmc workload done")

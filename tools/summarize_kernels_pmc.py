@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Condenses tools/profile_kernels.sh's rocprofv3 outputs (gpurun_out/pk_*) into profiles/<tag>_kernels_pmc.md: per kernel of the
+path (other than the LDPC decoder) and per workload size -- launches of one kernel name are split by grid size -- the average
+duration, calibrated fabric bytes (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; MI355X_MICROARCH.md HBM section), instruction
+counts and the busy / wait shares that say what bounds it."""
+import collections, csv, glob, os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+OUT = os.path.join(ROOT, "gpurun_out")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+
+
+def first(pattern):
+    g = sorted(glob.glob(os.path.join(OUT, pattern)), key=os.path.getmtime)
+    return g[-1] if g else None
+
+
+def short(n):
+    n = n.replace("void ", "").replace("dvbs2::", "")
+    return n.split("(")[0]
+
+
+want = ("front", "bch_decode", "sync_", "sff_", "vd_dmax", "demod", "monitor", "fir_")
+dur = collections.defaultdict(list)
+kt = first("pk_stats/*/*_kernel_trace.csv")
+if kt:
+    for r in csv.DictReader(open(kt)):
+        k = short(r["Kernel_Name"])
+        if any(w in k for w in want):
+            dur[(k, r["Grid_Size"] if "Grid_Size" in r else r.get("Grid_Size_X", "?"))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("pk_fetch", "pk_write", "pk_sq1", "pk_sq2", "pk_sq3"):
+    f = first(d + "/*/*_counter_collection.csv")
+    if not f:
+        continue
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if any(w in k for w in want):
+            pmc[(k, r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+lines = ["# rocprofv3 counters of the non-LDPC kernels (%s) -- `python3 tools/pmc_workload.py`, passes of tools/profile_kernels.sh" % tag, "",
+         "Per kernel and grid size (= workload): average over its launches.  fabric GB = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; FETCH_SIZE",
+         "reports half of the bytes of a coalesced stream on gfx950, WRITE_SIZE the bytes: calibrated in profiles/r02_ldpc_rocprof.md).",
+         "VALU busy = SQ_ACTIVE_INST_VALU / (4 SIMDs x SQ_BUSY_CYCLES summed over the chip's SQs) is shown as the share of wave-cycles instead:",
+         "valu/wave-cyc = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES, trans = v_exp / v_log / v_rcp / v_sqrt instructions.", "",
+         "| kernel | grid | launches | avg us | fabric GB | fabric TB/s | VALU inst | trans inst | LDS inst | VMEM rd / wr | valu / wave-cyc | wait / wave-cyc | LDS bank-conflict / LDS active | L2 hit |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+for key in sorted(dur, key=lambda k: -sum(dur[k])):
+    c = {n: sum(v) / len(v) for n, v in pmc.get(key, {}).items()}
+    us = sum(dur[key]) / len(dur[key])
+    fab = (2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024
+    wc = c.get("SQ_WAVE_CYCLES", 0)
+    def ratio(a, b): return "%.2f" % (a / b) if b else "-"
+    hit = c.get("TCC_HIT_sum", 0); miss = c.get("TCC_MISS_sum", 0)
+    lines.append("| `%s` | %s | %d | %.1f | %.3f | %.2f | %.3g | %.3g | %.3g | %.3g / %.3g | %s | %s | %s | %s |" % (
+        key[0], key[1], len(dur[key]), us, fab / 1e9, fab / (us * 1e-6) / 1e12 if us else 0, c.get("SQ_INSTS_VALU", 0), c.get("SQ_INSTS_VALU_TRANS_F32", 0),
+        c.get("SQ_INSTS_LDS", 0), c.get("SQ_INSTS_VMEM_RD", 0), c.get("SQ_INSTS_VMEM_WR", 0), ratio(c.get("SQ_ACTIVE_INST_VALU", 0), wc), ratio(c.get("SQ_WAIT_ANY", 0), wc),
+        ratio(c.get("SQ_LDS_BANK_CONFLICT", 0), c.get("SQ_LDS_IDX_ACTIVE", 0)), ratio(hit, hit + miss)))
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+open(os.path.join(ROOT, "profiles", "%s_kernels_pmc.md" % tag), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
