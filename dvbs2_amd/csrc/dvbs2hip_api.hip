@@ -1012,12 +1012,13 @@ int dvbs2hip_sync_frame_synchronize1_dev(dvbs2hip_t *h, const float *X_N1, float
     return 0;
 }
 
-int dvbs2hip_sync_frame_synchronize2_dev(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, const float *cor_PLSC, int32_t *DEL, int32_t *FLG,
-                                         float *TRI, float *Y_N2, int32_t F)
+// synchronize2, or (cor_SOF == cor_PLSC == null) the whole one-task synchronize with the correlators fused into the metric
+static int sfm_sync2(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, const float *cor_PLSC, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t F)
 {
     int r = check_frames(h, F); if (r) return r;
     int32_t *delay = DEL;
-    if (!X_N1 || !cor_SOF || !cor_PLSC || !delay || !Y_N2) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    const bool fused = !cor_SOF && !cor_PLSC;
+    if (!X_N1 || (!fused && (!cor_SOF || !cor_PLSC)) || !delay || !Y_N2) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
     if ((r = sfm_ready(h))) return r;
     auto &S = h->sfm;
     const int n = h->pl_frame;
@@ -1027,8 +1028,13 @@ int dvbs2hip_sync_frame_synchronize2_dev(dvbs2hip_t *h, const float *X_N1, const
         (r = ensure(h, B_SFM_DTAB, sizeof(int32_t) * (size_t)F, &dtab))) return r;
     Timer tm(h, DVBS2HIP_K_MISC);
     if (TRI) met = TRI;
-    HIPCHK(h, sync_metric_launch(cor_SOF, S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], cor_PLSC, S.cv, (float *)corr, delay, (float *)met, FLG, S.trigger,
-                                 n, F, S.alpha, S.vec_width, h->stream));
+    if (fused) {
+        HIPCHK(h, sync_corr_metric_launch(X_N1, S.xh[S.xh_cur], S.xh[S.xh_cur ^ 1], S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], S.cv, (float *)corr, delay, (float *)met,
+                                          FLG, S.trigger, n, F, S.alpha, S.vec_width, h->stream));
+        S.xh_cur ^= 1;
+    } else
+        HIPCHK(h, sync_metric_launch(cor_SOF, S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], cor_PLSC, S.cv, (float *)corr, delay, (float *)met, FLG, S.trigger,
+                                     n, F, S.alpha, S.vec_width, h->stream));
     S.sofh_cur ^= 1;
     // the delay line is a recurrence from frame to frame made of copies only: resolved per output sample, one launch (k_sync.hip)
     HIPCHK(h, sync_vdelay_launch(X_N1, S.yprev, Y_N2, S.buff2[S.od_cur], S.buff2[S.od_cur ^ 1], S.st[S.od_cur], S.st[S.od_cur ^ 1], delay,
@@ -1039,8 +1045,18 @@ int dvbs2hip_sync_frame_synchronize2_dev(dvbs2hip_t *h, const float *X_N1, const
     return 0;
 }
 
+int dvbs2hip_sync_frame_synchronize2_dev(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, const float *cor_PLSC, int32_t *DEL, int32_t *FLG,
+                                         float *TRI, float *Y_N2, int32_t F)
+{
+    if (h && (!cor_SOF || !cor_PLSC)) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    return sfm_sync2(h, X_N1, cor_SOF, cor_PLSC, DEL, FLG, TRI, Y_N2, F);
+}
+
 int dvbs2hip_sync_frame_synchronize_dev(dvbs2hip_t *h, const float *X_N1, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t F)
 {
+    // the one-task form: the two correlations are no sockets here and stay on chip (sync_corr_m_kernel); DVBS2HIP_SYNC_UNFUSED keeps
+    // the two-task path through device scratch (same numbers)
+    if (!getenv("DVBS2HIP_SYNC_UNFUSED")) return sfm_sync2(h, X_N1, nullptr, nullptr, DEL, FLG, TRI, Y_N2, F);
     int r = check_frames(h, F); if (r) return r;
     const size_t nb = sizeof(float) * 2 * (size_t)h->pl_frame * F;
     void *cs, *cp;

@@ -219,6 +219,8 @@ hipError_t awgn_launch(const float *x, float *y, const float *sigma, unsigned lo
 
 // ---------------------------------------------------------------- frame synchronizer (N4, k_sync.hip)
 hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s);
+hipError_t sync_corr_metric_launch(const float *x, const float *xh_in, float *xh_out, const float *sofh_in, float *sofh_out, float *cv, float *corr,
+                                   int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s);
 hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float *sofh_out, const float *cor_plsc, float *cv, float *corr,
                               int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s);
 hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp, float *FRQ, float *PHS, int n, int F, float alpha, hipStream_t s);

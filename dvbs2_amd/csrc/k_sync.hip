@@ -76,6 +76,91 @@ sync_corr_kernel(const float2 *__restrict__ x, const float2 *__restrict__ xh, fl
     for (int r = 0; r < SY_R; r++) if (i0 + r < n_total) { cor_plsc[i0 + r] = ap[r]; cor_sof[i0 + r] = as[r]; }
 }
 
+// ---- _synchronize (the one-task form, :46-128): the two correlations are not sockets there, so they never leave the chip.  Same
+// arithmetic as sync_corr_kernel + sync_m_kernel, output for output: a block forms cor_PLSC of its SY_T samples and cor_SOF of
+// those and of the 64 samples before them (the metric pairs cor_PLSC[g] with cor_SOF[g - 64], :236), keeps cor_SOF in LDS and
+// writes only the instantaneous metric m[g]: 8 B read + 4 B written per sample instead of 24 + 20.  The first block takes the
+// delayed cor_SOF from the handle's history (sofh), the last 64 cor_SOF values of the stream go to sofh_out.
+constexpr int SY_HX = 96;                     // samples of x before the block: 64 (SOF halo) + 24 (its taps) + 1 (differential), rounded up
+__global__ void __launch_bounds__(SY_THREADS)
+sync_corr_m_kernel(const float2 *__restrict__ x, const float2 *__restrict__ xh, const float2 *__restrict__ sofh, float2 *__restrict__ sofh_out,
+                   float *__restrict__ corr, long long n_total)
+{
+    __shared__ float2 xs[SY_T + SY_HX];                              // xs[k] = x[blk0 - 96 + k]
+    __shared__ float2 ds[SY_T + SY_HX + (SY_T + SY_HX) / 4 + 4];     // ds[pad(k)] = d[blk0 - 95 + k]
+    __shared__ float2 sof_s[SY_T + 64];                              // sof_s[k] = cor_SOF[blk0 - 64 + k]
+    const long long blk0 = (long long)blockIdx.x * SY_T;
+    for (int k = threadIdx.x; k < SY_T + SY_HX; k += SY_THREADS) {
+        const long long g = blk0 - SY_HX + k;
+        float2 v = make_float2(0.f, 0.f);
+        if (g < 0) { if (g >= -SY_H) v = xh[SY_H + g]; } else if (g < n_total) v = x[g];
+        xs[k] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < SY_T + SY_HX - 1; k += SY_THREADS) {
+        const float2 a = xs[k], b = xs[k + 1];
+        ds[sy_pad(k)] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    }
+    if (blk0 == 0 && threadIdx.x < 64) sof_s[threadIdx.x] = sofh[threadIdx.x];       // cor_SOF of the 64 samples before this call
+    __syncthreads();
+    const int l0 = threadIdx.x * SY_R;
+    const long long i0 = blk0 + l0;
+    // d[i - m] of output l (sample blk0 + l) sits at ds index l + 95 - m
+    float2 ap[SY_R], as[SY_R];
+#pragma unroll
+    for (int r = 0; r < SY_R; r++) { ap[r] = make_float2(0.f, 0.f); as[r] = make_float2(0.f, 0.f); }
+#pragma unroll
+    for (int jj = 0; jj < 64 + SY_R - 1; jj++) {                   // ds index l0 + 32 + jj, oldest first: exactly sync_corr_kernel's sums
+        const float2 v = ds[sy_pad(l0 + 32 + jj)];
+#pragma unroll
+        for (int r = 0; r < SY_R; r++) {
+            const int m = 63 + r - jj;
+            if (m >= 0 && m < 64 && K_CONJ_PLSC[m < 0 ? 0 : m > 63 ? 63 : m] != 0.f) {
+                const float b = K_CONJ_PLSC[m < 0 ? 0 : m > 63 ? 63 : m];
+                ap[r].x = fmaf(b, v.x, ap[r].x); ap[r].y = fmaf(b, v.y, ap[r].y);
+            }
+            if (m >= 0 && m < 25) {
+                const float b = K_CONJ_SOF[m < 0 ? 0 : m > 24 ? 24 : m];
+                as[r].x = fmaf(b, v.x, as[r].x); as[r].y = fmaf(b, v.y, as[r].y);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < SY_R; r++) sof_s[64 + l0 + r] = as[r];
+    if (blk0 > 0 && threadIdx.x < 64 / SY_R) {
+        // cor_SOF of the 64 samples before the block (outputs l = -64 + 4 tid + r): 25 taps, oldest first
+        const int h0 = threadIdx.x * SY_R;                          // sof_s index
+        float2 hs[SY_R];
+#pragma unroll
+        for (int r = 0; r < SY_R; r++) hs[r] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int jj = 0; jj < 25 + SY_R - 1; jj++) {                // ds index (h0 - 64) + 95 - 24 + jj = h0 + 7 + jj
+            const float2 v = ds[sy_pad(h0 + 7 + jj)];
+#pragma unroll
+            for (int r = 0; r < SY_R; r++) {
+                const int m = 24 + r - jj;
+                if (m >= 0 && m < 25) {
+                    const float b = K_CONJ_SOF[m < 0 ? 0 : m > 24 ? 24 : m];
+                    hs[r].x = fmaf(b, v.x, hs[r].x); hs[r].y = fmaf(b, v.y, hs[r].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < SY_R; r++) sof_s[h0 + r] = hs[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SY_R; r++) {
+        const long long g = i0 + r;
+        if (g >= n_total) break;
+        const float2 s = sof_s[l0 + r], p = ap[r];                   // cor_SOF[g - 64], cor_PLSC[g]
+        const float sr = p.x + s.x, si = p.y + s.y, dr = s.x - p.x, di = s.y - p.y;
+        const float a2s = fmaf(sr, sr, si * si), a2d = fmaf(dr, dr, di * di);
+        corr[g] = sqrtf(fmaxf(a2s, a2d));
+        if (g >= n_total - 64) sofh_out[g - (n_total - 64)] = as[r];
+    }
+}
+
 // new history = last H samples of (old history ++ x)
 __global__ void sync_hist_kernel(const float2 *x, const float2 *hist_in, float2 *hist_out, int H, long long n_total)
 {
@@ -110,7 +195,7 @@ __global__ void sync_metric_kernel(float *__restrict__ cv, float *__restrict__ c
     float c = cv[i];
     const float one_m = 1.0f - alpha;
     const bool avg = i < end_vec;                                      // the tail past the last full vector is not averaged (:284-285)
-    constexpr int UF = 8;
+    constexpr int UF = 32;          // a wave per 64 positions is all the parallelism there is (~2 waves per CU): keep 32 frames' loads in flight ahead of the chain
     int f = 0;
     for (; f + UF <= F; f += UF) {
         float m[UF];
@@ -171,31 +256,33 @@ sync_argmax_kernel(const float *__restrict__ corr, int32_t *__restrict__ delay, 
 // the walks below would otherwise pay two integer divisions per output sample
 __device__ __forceinline__ int vd_D(const int32_t *Dtab, int f, int) { return Dtab[f]; }
 
-__device__ __forceinline__ float vd_buff(const float *__restrict__ X, const float *__restrict__ buff0, const int32_t *__restrict__ delay_f,
-                                         int g, int k, int n)
+// (every D, head2, nbuff2 and frame size is an even number of floats, so a complex sample never straddles two of the copies: the
+// walks run once per complex sample and move 8 bytes)
+__device__ __forceinline__ float2 vd_buff(const float *__restrict__ X, const float *__restrict__ buff0, const int32_t *__restrict__ delay_f,
+                                          int g, int k, int n)
 {
     const int N = 2 * n;
     for (; g >= 0; g--) {
         const int Dg = vd_D(delay_f, g, n);
-        if (k < Dg) return X[(size_t)g * N + N - Dg + k];
+        if (k < Dg) return *reinterpret_cast<const float2 *>(&X[(size_t)g * N + N - Dg + k]);
     }
-    return buff0[k];
+    return *reinterpret_cast<const float2 *>(&buff0[k]);
 }
 
-__device__ __forceinline__ float vd_source(const float *__restrict__ X, const float *__restrict__ yprev0, const float *__restrict__ buff0,
+__device__ __forceinline__ float2 vd_source(const float *__restrict__ X, const float *__restrict__ yprev0, const float *__restrict__ buff0,
                                            const int *__restrict__ st0, const int32_t *__restrict__ delay_f, int f, int j, int n, int nbuff2)
 {
     const int N = 2 * n;
     for (;;) {
         const int D = vd_D(delay_f, f, n), head2 = f == 0 ? st0[0] : vd_D(delay_f, f - 1, n), first = f == 0 ? st0[1] : 0;
-        if (j >= D) return X[(size_t)f * N + j - D];
+        if (j >= D) return *reinterpret_cast<const float2 *>(&X[(size_t)f * N + j - D]);
         const int start_Y = D > head2 ? D - head2 : 0, start_buff = D < head2 ? head2 - D : 0;
         int end_buff = start_buff + D;
         end_buff = end_buff > nbuff2 ? nbuff2 : end_buff;
         end_buff = (end_buff - start_buff > N - start_Y) ? end_buff - ((end_buff - start_buff) - (N - start_Y)) : end_buff;
         if (j >= start_Y && j < start_Y + (end_buff - start_buff)) return vd_buff(X, buff0, delay_f, f - 1, start_buff + j - start_Y, n);
-        if (j < start_Y) { if (first) return 0.f; j = N - start_Y + j; }
-        if (--f < 0) return yprev0[j];                      // the output buffer as the previous call left it
+        if (j < start_Y) { if (first) return make_float2(0.f, 0.f); j = N - start_Y + j; }
+        if (--f < 0) return *reinterpret_cast<const float2 *>(&yprev0[j]);      // the output buffer as the previous call left it
     }
 }
 
@@ -216,12 +303,12 @@ __global__ void sync_vdelay_batch_kernel(const float *__restrict__ X, const floa
                                          int *__restrict__ st_new, const int32_t *__restrict__ delay_f, const int *__restrict__ dmax, int n, int nbuff2, int F)
 {
     const int N = 2 * n, f = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 2 * (blockIdx.x * blockDim.x + threadIdx.x);      // first float of this lane's complex sample
     if (f < F) {
-        if (j < N) Y[(size_t)f * N + j] = vd_source(X, yprev0, buff_old, st_old, delay_f, f, j, n, nbuff2);
+        if (j < N) *reinterpret_cast<float2 *>(&Y[(size_t)f * N + j]) = vd_source(X, yprev0, buff_old, st_old, delay_f, f, j, n, nbuff2);
         return;
     }
-    if (j < nbuff2) buff_new[j] = j < *dmax ? vd_buff(X, buff_old, delay_f, F - 1, j, n) : buff_old[j];
+    if (j < nbuff2) *reinterpret_cast<float2 *>(&buff_new[j]) = j < *dmax ? vd_buff(X, buff_old, delay_f, F - 1, j, n) : *reinterpret_cast<const float2 *>(&buff_old[j]);
     if (j == 0) { st_new[0] = vd_D(delay_f, F - 1, n); st_new[1] = 0; }
 }
 
@@ -389,6 +476,21 @@ hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, f
     return hipGetLastError();
 }
 
+// the one-task form: correlators + instantaneous metric fused (nothing but m leaves the chip), then the average / arg max as below
+hipError_t sync_corr_metric_launch(const float *x, const float *xh_in, float *xh_out, const float *sofh_in, float *sofh_out, float *cv, float *corr,
+                                   int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s)
+{
+    const long long tot = (long long)n * F;
+    const int end_vec = (n / vec_width) * vec_width;
+    hipLaunchKernelGGL(sync_corr_m_kernel, dim3((unsigned)((tot + SY_T - 1) / SY_T)), dim3(SY_THREADS), 0, s, reinterpret_cast<const float2 *>(x),
+                       reinterpret_cast<const float2 *>(xh_in), reinterpret_cast<const float2 *>(sofh_in), reinterpret_cast<float2 *>(sofh_out), corr, tot);
+    hipLaunchKernelGGL(sync_hist_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
+                       reinterpret_cast<float2 *>(xh_out), SY_H, tot);
+    hipLaunchKernelGGL(sync_metric_kernel, dim3((n + 63) / 64), dim3(64), 0, s, cv, corr, n, F, alpha, end_vec);
+    hipLaunchKernelGGL(sync_argmax_kernel, dim3(F), dim3(256), 0, s, corr, delay, metric, flag, trigger, n, 25, 64);
+    return hipGetLastError();
+}
+
 hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float *sofh_out, const float *cor_plsc, float *cv, float *corr,
                               int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s)
 {
@@ -407,7 +509,7 @@ hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float 
 hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
                               const int32_t *delay_f, int32_t *Dtab /* F ints of scratch */, int *dmax, int n, int nbuff2, int F, hipStream_t s)
 {
-    const int tot = nbuff2 > 2 * n ? nbuff2 : 2 * n;
+    const int tot = (nbuff2 > 2 * n ? nbuff2 : 2 * n) / 2;           // complex samples
     hipLaunchKernelGGL(vd_dmax_kernel, dim3(1), dim3(256), 0, s, delay_f, Dtab, dmax, n, F);
     hipLaunchKernelGGL(sync_vdelay_batch_kernel, dim3((tot + 255) / 256, F + 1), dim3(256), 0, s, X, Yprev, Y, buff_old, buff_new, st_old, st_new, Dtab,
                        dmax, n, nbuff2, F);

@@ -346,6 +346,7 @@ def fir2(taps, x, yh, n_frames=1, simd_width=8):
 
 def upfir(taps, osf, hist, x):
     taps, x = _f32(taps), _f32(x).ravel()
+    assert hist.dtype == np.float32 and hist.size == 2 * (taps.size - 1)      # orc_upfir filters the zero-stuffed stream: the history is in OUTPUT samples
     y = np.empty(x.size * osf, dtype=np.float32)
     lib().orc_upfir(_p(taps), taps.size, osf, _p(hist), _p(x), _p(y), x.size // 2)
     return y

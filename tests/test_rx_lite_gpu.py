@@ -31,7 +31,10 @@ def test_filtered_stream_with_unknown_frame_start_is_decoded(modcod, ebn0):
     # pilot-aided phase / residual-frequency correction works on PL-descrambled frames (Synchronizer_freq_phase_DVBS2_aib)
     desc = rx.pl_descramble(aligned)
     _, _, fixed = rx.sync_freq_phase_synchronize(desc)
-    out, c0, c1 = rx.rx_bb(aligned)                           # the chain takes the PL-scrambled frames
+    # the chain takes the PL-scrambled frames; 32APSK gets the true sigma like the reference's own APSK trace (refs/TX_RX_BB/16APSK_8_9.txt:
+    # --est-type PERFECT): the M2M4 estimator assumes a constant-modulus constellation
+    sig_sym = np.float32(P.esn0_to_sigma(P.ebn0_to_esn0(ebn0, mc.K_bch / mc.N_ldpc, mc.bps)))
+    out, c0, c1 = rx.rx_bb(aligned, sigma=sig_sym if mc.bps >= 5 else None)
     # every output frame from the lock on is one of the transmitted payloads, in order
     idx = []
     for f in range(3, F):

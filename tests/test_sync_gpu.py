@@ -38,6 +38,28 @@ def test_synchronize_matches_oracle_frame_by_frame(O, Rx, modcod, batch):
     rx.close()
 
 
+@pytest.mark.parametrize("modcod,F", [("QPSK-N_8/9", 5), ("32APSK-S_3/4", 37), ("QPSK-S_8/9", 1)])
+def test_fused_one_task_form_equals_the_two_task_path(O, Rx, monkeypatch, modcod, F):
+    """synchronize (one task) keeps the two correlations on chip (sync_corr_m_kernel: several blocks per frame, halo of cor_SOF
+    recomputed, first block from the handle's history); DVBS2HIP_SYNC_UNFUSED sends it through synchronize1 + synchronize2 over
+    device scratch.  Same delays, flags, metric BITS and aligned frames, across calls (the histories carry over)."""
+    rng = np.random.default_rng(12)
+    _, pl, _, _ = make_pl_frames(O, modcod, min(F, 6), 9.0, seed=7)
+    n = pl.shape[1] // 2
+    reps = -(-F // pl.shape[0])
+    base = np.concatenate([np.zeros(2 * 333, np.float32), np.tile(pl.reshape(-1), reps)])
+    a, b = Rx(modcod, max_frames=F), Rx(modcod, max_frames=F)
+    for call in range(3):
+        x = (base[call * 17 * 2: call * 17 * 2 + F * 2 * n] + 0.05 * rng.standard_normal(F * 2 * n).astype(np.float32)).reshape(F, 2 * n)
+        d1, f1, t1, Y1 = a.sync_frame_synchronize(x, with_flags=True)
+        monkeypatch.setenv("DVBS2HIP_SYNC_UNFUSED", "1")
+        d2, f2, t2, Y2 = b.sync_frame_synchronize(x, with_flags=True)
+        monkeypatch.delenv("DVBS2HIP_SYNC_UNFUSED")
+        assert np.array_equal(d1, d2) and np.array_equal(f1, f2) and np.array_equal(t1.view(np.uint32), t2.view(np.uint32)), call
+        assert np.array_equal(Y1, Y2), call
+    a.close(); b.close()
+
+
 def test_two_task_form_and_correlations(O, Rx):
     modcod = "8PSK-S_3/5"
     F = 5
