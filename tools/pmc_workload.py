@@ -24,14 +24,16 @@ def chain(modcod, F, n_ite, ebn0):
         rx.rx_bb_dev(pl.data_ptr(), sig.data_ptr() if mc.bps >= 4 else None, got.data_ptr(), None, None, F)
     rx.synchronize()
     # stand-alone BCH task on int32 sockets (Decoder_BCH_DVBS2::decode_hiho), the received word = a codeword with 3 bit errors per frame
-    cwb = torch.zeros((F, rx.K_ldpc), dtype=torch.int32, device=dev)
+    # (the three uses of bch_decode_kernel get grids of their own so that the summary can tell them apart: the fused chain above runs
+    # min(F, 2048) workgroups, the clean stand-alone task 1536, the one that has errors to correct 1024)
+    zero = torch.zeros((1536, rx.K_ldpc), dtype=torch.int32, device=dev)
+    out = torch.empty((1536, rx.K_bch), dtype=torch.int32, device=dev); cwd = torch.empty(1536, dtype=torch.int8, device=dev)
+    for _ in range(REPS):
+        rx.decode_hiho_dev(zero.data_ptr(), cwd.data_ptr(), out.data_ptr(), 1536)
+    cwb = torch.zeros((1024, rx.K_ldpc), dtype=torch.int32, device=dev)
     cwb[:, 5] = 1; cwb[:, 77] = 1; cwb[:, 1234] = 1
-    out = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev); cwd = torch.empty(F, dtype=torch.int8, device=dev)
     for _ in range(REPS):
-        rx.decode_hiho_dev(cwb.data_ptr(), cwd.data_ptr(), out.data_ptr(), F)
-    zero = torch.zeros_like(cwb)
-    for _ in range(REPS):
-        rx.decode_hiho_dev(zero.data_ptr(), cwd.data_ptr(), out.data_ptr(), F)
+        rx.decode_hiho_dev(cwb.data_ptr(), cwd.data_ptr(), out.data_ptr(), 1024)
     rx.synchronize(); rx.close()
 
 
