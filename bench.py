@@ -189,7 +189,9 @@ def main():
         bounded = {"resource": "L2 <-> Infinity Cache / HBM fabric: FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 --pmc, calibrated), Infinity-Cache hits included",
                    "achieved": fab, "peak": FABRIC_PEAK_GBPS, "unit": "GB/s", "frac": fab / FABRIC_PEAK_GBPS,
                    "peak_source": "MI355X_MICROARCH.md, Indexed rows: 38 MB table served by the Infinity Cache, 8.6 TB/s chip-wide",
-                   "bytes_per_frame": traffic / F, "measured": traffic_meta}
+                   "bytes_per_frame": traffic / F, "measured": traffic_meta,
+                   # the second resource the kernel runs close to: vector-ALU issue (same PMC passes; 4 cycles of a 16-lane SIMD per wave64 instruction)
+                   "valu": {"resource": "vector ALU issue slots: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x busy cycles)", "frac": traffic_meta.get("valu_occupancy")}}
     io_bytes = (4 * N + 4 * K) * F
 
     out = {
@@ -247,7 +249,7 @@ def _pmc_traffic(kernel_name, frames, n_ite):
         return None, None
     if d.get("kernel_sha") != kernel_sha() or d.get("frames") != frames or d.get("n_ite") != n_ite or d.get("kernel") not in (None, kernel_name):
         return None, {"stale": True, "file_kernel_sha": d.get("kernel_sha"), "running_kernel_sha": kernel_sha()}
-    return d.get("hbm_bytes_per_launch"), {k: d.get(k) for k in ("kernel_sha", "git_head", "source", "fetch_bytes_raw", "write_bytes_raw", "fetch_correction", "write_correction", "frames", "n_ite")}
+    return d.get("hbm_bytes_per_launch"), {k: d.get(k) for k in ("kernel_sha", "git_head", "source", "fetch_bytes_raw", "write_bytes_raw", "fetch_correction", "write_correction", "frames", "n_ite", "valu_occupancy", "l2_hit_rate")}
 
 
 def _copy_bandwidth(torch, dev):

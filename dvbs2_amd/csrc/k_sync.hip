@@ -81,6 +81,7 @@ sync_corr_kernel(const float2 *__restrict__ x, const float2 *__restrict__ xh, fl
 // those and of the 64 samples before them (the metric pairs cor_PLSC[g] with cor_SOF[g - 64], :236), keeps cor_SOF in LDS and
 // writes only the instantaneous metric m[g]: 8 B read + 4 B written per sample instead of 24 + 20.  The first block takes the
 // delayed cor_SOF from the handle's history (sofh), the last 64 cor_SOF values of the stream go to sofh_out.
+typedef float sy_f2 __attribute__((ext_vector_type(2)));
 constexpr int SY_HX = 96;                     // samples of x before the block: 64 (SOF halo) + 24 (its taps) + 1 (differential), rounded up
 __global__ void __launch_bounds__(SY_THREADS)
 sync_corr_m_kernel(const float2 *__restrict__ x, const float2 *__restrict__ xh, const float2 *__restrict__ sofh, float2 *__restrict__ sofh_out,
@@ -106,58 +107,57 @@ sync_corr_m_kernel(const float2 *__restrict__ x, const float2 *__restrict__ xh, 
     const int l0 = threadIdx.x * SY_R;
     const long long i0 = blk0 + l0;
     // d[i - m] of output l (sample blk0 + l) sits at ds index l + 95 - m
-    float2 ap[SY_R], as[SY_R];
+    // the taps are +-1 (or 0), and fma(+-1, v, acc) = acc +- v exactly: packed adds of (re, im) pairs (v_pk_add_f32), half the vector
+    // instructions of sync_corr_kernel's scalar fmas for the same bits
+    sy_f2 ap[SY_R], as[SY_R];
 #pragma unroll
-    for (int r = 0; r < SY_R; r++) { ap[r] = make_float2(0.f, 0.f); as[r] = make_float2(0.f, 0.f); }
+    for (int r = 0; r < SY_R; r++) { ap[r] = sy_f2{0.f, 0.f}; as[r] = sy_f2{0.f, 0.f}; }
 #pragma unroll
     for (int jj = 0; jj < 64 + SY_R - 1; jj++) {                   // ds index l0 + 32 + jj, oldest first: exactly sync_corr_kernel's sums
-        const float2 v = ds[sy_pad(l0 + 32 + jj)];
+        const float2 vv = ds[sy_pad(l0 + 32 + jj)];
+        const sy_f2 v = sy_f2{vv.x, vv.y};
 #pragma unroll
         for (int r = 0; r < SY_R; r++) {
             const int m = 63 + r - jj;
             if (m >= 0 && m < 64 && K_CONJ_PLSC[m < 0 ? 0 : m > 63 ? 63 : m] != 0.f) {
-                const float b = K_CONJ_PLSC[m < 0 ? 0 : m > 63 ? 63 : m];
-                ap[r].x = fmaf(b, v.x, ap[r].x); ap[r].y = fmaf(b, v.y, ap[r].y);
+                if (K_CONJ_PLSC[m < 0 ? 0 : m > 63 ? 63 : m] > 0.f) ap[r] = ap[r] + v; else ap[r] = ap[r] - v;
             }
             if (m >= 0 && m < 25) {
-                const float b = K_CONJ_SOF[m < 0 ? 0 : m > 24 ? 24 : m];
-                as[r].x = fmaf(b, v.x, as[r].x); as[r].y = fmaf(b, v.y, as[r].y);
+                if (K_CONJ_SOF[m < 0 ? 0 : m > 24 ? 24 : m] > 0.f) as[r] = as[r] + v; else as[r] = as[r] - v;
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < SY_R; r++) sof_s[64 + l0 + r] = as[r];
+    for (int r = 0; r < SY_R; r++) sof_s[64 + l0 + r] = make_float2(as[r].x, as[r].y);
     if (blk0 > 0 && threadIdx.x < 64 / SY_R) {
         // cor_SOF of the 64 samples before the block (outputs l = -64 + 4 tid + r): 25 taps, oldest first
         const int h0 = threadIdx.x * SY_R;                          // sof_s index
-        float2 hs[SY_R];
+        sy_f2 hs[SY_R];
 #pragma unroll
-        for (int r = 0; r < SY_R; r++) hs[r] = make_float2(0.f, 0.f);
+        for (int r = 0; r < SY_R; r++) hs[r] = sy_f2{0.f, 0.f};
 #pragma unroll
         for (int jj = 0; jj < 25 + SY_R - 1; jj++) {                // ds index (h0 - 64) + 95 - 24 + jj = h0 + 7 + jj
-            const float2 v = ds[sy_pad(h0 + 7 + jj)];
+            const float2 vv = ds[sy_pad(h0 + 7 + jj)];
+            const sy_f2 v = sy_f2{vv.x, vv.y};
 #pragma unroll
             for (int r = 0; r < SY_R; r++) {
                 const int m = 24 + r - jj;
-                if (m >= 0 && m < 25) {
-                    const float b = K_CONJ_SOF[m < 0 ? 0 : m > 24 ? 24 : m];
-                    hs[r].x = fmaf(b, v.x, hs[r].x); hs[r].y = fmaf(b, v.y, hs[r].y);
-                }
+                if (m >= 0 && m < 25) { if (K_CONJ_SOF[m < 0 ? 0 : m > 24 ? 24 : m] > 0.f) hs[r] = hs[r] + v; else hs[r] = hs[r] - v; }
             }
         }
 #pragma unroll
-        for (int r = 0; r < SY_R; r++) sof_s[h0 + r] = hs[r];
+        for (int r = 0; r < SY_R; r++) sof_s[h0 + r] = make_float2(hs[r].x, hs[r].y);
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SY_R; r++) {
         const long long g = i0 + r;
         if (g >= n_total) break;
-        const float2 s = sof_s[l0 + r], p = ap[r];                   // cor_SOF[g - 64], cor_PLSC[g]
+        const float2 s = sof_s[l0 + r], p = make_float2(ap[r].x, ap[r].y);      // cor_SOF[g - 64], cor_PLSC[g]
         const float sr = p.x + s.x, si = p.y + s.y, dr = s.x - p.x, di = s.y - p.y;
         const float a2s = fmaf(sr, sr, si * si), a2d = fmaf(dr, dr, di * di);
         corr[g] = sqrtf(fmaxf(a2s, a2d));
-        if (g >= n_total - 64) sofh_out[g - (n_total - 64)] = as[r];
+        if (g >= n_total - 64) sofh_out[g - (n_total - 64)] = make_float2(as[r].x, as[r].y);
     }
 }
 
@@ -257,32 +257,34 @@ sync_argmax_kernel(const float *__restrict__ corr, int32_t *__restrict__ delay, 
 __device__ __forceinline__ int vd_D(const int32_t *Dtab, int f, int) { return Dtab[f]; }
 
 // (every D, head2, nbuff2 and frame size is an even number of floats, so a complex sample never straddles two of the copies: the
-// walks run once per complex sample and move 8 bytes)
-__device__ __forceinline__ float2 vd_buff(const float *__restrict__ X, const float *__restrict__ buff0, const int32_t *__restrict__ delay_f,
-                                          int g, int k, int n)
+// walks run once per complex sample and move 8 bytes).  The walks only compute WHERE a sample comes from (they read nothing but the
+// small table of delays); the loads themselves are issued afterwards, several per lane at once -- one dependent load per lane was
+// latency-bound at 1.6 TB/s.  A null source stands for the zero of first_time.
+__device__ __forceinline__ const float *vd_buff(const float *__restrict__ X, const float *__restrict__ buff0, const int32_t *__restrict__ delay_f,
+                                                int g, int k, int n)
 {
     const int N = 2 * n;
     for (; g >= 0; g--) {
         const int Dg = vd_D(delay_f, g, n);
-        if (k < Dg) return *reinterpret_cast<const float2 *>(&X[(size_t)g * N + N - Dg + k]);
+        if (k < Dg) return &X[(size_t)g * N + N - Dg + k];
     }
-    return *reinterpret_cast<const float2 *>(&buff0[k]);
+    return &buff0[k];
 }
 
-__device__ __forceinline__ float2 vd_source(const float *__restrict__ X, const float *__restrict__ yprev0, const float *__restrict__ buff0,
+__device__ __forceinline__ const float *vd_source(const float *__restrict__ X, const float *__restrict__ yprev0, const float *__restrict__ buff0,
                                            const int *__restrict__ st0, const int32_t *__restrict__ delay_f, int f, int j, int n, int nbuff2)
 {
     const int N = 2 * n;
     for (;;) {
         const int D = vd_D(delay_f, f, n), head2 = f == 0 ? st0[0] : vd_D(delay_f, f - 1, n), first = f == 0 ? st0[1] : 0;
-        if (j >= D) return *reinterpret_cast<const float2 *>(&X[(size_t)f * N + j - D]);
+        if (j >= D) return &X[(size_t)f * N + j - D];
         const int start_Y = D > head2 ? D - head2 : 0, start_buff = D < head2 ? head2 - D : 0;
         int end_buff = start_buff + D;
         end_buff = end_buff > nbuff2 ? nbuff2 : end_buff;
         end_buff = (end_buff - start_buff > N - start_Y) ? end_buff - ((end_buff - start_buff) - (N - start_Y)) : end_buff;
         if (j >= start_Y && j < start_Y + (end_buff - start_buff)) return vd_buff(X, buff0, delay_f, f - 1, start_buff + j - start_Y, n);
-        if (j < start_Y) { if (first) return make_float2(0.f, 0.f); j = N - start_Y + j; }
-        if (--f < 0) return *reinterpret_cast<const float2 *>(&yprev0[j]);      // the output buffer as the previous call left it
+        if (j < start_Y) { if (first) return nullptr; j = N - start_Y + j; }
+        if (--f < 0) return &yprev0[j];                     // the output buffer as the previous call left it
     }
 }
 
@@ -297,19 +299,31 @@ __global__ void vd_dmax_kernel(const int32_t *__restrict__ delay_f, int32_t *__r
     if (threadIdx.x == 0) *dmax = red[0];
 }
 
+constexpr int VD_SPL = 4;        // complex samples per lane, their loads in flight together
 // blockIdx.y < F: output frame blockIdx.y; blockIdx.y == F: the delay line and {head2, first_time} after the last frame
 __global__ void sync_vdelay_batch_kernel(const float *__restrict__ X, const float *__restrict__ yprev0, float *__restrict__ Y,
                                          const float *__restrict__ buff_old, float *__restrict__ buff_new, const int *__restrict__ st_old,
                                          int *__restrict__ st_new, const int32_t *__restrict__ delay_f, const int *__restrict__ dmax, int n, int nbuff2, int F)
 {
     const int N = 2 * n, f = blockIdx.y;
-    const int j = 2 * (blockIdx.x * blockDim.x + threadIdx.x);      // first float of this lane's complex sample
-    if (f < F) {
-        if (j < N) *reinterpret_cast<float2 *>(&Y[(size_t)f * N + j]) = vd_source(X, yprev0, buff_old, st_old, delay_f, f, j, n, nbuff2);
-        return;
+    const float *src[VD_SPL];
+    int jj[VD_SPL];
+#pragma unroll
+    for (int i = 0; i < VD_SPL; i++) {
+        const int j = 2 * ((blockIdx.x * VD_SPL + i) * (int)blockDim.x + (int)threadIdx.x);      // first float of a complex sample
+        jj[i] = j; src[i] = nullptr;
+        if (f < F) { if (j < N) src[i] = vd_source(X, yprev0, buff_old, st_old, delay_f, f, j, n, nbuff2); }
+        else if (j < nbuff2) src[i] = j < *dmax ? vd_buff(X, buff_old, delay_f, F - 1, j, n) : &buff_old[j];
     }
-    if (j < nbuff2) *reinterpret_cast<float2 *>(&buff_new[j]) = j < *dmax ? vd_buff(X, buff_old, delay_f, F - 1, j, n) : *reinterpret_cast<const float2 *>(&buff_old[j]);
-    if (j == 0) { st_new[0] = vd_D(delay_f, F - 1, n); st_new[1] = 0; }
+    float2 v[VD_SPL];
+#pragma unroll
+    for (int i = 0; i < VD_SPL; i++) v[i] = src[i] ? *reinterpret_cast<const float2 *>(src[i]) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < VD_SPL; i++) {
+        if (f < F) { if (jj[i] < N) *reinterpret_cast<float2 *>(&Y[(size_t)f * N + jj[i]]) = v[i]; }
+        else if (jj[i] < nbuff2) *reinterpret_cast<float2 *>(&buff_new[jj[i]]) = v[i];
+    }
+    if (f == F && blockIdx.x == 0 && threadIdx.x == 0) { st_new[0] = vd_D(delay_f, F - 1, n); st_new[1] = 0; }
 }
 
 // ================================================================ fine frequency / phase synchronizers
@@ -511,7 +525,7 @@ hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Y, cons
 {
     const int tot = (nbuff2 > 2 * n ? nbuff2 : 2 * n) / 2;           // complex samples
     hipLaunchKernelGGL(vd_dmax_kernel, dim3(1), dim3(256), 0, s, delay_f, Dtab, dmax, n, F);
-    hipLaunchKernelGGL(sync_vdelay_batch_kernel, dim3((tot + 255) / 256, F + 1), dim3(256), 0, s, X, Yprev, Y, buff_old, buff_new, st_old, st_new, Dtab,
+    hipLaunchKernelGGL(sync_vdelay_batch_kernel, dim3((tot + 256 * VD_SPL - 1) / (256 * VD_SPL), F + 1), dim3(256), 0, s, X, Yprev, Y, buff_old, buff_new, st_old, st_new, Dtab,
                        dmax, n, nbuff2, F);
     return hipGetLastError();
 }
