@@ -40,7 +40,7 @@ def test_cfg_from_modcod_and_errors_without_gpu():
     cfg = B.Cfg()
     assert L.dvbs2hip_cfg_from_modcod(b"16APSK-S_8/9", ctypes.byref(cfg)) == 0
     assert (cfg.N_ldpc, cfg.K_ldpc, cfg.K_bch, cfg.bps, cfg.itl_cols, cfg.bch_m, cfg.bch_t) == (16200, 14400, 14232, 4, 4, 14, 12)
-    assert cfg.ldpc_n_ite == 50 and cfg.ldpc_alpha == 1.0 and cfg.fir_n_taps == 81       # reference defaults
+    assert cfg.ldpc_n_ite == 50 and cfg.ldpc_implem == 2 and cfg.ldpc_alpha == 1.0 and cfg.fir_n_taps == 81       # reference defaults: SPA (2), 50 ite (DVBS2.cpp:135-138)
     taps = np.ctypeslib.as_array(ctypes.cast(cfg.fir_taps, ctypes.POINTER(ctypes.c_float)), (81,))
     from dvbs2_amd import params as P
     assert np.array_equal(taps, P.rrc_taps(0.2, 2, 20))

@@ -118,6 +118,16 @@ def test_abi_error_behaviour(O, Rx):
     rx.close()
     with pytest.raises(Dvbs2HipError):
         Rx("QPSK-S_8/9", max_frames=0)
+    # a caller-supplied BCH field below GF(2^8) is refused (the syndrome kernel splits remainders into a low byte and m - 8 high bits)
+    import ctypes as C
+    from dvbs2_amd import lib_binding as B
+    L = B.load()
+    cfg = B.Cfg()
+    assert L.dvbs2hip_cfg_from_modcod(b"QPSK-S_8/9", C.byref(cfg)) == 0
+    assert cfg.ldpc_implem == 2 and cfg.ldpc_n_ite == 50            # the reference's defaults: SPA, 50 iterations (DVBS2.cpp:135-138)
+    cfg.bch_m = 7
+    h = C.c_void_p()
+    assert L.dvbs2hip_create(C.byref(cfg), C.byref(h)) == -1 and b"8 <= m" in L.dvbs2hip_last_error(None)
 
 
 def test_external_stream_reset_and_two_handles(O, Rx):
