@@ -269,3 +269,24 @@ def test_ldpc_headline_config_at_size_matches_oracle(O, Rx, n_ite, F, ebn0s):
             assert np.array_equal(V, V2) and np.array_equal(CWD, CWD2)
         rx.close()
     assert (CWD[0::2] if len(ebn0s) == 2 else CWD).mean() < 0.5      # 3.0 dB: most frames fail, which is the point
+
+
+@pytest.mark.parametrize("modcod,F", [("QPSK-N_8/9", 1100), ("QPSK-S_8/9", 2600)])
+def test_ldpc_spa_at_size_matches_oracle(O, Rx, modcod, F):
+    """The reference's default decoder (--dec-implem SPA) with more frames than the persistent grid holds: the per-edge message store
+    of a workgroup is reused frame after frame (its first-iteration reads are replaced by zeros, like the packed state of the NMS
+    kernel).  Two fixed iterations at 3.2 / 4.4 dB: posteriors of the last 6 frames and 6 random ones within the SPA bar of the oracle
+    (1e-4 max(1, |L|)); then the converging half with the early stop: hard decisions = the sent word."""
+    ch, sent, llr = _big_batch(O, modcod, F, (3.2, 4.4), seed=77, n_cw=4)
+    rng = np.random.default_rng(6)
+    pick = np.unique(np.concatenate([np.arange(F - 6, F), rng.choice(F - 6, 6, replace=False)]))
+    rx = Rx(modcod, max_frames=F, n_ite=2, early_stop=False, implem="SPA")
+    V, CWD, post, _ = rx.decode_siho(llr, with_post=True)
+    Vo, posto, cwdo, _ = ch.ldpc.decode(llr[pick], n_ite=2, implem=O.SPA, sched=O.QC, early_stop=False)
+    assert np.all(np.abs(post[pick] - posto) <= 1e-4 * np.maximum(1.0, np.abs(posto))), float(np.abs(post[pick] - posto).max())
+    assert (V[pick] != Vo).mean() < 1e-4
+    rx.close()
+    rx = Rx(modcod, max_frames=F, n_ite=30, early_stop=True, implem="SPA")
+    V, CWD = rx.decode_siho(llr)
+    assert CWD[1::2].mean() > 0.99 and np.array_equal(V[CWD == 1], sent[CWD == 1])
+    rx.close()

@@ -103,6 +103,28 @@ def test_inter_frame_simd_flavour_is_bit_identical(O):
     assert np.array_equal(b1, b2) and np.array_equal(b1, b3)
 
 
+def test_inter_frame_baseline_is_really_vector_code(O):
+    """The CPU baseline's inter-frame flavour counts on gcc vectorising its `omp simd` loops over the 16 frames of a block: check the
+    built library -- packed-single AVX instructions on ymm registers inside decode_inter_block (x86-64-v3 = AVX2: 2 x 8 frames per step)."""
+    import shutil
+    import subprocess
+    if not shutil.which("objdump"):
+        pytest.skip("no objdump in this image")
+    O.build()
+    dis = subprocess.run(["objdump", "-d", "--no-show-raw-insn", O._SO], capture_output=True, text=True).stdout
+    body, on = [], False
+    for line in dis.splitlines():
+        if line.endswith("<decode_inter_block>:"):
+            on = True
+        elif on and line.strip() == "":
+            break
+        elif on:
+            body.append(line)
+    assert body, "decode_inter_block not found (inlined?)"
+    ops = [l.split()[1] for l in body if "ymm" in l and len(l.split()) > 1]
+    assert any(o.startswith("vsubps") for o in ops) and any(o.startswith("vcmp") for o in ops) and any(o.startswith("vblendvps") for o in ops), sorted(set(ops))
+
+
 def test_two_schedules_agree_statistically(O):
     """Natural-order (AFF3CT) and QC-layer (GPU) schedules are different Gauss-Seidel orders of
     the same decoder: same fixed points, close iteration counts."""

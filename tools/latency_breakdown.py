@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dvbs2_amd.receiver import Dvbs2Hip
 from dvbs2_amd import lib_binding as B, params as P
 dev = torch.device("cuda", 0)
