@@ -86,20 +86,33 @@ def sync_case(modcod, F, reps=10):
     import ctypes
     rx = Dvbs2Hip(modcod, max_frames=F)
     n = rx.pl_frame
-    x = torch.randn((F, 2 * n), dtype=torch.float32, device=dev); y = torch.empty_like(x)
+    # a real PL stream that starts in the middle of a frame (TX mirror + AWGN at 10 dB), so that the synchronizer locks as it does in service;
+    # pure noise keeps the delay jumping from frame to frame and the delay line in its transitional branches
+    mc = P.get_modcod(modcod)
+    Ft = min(F, 512)
+    tx = Dvbs2Hip(modcod, max_frames=Ft)
+    sig = torch.full((Ft,), P.esn0_to_sigma(P.ebn0_to_esn0(10.0, mc.code_rate, mc.bps)), dtype=torch.float32, device=dev)
+    plt = torch.empty((Ft, 2 * n), dtype=torch.float32, device=dev); sent = torch.empty((Ft, tx.K_bch), dtype=torch.int32, device=dev)
+    tx.tx_bb_dev(None, 3, sig.data_ptr(), sent.data_ptr(), plt.data_ptr(), Ft); tx.synchronize(); tx.close()
+    reps_needed = -(-(F + 1) // Ft)
+    flat = plt.reshape(-1).repeat(reps_needed)
+    off = 2 * 1234
+    x = flat[off: off + F * 2 * n].reshape(F, 2 * n).contiguous(); y = torch.empty_like(x)
     DEL = torch.empty(F, dtype=torch.int32, device=dev); FLG = torch.empty_like(DEL); TRI = torch.empty(F, dtype=torch.float32, device=dev)
     FRQ = torch.empty(F, dtype=torch.float32, device=dev); PHS = torch.empty_like(FRQ)
     vp = ctypes.c_void_p
     calls = {"frame_sync(corr+metric+delay)": lambda: rx.sync_frame_synchronize_dev(vp(x.data_ptr()), vp(DEL.data_ptr()), vp(FLG.data_ptr()), vp(TRI.data_ptr()), vp(y.data_ptr()), F),
              "luise_reggiannini": lambda: rx._chk(rx.L.dvbs2hip_sync_lr_synchronize_dev(rx.h, vp(x.data_ptr()), vp(FRQ.data_ptr()), vp(PHS.data_ptr()), vp(y.data_ptr()), F)),
              "pilot_freq_phase": lambda: rx._chk(rx.L.dvbs2hip_sync_freq_phase_synchronize_dev(rx.h, vp(x.data_ptr()), vp(FRQ.data_ptr()), vp(PHS.data_ptr()), vp(y.data_ptr()), F))}
-    out = {"modcod": modcod, "frames": F, "samples": n * F}
+    out = {"modcod": modcod, "frames": F, "samples": n * F, "input": "PL frames of the TX mirror at Es/N0 10 dB, stream starting 1234 symbols into a frame (locks)"}
     for name, fn in calls.items():
         fn(); rx.synchronize(); t0 = time.perf_counter()
         for _ in range(reps): fn()
         rx.synchronize(); ms = (time.perf_counter() - t0) / reps * 1e3
         # 8 B in + 8 B out per sample (the frame synchronizer also writes and re-reads two fp32 correlations per sample)
         out[name] = {"call_ms": ms, "Msamples_per_s": n * F / ms / 1e3, "GBps_16B_per_sample": 16 * n * F / ms / 1e6}
+    calls["frame_sync(corr+metric+delay)"](); rx.synchronize()
+    out["delay_of_the_last_frame"] = int(DEL[-1].item()); out["locked"] = bool((DEL[F // 2:] == DEL[-1]).all().item())
     rx.close()
     return out
 

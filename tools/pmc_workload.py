@@ -40,7 +40,14 @@ def chain(modcod, F, n_ite, ebn0):
 def sync(modcod, F):
     rx = Dvbs2Hip(modcod, max_frames=F)
     n = rx.pl_frame
-    x = torch.randn((F, 2 * n), dtype=torch.float32, device=dev); y = torch.empty_like(x)
+    mc = P.get_modcod(modcod)
+    Ft = min(F, 512)                      # a real PL stream starting mid-frame: the synchronizer locks, as in service
+    tx = Dvbs2Hip(modcod, max_frames=Ft)
+    sig = torch.full((Ft,), P.esn0_to_sigma(P.ebn0_to_esn0(10.0, mc.code_rate, mc.bps)), dtype=torch.float32, device=dev)
+    plt = torch.empty((Ft, 2 * n), dtype=torch.float32, device=dev); sent = torch.empty((Ft, tx.K_bch), dtype=torch.int32, device=dev)
+    tx.tx_bb_dev(None, 3, sig.data_ptr(), sent.data_ptr(), plt.data_ptr(), Ft); tx.synchronize(); tx.close()
+    flat = plt.reshape(-1).repeat(-(-(F + 1) // Ft))
+    x = flat[2468: 2468 + F * 2 * n].reshape(F, 2 * n).contiguous(); y = torch.empty_like(x)
     DEL = torch.empty(F, dtype=torch.int32, device=dev); FLG = torch.empty_like(DEL); TRI = torch.empty(F, dtype=torch.float32, device=dev)
     FRQ = torch.empty(F, dtype=torch.float32, device=dev); PHS = torch.empty_like(FRQ)
     for _ in range(REPS):
