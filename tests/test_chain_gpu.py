@@ -15,7 +15,7 @@ def Rx():
 
 
 @pytest.mark.parametrize("modcod,ebn0", [("QPSK-S_8/9", 4.4), ("8PSK-S_3/5", 3.6), ("8PSK-S_8/9", 7.2),
-                                         ("16APSK-S_8/9", 8.2), ("QPSK-S_3/5", 2.2), ("QPSK-N_8/9", 4.3)])
+                                         ("16APSK-S_8/9", 8.2), ("QPSK-S_3/5", 2.2), ("QPSK-N_8/9", 4.3), ("8PSK-N_8/9", 7.4)])
 def test_rx_bb_perfect_sigma_matches_oracle(O, Rx, modcod, ebn0):
     ch = chain(O, modcod)
     F = 3

@@ -6,7 +6,7 @@ import pytest
 from helpers import chain
 
 pytestmark = pytest.mark.gpu
-ALL = ["QPSK-S_8/9", "QPSK-S_3/5", "8PSK-S_3/5", "8PSK-S_8/9", "16APSK-S_8/9", "32APSK-S_3/4", "QPSK-N_8/9", "16APSK-N_8/9"]
+ALL = ["QPSK-S_8/9", "QPSK-S_3/5", "8PSK-S_3/5", "8PSK-S_8/9", "16APSK-S_8/9", "32APSK-S_3/4", "QPSK-N_8/9", "8PSK-N_8/9", "16APSK-N_8/9"]
 
 
 @pytest.fixture(scope="module")
