@@ -13,5 +13,14 @@ int main(int argc, char **argv)
     const std::string e = ldpc_build_plan(pl, cfg.N_ldpc, cfg.K_ldpc, cfg.ldpc_n_rows, cfg.ldpc_row_ptr, cfg.ldpc_addr, -1, 160 * 1024, argc > 2);
     std::printf("plan: '%s' fast %d deg %d mode %d wg8 %d dups_in_lds %d | LDS rows %d (info %d) global rows %d (info %d) | lds bytes %d gwork words %d\n", e.c_str(), pl.fast,
                 pl.fast_deg, pl.fast_mode, pl.fast_wg8, pl.w8_dups_in_lds, pl.w8_nl, pl.w8_nl_info, pl.w8_ng, pl.w8_ng_info, pl.w8_lds_bytes, pl.w8_gwork_words);
+    if (pl.fast_wg8) {
+        for (int r = 0; r < pl.q; r++) {
+            const uint32_t *T = &pl.w8_tab[(size_t)r * LDPC_FAST_STRIDE];
+            const int ncf = (int)(T[28] & 0xFF);
+            std::printf("layer %2d: ncf %d :", r, ncf);
+            for (int i = 0; i < ncf; i++) std::printf(" (slot %u lvl %u shift %u)", T[48 + i] & 31u, T[48 + i] >> 8, (T[32 + i] & 0x7FFu) / 4);
+            std::printf("  prim %07x\n", T[27]);
+        }
+    }
     return 0;
 }
