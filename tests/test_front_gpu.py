@@ -8,7 +8,7 @@ from helpers import chain, make_pl_frames
 pytestmark = pytest.mark.gpu
 ALL = ["QPSK-S_8/9", "QPSK-S_3/5", "8PSK-S_3/5", "8PSK-S_8/9", "16APSK-S_8/9", "32APSK-S_3/4", "QPSK-N_8/9", "8PSK-N_8/9", "16APSK-N_8/9"]
 EBN0 = {"QPSK-S_8/9": 4.0, "8PSK-S_3/5": 3.2, "8PSK-S_8/9": 6.8, "16APSK-S_8/9": 7.6, "32APSK-S_3/4": 9.0,
-        "QPSK-N_8/9": 4.0, "16APSK-N_8/9": 7.6}
+        "QPSK-N_8/9": 4.0, "16APSK-N_8/9": 7.6, "QPSK-S_3/5": 1.6, "8PSK-N_8/9": 6.8}
 
 
 @pytest.fixture(scope="module")
