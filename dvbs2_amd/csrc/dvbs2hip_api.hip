@@ -346,7 +346,13 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         CREATE_FAIL(DVBS2HIP_EHIP, h->err);
     std::vector<uint32_t> prbs;
     bb_prbs(cfg->K_bch, prbs);
-    prbs.resize((size_t)cfg->K_ldpc / 32 + 4, 0u);       // zero words behind bit K_bch: the LDPC kernel's fused output reads 64-bit stretches up to K_ldpc
+    {
+        const int n_rows = cfg->K_ldpc / 360;
+        std::vector<uint32_t> rw((size_t)n_rows * 6 * 2, 0u);
+        for (int i = 0; i < cfg->K_bch; i++)
+            if ((prbs[i >> 5] >> (i & 31)) & 1u) { const int g = i / 360, e = i % 360, w = e >> 6, l = e & 63; rw[(size_t)(g * 6 + w) * 2 + (l >> 5)] |= 1u << (l & 31); }
+        if (upload(h, &h->bch.d_prbs_rw, rw.data(), rw.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+    }
     if (upload(h, &h->bch.d_prbs, prbs.data(), prbs.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
 
     // ---- TX mirror tables: encoder layer table, BCH generator, PLHEADER
@@ -507,7 +513,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
     if (h->s_out) (void)hipStreamDestroy(h->s_out);
     void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
-                        h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift, h->d_hist_zero, h->d_hist_junk, h->d_red};
+                        h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift, h->d_hist_zero, h->d_hist_junk, h->d_red, h->bch.d_prbs_rw};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
@@ -596,7 +602,7 @@ static int ldpc_dev(dvbs2hip_t *h, const float *Y, int8_t *CWD, int32_t *V, uint
     LdpcKParams p;
     memset(&p, 0, sizeof p);
     p.llr = Y; p.bits = V; p.packed = packed; p.cwd = CWD; p.post = post; p.ites = ites; p.gwork = h->d_gwork;
-    p.info_out = info_out; p.info_prbs = h->bch.d_prbs; p.K_info = h->K_bch;
+    p.info_out = info_out; p.info_prbs = h->bch.d_prbs_rw; p.K_info = h->K_bch;
     p.n_frames = F; p.n_ite = h->n_ite; p.early_stop = h->early_stop; p.alpha = h->alpha;
     if (h->ldpc_sched == DVBS2HIP_SCHED_NATURAL) {
         LdpcPlan &pl = h->ldpc;

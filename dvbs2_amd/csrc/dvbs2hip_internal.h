@@ -47,7 +47,7 @@ struct LdpcKParams {
     // fused chain (k_ldpc_wg8.hip): the first K_info hard decisions XOR the BB descrambling sequence, one int32 per bit, straight
     // into the chain's output socket -- what the BCH stage would write for a frame it does not have to correct
     int32_t *info_out;       // [F][K_info]       (may be null)
-    const uint32_t *info_prbs;  // packed PRBS, padded with 3 zero words behind bit K (read as wave-uniform scalars)
+    const uint32_t *info_prbs;  // PRBS by (row g, wave w): 64-bit word [g * 6 + w], bit l = PRBS bit 360 g + 64 w + l (zero from K_info on); wave-uniform scalars
     int32_t K_info;
     float *gwork;            // [grid][gwork_words] per-workgroup global workspace
     const LdpcEntry *entries;  // [q][deg_max_padded]
@@ -133,6 +133,7 @@ struct BchPlan {
     std::vector<uint16_t> exp_, log_;
     uint16_t *d_exp = nullptr, *d_log = nullptr;   // exp has 2n entries (no modulo on sums)
     uint32_t *d_prbs = nullptr;                    // BB scrambler sequence, packed, K bits
+    uint32_t *d_prbs_rw = nullptr;                 // the same by (bit-group row, wave) for the LDPC kernel's fused output (LdpcKParams::info_prbs)
     // syndrome tables, one set per odd j = 1, 3, .., 2t-1 (see k_bch.hip):
     //   [0 .. 256)            bit-reversed byte
     //   [256 + 768 k ..)      for the k-th odd j: 256 x (u(x) x^m mod m_j(x)) | 256 x eval(low byte) | 256 x eval(high byte)

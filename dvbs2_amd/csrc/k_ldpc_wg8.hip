@@ -482,11 +482,12 @@ ldpc_wg8_kernel(const LdpcKParams p)
         auto emit = [&](int g, float Lv) {
             if (p.info_out && role >= 0 && g < p.n_info) {
                 // fused chain: descrambled info bits as int32, the BCH stage's output for a frame it leaves alone.  The 64 PRBS bits
-                // of this wave's stretch of the row (bit 360 g + 64 role onwards) come in as three wave-uniform scalar words.
-                const uint32_t kb = (uint32_t)(g * LDPC_Z + role * 64), w0 = kb >> 5, sh = kb & 31u;
-                const unsigned long long lo = (unsigned long long)prbs_c[w0] | ((unsigned long long)prbs_c[w0 + 1] << 32);
-                const unsigned long long m64 = sh ? (lo >> sh) | ((unsigned long long)prbs_c[w0 + 2] << (64u - sh)) : lo;
-                const int k = (int)kb + lane;
+                // of this wave's stretch of the row (bit 360 g + 64 role onwards) come in as ONE wave-uniform 64-bit scalar word of a
+                // table laid out by (row, wave).
+                const int kb = g * LDPC_Z + role * 64;
+                const const_u32 pq = prbs_c + 2 * (g * 6 + role);
+                const unsigned long long m64 = (unsigned long long)pq[0] | ((unsigned long long)pq[1] << 32);
+                const int k = kb + lane;
                 if (act && k < p.K_info)
                     __builtin_nontemporal_store((int32_t)((Lv < 0.f ? 1u : 0u) ^ (uint32_t)((m64 >> lane) & 1ull)), &p.info_out[(size_t)f * p.K_info + k]);
             }
