@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <utility>
 
@@ -1323,8 +1324,10 @@ struct RcclApi {
     const char *(*GetErrorString)(int) = nullptr;
 };
 RcclApi g_rccl;
+std::mutex g_rccl_mutex;
 const char *rccl_load()
 {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);      // two handles of one process may initialise their reductions from different threads
     if (g_rccl.lib) return nullptr;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void *l = nullptr;
