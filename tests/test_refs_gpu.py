@@ -34,23 +34,28 @@ def test_gpu_spa50_fer_inside_reference_band(ref, ebn0):
     assert abs(r["esn0"] - row["esn0"]) < 0.0051
 
 
-def test_normal_frame_waterfall_sits_at_the_etsi_anchor():
-    """The N = 64800 code is an extension beyond the reference (its LDPC table is entered from ETSI EN 302 307 Annex B): the only
-    external number it can be held against is the standard's own performance table -- EN 302 307-1 Table 13, QPSK 8/9 normal
-    FECFRAME: Es/N0 = 6.20 dB for quasi-error-free operation (PER 1e-7, 50 iterations, ideal demodulation).  With SPA, 50 iterations,
-    the waterfall must sit right there: at the anchor frames essentially never fail (FER < 2e-3 over 40 960 frames; measured 2e-5),
-    0.3 dB below it most do (measured 0.95 at 5.89 dB).  A wrong address anywhere in the table moves the curve by far more."""
+@pytest.mark.parametrize("modcod,anchor_db", [("QPSK-N_8/9", 6.20), ("8PSK-N_8/9", 10.69), ("16APSK-N_8/9", 12.89)])
+def test_normal_frame_waterfall_sits_at_the_etsi_anchor(modcod, anchor_db):
+    """The N = 64800 codes are an extension beyond the reference (their LDPC table is entered from ETSI EN 302 307 Annex B): the only
+    external numbers they can be held against are the standard's own -- EN 302 307-1 Table 13, rate 8/9 normal FECFRAME, Es/N0 for
+    quasi-error-free operation (PER 1e-7, 50 iterations, ideal demodulation): QPSK 6.20 dB, 8PSK 10.69 dB, 16APSK 12.89 dB.  With SPA, 50
+    iterations, the waterfall must sit right there: at the anchor frames essentially never fail (FER < 2e-3 over 40 960 frames; measured
+    1e-5 .. 2e-5 for all three, results/r02/etsi_anchors.txt), 0.3 dB below it most do.  A wrong address in the table, a wrong bit order in a
+    constellation or a wrong interleaver moves the curve by far more."""
     from dvbs2_amd import sim
     from dvbs2_amd import params as P
-    mc = P.get_modcod("QPSK-N_8/9")
+    import math
+    mc = P.get_modcod(modcod)
     def run(esn0, max_frames):
-        ebn0 = esn0 - 10.0 * __import__("math").log10(mc.bps * mc.K_bch / mc.N_ldpc)
-        argv = ["--mod-cod", "QPSK-N_8/9", "-m", "%.3f" % ebn0, "-M", "%.3f" % (ebn0 + 0.001), "--dec-implem", "SPA", "--dec-ite", "50", "-F", "4096",
+        ebn0 = esn0 - 10.0 * math.log10(mc.bps * mc.K_bch / mc.N_ldpc)
+        argv = ["--mod-cod", modcod, "-m", "%.3f" % ebn0, "-M", "%.3f" % (ebn0 + 0.001), "--dec-implem", "SPA", "--dec-ite", "50", "-F", "4096",
                 "--max-frames", str(max_frames), "-e", "100"]
+        if mc.bps >= 4:
+            argv += ["--est-type", "PERFECT"]          # like the reference's own APSK trace: M2M4 assumes a constant modulus
         r = sim.run(sim.build_parser().parse_args(argv), out=io.StringIO())[0]
         assert abs(r["esn0"] - esn0) < 0.006
         return r
-    at = run(6.20, 40960)
+    at = run(anchor_db, 40960)
     assert at["fra"] >= 40960 and at["fer"] < 2e-3, at
-    below = run(5.90, 8192)
+    below = run(anchor_db - 0.30, 8192)
     assert below["fer"] > 0.5, below
