@@ -1346,6 +1346,28 @@ const char *rccl_load()
 std::string rccl_err(int e) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : ("rccl error " + std::to_string(e)); }
 }  // namespace
 
+// rank 0 publishes `bytes` bytes in the file `path` (written beside, then renamed: a reader never sees a partial file), every other rank polls
+// for it.  No GPU involved: this is the out-of-band step of the RCCL bootstrap, exported so that it can be exercised by two CPU processes.
+int dvbs2hip_rendezvous(int32_t rank, const char *path, void *blob, size_t bytes, int32_t timeout_ms)
+{
+    if (rank < 0 || !path || !*path || !blob || !bytes) return DVBS2HIP_EINVAL;
+    if (rank == 0) {
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(blob, bytes, 1, f) != 1) { if (f) fclose(f); return fail(nullptr, DVBS2HIP_EINVAL, "cannot write the rendezvous file " + tmp); }
+        fclose(f);
+        if (rename(tmp.c_str(), path)) return fail(nullptr, DVBS2HIP_EINVAL, std::string("cannot publish the rendezvous file ") + path);
+        return 0;
+    }
+    const int step_ms = 20;
+    for (int waited = 0;; waited += step_ms) {
+        FILE *f = fopen(path, "rb");
+        if (f) { const size_t n = fread(blob, 1, bytes, f); fclose(f); if (n == bytes) return 0; }
+        if (timeout_ms >= 0 && waited >= timeout_ms) return fail(nullptr, DVBS2HIP_EHIP, std::string("timed out waiting for the rendezvous file ") + path);
+        usleep(step_ms * 1000);
+    }
+}
+
 int dvbs2hip_monitor_reduce_init(dvbs2hip_t *h, int32_t rank, int32_t world, const char *rendezvous, int32_t timeout_ms)
 {
     int r0 = enter(h); if (r0) return r0;
@@ -1358,22 +1380,10 @@ int dvbs2hip_monitor_reduce_init(dvbs2hip_t *h, int32_t rank, int32_t world, con
     if (rank == 0) {
         int e = g_rccl.GetUniqueId(&id);
         if (e) return fail(h, DVBS2HIP_EHIP, "ncclGetUniqueId: " + rccl_err(e));
-        if (world > 1) {                                    // publish atomically: write beside, then rename
-            const std::string tmp = std::string(rendezvous) + ".tmp";
-            FILE *f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(&id, sizeof id, 1, f) != 1) { if (f) fclose(f); return fail(h, DVBS2HIP_EINVAL, "cannot write the rendezvous file " + tmp); }
-            fclose(f);
-            if (rename(tmp.c_str(), rendezvous)) return fail(h, DVBS2HIP_EINVAL, std::string("cannot publish the rendezvous file ") + rendezvous);
-        }
-    } else {
-        const int step_ms = 20;
-        int waited = 0;
-        for (;;) {
-            FILE *f = fopen(rendezvous, "rb");
-            if (f) { const size_t n = fread(&id, 1, sizeof id, f); fclose(f); if (n == sizeof id) break; }
-            if (timeout_ms >= 0 && waited >= timeout_ms) return fail(h, DVBS2HIP_EHIP, std::string("timed out waiting for the rendezvous file ") + rendezvous);
-            usleep(step_ms * 1000); waited += step_ms;
-        }
+    }
+    if (world > 1) {
+        const int rr = dvbs2hip_rendezvous(rank, rendezvous, &id, sizeof id, timeout_ms);
+        if (rr) return fail(h, rr, dvbs2hip_last_error(nullptr));
     }
     void *comm = nullptr;
     int e = g_rccl.CommInitRank(&comm, world, id, rank);

@@ -260,6 +260,9 @@ int dvbs2hip_monitor_check_errors2_dev(dvbs2hip_t *h, const int32_t *U, const in
  *   reduce  : the reduced counters; on a handle without _init it is dvbs2hip_monitor_get (a single process).
  *   finalize: destroys the communicator (also done by dvbs2hip_destroy).                                              */
 int dvbs2hip_monitor_reduce_init(dvbs2hip_t *h, int32_t rank, int32_t world_size, const char *rendezvous_path, int32_t timeout_ms);
+/* the out-of-band step of _reduce_init on its own (no GPU needed): rank 0 publishes `bytes` bytes of `blob` in the file, every other rank
+ * waits for the complete file and reads them into `blob`.  0, DVBS2HIP_EINVAL (cannot write) or DVBS2HIP_EHIP (timed out).              */
+int dvbs2hip_rendezvous(int32_t rank, const char *rendezvous_path, void *blob, size_t bytes, int32_t timeout_ms);
 int dvbs2hip_monitor_reduce(dvbs2hip_t *h, uint64_t fra_be_fe[3]);
 int dvbs2hip_monitor_reduce_finalize(dvbs2hip_t *h);
 
