@@ -73,6 +73,7 @@ struct dvbs2hip_handle {
         int *st[2] = {nullptr, nullptr};       // output_delay {head2, first_time}
         float *yprev = nullptr;                // the output frame of the previous call
         float *metric = nullptr;               // max_corr of the last frame
+        uint16_t *frag = nullptr;              // band fragments of the two correlators for the matrix cores (k_sync_mfma.hip)
         int xh_cur = 0, sofh_cur = 0, od_cur = 0;
     } sfm;
     // L&R fine frequency synchronizer (N4): damped autocorrelation R_l, alpha (factory default 0.999)
@@ -514,7 +515,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
     if (h->s_out) (void)hipStreamDestroy(h->s_out);
     void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
-                        h->sfm.yprev, h->sfm.metric, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift, h->d_hist_zero, h->d_hist_junk, h->d_red, h->bch.d_prbs_rw};
+                        h->sfm.yprev, h->sfm.metric, h->sfm.frag, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift, h->d_hist_zero, h->d_hist_junk, h->d_red, h->bch.d_prbs_rw};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
@@ -951,6 +952,13 @@ int dvbs2hip_extract_dev(dvbs2hip_t *h, const float *X, float *Y, int32_t n_cplx
 }
 
 // ------------------------------------------------------------------ N4: frame synchronizer (Synchronizer_frame_DVBS2_fast)
+// DVBS2HIP_SYNC=valu (read at every call): the correlators as fp32 vector sums in the reference's order instead of the matrix cores
+static const uint16_t *sfm_frag(dvbs2hip_t *h)
+{
+    const char *e = getenv("DVBS2HIP_SYNC");
+    return e && !strcmp(e, "valu") ? nullptr : h->sfm.frag;
+}
+
 static int sfm_state_reset(dvbs2hip_t *h, bool all)
 {
     const int n = h->pl_frame;
@@ -985,6 +993,9 @@ static int sfm_ready(dvbs2hip_t *h)
     HIPCHK(h, hipMalloc((void **)&S.cv, sizeof(float) * (size_t)n));
     HIPCHK(h, hipMalloc((void **)&S.yprev, sizeof(float) * 2 * (size_t)n));
     HIPCHK(h, hipMalloc((void **)&S.metric, sizeof(float)));
+    const std::vector<uint16_t> fr = sync_frag_default();
+    HIPCHK(h, hipMalloc((void **)&S.frag, fr.size() * sizeof(uint16_t)));
+    HIPCHK(h, hipMemcpy(S.frag, fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     int r = sfm_state_reset(h, true);
     if (r) return r;
     S.ready = true;
@@ -1014,7 +1025,7 @@ int dvbs2hip_sync_frame_synchronize1_dev(dvbs2hip_t *h, const float *X_N1, float
     if ((r = sfm_ready(h))) return r;
     auto &S = h->sfm;
     Timer tm(h, DVBS2HIP_K_MISC);
-    HIPCHK(h, sync_corr_launch(X_N1, S.xh[S.xh_cur], S.xh[S.xh_cur ^ 1], cor_SOF, cor_PLSC, (long long)h->pl_frame * F, h->stream));
+    HIPCHK(h, sync_corr_launch(X_N1, S.xh[S.xh_cur], S.xh[S.xh_cur ^ 1], sfm_frag(h), cor_SOF, cor_PLSC, (long long)h->pl_frame * F, h->stream));
     S.xh_cur ^= 1;
     return 0;
 }
@@ -1036,7 +1047,7 @@ static int sfm_sync2(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, con
     Timer tm(h, DVBS2HIP_K_MISC);
     if (TRI) met = TRI;
     if (fused) {
-        HIPCHK(h, sync_corr_metric_launch(X_N1, S.xh[S.xh_cur], S.xh[S.xh_cur ^ 1], S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], S.cv, (float *)corr, delay, (float *)met,
+        HIPCHK(h, sync_corr_metric_launch(X_N1, S.xh[S.xh_cur], S.xh[S.xh_cur ^ 1], sfm_frag(h), S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], S.cv, (float *)corr, delay, (float *)met,
                                           FLG, S.trigger, n, F, S.alpha, S.vec_width, h->stream));
         S.xh_cur ^= 1;
     } else

@@ -219,8 +219,14 @@ hipError_t decimate_launch(const float *x, float *y, long long n_out, int osf, l
 hipError_t awgn_launch(const float *x, float *y, const float *sigma, unsigned long long seed, long long n_pairs, int F, hipStream_t s);
 
 // ---------------------------------------------------------------- frame synchronizer (N4, k_sync.hip)
-hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s);
-hipError_t sync_corr_metric_launch(const float *x, const float *xh_in, float *xh_out, const float *sofh_in, float *sofh_out, float *cv, float *corr,
+hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s);
+std::vector<uint16_t> sync_mfma_frag(const float *sof25, const float *plsc64);       // k_sync_mfma.hip: band fragments of the two correlators
+bool sync_mfma_usable(const float *x, const void *frag);
+hipError_t sync_corr_mfma_launch(const float *x, const float *xh_in, const uint16_t *frag, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s);
+hipError_t sync_corr_m_mfma_launch(const float *x, const float *xh_in, const uint16_t *frag, const float *sofh_in, float *sofh_out, float *corr, long long n_total,
+                                   hipStream_t s);
+std::vector<uint16_t> sync_frag_default();                                            // k_sync.hip: the fragments of conj_SOF / conj_PLSC
+hipError_t sync_corr_metric_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, const float *sofh_in, float *sofh_out, float *cv, float *corr,
                                    int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s);
 hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float *sofh_out, const float *cor_plsc, float *cv, float *corr,
                               int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s);

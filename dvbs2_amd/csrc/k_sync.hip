@@ -480,10 +480,14 @@ hipError_t sff_fp_launch(const float *X, float *Y, float *tmp /* 2 F floats */, 
     return hipGetLastError();
 }
 
-hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s)
+std::vector<uint16_t> sync_frag_default() { return sync_mfma_frag(K_CONJ_SOF, K_CONJ_PLSC); }
+
+hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s)
 {
     const unsigned grid = (unsigned)((n_total + SY_T - 1) / SY_T);
-    hipLaunchKernelGGL(sync_corr_kernel, dim3(grid), dim3(SY_THREADS), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
+    // frag: the correlators on the matrix cores (k_sync_mfma.hip); null = the fp32 vector kernel
+    if (sync_mfma_usable(x, frag)) (void)sync_corr_mfma_launch(x, xh_in, frag, cor_sof, cor_plsc, n_total, s);
+    else hipLaunchKernelGGL(sync_corr_kernel, dim3(grid), dim3(SY_THREADS), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
                        reinterpret_cast<float2 *>(cor_sof), reinterpret_cast<float2 *>(cor_plsc), n_total);
     hipLaunchKernelGGL(sync_hist_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
                        reinterpret_cast<float2 *>(xh_out), SY_H, n_total);
@@ -491,12 +495,13 @@ hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, f
 }
 
 // the one-task form: correlators + instantaneous metric fused (nothing but m leaves the chip), then the average / arg max as below
-hipError_t sync_corr_metric_launch(const float *x, const float *xh_in, float *xh_out, const float *sofh_in, float *sofh_out, float *cv, float *corr,
+hipError_t sync_corr_metric_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, const float *sofh_in, float *sofh_out, float *cv, float *corr,
                                    int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s)
 {
     const long long tot = (long long)n * F;
     const int end_vec = (n / vec_width) * vec_width;
-    hipLaunchKernelGGL(sync_corr_m_kernel, dim3((unsigned)((tot + SY_T - 1) / SY_T)), dim3(SY_THREADS), 0, s, reinterpret_cast<const float2 *>(x),
+    if (sync_mfma_usable(x, frag)) (void)sync_corr_m_mfma_launch(x, xh_in, frag, sofh_in, sofh_out, corr, tot, s);
+    else hipLaunchKernelGGL(sync_corr_m_kernel, dim3((unsigned)((tot + SY_T - 1) / SY_T)), dim3(SY_THREADS), 0, s, reinterpret_cast<const float2 *>(x),
                        reinterpret_cast<const float2 *>(xh_in), reinterpret_cast<const float2 *>(sofh_in), reinterpret_cast<float2 *>(sofh_out), corr, tot);
     hipLaunchKernelGGL(sync_hist_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
                        reinterpret_cast<float2 *>(xh_out), SY_H, tot);

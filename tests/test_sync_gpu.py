@@ -38,11 +38,15 @@ def test_synchronize_matches_oracle_frame_by_frame(O, Rx, modcod, batch):
     rx.close()
 
 
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
 @pytest.mark.parametrize("modcod,F", [("QPSK-N_8/9", 5), ("32APSK-S_3/4", 37), ("QPSK-S_8/9", 1)])
-def test_fused_one_task_form_equals_the_two_task_path(O, Rx, monkeypatch, modcod, F):
+def test_fused_one_task_form_equals_the_two_task_path(O, Rx, monkeypatch, modcod, F, kernel):
     """synchronize (one task) keeps the two correlations on chip (sync_corr_m_kernel: several blocks per frame, halo of cor_SOF
     recomputed, first block from the handle's history); DVBS2HIP_SYNC_UNFUSED sends it through synchronize1 + synchronize2 over
-    device scratch.  Same delays, flags, metric BITS and aligned frames, across calls (the histories carry over)."""
+    device scratch.  Same delays, flags, metric BITS and aligned frames, across calls (the histories carry over) -- with the
+    correlators on the matrix cores (k_sync_mfma.hip, the default) and as fp32 vector sums (DVBS2HIP_SYNC=valu)."""
+    if kernel == "valu":
+        monkeypatch.setenv("DVBS2HIP_SYNC", "valu")
     rng = np.random.default_rng(12)
     _, pl, _, _ = make_pl_frames(O, modcod, min(F, 6), 9.0, seed=7)
     n = pl.shape[1] // 2
@@ -57,6 +61,39 @@ def test_fused_one_task_form_equals_the_two_task_path(O, Rx, monkeypatch, modcod
         monkeypatch.delenv("DVBS2HIP_SYNC_UNFUSED")
         assert np.array_equal(d1, d2) and np.array_equal(f1, f2) and np.array_equal(t1.view(np.uint32), t2.view(np.uint32)), call
         assert np.array_equal(Y1, Y2), call
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("modcod,F", [("QPSK-N_8/9", 3), ("32APSK-S_3/4", 5)])
+def test_matrix_core_correlators_against_the_vector_kernel_and_fp64(O, Rx, monkeypatch, modcod, F):
+    """The +-1 taps are exact in bf16 and the differential samples are split exactly into three bf16 terms, so the matrix-core sums
+    differ from the vector kernel's (the reference's order of fp32 additions) by rounding order only: both within 4e-6 of the fp64
+    correlation on unit-power input, the delays and the aligned frames identical, over two calls (the memories carry over)."""
+    rng = np.random.default_rng(5)
+    _, pl, _, _ = make_pl_frames(O, modcod, F, 5.0, seed=9)
+    n = pl.shape[1] // 2
+    stream = np.concatenate([0.7 * rng.standard_normal(2 * 4321).astype(np.float32), pl.reshape(-1), pl.reshape(-1)])[:2 * F * 2 * n]
+    a, b = Rx(modcod, max_frames=F), Rx(modcod, max_frames=F)
+    z = np.concatenate([np.zeros(63), [1.0], stream[0::2].astype(np.float64) + 1j * stream[1::2]])       # reg_channel = (1, 0), .cpp:19
+    dz = np.zeros(len(z), complex)
+    dz[1:] = z[:-1] * np.conj(z[1:])
+    sof = np.array([1, -1, -1, 1, -1, 1, 1, -1, 1, 1, -1, -1, 1, -1, -1, -1, 1, -1, -1, -1, -1, 1, 1, 1, 1], float)
+    ref_sof = np.convolve(dz, sof)[64:64 + 2 * F * n]
+    for call in range(2):
+        x = stream[call * F * 2 * n:(call + 1) * F * 2 * n].reshape(F, 2 * n)
+        cs1, cp1 = a.sync_frame_synchronize1(x)
+        d1, Y1 = a.sync_frame_synchronize2(x, cs1, cp1)
+        monkeypatch.setenv("DVBS2HIP_SYNC", "valu")
+        cs2, cp2 = b.sync_frame_synchronize1(x)
+        d2, Y2 = b.sync_frame_synchronize2(x, cs2, cp2)
+        monkeypatch.delenv("DVBS2HIP_SYNC")
+        r = ref_sof[call * F * n:(call + 1) * F * n]
+        for cs in (cs1, cs2):
+            got = cs.reshape(-1)[0::2].astype(np.float64) + 1j * cs.reshape(-1)[1::2]
+            assert np.max(np.abs(got - r)) <= 4e-6 * 25, call
+        assert np.max(np.abs(cs1 - cs2)) <= 4e-6 * 25 and np.max(np.abs(cp1 - cp2)) <= 4e-6 * 32, call
+        assert not np.array_equal(cp1, cp2)                                    # two different kernels did run
+        assert np.array_equal(d1, d2) and np.array_equal(Y1, Y2), call
     a.close(); b.close()
 
 
