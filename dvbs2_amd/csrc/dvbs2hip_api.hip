@@ -71,10 +71,11 @@ struct dvbs2hip_handle {
         float *cv = nullptr;                   // corr_vec
         float *buff2[2] = {nullptr, nullptr};  // output_delay.buff2
         int *st[2] = {nullptr, nullptr};       // output_delay {head2, first_time}
-        float *yprev = nullptr;                // the output frame of the previous call
+        float *yprev[2] = {nullptr, nullptr};  // the last output frame of the previous call
+        unsigned long long *keys = nullptr;    // arg max keys, max_frames x ceil(pl_frame / 64)
         float *metric = nullptr;               // max_corr of the last frame
         uint16_t *frag = nullptr;              // band fragments of the two correlators for the matrix cores (k_sync_mfma.hip)
-        int xh_cur = 0, sofh_cur = 0, od_cur = 0;
+        int xh_cur = 0, sofh_cur = 0, od_cur = 0, yp_cur = 0;
     } sfm;
     // L&R fine frequency synchronizer (N4): damped autocorrelation R_l, alpha (factory default 0.999)
     // host sockets the integrator has pinned (dvbs2hip_host_register): base address -> bytes; copy streams + events of
@@ -515,7 +516,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
     if (h->s_out) (void)hipStreamDestroy(h->s_out);
     void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
-                        h->sfm.yprev, h->sfm.metric, h->sfm.frag, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift, h->d_hist_zero, h->d_hist_junk, h->d_red, h->bch.d_prbs_rw};
+                        h->sfm.yprev[0], h->sfm.yprev[1], h->sfm.keys, h->sfm.metric, h->sfm.frag, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift, h->d_hist_zero, h->d_hist_junk, h->d_red, h->bch.d_prbs_rw};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
@@ -973,7 +974,7 @@ static int sfm_state_reset(dvbs2hip_t *h, bool all)
     }
     HIPCHK(h, hipMemcpyAsync(S.xh[S.xh_cur] + 2 * 63, one, sizeof one, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(S.cv, 0, sizeof(float) * (size_t)n, h->stream));
-    if (all) { HIPCHK(h, hipMemsetAsync(S.yprev, 0, sizeof(float) * 2 * (size_t)n, h->stream)); HIPCHK(h, hipMemsetAsync(S.metric, 0, sizeof(float), h->stream)); }
+    if (all) { HIPCHK(h, hipMemsetAsync(S.yprev[S.yp_cur], 0, sizeof(float) * 2 * (size_t)n, h->stream)); HIPCHK(h, hipMemsetAsync(S.metric, 0, sizeof(float), h->stream)); }
     HIPCHK(h, hipStreamSynchronize(h->stream));                                    // `one` / `st` live on this stack
     return 0;
 }
@@ -991,7 +992,8 @@ static int sfm_ready(dvbs2hip_t *h)
         HIPCHK(h, hipMalloc((void **)&S.st[i], sizeof(int) * 4));
     }
     HIPCHK(h, hipMalloc((void **)&S.cv, sizeof(float) * (size_t)n));
-    HIPCHK(h, hipMalloc((void **)&S.yprev, sizeof(float) * 2 * (size_t)n));
+    for (int i = 0; i < 2; i++) HIPCHK(h, hipMalloc((void **)&S.yprev[i], sizeof(float) * 2 * (size_t)n));
+    HIPCHK(h, hipMalloc((void **)&S.keys, sizeof(unsigned long long) * (size_t)h->max_frames * (size_t)((n + 63) / 64)));
     HIPCHK(h, hipMalloc((void **)&S.metric, sizeof(float)));
     const std::vector<uint16_t> fr = sync_frag_default();
     HIPCHK(h, hipMalloc((void **)&S.frag, fr.size() * sizeof(uint16_t)));
@@ -1046,20 +1048,19 @@ static int sfm_sync2(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, con
         (r = ensure(h, B_SFM_DTAB, sizeof(int32_t) * (size_t)F, &dtab))) return r;
     Timer tm(h, DVBS2HIP_K_MISC);
     if (TRI) met = TRI;
+    const SyncTail tail{S.keys, delay, (float *)met, FLG, S.trigger, (int32_t *)dtab, S.metric};
     if (fused) {
-        HIPCHK(h, sync_corr_metric_launch(X_N1, S.xh[S.xh_cur], S.xh[S.xh_cur ^ 1], sfm_frag(h), S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], S.cv, (float *)corr, delay, (float *)met,
-                                          FLG, S.trigger, n, F, S.alpha, S.vec_width, h->stream));
+        HIPCHK(h, sync_corr_metric_launch(X_N1, S.xh[S.xh_cur], S.xh[S.xh_cur ^ 1], sfm_frag(h), S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], S.cv, (float *)corr, tail,
+                                          n, F, S.alpha, S.vec_width, h->stream));
         S.xh_cur ^= 1;
     } else
-        HIPCHK(h, sync_metric_launch(cor_SOF, S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], cor_PLSC, S.cv, (float *)corr, delay, (float *)met, FLG, S.trigger,
-                                     n, F, S.alpha, S.vec_width, h->stream));
+        HIPCHK(h, sync_metric_launch(cor_SOF, S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], cor_PLSC, S.cv, (float *)corr, tail, n, F, S.alpha, S.vec_width, h->stream));
     S.sofh_cur ^= 1;
     // the delay line is a recurrence from frame to frame made of copies only: resolved per output sample, one launch (k_sync.hip)
-    HIPCHK(h, sync_vdelay_launch(X_N1, S.yprev, Y_N2, S.buff2[S.od_cur], S.buff2[S.od_cur ^ 1], S.st[S.od_cur], S.st[S.od_cur ^ 1], delay,
-                                 (int32_t *)dtab, S.st[S.od_cur ^ 1] + 2, n, S.nbuff2, F, h->stream));
+    HIPCHK(h, sync_vdelay_launch(X_N1, S.yprev[S.yp_cur], S.yprev[S.yp_cur ^ 1], Y_N2, S.buff2[S.od_cur], S.buff2[S.od_cur ^ 1], S.st[S.od_cur], S.st[S.od_cur ^ 1],
+                                 (const int32_t *)dtab, n, S.nbuff2, F, h->stream));
     S.od_cur ^= 1;
-    HIPCHK(h, hipMemcpyAsync(S.yprev, Y_N2 + (size_t)2 * n * (F - 1), sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(S.metric, (float *)met + (F - 1), sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    S.yp_cur ^= 1;
     return 0;
 }
 

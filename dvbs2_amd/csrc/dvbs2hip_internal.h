@@ -219,20 +219,26 @@ hipError_t decimate_launch(const float *x, float *y, long long n_out, int osf, l
 hipError_t awgn_launch(const float *x, float *y, const float *sigma, unsigned long long seed, long long n_pairs, int F, hipStream_t s);
 
 // ---------------------------------------------------------------- frame synchronizer (N4, k_sync.hip)
+// per-frame results of the frame synchronizer's arg max (sync_finalize_kernel): the sockets, the delay line's table, the handle's state
+struct SyncTail {
+    unsigned long long *keys;        // F x ceil(n / 64) words of device scratch
+    int32_t *delay; float *metric; int32_t *flag; float trigger;
+    int32_t *Dtab; float *last_metric;
+};
 hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s);
 std::vector<uint16_t> sync_mfma_frag(const float *sof25, const float *plsc64);       // k_sync_mfma.hip: band fragments of the two correlators
 bool sync_mfma_usable(const float *x, const void *frag);
-hipError_t sync_corr_mfma_launch(const float *x, const float *xh_in, const uint16_t *frag, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s);
-hipError_t sync_corr_m_mfma_launch(const float *x, const float *xh_in, const uint16_t *frag, const float *sofh_in, float *sofh_out, float *corr, long long n_total,
-                                   hipStream_t s);
+hipError_t sync_corr_mfma_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s);
+hipError_t sync_corr_m_mfma_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, const float *sofh_in, float *sofh_out, float *corr,
+                                   long long n_total, hipStream_t s);
 std::vector<uint16_t> sync_frag_default();                                            // k_sync.hip: the fragments of conj_SOF / conj_PLSC
 hipError_t sync_corr_metric_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, const float *sofh_in, float *sofh_out, float *cv, float *corr,
-                                   int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s);
+                                   const SyncTail &t, int n, int F, float alpha, int vec_width, hipStream_t s);
 hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float *sofh_out, const float *cor_plsc, float *cv, float *corr,
-                              int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s);
+                              const SyncTail &t, int n, int F, float alpha, int vec_width, hipStream_t s);
 hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp, float *FRQ, float *PHS, int n, int F, float alpha, hipStream_t s);
 hipError_t sff_fp_launch(const float *X, float *Y, float *tmp, float *FRQ, float *PHS, int n, int F, hipStream_t s);
-hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
-                              const int32_t *delay_f, int32_t *Dtab, int *dmax, int n, int nbuff2, int F, hipStream_t s);
+hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Yprev_new, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
+                              const int32_t *Dtab, int n, int nbuff2, int F, hipStream_t s);
 
 }  // namespace dvbs2

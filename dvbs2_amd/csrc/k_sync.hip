@@ -10,6 +10,7 @@
 // (the average per position, the arg max per frame, the delay line), which run frame after frame on
 // device-resident state: no host round trip between the stages.
 #include "dvbs2hip_internal.h"
+#include <type_traits>
 
 namespace dvbs2 {
 
@@ -173,9 +174,7 @@ __global__ void sync_hist_kernel(const float2 *x, const float2 *hist_in, float2 
 // ---- _synchronize2, first half (:236-267, :278-285).  The instantaneous metric m[f][i] = max(|plsc + sof|, |sof - plsc|) of
 // every sample is independent work (sync_m_kernel, one lane per sample of the batch); the average over frames
 // corr_vec[i] = alpha corr_vec[i] + (1 - alpha) m[f][i] is a recurrence across frames and parallel across positions only
-// (sync_metric_kernel, one lane per position, frames in turn, the loads of 8 frames in flight ahead of the dependent
-// multiply-adds; same operations in the same order as the reference).
-// corr[f][i] = the averaged correlation the arg max of frame f sees; cv = corr_vec (carried between calls).
+// (sync_metric_argmax_kernel below); cv = corr_vec (carried between calls).
 __global__ void sync_m_kernel(const float2 *__restrict__ cor_sof, const float2 *__restrict__ sofh, const float2 *__restrict__ cor_plsc,
                               float *__restrict__ corr, long long n_total)
 {
@@ -188,57 +187,134 @@ __global__ void sync_m_kernel(const float2 *__restrict__ cor_sof, const float2 *
     corr[g] = sqrtf(fmaxf(a2s, a2d));
 }
 
-__global__ void sync_metric_kernel(float *__restrict__ cv, float *__restrict__ corr, int n, int F, float alpha, int end_vec)
+// four wave-wide maxima side by side (the row_shr / row_bcast ladder of gfx9, the four registers interleaved so that no step waits for the
+// data-parallel-primitive hazard of the one before): lane 63 of each register ends up with the wave's maximum
+__device__ __forceinline__ void sy_wave_umax4(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float c = cv[i];
-    const float one_m = 1.0f - alpha;
-    const bool avg = i < end_vec;                                      // the tail past the last full vector is not averaged (:284-285)
-    constexpr int UF = 32;          // a wave per 64 positions is all the parallelism there is (~2 waves per CU): keep 32 frames' loads in flight ahead of the chain
-    int f = 0;
-    for (; f + UF <= F; f += UF) {
-        float m[UF];
-#pragma unroll
-        for (int k = 0; k < UF; k++) m[k] = corr[(long long)(f + k) * n + i];
-#pragma unroll
-        for (int k = 0; k < UF; k++) { c = avg ? alpha * c + one_m * m[k] : m[k]; corr[(long long)(f + k) * n + i] = c; }
-    }
-    for (; f < F; f++) { const float m = corr[(long long)f * n + i]; c = avg ? alpha * c + one_m * m : m; corr[(long long)f * n + i] = c; }
-    cv[i] = c;
+#define SY_DPP4(ctl) "v_max_u32_dpp %0, %0, %0 " ctl "\n\tv_max_u32_dpp %1, %1, %1 " ctl "\n\tv_max_u32_dpp %2, %2, %2 " ctl "\n\tv_max_u32_dpp %3, %3, %3 " ctl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 SY_DPP4("row_shr:1 row_mask:0xf bank_mask:0xf") SY_DPP4("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 SY_DPP4("row_shr:4 row_mask:0xf bank_mask:0xf") SY_DPP4("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 SY_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf") SY_DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef SY_DPP4
 }
 
-// ---- arg max of one frame (:269-276): the FIRST index of the largest value above 0; delay (:296)
+
+// ---- the average over frames and the arg max of every frame (:269-285).
+// One workgroup per 64 positions, four waves on the CU's four SIMDs.  The time of this stage is (frames) x (instructions a wave issues per frame):
+// a position's chain runs over all F frames of the call and there are only n / 64 waves' worth of positions, so the chain is kept as short as
+// it can be and the arg max work is taken off it.  Wave 0 runs the recurrence (the loads of a chunk of 24 frames in flight while the previous
+// chunk goes through the dependent multiply-adds; same operations in the same order as the reference) and leaves the averaged values of a
+// chunk in LDS; waves 1-3 take the wave-wide maxima of eight frames each (DPP ladder, four registers interleaved) while wave 0 is already on
+// the next chunk -- one LDS-only barrier per chunk, two chunk buffers.  The averaged metric never goes to memory (it has no other reader).
+// A frame's result is the 64-bit key (value bits << 32) | ~index, whose maximum over the workgroups is the largest value and, among equal
+// values, the smallest index (= the reference's first maximum, :269-276; the metric is >= 0, so its bit pattern orders like the value).
+// Every workgroup leaves its key of every frame in keys[frame][workgroup] (plain stores: agent-scope atomics on one word per frame from 521
+// workgroups were what this kernel waited for); sync_finalize_kernel takes their maximum.  A frame without a value above 0 gets key 0.
+constexpr int SYM_UF = 24;
+__device__ __forceinline__ void sy_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ void __launch_bounds__(256)
-sync_argmax_kernel(const float *__restrict__ corr, int32_t *__restrict__ delay, float *__restrict__ metric, int32_t *__restrict__ flag, float trigger,
-                   int n, int n_sof, int n_plsc)
+sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr, unsigned long long *__restrict__ keys, int n, int F, float alpha, int end_vec)
 {
-    __shared__ float sv[256];
-    __shared__ int si[256];
-    const float *c = corr + (long long)blockIdx.x * n;
-    float bv = 0.f;
-    int bi = 0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float v = c[i];
-        if (v > bv) { bv = v; bi = i; }          // ascending i per lane: keeps the first of equal values
-    }
-    sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            const float ov = sv[threadIdx.x + s];
-            const int oi = si[threadIdx.x + s];
-            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+    __shared__ uint32_t ring[2][SYM_UF][64];
+    // which of the four waves runs the chain rotates with the workgroup, so that the chain waves of the two or three workgroups a CU holds do
+    // not sit on one SIMD (waves go to the SIMDs in order; workgroup b + 256 lands on the CU of workgroup b)
+    const int lane = threadIdx.x & 63, chain = ((blockIdx.x >> 3) + (blockIdx.x >> 8)) & 3, wv = ((threadIdx.x >> 6) - chain) & 3;
+    const int i = blockIdx.x * 64 + lane;
+    const bool act = i < n;
+    const int il = act ? i : n - 1;
+    const int nq = (F + SYM_UF - 1) / SYM_UF;
+    if (wv == 0) {
+        float c = act ? cv[il] : 0.f;
+        // positions past the last full vector are not averaged (:284-285): 0 c + 1 m = m exactly
+        // (lanes past the last position carry 0)
+        const float al = il < end_vec ? alpha : 0.f, om = !act ? 0.f : il < end_vec ? 1.0f - alpha : 1.f;
+        float ma[SYM_UF], mb[SYM_UF];
+        const char *pl = reinterpret_cast<const char *>(corr);        // wave-uniform pointer of the next frame to load, the lane's offset in 32 bits
+        const unsigned ob = 4u * (unsigned)il;
+        const size_t stride = sizeof(float) * (size_t)n;
+        // The loads of the steady state are unconditional (a chunk that does not exist re-reads chunk 0), so that the loads of a chunk leave as
+        // one batch and the wait before a chunk's arithmetic leaves the next chunk's loads in flight
+        auto load = [&](float (&m)[SYM_UF], bool there) {
+            const char *p = there ? pl : reinterpret_cast<const char *>(corr);
+#pragma unroll
+            for (int k = 0; k < SYM_UF; k++) { m[k] = *reinterpret_cast<const float *>(p + ob); p += stride; }
+            if (there) pl = p;
+        };
+        auto run = [&](const float (&m)[SYM_UF], int q) {
+#pragma unroll
+            for (int k = 0; k < SYM_UF; k++) { c = al * c + om * m[k]; ring[q & 1][k][lane] = __float_as_uint(c); }
+            sy_lds_barrier();
+        };
+        const int nfull = F / SYM_UF, rem = F - nfull * SYM_UF;
+        if (nfull > 0) load(ma, true);
+        int q = 0;
+        for (; q + 2 <= nfull; q += 2) {
+            load(mb, true);                                            // chunk q + 1
+            run(ma, q);
+            load(ma, q + 2 < nfull);                                   // chunk q + 2 if it is a whole one
+            run(mb, q + 1);
         }
-        __syncthreads();
+        if (q < nfull) run(ma, q++);                                   // an odd number of whole chunks: the last one is in ma
+        if (rem > 0) {                                                 // the frames of a partial last chunk, one at a time
+            for (int k = 0; k < rem; k++) {
+                const float m = __builtin_nontemporal_load(reinterpret_cast<const float *>(pl + ob));
+                pl += stride;
+                c = al * c + om * m;
+                ring[q & 1][k][lane] = __float_as_uint(c);
+            }
+            sy_lds_barrier();
+        }
+        if (act) cv[i] = c;
+    } else {
+        for (int q = 0; q < nq; q++) {
+            sy_lds_barrier();                                          // chunk q is in ring[q & 1]
+            const int cnt = F - q * SYM_UF < SYM_UF ? F - q * SYM_UF : SYM_UF;
+            uint32_t b[8], w[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { b[j] = ring[q & 1][3 * j + wv - 1][lane]; w[j] = b[j]; }      // (slots past cnt hold older frames: not used below)
+            sy_wave_umax4(w[0], w[1], w[2], w[3]);
+            sy_wave_umax4(w[4], w[5], w[6], w[7]);
+            int hi = 0, lo = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t wk = (uint32_t)__builtin_amdgcn_readlane((int)w[j], 63);
+                const unsigned long long eq = __ballot(b[j] == wk);
+                const uint32_t idx = (uint32_t)(blockIdx.x * 64 + __ffsll((long long)eq) - 1);
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"(wk), "n"(j));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"(0xffffffffu - idx), "n"(j));
+            }
+            const int k = 3 * lane + wv - 1;                           // lane j < 8 holds the key of frame slot 3 j + wv - 1
+            if (lane < 8 && k < cnt) keys[(size_t)(q * SYM_UF + k) * gridDim.x + blockIdx.x] = hi != 0 ? ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo : 0ull;
+        }
     }
-    if (threadIdx.x == 0) {
-        // a lane that never saw a value above 0 reports index 0, as the reference's initial max_idx
-        const int idx = sv[0] > 0.f ? si[0] : 0;
-        delay[blockIdx.x] = (n + idx - n_sof - n_plsc) % n;
-        metric[blockIdx.x] = sv[0];                                  // TRI = get_metric(), Synchronizer_frame.hxx:181
-        if (flag) flag[blockIdx.x] = sv[0] > trigger ? 1 : 0;        // FLG = get_packet_flag(), .hpp:60
-    }
+}
+
+// per frame (one wave each): the maximum of the workgroups' keys -> delay (:296), TRI = get_metric() (Synchronizer_frame.hxx:181),
+// FLG = get_packet_flag() (.hpp:60); the delay line's table D[f] = 2 ((n - delay[f]) % n) (set_delay((cplx_in_sz - delay) % cplx_in_sz), :298);
+// max_corr of the last frame into the handle's state
+__global__ void __launch_bounds__(64)
+sync_finalize_kernel(const unsigned long long *__restrict__ keys, int nwg, int32_t *__restrict__ delay, float *__restrict__ metric, int32_t *__restrict__ flag,
+                     float trigger, int32_t *__restrict__ Dtab, float *__restrict__ last_metric, int n, int n_sof, int n_plsc, int F)
+{
+    const int f = blockIdx.x;
+    unsigned long long k = 0ull;
+    for (int g = threadIdx.x; g < nwg; g += 64) { const unsigned long long v = keys[(size_t)f * nwg + g]; k = v > k ? v : k; }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) { const unsigned long long o = __shfl_xor(k, sft); k = o > k ? o : k; }
+    if (threadIdx.x != 0) return;
+    const uint32_t hi = (uint32_t)(k >> 32);
+    const float bv = __uint_as_float(hi);
+    const int idx = hi ? (int)(0xffffffffu - (uint32_t)k) : 0;       // no value above 0: index 0, as the reference's initial max_idx
+    const int d = (n + idx - n_sof - n_plsc) % n;
+    delay[f] = d;
+    metric[f] = bv;
+    if (flag) flag[f] = bv > trigger ? 1 : 0;
+    if (f == F - 1) *last_metric = bv;
+    Dtab[f] = 2 * ((n - d) % n);
 }
 
 // ---- Variable_delay_cc_naive::_filter (Variable_delay_cc_naive.cpp:56-79), the whole batch in ONE launch.
@@ -251,8 +327,8 @@ sync_argmax_kernel(const float *__restrict__ corr, int32_t *__restrict__ delay, 
 //   * an output sample that the reference takes from output f - 1 is resolved by looking at frame f - 1 in turn (vd_source).
 // In lock (constant delay) neither walk takes a step; while the delay moves they take one or two.  One lane per output
 // sample, no frame-to-frame launches: the per-frame form cost 4 us per frame (a launch each) whatever the frame size.
-// st = {head2, first_time}; Dmax = the largest D of the call (vd_dmax_kernel), which bounds vd_buff's walk.
-// D[f] = 2 * ((n - delay[f]) % n) (set_delay((cplx_in_sz - delay) % cplx_in_sz), :298), tabulated per frame by vd_dmax_kernel:
+// st = {head2, first_time}; Dmax = the largest D of the call, which bounds vd_buff's walk.
+// D[f] = 2 * ((n - delay[f]) % n) (set_delay((cplx_in_sz - delay) % cplx_in_sz), :298), tabulated per frame by sync_finalize_kernel:
 // the walks below would otherwise pay two integer divisions per output sample
 __device__ __forceinline__ int vd_D(const int32_t *Dtab, int f, int) { return Dtab[f]; }
 
@@ -288,24 +364,22 @@ __device__ __forceinline__ const float *vd_source(const float *__restrict__ X, c
     }
 }
 
-__global__ void vd_dmax_kernel(const int32_t *__restrict__ delay_f, int32_t *__restrict__ Dtab, int *__restrict__ dmax, int n, int F)
-{
-    __shared__ int red[256];
-    int m = 0;
-    for (int f = threadIdx.x; f < F; f += 256) { const int D = 2 * ((n - delay_f[f]) % n); Dtab[f] = D; m = D > m ? D : m; }
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s]; __syncthreads(); }
-    if (threadIdx.x == 0) *dmax = red[0];
-}
-
 constexpr int VD_SPL = 4;        // complex samples per lane, their loads in flight together
 // blockIdx.y < F: output frame blockIdx.y; blockIdx.y == F: the delay line and {head2, first_time} after the last frame
-__global__ void sync_vdelay_batch_kernel(const float *__restrict__ X, const float *__restrict__ yprev0, float *__restrict__ Y,
+__global__ void sync_vdelay_batch_kernel(const float *__restrict__ X, const float *__restrict__ yprev0, float *__restrict__ yprev_new, float *__restrict__ Y,
                                          const float *__restrict__ buff_old, float *__restrict__ buff_new, const int *__restrict__ st_old,
-                                         int *__restrict__ st_new, const int32_t *__restrict__ delay_f, const int *__restrict__ dmax, int n, int nbuff2, int F)
+                                         int *__restrict__ st_new, const int32_t *__restrict__ delay_f, int n, int nbuff2, int F)
 {
     const int N = 2 * n, f = blockIdx.y;
+    __shared__ int red[256];
+    int dmax = 0;
+    if (f == F) {                                                     // the largest D of the call (a few thousand ints out of L2)
+        for (int g = threadIdx.x; g < F; g += 256) dmax = delay_f[g] > dmax ? delay_f[g] : dmax;
+        red[threadIdx.x] = dmax;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s]; __syncthreads(); }
+        dmax = red[0];
+    }
     const float *src[VD_SPL];
     int jj[VD_SPL];
 #pragma unroll
@@ -313,14 +387,19 @@ __global__ void sync_vdelay_batch_kernel(const float *__restrict__ X, const floa
         const int j = 2 * ((blockIdx.x * VD_SPL + i) * (int)blockDim.x + (int)threadIdx.x);      // first float of a complex sample
         jj[i] = j; src[i] = nullptr;
         if (f < F) { if (j < N) src[i] = vd_source(X, yprev0, buff_old, st_old, delay_f, f, j, n, nbuff2); }
-        else if (j < nbuff2) src[i] = j < *dmax ? vd_buff(X, buff_old, delay_f, F - 1, j, n) : &buff_old[j];
+        else if (j < nbuff2) src[i] = j < dmax ? vd_buff(X, buff_old, delay_f, F - 1, j, n) : &buff_old[j];
     }
     float2 v[VD_SPL];
 #pragma unroll
     for (int i = 0; i < VD_SPL; i++) v[i] = src[i] ? *reinterpret_cast<const float2 *>(src[i]) : make_float2(0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < VD_SPL; i++) {
-        if (f < F) { if (jj[i] < N) *reinterpret_cast<float2 *>(&Y[(size_t)f * N + jj[i]]) = v[i]; }
+        if (f < F) {
+            if (jj[i] < N) {
+                *reinterpret_cast<float2 *>(&Y[(size_t)f * N + jj[i]]) = v[i];
+                if (f == F - 1) *reinterpret_cast<float2 *>(&yprev_new[jj[i]]) = v[i];      // the output buffer as the NEXT call finds it
+            }
+        }
         else if (jj[i] < nbuff2) *reinterpret_cast<float2 *>(&buff_new[jj[i]]) = v[i];
     }
     if (f == F && blockIdx.x == 0 && threadIdx.x == 0) { st_new[0] = vd_D(delay_f, F - 1, n); st_new[1] = 0; }
@@ -484,54 +563,59 @@ std::vector<uint16_t> sync_frag_default() { return sync_mfma_frag(K_CONJ_SOF, K_
 
 hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s)
 {
+    // frag: the correlators on the matrix cores (k_sync_mfma.hip, which also leaves the next call's memory in xh_out); null = the fp32 vector kernel
+    if (sync_mfma_usable(x, frag)) return sync_corr_mfma_launch(x, xh_in, xh_out, frag, cor_sof, cor_plsc, n_total, s);
     const unsigned grid = (unsigned)((n_total + SY_T - 1) / SY_T);
-    // frag: the correlators on the matrix cores (k_sync_mfma.hip); null = the fp32 vector kernel
-    if (sync_mfma_usable(x, frag)) (void)sync_corr_mfma_launch(x, xh_in, frag, cor_sof, cor_plsc, n_total, s);
-    else hipLaunchKernelGGL(sync_corr_kernel, dim3(grid), dim3(SY_THREADS), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
+    hipLaunchKernelGGL(sync_corr_kernel, dim3(grid), dim3(SY_THREADS), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
                        reinterpret_cast<float2 *>(cor_sof), reinterpret_cast<float2 *>(cor_plsc), n_total);
     hipLaunchKernelGGL(sync_hist_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
                        reinterpret_cast<float2 *>(xh_out), SY_H, n_total);
     return hipGetLastError();
 }
 
-// the one-task form: correlators + instantaneous metric fused (nothing but m leaves the chip), then the average / arg max as below
+// the average over frames with the arg max of every frame, then the per-frame sockets / delay-line table
+static void sync_average_argmax(float *cv, float *corr, int n, int F, float alpha, int vec_width, const SyncTail &t, hipStream_t s)
+{
+    const int end_vec = (n / vec_width) * vec_width, nwg = (n + 63) / 64;
+    hipLaunchKernelGGL(sync_metric_argmax_kernel, dim3(nwg), dim3(256), 0, s, cv, corr, t.keys, n, F, alpha, end_vec);
+    hipLaunchKernelGGL(sync_finalize_kernel, dim3(F), dim3(64), 0, s, t.keys, nwg, t.delay, t.metric, t.flag, t.trigger, t.Dtab, t.last_metric, n, 25, 64, F);
+}
+
+// the one-task form: correlators + instantaneous metric fused (nothing but m leaves the chip), then the average / arg max as above
 hipError_t sync_corr_metric_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, const float *sofh_in, float *sofh_out, float *cv, float *corr,
-                                   int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s)
+                                   const SyncTail &t, int n, int F, float alpha, int vec_width, hipStream_t s)
 {
     const long long tot = (long long)n * F;
-    const int end_vec = (n / vec_width) * vec_width;
-    if (sync_mfma_usable(x, frag)) (void)sync_corr_m_mfma_launch(x, xh_in, frag, sofh_in, sofh_out, corr, tot, s);
-    else hipLaunchKernelGGL(sync_corr_m_kernel, dim3((unsigned)((tot + SY_T - 1) / SY_T)), dim3(SY_THREADS), 0, s, reinterpret_cast<const float2 *>(x),
-                       reinterpret_cast<const float2 *>(xh_in), reinterpret_cast<const float2 *>(sofh_in), reinterpret_cast<float2 *>(sofh_out), corr, tot);
-    hipLaunchKernelGGL(sync_hist_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
-                       reinterpret_cast<float2 *>(xh_out), SY_H, tot);
-    hipLaunchKernelGGL(sync_metric_kernel, dim3((n + 63) / 64), dim3(64), 0, s, cv, corr, n, F, alpha, end_vec);
-    hipLaunchKernelGGL(sync_argmax_kernel, dim3(F), dim3(256), 0, s, corr, delay, metric, flag, trigger, n, 25, 64);
+    if (sync_mfma_usable(x, frag)) (void)sync_corr_m_mfma_launch(x, xh_in, xh_out, frag, sofh_in, sofh_out, corr, tot, s);
+    else {
+        hipLaunchKernelGGL(sync_corr_m_kernel, dim3((unsigned)((tot + SY_T - 1) / SY_T)), dim3(SY_THREADS), 0, s, reinterpret_cast<const float2 *>(x),
+                           reinterpret_cast<const float2 *>(xh_in), reinterpret_cast<const float2 *>(sofh_in), reinterpret_cast<float2 *>(sofh_out), corr, tot);
+        hipLaunchKernelGGL(sync_hist_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
+                           reinterpret_cast<float2 *>(xh_out), SY_H, tot);
+    }
+    sync_average_argmax(cv, corr, n, F, alpha, vec_width, t, s);
     return hipGetLastError();
 }
 
 hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float *sofh_out, const float *cor_plsc, float *cv, float *corr,
-                              int32_t *delay, float *metric, int32_t *flag, float trigger, int n, int F, float alpha, int vec_width, hipStream_t s)
+                              const SyncTail &t, int n, int F, float alpha, int vec_width, hipStream_t s)
 {
-    const int end_vec = (n / vec_width) * vec_width;
     const long long tot = (long long)n * F;
     hipLaunchKernelGGL(sync_m_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(cor_sof),
                        reinterpret_cast<const float2 *>(sofh_in), reinterpret_cast<const float2 *>(cor_plsc), corr, tot);
-    hipLaunchKernelGGL(sync_metric_kernel, dim3((n + 63) / 64), dim3(64), 0, s, cv, corr, n, F, alpha, end_vec);
     hipLaunchKernelGGL(sync_hist_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float2 *>(cor_sof), reinterpret_cast<const float2 *>(sofh_in),
-                       reinterpret_cast<float2 *>(sofh_out), 64, (long long)n * F);
-    hipLaunchKernelGGL(sync_argmax_kernel, dim3(F), dim3(256), 0, s, corr, delay, metric, flag, trigger, n, 25, 64);
+                       reinterpret_cast<float2 *>(sofh_out), 64, tot);
+    sync_average_argmax(cv, corr, n, F, alpha, vec_width, t, s);
     return hipGetLastError();
 }
 
-// all F frames of a call; dmax = one int, Dtab = F ints of device scratch
-hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
-                              const int32_t *delay_f, int32_t *Dtab /* F ints of scratch */, int *dmax, int n, int nbuff2, int F, hipStream_t s)
+// all F frames of a call; Dtab (F ints) comes from sync_finalize_kernel; Yprev_new = the last output frame for the next call
+hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Yprev_new, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
+                              const int32_t *Dtab, int n, int nbuff2, int F, hipStream_t s)
 {
     const int tot = (nbuff2 > 2 * n ? nbuff2 : 2 * n) / 2;           // complex samples
-    hipLaunchKernelGGL(vd_dmax_kernel, dim3(1), dim3(256), 0, s, delay_f, Dtab, dmax, n, F);
-    hipLaunchKernelGGL(sync_vdelay_batch_kernel, dim3((tot + 256 * VD_SPL - 1) / (256 * VD_SPL), F + 1), dim3(256), 0, s, X, Yprev, Y, buff_old, buff_new, st_old, st_new, Dtab,
-                       dmax, n, nbuff2, F);
+    hipLaunchKernelGGL(sync_vdelay_batch_kernel, dim3((tot + 256 * VD_SPL - 1) / (256 * VD_SPL), F + 1), dim3(256), 0, s, X, Yprev, Yprev_new, Y, buff_old, buff_new, st_old,
+                       st_new, Dtab, n, nbuff2, F);
     return hipGetLastError();
 }
 

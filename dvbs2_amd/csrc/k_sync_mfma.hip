@@ -80,7 +80,7 @@ __device__ __forceinline__ void sm_stage(uint16_t *lds, int o, float2 a, float2 
 // frag: [PLSC | SOF][K step][lane] band fragments (host-made, 6 KB, L2-resident)
 template <bool FUSED>
 __global__ void __launch_bounds__(SM_THREADS)
-sync_corr_mfma_kernel(const float2 *__restrict__ x, const float2 *__restrict__ xh, const uint4 *__restrict__ frag, const float2 *__restrict__ sofh,
+sync_corr_mfma_kernel(const float2 *__restrict__ x, const float2 *__restrict__ xh, float2 *__restrict__ xh_out, const uint4 *__restrict__ frag, const float2 *__restrict__ sofh,
                       float2 *__restrict__ sofh_out, float *__restrict__ corr, float2 *__restrict__ cor_sof, float2 *__restrict__ cor_plsc, long long n_total)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lds[6 * SM_PLANE];
@@ -95,6 +95,11 @@ sync_corr_mfma_kernel(const float2 *__restrict__ x, const float2 *__restrict__ x
         const bool in = gi >= 1 && gi + 2 <= n_total;               // pairs at the edges are fetched sample by sample below
         v[ps] = *reinterpret_cast<const sm_f32x4 *>(x + (in ? gi : 0));
         pv[ps] = *reinterpret_cast<const sm_f32x2 *>(x + (in ? gi - 1 : 0));
+    }
+    // the memory of the next call = the last 64 samples of (old memory ++ x); xh_out is not xh
+    if (blockIdx.x == 0 && tid >= SM_THREADS - SM_H) {
+        const long long gi = n_total - SM_THREADS + tid;
+        xh_out[tid - (SM_THREADS - SM_H)] = gi >= 0 ? x[gi] : xh[SM_H + gi];
     }
     if (tid < SM_HALO / 2) {
         const long long gi = blk0 - SM_HALO + 2 * tid;
@@ -197,21 +202,21 @@ std::vector<uint16_t> sync_mfma_frag(const float *sof25, const float *plsc64)
 bool sync_mfma_usable(const float *x, const void *frag) { return frag && (reinterpret_cast<uintptr_t>(x) & 15) == 0; }
 
 // two-task form: both correlations to their sockets
-hipError_t sync_corr_mfma_launch(const float *x, const float *xh_in, const uint16_t *frag, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s)
+hipError_t sync_corr_mfma_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s)
 {
     const unsigned grid = (unsigned)((n_total + SM_TILE - 1) / SM_TILE);
     hipLaunchKernelGGL(sync_corr_mfma_kernel<false>, dim3(grid), dim3(SM_THREADS), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
-                       reinterpret_cast<const uint4 *>(frag), nullptr, nullptr, nullptr, reinterpret_cast<float2 *>(cor_sof), reinterpret_cast<float2 *>(cor_plsc), n_total);
+                       reinterpret_cast<float2 *>(xh_out), reinterpret_cast<const uint4 *>(frag), nullptr, nullptr, nullptr, reinterpret_cast<float2 *>(cor_sof), reinterpret_cast<float2 *>(cor_plsc), n_total);
     return hipGetLastError();
 }
 
 // one-task form: the instantaneous metric only
-hipError_t sync_corr_m_mfma_launch(const float *x, const float *xh_in, const uint16_t *frag, const float *sofh_in, float *sofh_out, float *corr, long long n_total,
-                                   hipStream_t s)
+hipError_t sync_corr_m_mfma_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, const float *sofh_in, float *sofh_out, float *corr,
+                                   long long n_total, hipStream_t s)
 {
     const unsigned grid = (unsigned)((n_total + SM_TILE - 1) / SM_TILE);
     hipLaunchKernelGGL(sync_corr_mfma_kernel<true>, dim3(grid), dim3(SM_THREADS), 0, s, reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(xh_in),
-                       reinterpret_cast<const uint4 *>(frag), reinterpret_cast<const float2 *>(sofh_in), reinterpret_cast<float2 *>(sofh_out), corr, nullptr, nullptr,
+                       reinterpret_cast<float2 *>(xh_out), reinterpret_cast<const uint4 *>(frag), reinterpret_cast<const float2 *>(sofh_in), reinterpret_cast<float2 *>(sofh_out), corr, nullptr, nullptr,
                        n_total);
     return hipGetLastError();
 }
