@@ -336,7 +336,7 @@ __device__ __forceinline__ int vd_D(const int32_t *Dtab, int f, int) { return Dt
 // walks run once per complex sample and move 8 bytes).  The walks only compute WHERE a sample comes from (they read nothing but the
 // small table of delays); the loads themselves are issued afterwards, several per lane at once -- one dependent load per lane was
 // latency-bound at 1.6 TB/s.  A null source stands for the zero of first_time.
-__device__ __forceinline__ const float *vd_buff(const float *__restrict__ X, const float *__restrict__ buff0, const int32_t *__restrict__ delay_f,
+__device__ __noinline__ const float *vd_buff(const float *__restrict__ X, const float *__restrict__ buff0, const int32_t *__restrict__ delay_f,
                                                 int g, int k, int n)
 {
     const int N = 2 * n;
@@ -347,7 +347,7 @@ __device__ __forceinline__ const float *vd_buff(const float *__restrict__ X, con
     return &buff0[k];
 }
 
-__device__ __forceinline__ const float *vd_source(const float *__restrict__ X, const float *__restrict__ yprev0, const float *__restrict__ buff0,
+__device__ __noinline__ const float *vd_source(const float *__restrict__ X, const float *__restrict__ yprev0, const float *__restrict__ buff0,
                                            const int *__restrict__ st0, const int32_t *__restrict__ delay_f, int f, int j, int n, int nbuff2)
 {
     const int N = 2 * n;
@@ -364,8 +364,39 @@ __device__ __forceinline__ const float *vd_source(const float *__restrict__ X, c
     }
 }
 
-constexpr int VD_SPL = 4;        // complex samples per lane, their loads in flight together
-// blockIdx.y < F: output frame blockIdx.y; blockIdx.y == F: the delay line and {head2, first_time} after the last frame
+// The first step of vd_source / vd_buff on values that are uniform over the workgroup (D of this frame, D of the one before = head2, the
+// bounds of the four copies): no load before the sample's own.  In lock this resolves every sample (a whole output frame is one run of the
+// input stream, X[f N - D ...)); what it cannot resolve goes through the general walks above.
+struct VdU { int D, head2, first, start_Y, len, start_buff; };
+__device__ __forceinline__ VdU vd_uniform(const int *__restrict__ st0, const int32_t *__restrict__ Dtab, int f, int n, int nbuff2)
+{
+    VdU u;
+    const int N = 2 * n;
+    u.D = Dtab[f]; u.head2 = f == 0 ? st0[0] : Dtab[f - 1]; u.first = f == 0 ? st0[1] : 0;
+    u.start_Y = u.D > u.head2 ? u.D - u.head2 : 0; u.start_buff = u.D < u.head2 ? u.head2 - u.D : 0;
+    int end_buff = u.start_buff + u.D;
+    end_buff = end_buff > nbuff2 ? nbuff2 : end_buff;
+    end_buff = (end_buff - u.start_buff > N - u.start_Y) ? end_buff - ((end_buff - u.start_buff) - (N - u.start_Y)) : end_buff;
+    u.len = end_buff - u.start_buff;
+    return u;
+}
+__device__ __forceinline__ const float *vd_source_fast(const VdU &u, const float *__restrict__ X, const float *__restrict__ yprev0, const float *__restrict__ buff0,
+                                                       const int *__restrict__ st0, const int32_t *__restrict__ Dtab, int f, int j, int n, int nbuff2)
+{
+    const int N = 2 * n;
+    if (j >= u.D) return &X[(size_t)f * N + j - u.D];
+    if (f > 0 && j >= u.start_Y && j < u.start_Y + u.len) {
+        const int k = u.start_buff + j - u.start_Y;
+        if (k < u.head2) return &X[(size_t)(f - 1) * N + N - u.head2 + k];
+    }
+    return vd_source(X, yprev0, buff0, st0, Dtab, f, j, n, nbuff2);
+}
+
+constexpr int VD_SPL = 2;        // PAIRS of complex samples per lane, their loads in flight together
+typedef float vd_f4 __attribute__((ext_vector_type(4), aligned(4)));     // a pair of complex samples wherever it lies (the delays are even numbers of floats only)
+// blockIdx.y < F: output frame blockIdx.y; blockIdx.y == F: the delay line and {head2, first_time} after the last frame.
+// A lane resolves two neighbouring complex samples; almost always they are neighbours at the source too (in lock a whole output frame is ONE
+// run of the input stream, X[f N - D ...)), and the pair then moves as 16 bytes.
 __global__ void sync_vdelay_batch_kernel(const float *__restrict__ X, const float *__restrict__ yprev0, float *__restrict__ yprev_new, float *__restrict__ Y,
                                          const float *__restrict__ buff_old, float *__restrict__ buff_new, const int *__restrict__ st_old,
                                          int *__restrict__ st_new, const int32_t *__restrict__ delay_f, int n, int nbuff2, int F)
@@ -380,27 +411,43 @@ __global__ void sync_vdelay_batch_kernel(const float *__restrict__ X, const floa
         for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s]; __syncthreads(); }
         dmax = red[0];
     }
-    const float *src[VD_SPL];
+    const int lim = f < F ? N : nbuff2;
+    const VdU u = vd_uniform(st_old, delay_f, f < F ? f : F - 1, n, nbuff2);
+    const float *sa[VD_SPL], *sb[VD_SPL];
     int jj[VD_SPL];
 #pragma unroll
     for (int i = 0; i < VD_SPL; i++) {
-        const int j = 2 * ((blockIdx.x * VD_SPL + i) * (int)blockDim.x + (int)threadIdx.x);      // first float of a complex sample
-        jj[i] = j; src[i] = nullptr;
-        if (f < F) { if (j < N) src[i] = vd_source(X, yprev0, buff_old, st_old, delay_f, f, j, n, nbuff2); }
-        else if (j < nbuff2) src[i] = j < dmax ? vd_buff(X, buff_old, delay_f, F - 1, j, n) : &buff_old[j];
+        const int j = 4 * ((blockIdx.x * VD_SPL + i) * (int)blockDim.x + (int)threadIdx.x);      // first float of a pair of complex samples
+        jj[i] = j; sa[i] = nullptr; sb[i] = nullptr;
+        if (f < F) {
+            if (j < lim) sa[i] = vd_source_fast(u, X, yprev0, buff_old, st_old, delay_f, f, j, n, nbuff2);
+            if (j + 2 < lim) sb[i] = vd_source_fast(u, X, yprev0, buff_old, st_old, delay_f, f, j + 2, n, nbuff2);
+        } else {                                                      // buff2 after the last frame: its first D entries are that frame's tail
+            if (j < lim) sa[i] = j < u.D ? &X[(size_t)(F - 1) * N + N - u.D + j] : j < dmax ? vd_buff(X, buff_old, delay_f, F - 2, j, n) : &buff_old[j];
+            if (j + 2 < lim) sb[i] = j + 2 < u.D ? &X[(size_t)(F - 1) * N + N - u.D + j + 2] : j + 2 < dmax ? vd_buff(X, buff_old, delay_f, F - 2, j + 2, n) : &buff_old[j + 2];
+        }
     }
-    float2 v[VD_SPL];
-#pragma unroll
-    for (int i = 0; i < VD_SPL; i++) v[i] = src[i] ? *reinterpret_cast<const float2 *>(src[i]) : make_float2(0.f, 0.f);
+    vd_f4 v[VD_SPL];
 #pragma unroll
     for (int i = 0; i < VD_SPL; i++) {
-        if (f < F) {
-            if (jj[i] < N) {
-                *reinterpret_cast<float2 *>(&Y[(size_t)f * N + jj[i]]) = v[i];
-                if (f == F - 1) *reinterpret_cast<float2 *>(&yprev_new[jj[i]]) = v[i];      // the output buffer as the NEXT call finds it
-            }
+        if (sa[i] && sb[i] == sa[i] + 2) v[i] = *reinterpret_cast<const vd_f4 *>(sa[i]);
+        else {
+            const float2 lo = sa[i] ? *reinterpret_cast<const float2 *>(sa[i]) : make_float2(0.f, 0.f);       // a null source stands for the zero of first_time
+            const float2 hi = sb[i] ? *reinterpret_cast<const float2 *>(sb[i]) : make_float2(0.f, 0.f);
+            v[i] = vd_f4{lo.x, lo.y, hi.x, hi.y};
         }
-        else if (jj[i] < nbuff2) *reinterpret_cast<float2 *>(&buff_new[jj[i]]) = v[i];
+    }
+    float *dst = f < F ? Y + (size_t)f * N : buff_new;
+#pragma unroll
+    for (int i = 0; i < VD_SPL; i++) {
+        const int j = jj[i];
+        if (j + 2 < lim) {
+            *reinterpret_cast<vd_f4 *>(dst + j) = v[i];
+            if (f == F - 1) *reinterpret_cast<vd_f4 *>(yprev_new + j) = v[i];                    // the output buffer as the NEXT call finds it
+        } else if (j < lim) {
+            *reinterpret_cast<float2 *>(dst + j) = make_float2(v[i].x, v[i].y);
+            if (f == F - 1) *reinterpret_cast<float2 *>(yprev_new + j) = make_float2(v[i].x, v[i].y);
+        }
     }
     if (f == F && blockIdx.x == 0 && threadIdx.x == 0) { st_new[0] = vd_D(delay_f, F - 1, n); st_new[1] = 0; }
 }
@@ -613,7 +660,7 @@ hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float 
 hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Yprev_new, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
                               const int32_t *Dtab, int n, int nbuff2, int F, hipStream_t s)
 {
-    const int tot = (nbuff2 > 2 * n ? nbuff2 : 2 * n) / 2;           // complex samples
+    const int tot = ((nbuff2 > 2 * n ? nbuff2 : 2 * n) + 3) / 4;     // pairs of complex samples
     hipLaunchKernelGGL(sync_vdelay_batch_kernel, dim3((tot + 256 * VD_SPL - 1) / (256 * VD_SPL), F + 1), dim3(256), 0, s, X, Yprev, Yprev_new, Y, buff_old, buff_new, st_old,
                        st_new, Dtab, n, nbuff2, F);
     return hipGetLastError();

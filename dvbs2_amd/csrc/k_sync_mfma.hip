@@ -77,33 +77,31 @@ __device__ __forceinline__ void sm_stage(uint16_t *lds, int o, float2 a, float2 
     *reinterpret_cast<uint32_t *>(lds + 5 * SM_PLANE + o) = p3;
 }
 
-// frag: [PLSC | SOF][K step][lane] band fragments (host-made, 6 KB, L2-resident)
-template <bool FUSED>
-__global__ void __launch_bounds__(SM_THREADS)
-sync_corr_mfma_kernel(const float2 *__restrict__ x, const float2 *__restrict__ xh, float2 *__restrict__ xh_out, const uint4 *__restrict__ frag, const float2 *__restrict__ sofh,
-                      float2 *__restrict__ sofh_out, float *__restrict__ corr, float2 *__restrict__ cor_sof, float2 *__restrict__ cor_plsc, long long n_total)
+// One workgroup = 2048 outputs.  EDGE = false is the body of every workgroup whose samples, halo included, lie inside this call's stream and
+// that has nothing to do with the memories (all but the first and the last one or two): no range test per lane, uniform base pointers with
+// 32-bit lane offsets.  The kernel is bound by the instructions it issues (staging ~45 per pair of samples, 30 matrix products and ~45 vector
+// instructions per 256 outputs; profiles/), not by the 12 bytes per sample it moves, so the tests the edges need stay out of the common path.
+template <bool FUSED, bool EDGE>
+__device__ __forceinline__ void sm_body(uint16_t *lds, const float2 *__restrict__ x, const float2 *__restrict__ xh, const uint4 *__restrict__ frag,
+                                        const float2 *__restrict__ sofh, float2 *__restrict__ sofh_out, float *__restrict__ corr, float2 *__restrict__ cor_sof,
+                                        float2 *__restrict__ cor_plsc, long long n_total, long long blk0)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lds[6 * SM_PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long long blk0 = (long long)blockIdx.x * SM_TILE;
+    const float2 *xb = x + blk0;                                     // uniform; EDGE = false: xb[-145 .. 2047] are samples of this call
     // ---- stage d[blk0 - 144 .. blk0 + 2047]: a pair of samples per lane and pass, all loads of the workgroup issued before the first use
     sm_f32x4 v[SM_NPASS];
     sm_f32x2 pv[SM_NPASS];
 #pragma unroll
     for (int ps = 0; ps < SM_NPASS; ps++) {
-        const long long gi = blk0 + 2 * tid + ps * 2 * SM_THREADS;
-        const bool in = gi >= 1 && gi + 2 <= n_total;               // pairs at the edges are fetched sample by sample below
-        v[ps] = *reinterpret_cast<const sm_f32x4 *>(x + (in ? gi : 0));
-        pv[ps] = *reinterpret_cast<const sm_f32x2 *>(x + (in ? gi - 1 : 0));
-    }
-    // the memory of the next call = the last 64 samples of (old memory ++ x); xh_out is not xh
-    if (blockIdx.x == 0 && tid >= SM_THREADS - SM_H) {
-        const long long gi = n_total - SM_THREADS + tid;
-        xh_out[tid - (SM_THREADS - SM_H)] = gi >= 0 ? x[gi] : xh[SM_H + gi];
+        const int j = 2 * tid + ps * 2 * SM_THREADS;
+        const bool in = !EDGE || (blk0 + j >= 1 && blk0 + j + 2 <= n_total);      // pairs at the edges are fetched sample by sample below
+        v[ps] = __builtin_nontemporal_load(reinterpret_cast<const sm_f32x4 *>(in ? xb + j : x));
+        pv[ps] = __builtin_nontemporal_load(reinterpret_cast<const sm_f32x2 *>(in ? xb + j - 1 : x));
     }
     if (tid < SM_HALO / 2) {
-        const long long gi = blk0 - SM_HALO + 2 * tid;
-        sm_stage(lds, 2 * tid, sm_fetch(x, xh, n_total, gi - 1), sm_fetch(x, xh, n_total, gi), sm_fetch(x, xh, n_total, gi + 1));
+        const int j = 2 * tid - SM_HALO;
+        if (EDGE) sm_stage(lds, 2 * tid, sm_fetch(x, xh, n_total, blk0 + j - 1), sm_fetch(x, xh, n_total, blk0 + j), sm_fetch(x, xh, n_total, blk0 + j + 1));
+        else sm_stage(lds, 2 * tid, xb[j - 1], xb[j], xb[j + 1]);
     }
     sm_bf16x8 TP[3], TS[2];
 #pragma unroll
@@ -113,9 +111,10 @@ sync_corr_mfma_kernel(const float2 *__restrict__ x, const float2 *__restrict__ x
 #pragma unroll
     for (int ps = 0; ps < SM_NPASS; ps++) {
         const int j = 2 * tid + ps * 2 * SM_THREADS;
-        const long long gi = blk0 + j;
         float2 a = make_float2(pv[ps].x, pv[ps].y), b = make_float2(v[ps].x, v[ps].y), c = make_float2(v[ps].z, v[ps].w);
-        if (!(gi >= 1 && gi + 2 <= n_total)) { a = sm_fetch(x, xh, n_total, gi - 1); b = sm_fetch(x, xh, n_total, gi); c = sm_fetch(x, xh, n_total, gi + 1); }
+        if (EDGE && !(blk0 + j >= 1 && blk0 + j + 2 <= n_total)) {
+            a = sm_fetch(x, xh, n_total, blk0 + j - 1); b = sm_fetch(x, xh, n_total, blk0 + j); c = sm_fetch(x, xh, n_total, blk0 + j + 1);
+        }
         sm_stage(lds, SM_HALO + j, a, b, c);
     }
     __syncthreads();
@@ -125,58 +124,67 @@ sync_corr_mfma_kernel(const float2 *__restrict__ x, const float2 *__restrict__ x
     for (int t2 = 0; t2 < SM_TILE / 256 / (SM_THREADS / 64); t2++) {
         const int tt = wv + t2 * (SM_THREADS / 64);
         const long long o0 = blk0 + 256 * tt;
-        if (o0 >= n_total) break;
-        const bool tail = FUSED && o0 + 256 > n_total - 64;         // this tile holds some of the call's last 64 outputs
+        if (EDGE && o0 >= n_total) break;
+        const bool tail = EDGE && FUSED && o0 + 256 > n_total - 64;  // this tile holds some of the call's last 64 outputs
         sm_f32x4 P[2], S[2], S2[2];
 #pragma unroll
         for (int pl = 0; pl < 2; pl++) {
             // windows of block c + 16 tt: K step s of the band at plane index 64 + 16 (c + 2 s + 16 tt) + 8 g = fragment s + 1 below; the delayed
             // SOF correlation reads its K steps 1, 2 64 entries earlier (fragments 0, 1), the SOF correlation in place fragments 2, 3
-            sm_bf16x8 W[3][4];                                      // [part][fragment at 32 + 16 (c + 2 f + 16 tt) + 8 g]
+            // parts smallest first, the three chains side by side (independent accumulators, four fragments live at a time)
+            sm_f32x4 dP = {0.f, 0.f, 0.f, 0.f}, dS = {0.f, 0.f, 0.f, 0.f}, dT = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int p = 0; p < 3; p++)
+            for (int p = 2; p >= 0; p--) {
+                sm_bf16x8 W[4];                                     // fragment f at plane index 32 + 16 (c + 2 f + 16 tt) + 8 g
 #pragma unroll
-                for (int s = FUSED ? 0 : 1; s < 4; s++)
-                    W[p][s] = __builtin_bit_cast(sm_bf16x8, *reinterpret_cast<const uint4 *>(lds + (2 * p + pl) * SM_PLANE + 32 + 16 * (c + 2 * s + 16 * tt) + 8 * g));
-            sm_f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                for (int f = FUSED ? 0 : 1; f < 4; f++)
+                    W[f] = __builtin_bit_cast(sm_bf16x8, *reinterpret_cast<const uint4 *>(lds + (2 * p + pl) * SM_PLANE + 32 + 16 * (c + 2 * f + 16 * tt) + 8 * g));
 #pragma unroll
-            for (int p = 2; p >= 0; p--)
-#pragma unroll
-                for (int s = 0; s < 3; s++) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[p][s + 1], TP[s], d, 0, 0, 0);
-            P[pl] = d;
-            d = sm_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int p = 2; p >= 0; p--)
-#pragma unroll
-                for (int s = 0; s < 2; s++) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[p][s + (FUSED ? 0 : 2)], TS[s], d, 0, 0, 0);
-            S[pl] = d;
-            if (tail) {
-                d = sm_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int p = 2; p >= 0; p--)
-#pragma unroll
-                    for (int s = 0; s < 2; s++) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[p][s + 2], TS[s], d, 0, 0, 0);
-                S2[pl] = d;
+                for (int s = 0; s < 3; s++) {
+                    dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[s + 1], TP[s], dP, 0, 0, 0);
+                    if (s < 2) dS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[s + (FUSED ? 0 : 2)], TS[s], dS, 0, 0, 0);
+                    if (s < 2 && tail) dT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[s + 2], TS[s], dT, 0, 0, 0);
+                }
             }
+            P[pl] = dP; S[pl] = dS; S2[pl] = dT;
         }
+        const int ol = 256 * tt + 64 * g + c;                        // output of accumulator register r: blk0 + ol + 16 r
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const long long o = o0 + 16 * (4 * g + r) + c;
-            if (o >= n_total) continue;
+            const long long o = blk0 + ol + 16 * r;
+            if (EDGE && o >= n_total) continue;
             if (FUSED) {
                 float2 s = make_float2(S[0][r], S[1][r]);
-                if (o < 64) s = sofh[o];                            // cor_SOF of the 64 samples before this call
+                if (EDGE && o < 64) s = sofh[o];                    // cor_SOF of the 64 samples before this call
                 const float2 p = make_float2(P[0][r], P[1][r]);
                 const float sr = p.x + s.x, si = p.y + s.y, dr = s.x - p.x, di = s.y - p.y;
                 const float a2s = fmaf(sr, sr, si * si), a2d = fmaf(dr, dr, di * di);
-                corr[o] = sqrtf(fmaxf(a2s, a2d));
+                (corr + blk0)[ol + 16 * r] = sqrtf(fmaxf(a2s, a2d));
                 if (tail && o >= n_total - 64) sofh_out[o - (n_total - 64)] = make_float2(S2[0][r], S2[1][r]);
             } else {
-                cor_plsc[o] = make_float2(P[0][r], P[1][r]);
-                cor_sof[o] = make_float2(S[0][r], S[1][r]);
+                (cor_plsc + blk0)[ol + 16 * r] = make_float2(P[0][r], P[1][r]);
+                (cor_sof + blk0)[ol + 16 * r] = make_float2(S[0][r], S[1][r]);
             }
         }
     }
+}
+
+// frag: [PLSC | SOF][K step][lane] band fragments (host-made, 6 KB, L2-resident)
+// (26 KB of LDS leave six workgroups per CU; the register allocator is told so, or it settles for 104 registers = four)
+template <bool FUSED>
+__global__ void __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+sync_corr_mfma_kernel(const float2 *__restrict__ x, const float2 *__restrict__ xh, float2 *__restrict__ xh_out, const uint4 *__restrict__ frag, const float2 *__restrict__ sofh,
+                      float2 *__restrict__ sofh_out, float *__restrict__ corr, float2 *__restrict__ cor_sof, float2 *__restrict__ cor_plsc, long long n_total)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t lds[6 * SM_PLANE];
+    const long long blk0 = (long long)blockIdx.x * SM_TILE;
+    // the memory of the next call = the last 64 samples of (old memory ++ x); xh_out is not xh
+    if (blockIdx.x == 0 && threadIdx.x >= SM_THREADS - SM_H) {
+        const long long gi = n_total - SM_THREADS + threadIdx.x;
+        xh_out[threadIdx.x - (SM_THREADS - SM_H)] = gi >= 0 ? x[gi] : xh[SM_H + gi];
+    }
+    if (blk0 >= SM_HALO + 1 && blk0 + SM_TILE + 2 <= n_total - 64) sm_body<FUSED, false>(lds, x, xh, frag, sofh, sofh_out, corr, cor_sof, cor_plsc, n_total, blk0);
+    else sm_body<FUSED, true>(lds, x, xh, frag, sofh, sofh_out, corr, cor_sof, cor_plsc, n_total, blk0);
 }
 
 static inline uint16_t sm_bf16_of(float v) { uint32_t u; std::memcpy(&u, &v, 4); return (uint16_t)(u >> 16); }     // +-1 and 0: exact
