@@ -97,6 +97,29 @@ def test_matrix_core_correlators_against_the_vector_kernel_and_fp64(O, Rx, monke
     a.close(); b.close()
 
 
+def test_frame_synchronizer_at_size_locks_and_realigns_the_stream(O, Rx):
+    """BASELINE-size call (611 normal frames = 20 M samples in ONE call: many workgroups per frame in the correlators, 25 whole chunks of 24
+    frames + a partial one in the average, the delay line in lock) through size-independent properties: the delay settles on the stream's
+    offset, the flag is up, the metric is the same for every period of the (6-periodic) stream once the average has converged, and every
+    output frame is, bit for bit, the PL frame that started `off` samples into the previous input frame."""
+    modcod, F, off = "QPSK-N_8/9", 611, 12345
+    _, pl, _, _ = make_pl_frames(O, modcod, 6, 10.0, seed=21)
+    n = pl.shape[1] // 2
+    stream = np.concatenate([np.zeros(2 * off, np.float32), np.tile(pl.reshape(-1), F // 6 + 1)])[:F * 2 * n].reshape(F, 2 * n)
+    rx = Rx(modcod, max_frames=F)
+    d, flg, tri, Y = rx.sync_frame_synchronize(stream, with_flags=True)
+    assert np.all(d[8:] == off) and np.all(flg[8:] == 1)                 # (the average over frames needs a few of them)
+    for f in range(9, F):
+        assert np.array_equal(Y[f], pl[(f - 1) % 6]), f
+    assert np.array_equal(tri[200:206], tri[206:212]) and np.all(tri[200:] > 30.0)
+    # the same stream cut into calls of 100, 1 and 510 frames: same sockets (the memories carry over)
+    rx2 = Rx(modcod, max_frames=F)
+    parts = [rx2.sync_frame_synchronize(stream[a:b], with_flags=True) for a, b in ((0, 100), (100, 101), (101, F))]
+    assert np.array_equal(np.concatenate([q[0] for q in parts]), d) and np.array_equal(np.concatenate([q[3] for q in parts]), Y)
+    assert np.array_equal(np.concatenate([q[2] for q in parts]).view(np.uint32), tri.view(np.uint32))
+    rx.close(); rx2.close()
+
+
 def test_two_task_form_and_correlations(O, Rx):
     modcod = "8PSK-S_3/5"
     F = 5
