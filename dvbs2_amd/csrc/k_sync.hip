@@ -488,41 +488,68 @@ sff_lr_pilot_kernel(const float *__restrict__ X, float2 *__restrict__ tR, int n)
 }
 
 // ---- L&R, the damped autocorrelation from frame to frame (:131-135); fr[f] = {estimated_freq, est * pi}.  One wave:
-// 64 frames at a time are staged in LDS, lane 0 runs the recurrence over them (two multiply-adds per frame, the only
-// serial part), then every lane forms the estimate of one frame (atan2 and the double-precision scaling, in parallel).
-__global__ void __launch_bounds__(64)
+// 64 frames at a time are staged in LDS (the next 64 already on their way from memory), lane 0 runs the recurrence over them (two
+// multiply-adds per frame, the only serial part: 16 frames' values are read from LDS ahead of their dependent operations, so the chain
+// pays one LDS round trip per 16 frames instead of one per frame), then every lane forms the estimate of one frame (atan2 and the
+// double-precision scaling, in parallel).
+template <bool FULL>
+__device__ __forceinline__ void sff_lr_chain(float2 *sh, float &r0, float &r1, float alpha, float one_m, int cnt)
+{
+#pragma unroll 1
+    for (int k0 = 0; k0 < 64; k0 += 16) {
+        if (!FULL && k0 >= cnt) break;
+        float2 t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = sh[k0 + k];
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (FULL || k0 + k < cnt) {
+                r0 = alpha * r0 + one_m * t[k].x;
+                r1 = alpha * r1 + one_m * t[k].y;
+                t[k] = make_float2(r0, r1);
+            }
+#pragma unroll
+        for (int k = 0; k < 16; k++) sh[k0 + k] = t[k];           // (entries past cnt are not read again)
+    }
+}
+
+// Two waves: wave 0 stages 64 frames in LDS (the next 64 already on their way from memory) and its lane 0 runs the recurrence over them;
+// wave 1 forms the estimates of the batch before (atan2 and the double-precision scaling, one frame per lane) meanwhile -- one LDS-only
+// barrier per batch, two batch buffers.
+__global__ void __launch_bounds__(128)
 sff_lr_iir_kernel(const float2 *__restrict__ tR, float *__restrict__ R_l, float2 *__restrict__ fr, float *__restrict__ FRQ,
                   float *__restrict__ PHS, int F, float alpha)
 {
-    __shared__ float2 sh[64];
-    __shared__ float2 carry;
-    const int lane = threadIdx.x;
-    if (lane == 0) carry = make_float2(R_l[0], R_l[1]);
-    for (int f0 = 0; f0 < F; f0 += 64) {
-        const int f = f0 + lane, cnt = F - f0 < 64 ? F - f0 : 64;
-        if (f < F) sh[lane] = tR[f];
-        __syncthreads();
-        if (lane == 0) {
-            float r0 = carry.x, r1 = carry.y;
-            for (int k = 0; k < cnt; k++) {
-                const float2 t = sh[k];
-                r0 = alpha * r0 + (1 - alpha) * t.x;
-                r1 = alpha * r1 + (1 - alpha) * t.y;
-                sh[k] = make_float2(r0, r1);
+    __shared__ float2 sh[2][64];
+    const int lane = threadIdx.x & 63, nb = (F + 63) / 64;
+    if (threadIdx.x < 64) {
+        float r0 = R_l[0], r1 = R_l[1];                           // (lane 0's copy is the one that counts)
+        const float one_m = 1 - alpha;
+        float2 nxt = lane < F ? tR[lane] : make_float2(0.f, 0.f);
+        for (int b = 0; b < nb; b++) {
+            const int f = b * 64 + lane, cnt = F - b * 64 < 64 ? F - b * 64 : 64;
+            sh[b & 1][lane] = nxt;
+            if (f + 64 < F) nxt = tR[f + 64];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) { if (cnt == 64) sff_lr_chain<true>(sh[b & 1], r0, r1, alpha, one_m, cnt); else sff_lr_chain<false>(sh[b & 1], r0, r1, alpha, one_m, cnt); }
+            sy_lds_barrier();                                     // batch b is in sh[b & 1]
+        }
+        if (lane == 0) { R_l[0] = r0; R_l[1] = r1; }
+    } else {
+        for (int b = 0; b < nb; b++) {
+            sy_lds_barrier();
+            const int f = b * 64 + lane;
+            if (f < F) {
+                const float2 r = sh[b & 1][lane];
+                float est = atan2f(r.y, r.x);
+                est = (float)((double)est / ((18 / 2 + 1) * 3.1415926535897932384626433832795));
+                fr[f] = make_float2(est, (float)((double)est * 3.1415926535897932384626433832795));
+                if (FRQ) FRQ[f] = est;
+                if (PHS) PHS[f] = 0.f;
             }
-            carry = make_float2(r0, r1);
         }
-        __syncthreads();
-        if (f < F) {
-            float est = atan2f(sh[lane].y, sh[lane].x);
-            est = (float)((double)est / ((18 / 2 + 1) * 3.1415926535897932384626433832795));
-            fr[f] = make_float2(est, (float)((double)est * 3.1415926535897932384626433832795));
-            if (FRQ) FRQ[f] = est;
-            if (PHS) PHS[f] = 0.f;
-        }
-        __syncthreads();
     }
-    if (lane == 0) { R_l[0] = carry.x; R_l[1] = carry.y; }
 }
 
 // ---- freq_phase, per frame: fr[f] = {estimated_freq, estimated_phase} (.cpp:53-101)
@@ -589,7 +616,7 @@ hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp /* 4 F
 {
     float2 *tR = reinterpret_cast<float2 *>(tmp), *fr = tR + F;
     hipLaunchKernelGGL(sff_lr_pilot_kernel, dim3(F), dim3(256), 0, s, X, tR, n);
-    hipLaunchKernelGGL(sff_lr_iir_kernel, dim3(1), dim3(64), 0, s, tR, R_l, fr, FRQ, PHS, F, alpha);
+    hipLaunchKernelGGL(sff_lr_iir_kernel, dim3(1), dim3(128), 0, s, tR, R_l, fr, FRQ, PHS, F, alpha);
     const long long tot = (long long)n * F;
     hipLaunchKernelGGL(sff_rotate_kernel<0>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(X),
                        reinterpret_cast<float2 *>(Y), fr, n, tot);
