@@ -279,6 +279,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
     if (!cfg || !out) return fail(nullptr, DVBS2HIP_EINVAL, "null argument");
     *out = nullptr;
     if (cfg->max_frames < 1) return fail(nullptr, DVBS2HIP_EINVAL, "'max_frames' has to be greater than 0");
+    if (cfg->max_frames > 65534) return fail(nullptr, DVBS2HIP_EINVAL, "'max_frames' has to be at most 65534 (frames are the second grid dimension of several kernels)");
     if (cfg->bps < 1 || cfg->bps > 5 || !cfg->cstl) return fail(nullptr, DVBS2HIP_EINVAL, "'bps' has to be in [1,5] with a constellation");
     if (cfg->N_ldpc <= 0 || cfg->N_ldpc % cfg->bps) return fail(nullptr, DVBS2HIP_EINVAL, "'N_ldpc' has to be a positive multiple of 'bps'");
     if (cfg->itl_cols > 1 && cfg->N_ldpc % cfg->itl_cols) return fail(nullptr, DVBS2HIP_EINVAL, "'N_ldpc' has to be a multiple of 'itl_cols'");

@@ -85,7 +85,7 @@ typedef struct dvbs2hip_cfg {
     const float *fir_taps;
     int32_t      fir_osf;      /* samples per symbol of the filter input           */
     /* runtime */
-    int32_t max_frames;        /* capacity of one call (the -F of the socket)      */
+    int32_t max_frames;        /* capacity of one call (the -F of the socket), 1 .. 65534 */
     int32_t device;            /* HIP device ordinal                               */
     void   *stream;            /* hipStream_t to enqueue on, or NULL: own stream   */
     int32_t ldpc_lds_groups;   /* tuning: < 0 = automatic                          */

@@ -128,6 +128,10 @@ def test_abi_error_behaviour(O, Rx):
     cfg.bch_m = 7
     h = C.c_void_p()
     assert L.dvbs2hip_create(C.byref(cfg), C.byref(h)) == -1 and b"8 <= m" in L.dvbs2hip_last_error(None)
+    # frames are the second grid dimension of several kernels: a socket of more than 65534 frames is refused at create
+    assert L.dvbs2hip_cfg_from_modcod(b"QPSK-S_8/9", C.byref(cfg)) == 0
+    cfg.max_frames = 65535
+    assert L.dvbs2hip_create(C.byref(cfg), C.byref(h)) == -1 and b"65534" in L.dvbs2hip_last_error(None)
 
 
 def test_external_stream_reset_and_two_handles(O, Rx):
