@@ -596,20 +596,46 @@ sff_fp_pilot_kernel(const float *__restrict__ X, float2 *__restrict__ fr, float 
 
 // ---- rotation of the frame: y = x conj(e^{j theta}); MODE 0 (L&R, :141-166): theta = (est pi) * (2 k);
 // MODE 1 (freq_phase, :103-112): theta = 2 pi (freq k + phase), formed in double as the reference's expression is
+typedef float vd_f4n __attribute__((ext_vector_type(4)));      // a 16-byte type the non-temporal builtins accept
+template <int MODE>
+__device__ __forceinline__ float2 sff_rotate(float2 v, float2 e, int k)
+{
+    float theta;
+    if (MODE == 0) theta = e.y * (float)(2 * k);
+    else theta = (float)(2 * 3.1415926535897932384626433832795 * (double)(e.x * (float)k + e.y));
+    float sn, c;
+    sincosf(theta, &sn, &c);
+    return make_float2(v.x * c + v.y * sn, v.y * c - v.x * sn);
+}
 template <int MODE>
 __global__ void sff_rotate_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const float2 *__restrict__ fr, int n, long long n_total)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_total) return;
     const int f = (int)(g / n), k = (int)(g - (long long)f * n);
+    y[g] = sff_rotate<MODE>(x[g], fr[f], k);
+}
+// even frame lengths (every DVB-S2 PL frame) and 16-byte aligned sockets: two samples of one frame per lane, 16 bytes per access
+template <int MODE>
+__global__ void sff_rotate2_kernel(const vd_f4n *__restrict__ x, vd_f4n *__restrict__ y, const float2 *__restrict__ fr, int n, long long n_pairs)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_pairs) return;
+    const int f = (int)((2 * g) / n), k = (int)(2 * g - (long long)f * n);
     const float2 e = fr[f];
-    float theta;
-    if (MODE == 0) theta = e.y * (float)(2 * k);
-    else theta = (float)(2 * 3.1415926535897932384626433832795 * (double)(e.x * (float)k + e.y));
-    float sn, c;
-    sincosf(theta, &sn, &c);
-    const float2 v = x[g];
-    y[g] = make_float2(v.x * c + v.y * sn, v.y * c - v.x * sn);
+    const vd_f4n v = __builtin_nontemporal_load(x + g);
+    const float2 a = sff_rotate<MODE>(make_float2(v.x, v.y), e, k), b = sff_rotate<MODE>(make_float2(v.z, v.w), e, k + 1);
+    __builtin_nontemporal_store(vd_f4n{a.x, a.y, b.x, b.y}, y + g);
+}
+template <int MODE>
+static void sff_rotate_launch(const float *X, float *Y, const float2 *fr, int n, long long tot, hipStream_t s)
+{
+    if (n % 2 == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0)
+        hipLaunchKernelGGL(sff_rotate2_kernel<MODE>, dim3((unsigned)((tot / 2 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const vd_f4n *>(X),
+                           reinterpret_cast<vd_f4n *>(Y), fr, n, tot / 2);
+    else
+        hipLaunchKernelGGL(sff_rotate_kernel<MODE>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(X),
+                           reinterpret_cast<float2 *>(Y), fr, n, tot);
 }
 
 hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp /* 4 F floats */, float *FRQ, float *PHS, int n, int F, float alpha, hipStream_t s)
@@ -618,8 +644,7 @@ hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp /* 4 F
     hipLaunchKernelGGL(sff_lr_pilot_kernel, dim3(F), dim3(256), 0, s, X, tR, n);
     hipLaunchKernelGGL(sff_lr_iir_kernel, dim3(1), dim3(128), 0, s, tR, R_l, fr, FRQ, PHS, F, alpha);
     const long long tot = (long long)n * F;
-    hipLaunchKernelGGL(sff_rotate_kernel<0>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(X),
-                       reinterpret_cast<float2 *>(Y), fr, n, tot);
+    sff_rotate_launch<0>(X, Y, fr, n, tot, s);
     return hipGetLastError();
 }
 
@@ -628,8 +653,7 @@ hipError_t sff_fp_launch(const float *X, float *Y, float *tmp /* 2 F floats */, 
     float2 *fr = reinterpret_cast<float2 *>(tmp);
     hipLaunchKernelGGL(sff_fp_pilot_kernel, dim3(F), dim3(64), 0, s, X, fr, FRQ, PHS, n);
     const long long tot = (long long)n * F;
-    hipLaunchKernelGGL(sff_rotate_kernel<1>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(X),
-                       reinterpret_cast<float2 *>(Y), fr, n, tot);
+    sff_rotate_launch<1>(X, Y, fr, n, tot, s);
     return hipGetLastError();
 }
 
