@@ -333,12 +333,76 @@ front_reg_kernel(const FrontKParams p)
     }
 }
 
+// ---- the same for the separable QPSK mappings without an interleaver (every reference QPSK MODCOD), two neighbouring symbols per lane and
+// access: a pair never straddles a pilot block (16 slots = 1440 symbols, even), so it is 16 bytes of the PL frame, two bytes of the
+// PL sequence and 16 bytes of LLRs -- half the vector-memory instructions of front_reg_kernel for the same bytes (same-box: QPSK-N
+// 4096 frames 0.451 -> see DESIGN section 4).  PPT pairs per lane; needs 16-byte aligned sockets and an even number of symbols.
+typedef float front_f4 __attribute__((ext_vector_type(4)));
+template <int PPT>
+__global__ void __launch_bounds__(FRONT_WIDE)
+front_reg2_kernel(const FrontKParams p)
+{
+    __shared__ float red[2][FRONT_WIDE / 64];
+    const int tid = threadIdx.x, f = blockIdx.x;
+    const int n_sym = p.n_sym, n_pil = n_sym / (PL_SLOTS * PL_M), n_pairs = n_sym / 2;
+    const float2 *in = reinterpret_cast<const float2 *>(p.in + (size_t)f * 2 * (size_t)p.pl_frame);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(in), 0, 8 * p.pl_frame, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.pl_seq), 0, p.pl_frame, 0x00020000);
+    front_f4 y[PPT];
+    int pio[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; i++) {
+        const int j = tid + i * FRONT_WIDE;                       // pair j = symbols 2 j, 2 j + 1
+        pio[i] = j < n_pairs ? pl_index(2 * j, n_pil) : p.pl_frame;      // past the frame: the load returns zeros (padding lanes)
+        y[i] = __builtin_bit_cast(front_f4, __builtin_amdgcn_raw_buffer_load_b128(rin, 8 * pio[i], 0, 2));      // nt: read once
+    }
+    float sigma;
+    if (p.sigma_in == nullptr) {
+        // the moments in the order of front_reg_kernel's lanes would need the same symbol-to-lane map; the sums differ from it in the last
+        // bits (summation order), as any two estimators' do (tests/test_front_gpu.py: 1e-4 relative against the oracle's serial sum)
+        float m2 = 0.f, m4 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPT; i++) {
+            const float e0 = y[i].x * y[i].x + y[i].y * y[i].y, e1 = y[i].z * y[i].z + y[i].w * y[i].w;
+            m2 += e0; m4 += e0 * e0; m2 += e1; m4 += e1 * e1;
+        }
+        for (int o = 32; o > 0; o >>= 1) { m2 += __shfl_xor(m2, o); m4 += __shfl_xor(m4, o); }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = m2; red[1][tid >> 6] = m4; }
+        __syncthreads();
+        m2 = 0.f; m4 = 0.f;
+        for (int i = 0; i < FRONT_WIDE / 64; i++) { m2 += red[0][i]; m4 += red[1][i]; }
+        float ebn0, esn0;
+        m2m4_finish(m2, m4, n_sym, p.code_rate, p.bps, sigma, ebn0, esn0);
+        if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = ebn0; p.est[3 * f + 2] = esn0; }
+    } else {
+        sigma = p.sigma_in[f];
+        if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = 0.f; p.est[3 * f + 2] = 0.f; }
+    }
+    const float inv2s2 = 1.0f / (2.0f * sigma * sigma);
+    front_f4 *llr = reinterpret_cast<front_f4 *>(p.llr + (size_t)f * n_sym * 2);
+#pragma unroll
+    for (int i = 0; i < PPT; i++) {
+        const int j = tid + i * FRONT_WIDE;
+        if (j >= n_pairs) continue;
+        const uint32_t R = __builtin_amdgcn_raw_buffer_load_b16(rsq, pio[i] - PL_M, 0, 0);      // two bytes of the L2-resident PL sequence
+        const float2 a = pl_derotate(make_float2(y[i].x, y[i].y), (int)(R & 0xffu)), b = pl_derotate(make_float2(y[i].z, y[i].w), (int)(R >> 8));
+        float oa[2], ob[2];
+        demap_sep2(a, inv2s2, p, oa);
+        demap_sep2(b, inv2s2, p, ob);
+        __builtin_nontemporal_store(front_f4{oa[0], oa[1], ob[0], ob[1]}, llr + j);
+    }
+}
+
 static bool front_reg_try(const FrontKParams &p, hipStream_t s)
 {
     if (getenv("DVBS2HIP_FRONT_TWO_SWEEP")) return false;
     dim3 g(p.n_frames), b(FRONT_WIDE);
     const bool small = p.n_sym <= 8 * FRONT_WIDE, big = p.n_sym <= 32 * FRONT_WIDE;
-    if (p.bps == 2 && p.sep && small) hipLaunchKernelGGL((front_reg_kernel<2, 8, true>), g, b, 0, s, p);
+    const bool pair_ok = p.bps == 2 && p.sep && p.itl_cols <= 1 && p.n_sym % 2 == 0 && p.pl_frame % 2 == 0 && !getenv("DVBS2HIP_FRONT_SINGLE") &&
+                         ((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.llr)) & 15) == 0;
+    if (pair_ok && small) hipLaunchKernelGGL((front_reg2_kernel<4>), g, b, 0, s, p);
+    else if (pair_ok && big) hipLaunchKernelGGL((front_reg2_kernel<16>), g, b, 0, s, p);
+    else if (p.bps == 2 && p.sep && small) hipLaunchKernelGGL((front_reg_kernel<2, 8, true>), g, b, 0, s, p);
     else if (p.bps == 2 && p.sep && big) hipLaunchKernelGGL((front_reg_kernel<2, 32, true>), g, b, 0, s, p);
     else if (p.bps == 2 && small) hipLaunchKernelGGL((front_reg_kernel<2, 8, false>), g, b, 0, s, p);
     else if (p.bps == 2 && big) hipLaunchKernelGGL((front_reg_kernel<2, 32, false>), g, b, 0, s, p);
