@@ -531,14 +531,31 @@ hipError_t bb_descramble_launch(const int32_t *in, int32_t *out, const uint32_t 
     return hipGetLastError();
 }
 
+// bit errors of one frame seen by lane tid of its workgroup: four bits (16 bytes of each socket, read once: non-temporal) per access where the
+// frame allows it
+typedef int mon_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int monitor_frame_errors(const int32_t *__restrict__ u, const int32_t *__restrict__ v, int K, int tid)
+{
+    int be = 0;
+    if ((K & 3) == 0 && ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        const mon_i4 *u4 = reinterpret_cast<const mon_i4 *>(u), *v4 = reinterpret_cast<const mon_i4 *>(v);
+        for (int k = tid; k < K / 4; k += FRONT_THREADS) {
+            const mon_i4 a = __builtin_nontemporal_load(u4 + k), b = __builtin_nontemporal_load(v4 + k);
+            be += (a.x != b.x) + (a.y != b.y) + (a.z != b.z) + (a.w != b.w);
+        }
+    } else
+        for (int k = tid; k < K; k += FRONT_THREADS) be += (u[k] != v[k]) ? 1 : 0;
+    return be;
+}
+
 // ---------------------------------------------------------------- a9
 __global__ void __launch_bounds__(FRONT_THREADS)
 monitor_kernel(const int32_t *U, const int32_t *V, unsigned long long *ctr, int K)
 {
     __shared__ int red[FRONT_THREADS / 64];
     const int f = blockIdx.x, tid = threadIdx.x;
-    int be = 0;
-    for (int k = tid; k < K; k += FRONT_THREADS) be += (U[(size_t)f * K + k] != V[(size_t)f * K + k]) ? 1 : 0;
+    const int be0 = monitor_frame_errors(U + (size_t)f * K, V + (size_t)f * K, K, tid);
+    int be = be0;
     for (int o = 32; o > 0; o >>= 1) be += __shfl_xor(be, o);
     if ((tid & 63) == 0) red[tid >> 6] = be;
     __syncthreads();
@@ -563,8 +580,8 @@ monitor_be_kernel(const int32_t *U, const int32_t *V, int32_t *be_out, int K)
 {
     __shared__ int red[FRONT_THREADS / 64];
     const int f = blockIdx.x, tid = threadIdx.x;
-    int be = 0;
-    for (int k = tid; k < K; k += FRONT_THREADS) be += (U[(size_t)f * K + k] != V[(size_t)f * K + k]) ? 1 : 0;
+    const int be0 = monitor_frame_errors(U + (size_t)f * K, V + (size_t)f * K, K, tid);
+    int be = be0;
     for (int o = 32; o > 0; o >>= 1) be += __shfl_xor(be, o);
     if ((tid & 63) == 0) red[tid >> 6] = be;
     __syncthreads();
