@@ -161,7 +161,7 @@ def main():
         rx.synchronize()
         return (time.perf_counter() - t) / reps
     Fh = int(llr_hard.shape[0])
-    hard, es, copy_gbps = None, {}, None
+    hard, es, copy_gbps, chain = None, {}, None, None
     if not args.no_extras:
       dt_hard = timed(llr_hard, Fh, 3)
       ref_h = torch.from_numpy(info).to(dev)[sel_h]
@@ -175,6 +175,25 @@ def main():
           es[name] = {"fec_frames_per_s": n_fr / dt, "info_bits_per_s": n_fr / dt * mc.K_bch, "frames": n_fr, "cwd": int(cwd[:n_fr].sum().item())}
       rx.set_ldpc_params(N_ITE, 1.0, False)
       copy_gbps = _copy_bandwidth(torch, dev)
+      # (3) the fused RX chain of the same MODCOD (PL frames of the on-device TX mirror -> information bits: a7 a6 a3 a4 a1 a2 a8), the rate
+      # a dvbs2_rx drop-in sees behind the synchronizers; fixed 10 iterations like `value`
+      from dvbs2_amd import params as P
+      sig_c = torch.full((F,), P.esn0_to_sigma(P.ebn0_to_esn0(EBN0_DB, mc.code_rate, mc.bps)), dtype=torch.float32, device=dev)
+      pl = torch.empty((F, 2 * rx.pl_frame), dtype=torch.float32, device=dev)
+      sent = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev)
+      got = torch.empty_like(sent)
+      rx.tx_bb_dev(None, 20260 + rank, sig_c.data_ptr(), sent.data_ptr(), pl.data_ptr(), F)
+      def chain_once():
+          rx.rx_bb_dev(pl.data_ptr(), None, got.data_ptr(), None, None, F)
+      chain_once(); chain_once(); rx.synchronize()
+      t = time.perf_counter()
+      for _ in range(5):
+          chain_once()
+      rx.synchronize()
+      dt_c = (time.perf_counter() - t) / 5
+      chain = {"what": "dvbs2hip_rx_bb_dev on %d PL frames of the TX mirror at %.1f dB, sigma estimated (M2M4), 10 iterations fixed" % (F, EBN0_DB),
+               "ms": 1e3 * dt_c, "frames_per_s": F / dt_c, "info_bits_per_s": F / dt_c * mc.K_bch, "bit_errors": int((got != sent).sum().item())}
+      del pl, sent, got
 
     frames_total = world * F * args.steps
     fps = frames_total / elapsed
@@ -224,7 +243,7 @@ def main():
                                   "frac": io_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBPS if k_n else 0.0,
                                   "what": "(4 N + 4 K) bytes per frame: the LLRs in and the hard decisions out, the only bytes that have to cross HBM"},
                      "hbm_copy_GBps_measured": copy_gbps},
-        "extra": {"hard_batch_fixed_10_ite": hard,
+        "extra": {"hard_batch_fixed_10_ite": hard, "fused_rx_chain": chain,
                   "early_stop_fps": {k: v["fec_frames_per_s"] for k, v in es.items()}, "early_stop": es,
                   "early_stop_note": "the reference's default rule (syndrome check after every iteration, enable_syndrome); untimed for `value`, 3 launches each"},
     }
