@@ -92,6 +92,34 @@ def test_rx_bb_estimated_sigma_recovers_payload(O, Rx):
     rx.close()
 
 
+@pytest.mark.parametrize("modcod,ebn0", [("QPSK-S_8/9", 3.9), ("QPSK-N_8/9", 3.7)])
+def test_qpsk_front_end_pairs_equal_single_symbols(O, Rx, monkeypatch, modcod, ebn0):
+    """The QPSK front end with two neighbouring symbols per lane and access (front_reg2_kernel, the default on 16-byte aligned sockets)
+    against the one-symbol form (DVBS2HIP_FRONT_SINGLE=1): given sigma the LLRs are the same numbers, so the fused chain returns the
+    same bits and flags frame for frame around the waterfall (converged or not); with the estimator (its sums run in another order,
+    sigma differs in the last bits and min-sum with alpha = 1 is scale-invariant) the payload is recovered either way."""
+    F = 24
+    info, pl, cw, sigma = make_pl_frames(O, modcod, F, ebn0, seed=321)
+    res = {}
+    for single in (False, True):
+        if single:
+            monkeypatch.setenv("DVBS2HIP_FRONT_SINGLE", "1")
+        else:
+            monkeypatch.delenv("DVBS2HIP_FRONT_SINGLE", raising=False)
+        rx = Rx(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=True)
+        res[single] = rx.rx_bb(pl, sigma=sigma)
+        rx.close()
+    for a, b in zip(res[False], res[True]):
+        assert np.array_equal(a, b)
+    assert 0 < int(res[False][1].sum()) < F                             # some frames converge, some do not: both kinds were compared
+    info2, pl2, _, _ = make_pl_frames(O, modcod, 4, ebn0 + 1.5, seed=322)
+    monkeypatch.delenv("DVBS2HIP_FRONT_SINGLE", raising=False)
+    rx = Rx(modcod, max_frames=4, n_ite=10, alpha=1.0, early_stop=True)
+    out, c0, c1 = rx.rx_bb(pl2)
+    assert np.array_equal(out, info2) and c0.all()
+    rx.close()
+
+
 def test_rx_bb_low_snr_reports_failure(O, Rx):
     modcod = "QPSK-S_8/9"
     F = 4
