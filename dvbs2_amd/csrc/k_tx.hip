@@ -179,7 +179,19 @@ tx_ldpc_kernel(const TxKParams p)
         tot[t] = (uint8_t)run;
     }
     __syncthreads();
-    if (t == 0) { uint32_t e = 0; for (int i = 0; i < LDPC_Z; i++) { const uint32_t v = tot[i]; tot[i] = (uint8_t)e; e ^= v; } }   // exclusive scan over t
+    {   // exclusive prefix XOR over t (the chain p_c ^= p_{c-1} across the columns): inside a wave by shuffles, across waves through LDS
+        __shared__ uint32_t wtot[LDPC_THREADS / 64];
+        const int lane = t & 63, wv = t >> 6;
+        const uint32_t v = t < LDPC_Z ? tot[t] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if (lane >= o) incl ^= u; }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        uint32_t base = 0u;
+        for (int w = 0; w < wv; w++) base ^= wtot[w];
+        if (t < LDPC_Z) tot[t] = (uint8_t)(incl ^ v ^ base);
+    }
     __syncthreads();
     uint32_t *dst = p.ldpc_cw + (size_t)f * nw_out;
     for (int w = t; w < nw_out; w += LDPC_THREADS) {
