@@ -226,27 +226,31 @@ tx_ldpc_kernel(const TxKParams p)
 template <int BPS, bool ITL>
 __device__ __forceinline__ float2 tx_symbol(const TxKParams &p, const float *cs, const uint32_t *cw, int i, int n_pil)
 {
-    if (i < 90) return make_float2(p.plh[2 * i], p.plh[2 * i + 1]);
+    // Branch-free for the compile-time BPS forms: header, pilot and data symbols take the same instructions (indices clamped, the
+    // right value selected at the end) -- a wave nearly always holds one kind only, but every branch costs the scalar unit a
+    // save / restore of the execution mask, and there were seventy of those per pair of symbols.
     // inverse of the RX map: position i-90 inside [16 slots data | 36 pilots] blocks
-    const int j = i - 90, blk = j / (1440 + 36), off = j - blk * (1440 + 36);
-    int k = -1;
-    if (blk < n_pil) { if (off < 1440) k = blk * 1440 + off; }
-    else k = n_pil * 1440 + (j - n_pil * (1440 + 36));
+    const int j = i >= 90 ? i - 90 : 0, blk = j / (1440 + 36), off = j - blk * (1440 + 36);
+    const bool pilot = blk < n_pil && off >= 1440;
+    int k = blk < n_pil ? blk * 1440 + off : n_pil * 1440 + (j - n_pil * (1440 + 36));
     float2 y;
-    if (k < 0) y = make_float2(0.70710678118654752440f, 0.70710678118654752440f);     // pilot (Framer.hxx:252-260)
+    if (BPS > 0) {
+        k = pilot ? 0 : k;                                           // (any valid symbol: its value is not used)
+        const int n_rows = p.N_ldpc / BPS;
+        uint32_t wd[BPS > 0 ? BPS : 1];
+#pragma unroll
+        for (int b = 0; b < BPS; b++) {
+            const int nat = ITL ? (p.itl_order == 0 ? b : BPS - 1 - b) * n_rows + k : k * BPS + b;
+            wd[b] = cw[nat >> 5] >> (nat & 31);
+        }
+        int idx = 0;
+#pragma unroll
+        for (int b = 0; b < BPS; b++) idx |= (int)(wd[b] & 1u) << b;
+        y = make_float2(cs[2 * idx], cs[2 * idx + 1]);
+        if (pilot) y = make_float2(0.70710678118654752440f, 0.70710678118654752440f);     // pilot (Framer.hxx:252-260)
+    } else if (pilot) y = make_float2(0.70710678118654752440f, 0.70710678118654752440f);
     else {
         int idx = 0;
-        if (BPS > 0) {
-            const int n_rows = p.N_ldpc / BPS;
-            uint32_t wd[BPS > 0 ? BPS : 1];
-#pragma unroll
-            for (int b = 0; b < BPS; b++) {
-                const int nat = ITL ? (p.itl_order == 0 ? b : BPS - 1 - b) * n_rows + k : k * BPS + b;
-                wd[b] = cw[nat >> 5] >> (nat & 31);
-            }
-#pragma unroll
-            for (int b = 0; b < BPS; b++) idx |= (int)(wd[b] & 1u) << b;
-        } else
         for (int b = 0; b < p.bps; b++) {
             // interleaved bit k*bps+b comes from natural position col*n_rows + row (column/row interleaver)
             int nat = k * p.bps + b;
@@ -255,13 +259,13 @@ __device__ __forceinline__ float2 tx_symbol(const TxKParams &p, const float *cs,
         }
         y = make_float2(cs[2 * idx], cs[2 * idx + 1]);
     }
-    switch (p.pl_seq[i - 90] & 3) {                        // multiply by exp(j pi/2 R) (Scrambler_PL.hxx:66-76, scr_flag = true)
-        case 0: break;
-        case 1: y = make_float2(-y.y, y.x); break;
-        case 2: y = make_float2(-y.x, -y.y); break;
-        default: y = make_float2(y.y, -y.x); break;
-    }
-    return y;
+    // multiply by exp(j pi/2 R) (Scrambler_PL.hxx:66-76, scr_flag = true): R = 1: (-y, x), 2: (-x, -y), 3: (y, -x) -- a swap and sign flips
+    const int R = p.pl_seq[j] & 3;
+    const float a = (R & 1) ? -y.y : y.x, b = (R & 1) ? y.x : y.y;
+    y = (R & 2) ? make_float2(-a, -b) : make_float2(a, b);
+    const int ih = i < 90 ? i : 0;
+    const float2 h = make_float2(p.plh[2 * ih], p.plh[2 * ih + 1]);   // the PL header is neither scrambled nor modulated here
+    return i < 90 ? h : y;
 }
 
 constexpr int TX_MOD_U = 4;                               // pairs of PL symbols per lane (independent: their loads overlap)
