@@ -46,6 +46,9 @@ __device__ __forceinline__ float2 pl_derotate(float2 x, int R)
 __device__ __forceinline__ int deitl_index(int k, int b, int bps, int cols, int order, int n_rows)
 {
     if (cols <= 1) return k * bps + b;
+    // every DVB-S2 interleaver has as many columns as the symbol has bits: LLR b of symbol k is row k of column b -- no division
+    // (a division by a run-time `cols` is ~25 instructions per LLR, which was a third of the APSK front end's time)
+    if (cols == bps) return (order == DVBS2HIP_ITL_TOP_LEFT ? b : cols - 1 - b) * n_rows + k;
     const int i = k * bps + b, row = i / cols, j = i - row * cols;
     return (order == DVBS2HIP_ITL_TOP_LEFT ? j : cols - 1 - j) * n_rows + row;
 }
