@@ -448,7 +448,8 @@ __global__ void deinterleave_kernel(const float *itl, float *nat, int N, int col
     if (i >= N) return;
     int dst = i;
     if (cols > 1) {
-        const int row = i / cols, j = i - row * cols;
+        // the DVB-S2 column counts divide by a constant (multiply + shift); any other count takes the general division
+        const int row = cols == 3 ? i / 3 : cols == 4 ? i / 4 : cols == 5 ? i / 5 : cols == 2 ? i / 2 : i / cols, j = i - row * cols;
         dst = (order == DVBS2HIP_ITL_TOP_LEFT ? j : cols - 1 - j) * n_rows + row;
     }
     nat[(size_t)f * N + dst] = itl[(size_t)f * N + i];
