@@ -450,11 +450,11 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 // ---- syndrome of the hard decisions (this lane's check of every layer), layer by layer: the posteriors are final, so the
                 //      order is free and the first layer with an unsatisfied check settles the answer -- a frame that has not converged
                 //      (every iteration but the last of a frame under the reference's stopping rule) pays for one layer instead of q.
-                //      Same-box A/B: the simulator with the early stop +13..14 % (same frame errors), the fixed-iteration bench +0.4 %
-                //      slower (one vote per layer or three stages alike: the register allocation, not the votes)
+                //      Same-box A/B: the simulator with the early stop +13 % (same frame errors).  With a fixed number of iterations there is
+                //      one vote, after the last layer, as before (a vote per layer in that mode too made the bench 0.4 % slower)
                 ok = true;
+                int bad = 0;
                 for (int r = 0; r < q; r++) {
-                    int bad = 0;
                     if (act) {
                         const const_u32 T = tab + r * LDPC_FAST_STRIDE;
                         float Lv[DEG];
@@ -469,9 +469,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         uint32_t x = 0u;
 #pragma unroll
                         for (int j = 0; j < DEG; j++) x ^= __float_as_uint(Lv[j]);             // NULL slots read +inf
-                        bad = (int)(x >> 31);
+                        bad |= (int)(x >> 31);
                     }
-                    if (__syncthreads_or(bad)) { ok = false; break; }
+                    if ((p.early_stop || r == q - 1) && __syncthreads_or(bad)) { ok = false; break; }
                 }
                 PROF_MARK(6);
                 if (ok) break;
