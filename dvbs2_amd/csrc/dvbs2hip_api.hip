@@ -395,9 +395,9 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
                 tab[3 * u] = s[0]; tab[3 * u + 1] = s[1]; tab[3 * u + 2] = s[2];
             }
             if (upload(h, &h->d_bch_tab, tab.data(), tab.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
-            // segmented division (tx_bchpar_kernel): segment s of 16 is followed by after_s bytes; shift[s][b] = x^(b + 8 after_s) mod g
+            // segmented division (tx_bchpar_kernel): segment s of TX_BCH_SEG is followed by after_s bytes; shift[s][b] = x^(b + 8 after_s) mod g
             {
-                const int SEG = 16, nbytes = h->K_bch / 8, L = (nbytes + SEG - 1) / SEG;
+                const int SEG = TX_BCH_SEG, nbytes = h->K_bch / 8, L = (nbytes + SEG - 1) / SEG;
                 std::vector<unsigned long long> sh((size_t)SEG * r * 3, 0ull);
                 std::vector<long long> base(SEG);
                 long long nmax = 0;

@@ -34,6 +34,7 @@ struct LdpcGroup {    // where the 360 posteriors of one bit-group live
 };
 
 constexpr int LDPC_Z = 360;          // DVB-S2 parallelism factor
+constexpr int TX_BCH_SEG = 16;       // segments (lanes) per frame of the TX BCH encoder (k_tx.hip, host-made shift table): 32 / 64 help 512-frame calls (61 -> 46 / 41 us) and cost 4096-frame ones (0.754 -> 0.768 / 0.812 ms per TX)
 constexpr int LDPC_THREADS = 384;    // 6 wavefronts, 360 active lanes
 constexpr int LDPC_MAX_SLOTS = 27;   // 27 sign bits + 5 index bits = one packed dword
 

@@ -56,7 +56,6 @@ tx_src_kernel(const TxKParams p)
 // in three 64-bit words), moves its remainder to the segment's place -- times x^(8 * bytes behind the segment) mod g, a
 // linear map applied bit by bit from a host-made table of x^(b + 8 after_s) mod g -- and the 16 remainders are XORed.
 // (One lane per whole frame, the first version, left 4096 lanes with 7184 dependent steps each: 0.90 ms of the 2.36 ms TX.)
-constexpr int TX_BCH_SEG = 16;
 __global__ void __launch_bounds__(64)
 tx_bchpar_kernel(const TxKParams p)
 {
