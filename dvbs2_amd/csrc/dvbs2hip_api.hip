@@ -331,7 +331,6 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         upload(h, &lp.d_layer_lvl, lp.layer_lvl.data(), lp.layer_lvl.size()) ||
         upload(h, &lp.d_groups, lp.groups.data(), lp.groups.size()))
         CREATE_FAIL(DVBS2HIP_EHIP, h->err);
-    if (lp.fast && upload(h, &lp.d_fast_tab, lp.fast_tab.data(), lp.fast_tab.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
     if (lp.fast_wg8) {
         if (upload(h, &lp.d_w8_tab, lp.w8_tab.data(), lp.w8_tab.size()) || upload(h, &lp.d_w8_rows, lp.w8_rows.data(), lp.w8_rows.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
         CREATE_HIP(hipMalloc((void **)&lp.d_cu_ctr, (LDPC_CU_CTR_WORDS + LDPC_PROF_WORDS) * sizeof(uint32_t)));
@@ -339,7 +338,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
     }
     lp.grid_max = ldpc_blocks_per_cu(lp) * h->n_cus;
     if (const char *ev = getenv("DVBS2HIP_LDPC_GRID_MAX")) { const int g = atoi(ev); if (g >= 1 && g < lp.grid_max) lp.grid_max = g; }   // scaling experiments
-    if (lp.gwork_words > 0) CREATE_HIP(hipMalloc((void **)&h->d_gwork, (size_t)lp.grid_max * (lp.fast ? lp.fast_wf : 1) * lp.gwork_words * sizeof(float)));
+    if (lp.gwork_words > 0) CREATE_HIP(hipMalloc((void **)&h->d_gwork, (size_t)lp.grid_max * lp.gwork_words * sizeof(float)));
 
     // ---- BCH
     e = bch_build_plan(h->bch, cfg->bch_m, cfg->bch_prim, cfg->bch_t, cfg->K_ldpc, cfg->K_bch);
@@ -519,7 +518,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
                         h->sfm.yprev[0], h->sfm.yprev[1], h->sfm.keys, h->sfm.metric, h->sfm.frag, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift, h->d_hist_zero, h->d_hist_junk, h->d_red, h->bch.d_prbs_rw};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
-    void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->ldpc.d_fast_tab, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
+    void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -555,9 +554,7 @@ const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
         const LdpcPlan &pl = h->ldpc;
         char buf[96];
         if (!pl.fast) snprintf(buf, sizeof buf, "ldpc_layered_nms_kernel<%d,%s,%s>", pl.ent_stride, pl.hybrid ? "true" : "false", pl.c2v_lds ? "true" : "false");
-        else if (pl.fast_wg8) snprintf(buf, sizeof buf, pl.spa ? "ldpc_wg8_kernel<%d,%d,true>" : "ldpc_wg8_kernel<%d,%d>", pl.fast_deg, pl.fast_mode);
-        else if (pl.spa) snprintf(buf, sizeof buf, "ldpc_fast2_kernel<%d,%d,true>", pl.fast_deg, pl.fast_mode);
-        else snprintf(buf, sizeof buf, "ldpc_fast2_kernel<%d,%d,false>", pl.fast_deg, pl.fast_mode);
+        else snprintf(buf, sizeof buf, pl.spa ? "ldpc_wg8_kernel<%d,%d,true>" : "ldpc_wg8_kernel<%d,%d>", pl.fast_deg, pl.fast_mode);
         const_cast<dvbs2hip_t *>(h)->ldpc_name = buf;
     }
     return h->ldpc_name.c_str();

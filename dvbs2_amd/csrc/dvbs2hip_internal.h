@@ -63,7 +63,6 @@ struct LdpcKParams {
     int32_t n_frames, n_ite, early_stop;
     float alpha;
     int32_t inf_row;           // fast path: byte offset of the +inf row (padded layers) or -1
-    const uint32_t *fast_tab;  // regular-code fast path: [q][LDPC_FAST_STRIDE] (see k_ldpc_fast.hip)
     uint32_t *cu_ctr;          // 8-wave workgroups: per-CU arrival counter (zeroed before the launch) or null
     struct {                   // k_ldpc_wg8.hip
         const uint32_t *tab;   // [q][LDPC_FAST_STRIDE]: byte shift | byte offset of the bit-group row << 11 | LDS flag << 29
@@ -90,14 +89,13 @@ struct LdpcPlan {             // host-side description, built once per handle
     LdpcEntry *d_entries = nullptr;
     int32_t *d_layer_deg = nullptr, *d_layer_lvl = nullptr;
     LdpcGroup *d_groups = nullptr;
-    // regular-code fast path (k_ldpc_fast.hip): every layer has exactly deg_max slots
+    // regular-code fast path (k_ldpc_wg8.hip): every layer has exactly fast_deg slots
     bool fast = false;
     bool spa = false;             // sum-product check node: per-edge fp32 messages instead of the packed min-sum state
     int fast_deg = 0;             // slots per layer in the unrolled kernel (11, 13 or 27)
     bool fast_pad = false;        // layers padded with NULL slots (irregular code)
     int fast_inf_row = -1;        // byte offset of the +inf row the NULL slots read, or -1
     int fast_mode = 0;            // posterior image -- 0: in LDS, 1: in the workgroup's global slot, 3: static hybrid (k_ldpc.hip plan)
-    int fast_wf = 1;              // workspace slots per workgroup: 2 for the 12-wave two-frame kernel (k_ldpc_fast.hip), 1 for k_ldpc_wg8.hip
     std::vector<uint32_t> nat_tab, nat_haz;   // k_ldpc_nat.hip: natural-row-order tables
     uint32_t *d_nat_tab = nullptr, *d_nat_haz = nullptr;
     bool fast_wg8 = false;        // one frame per 8-wave workgroup, SIMD-aware roles, two independent workgroups per CU (k_ldpc_wg8.hip)
@@ -106,17 +104,14 @@ struct LdpcPlan {             // host-side description, built once per handle
     uint32_t *d_w8_tab = nullptr, *d_w8_rows = nullptr;
     uint32_t w8_st_base = 0, w8_lds_junk = 0;
     int w8_lds_bytes = 0, w8_gwork_words = 0, w8_nl_info = 0, w8_nl = 0, w8_ng_info = 0, w8_ng = 0;
-    std::vector<uint32_t> fast_tab;
-    uint32_t *d_fast_tab = nullptr;
     uint32_t *d_cu_ctr = nullptr; // [LDPC_CU_CTR_WORDS]
 };
 constexpr int LDPC_PROF_WORDS = 1024 * 64;   // development aid (LDPC_PHASE_PROF builds): per-wave phase timers
 constexpr int LDPC_CU_CTR_WORDS = 4096 + 64;   // [0, 4096): arrivals per CU, key = XCC_ID << 8 | SE_ID << 5 | SH_ID << 4 | CU_ID; [4096]: frames handed out (work queue)
 constexpr int LDPC_FRAME_CTR = 4096;
-constexpr int LDPC_FAST_STRIDE = 64;   // dwords per layer: 27 entries | prim mask | n_conf | 16 conf entries | 16 conf meta
+constexpr int LDPC_FAST_STRIDE = 64;   // dwords per layer: 27 entries | prim mask | conflict info | conflict entries 0, 1 | slots with a duplicate edge | 16 conf entries | 16 conf meta
 constexpr int LDPC_FAST_MAXC = 16;
-hipError_t ldpc_fast_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
-int ldpc_fast_blocks_per_cu(const LdpcPlan &pl);
+constexpr int LDPC_SPA_MAXC = 6;       // SPA: duplicate edges per layer whose old messages a lane keeps in registers (the DVB-S2 codes have at most 6)
 hipError_t ldpc_nat_launch(const LdpcPlan &pl, const LdpcKParams &kp, float *work, hipStream_t s);
 size_t ldpc_nat_group_words(const LdpcPlan &pl);
 hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);

@@ -44,8 +44,10 @@ namespace dvbs2 {
 // ------------------------------------------------------------------------------------------
 // host: layer tables
 // ------------------------------------------------------------------------------------------
-std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,
-                            const int32_t *addr, int lds_groups_req, size_t lds_limit, bool spa)
+static const char *const PLAN_RETRY_GENERIC = "\x01generic";
+
+static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,
+                                   const int32_t *addr, int lds_groups_req, size_t lds_limit, bool spa, bool allow_fast)
 {
     pl.spa = spa;
     if (N <= 0 || K <= 0 || K >= N) return "LDPC: need 0 < K < N";
@@ -130,7 +132,7 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             maxc = std::max(maxc, c);
         }
         const char *env_path = getenv("DVBS2HIP_LDPC_PATH");
-        if (env_path && !strcmp(env_path, "generic")) regular = false;
+        if ((env_path && !strcmp(env_path, "generic")) || !allow_fast) regular = false;
         if (regular && maxc <= LDPC_FAST_MAXC) {
             pl.fast = true;
             pl.fast_deg = (uniform && pl.deg_max == 11) ? 11 : (uniform && pl.deg_max == 27) ? 27 : pl.deg_max <= 13 ? 13 : 27;
@@ -141,7 +143,6 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             const char *env_mode = getenv("DVBS2HIP_LDPC_FAST_MODE");
             pl.fast_mode = ((size_t)(pl.n_groups + 1 + xrows) * grp_bytes * 2 <= lds_limit + 1024) ? 0 : 1;
             if (env_mode && strcmp(env_mode, "static")) pl.fast_mode = (!strcmp(env_mode, "lds") && pl.fast_mode == 0) ? 0 : 1;
-            pl.fast_wf = 2;      // k_ldpc_fast.hip: two frames per 12-wave workgroup
             std::vector<uint32_t> gbase(pl.n_groups), glds(pl.n_groups, 0u);
             int n_l = 0, n_g = 0;
             // mode 3 (STATIC hybrid, normal frames): pick the LDS-resident bit-groups so that EVERY layer has
@@ -215,14 +216,9 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
             } else
                 for (int g = 0; g < pl.n_groups; g++) { gbase[g] = (uint32_t)(g * LDPC_Z); glds[g] = pl.fast_mode == 0 ? 1u : 0u; }
             for (int g = 0; g < pl.n_groups; g++) pl.groups[g] = {gbase[g], glds[g]};
-            pl.fast_tab.assign((size_t)q * LDPC_FAST_STRIDE, 0u);
             // +inf row: LDS image = [groups | junk row | inf row]; global image = [groups | inf row]
             const uint32_t inf_row_words = (uint32_t)((pl.n_groups + (pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z);
-            auto pack = [&](const Slot &sl) {
-                if (sl.group < 0) return (inf_row_words * 4u) << 11;
-                return (uint32_t)(sl.t0 * 4) | ((gbase[sl.group] * 4u) << 11) | (pl.fast_mode == 3 && glds[sl.group] ? (1u << 29) : 0u);
-            };
-            // k_ldpc_wg8.hip: same slot order, its own image layout -- LDS: [rows | junk | +inf]; global: [junk | +inf | rows]
+            // k_ldpc_wg8.hip image layout -- LDS: [rows | junk | +inf]; global: [junk | +inf | rows]
             pl.w8_tab.assign((size_t)q * LDPC_FAST_STRIDE, 0u);
             const int w8_lrows = pl.fast_mode == 0 ? pl.n_groups : pl.fast_mode == 3 ? n_l : 0;
             auto pack8 = [&](const Slot &sl) -> uint32_t {
@@ -232,16 +228,14 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 return (uint32_t)(sl.t0 * 4) | (base << 11) | (il ? (1u << 29) : 0u);
             };
             for (int r = 0; r < q; r++) {
-                uint32_t *T = &pl.fast_tab[(size_t)r * LDPC_FAST_STRIDE];
                 uint32_t *T8 = &pl.w8_tab[(size_t)r * LDPC_FAST_STRIDE];
-                uint32_t prim = 0; int nc = 0;
+                uint32_t prim = 0, dupmask = 0; int nc = 0;
                 // slot order: EARLY slots first (bit-group not touched by the previous layer, cyclically),
                 // then the late ones; the absent-for-check-0 parity slot stays last.  Conflict levels were
                 // fixed above in table order and travel with the slot.
                 std::vector<char> prev_touch(pl.n_groups, 0);
                 for (const Slot &sl : layers[(r + q - 1) % q]) prev_touch[sl.group] = 1;      // (layers[] hold real slots only)
                 std::vector<Slot> ord;
-                int n_early = 0;
                 if (pl.fast_mode == 3) {      // static hybrid: the LDS-resident slots first (exactly 9 of them), then the others
                     for (const Slot &sl : layers[r]) if (in_lds[sl.group]) ord.push_back(sl);
                     if ((int)ord.size() != 9) return "LDPC: internal: static hybrid balance broken";
@@ -251,7 +245,6 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                         return "LDPC: internal: static hybrid needs p_c and p_{c-1} at the last two slots (parity chain forwarding)";
                 } else {
                     for (const Slot &sl : layers[r]) if (!prev_touch[sl.group]) ord.push_back(sl);
-                    n_early = (int)ord.size();
                     for (const Slot &sl : layers[r]) if (prev_touch[sl.group]) ord.push_back(sl);
                 }
                 if (!ord.empty() && layers[r].back().mask0 && !ord.back().mask0) return "LDPC: internal: masked slot must stay last";
@@ -261,19 +254,19 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 for (int lvl = 1; lvl <= 3; lvl++)
                     for (size_t j = 0; j < ord.size(); j++)
                         if (ord[j].lvl == lvl && ord[j].group >= 0) {
-                            T[32 + nc] = pack(ord[j]); T8[32 + nc] = pack8(ord[j]);
-                            T[48 + nc] = T8[48 + nc] = (uint32_t)j | ((uint32_t)lvl << 8);
+                            T8[32 + nc] = pack8(ord[j]);
+                            T8[48 + nc] = (uint32_t)j | ((uint32_t)lvl << 8);
+                            dupmask |= 1u << j;
                             if (pl.fast_mode == 3 && !glds[ord[j].group]) pl.w8_dups_in_lds = false;
                             nc++;
                         }
                 for (size_t j = 0; j < ord.size(); j++) {
                     // byte shift (11 bits) | byte offset of the bit-group in its store (18 bits) | LDS flag
-                    T[j] = pack(ord[j]); T8[j] = pack8(ord[j]);
+                    T8[j] = pack8(ord[j]);
                     if (ord[j].lvl == 0 && ord[j].group >= 0) prim |= 1u << j;
                 }
-                T[27] = prim; T[28] = (uint32_t)nc; T[29] = (uint32_t)n_early;
-                // wg8: ncf | slot of entry 0 << 8 | level << 13 | slot of entry 1 << 16 | level << 21 ; entries 0 and 1
-                T8[27] = prim; T8[28] = (uint32_t)nc;
+                // ncf | slot of entry 0 << 8 | level << 13 | slot of entry 1 << 16 | level << 21 ; entries 0 and 1 ; slots with a duplicate edge
+                T8[27] = prim; T8[28] = (uint32_t)nc; T8[31] = dupmask;
                 for (int i = 0; i < 2 && i < nc; i++) {
                     T8[28] |= ((T8[48 + i] & 31u) | ((T8[48 + i] >> 8) << 5)) << (8 + 8 * i);
                     T8[29 + i] = T8[32 + i];
@@ -348,16 +341,12 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                     if (hz) pl.nat_haz[c >> 5] |= 1u << (c & 31);
                 }
             }
-            // production shape: one frame per 8-wave workgroup, two independent workgroups per CU (k_ldpc_fast.hip);
-            // DVBS2HIP_LDPC_WG=12 keeps the two-frames-per-12-wave-workgroup kernel
+            // one frame per 8-wave workgroup, two independent workgroups per CU (k_ldpc_wg8.hip); a code it cannot take (a static hybrid
+            // whose doubly connected bit-groups do not all fit in LDS) goes to the generic table-driven kernel below
             {
-                const char *env_wg = getenv("DVBS2HIP_LDPC_WG");
                 const bool w8_ok = pl.fast_mode == 0 || pl.fast_mode == 1 || (pl.fast_mode == 3 && pl.w8_dups_in_lds);
-                if (w8_ok && (size_t)pl.w8_lds_bytes <= lds_limit + 512 && !(env_wg && atoi(env_wg) == 12)) {
-                    pl.fast_wg8 = true; pl.fast_wf = 1; pl.gwork_words = pl.w8_gwork_words;
-                }
-                // the SPA kernel of k_ldpc_fast.hip knows the LDS and the global image only
-                if (spa && !pl.fast_wg8 && pl.fast_mode == 3) return "LDPC: SPA on the 12-wave kernel needs DVBS2HIP_LDPC_FAST_MODE=global for this code";
+                if (!(w8_ok && (size_t)pl.w8_lds_bytes <= lds_limit + 512) || (spa && maxc > LDPC_SPA_MAXC)) return PLAN_RETRY_GENERIC;
+                pl.fast_wg8 = true; pl.gwork_words = pl.w8_gwork_words;
             }
         }
     }
@@ -374,8 +363,16 @@ std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_
                 (LdpcEntry)s.t0 | ((gl.base / LDPC_Z) << LE_SLOT_SHIFT) | (gl.lds ? LE_LDS : 0u) |
                 (s.mask0 ? LE_MASK0 : 0u) | ((uint32_t)s.lvl << LE_LVL_SHIFT);
         }
-    if (spa && !pl.fast) return "LDPC: SPA is only implemented for codes the fast path accepts (check degree <= 27)";
+    if (spa && !pl.fast) return "LDPC: SPA is only implemented for codes the fast path accepts (check degree <= 27, at most 6 duplicate edges per layer)";
     return "";
+}
+
+std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,
+                            const int32_t *addr, int lds_groups_req, size_t lds_limit, bool spa)
+{
+    std::string e = build_plan_impl(pl, N, K, n_rows, row_ptr, addr, lds_groups_req, lds_limit, spa, true);
+    if (e == PLAN_RETRY_GENERIC) { pl = LdpcPlan(); e = build_plan_impl(pl, N, K, n_rows, row_ptr, addr, lds_groups_req, lds_limit, spa, false); }
+    return e;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -639,7 +636,6 @@ static int occ_inst(const LdpcPlan &pl)
 int ldpc_blocks_per_cu(const LdpcPlan &pl)
 {
     if (pl.fast && pl.fast_wg8) return ldpc_wg8_blocks_per_cu(pl);
-    if (pl.fast) return ldpc_fast_blocks_per_cu(pl);
     const bool small = pl.ent_stride == 13;
 #define OCC(H, C) (small ? occ_inst<13, H, C>(pl) : occ_inst<LDPC_MAX_SLOTS, H, C>(pl))
     if (pl.hybrid) return pl.c2v_lds ? OCC(true, true) : OCC(true, false);
@@ -650,7 +646,6 @@ int ldpc_blocks_per_cu(const LdpcPlan &pl)
 hipError_t ldpc_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
     if (pl.fast && pl.fast_wg8) return ldpc_wg8_launch(pl, p, s);
-    if (pl.fast) return ldpc_fast_launch(pl, p, s);
     p.entries = pl.d_entries; p.layer_deg = pl.d_layer_deg; p.layer_lvl = pl.d_layer_lvl; p.groups = pl.d_groups;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.ent_stride = pl.ent_stride; p.lds_post_words = pl.lds_post_words; p.glb_post_words = pl.glb_post_words;

@@ -139,7 +139,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
     auto st_off = [&](int arr, int r) { return st_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u; };
     const int nl_info = p.w8.nl_info, nl = p.w8.nl, ng_info = p.w8.ng_info, ng = p.w8.ng;
     const uint32_t grow0 = 2u * W8_ROW;                      // global image: [junk row][+inf row][group rows ..]
-    constexpr bool FWD = MODE == 3 && !SPA;                  // parity chain forwarded in a register (plan: p_c at slot DEG-2, p_{c-1} at DEG-1, both global)
+    constexpr bool FWD = MODE == 3;                    // parity chain forwarded in a register (plan: p_c at slot DEG-2, p_{c-1} at DEG-1, both global)
 #ifdef LDPC_PHASE_PROF
     uint32_t prof[12];
     for (int i = 0; i < 12; i++) prof[i] = 0u;
@@ -226,75 +226,135 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 const bool mask0 = (r == 0) && (t == 0);        // p_{c-1} of check 0 does not exist
                 if (SPA) {
                     // ================= sum-product layer =================
+                    // Exact check node in the COMPLEMENT-PRODUCT domain (what the oracle's pairwise boxplus recursions evaluate):
+                    //     |out_j| = 2 atanh( prod_{i != j} tanh(a_i / 2) ),  a_i = |v->c_i|.
+                    // With u_i = 1 - tanh(a_i / 2) = 2 e^-a_i / (1 + e^-a_i) -- precise however large a_i is, where tanh itself saturates --
+                    // Q_j = 1 - prod_{i != j} (1 - u_i) follows from prefix and suffix recursions Q_ab = Q_a + Q_b (1 - Q_a) made of
+                    // additions of positive terms only (no cancellation, unlike prod / tanh(a_j / 2)), and |out_j| = ln((2 - Q_j) / Q_j).
+                    // To keep Q inside the fp32 range for LLRs of hundreds, the lane carries Q' = 2^s2 Q with s2 = max(0, (min2 - 16) log2 e):
+                    // an exact change of variable (Q'_ab = Q'_a + Q'_b (1 - kap Q'_a), kap = 2^-s2), chosen from the second smallest
+                    // magnitude so that the sum seen by the WEAKEST edge is representable; should the weakest edge itself then overflow
+                    // (min2 - min1 > 60), the other edges' outputs are min1 to within e^-60.  Per edge: 2 exp + 1 rcp on the way in, 2 log
+                    // on the way out and ~20 full-rate operations, against 2.8 boxplus x (2 exp + 2 log + 12) of the forward / backward form.
                     const uint32_t mrow = st_base + (uint32_t)(r * DEG) * W8_ROW;       // messages of this layer: [slot][360]
+                    const uint32_t dupmask = TE[31];
+                    // the circulant offsets are formed twice, for the loads and again for the stores (an opaque copy of t4 keeps the compiler
+                    // from holding 27 of them across the arithmetic: registers, not instructions, are what this layer is short of)
+                    uint32_t t4s = t4;
                     auto woff = [&](int j) { const uint32_t d = t4 - (E[j] & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
-                    float x[DEG], nw[DEG], dl[DEG];         // v->c, new c->v, new - old (what a duplicate edge adds)
+                    auto woff_s = [&](int j) { const uint32_t d = t4s - (E[j] & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
+                    auto dup_slot = [&](int i) -> uint32_t { return i == 0 ? (cinfo >> 8) & 31u : i == 1 ? (cinfo >> 16) & 31u : T[48 + i] & 31u; };
+                    // suffix values are kept for every BS-th slot only and rebuilt from there on the way forward (one or two steps off the
+                    // critical path): the full array does not fit the 128-VGPR budget of two workgroups per CU beside x[] and u[]
+                    constexpr int BS = 3, NB = (DEG + BS - 1) / BS;
+                    float x[DEG], u[DEG], B[NB];                    // v->c ; 2^s2 (1 - tanh(|v->c| / 2)) ; suffix recursion
+                    float od[LDPC_SPA_MAXC];                        // old c->v of the duplicate edges, then new - old (what such an edge adds)
+                    float mn1 = INFINITY, kap = 1.f, cln = 0.f, key = 0.f;
+                    uint32_t sx = 0u;
+                    auto comb = [&](float a, float b) { return __builtin_fmaf(b, __builtin_fmaf(-kap, a, 1.f), a); };      // Q'_ab
+#pragma unroll
+                    for (int i = 0; i < LDPC_SPA_MAXC; i++) od[i] = 0.f;
                     if (act) {
                         __builtin_amdgcn_s_setprio(3);            // as in the min-sum layer: load issue first, the long arithmetic last
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
                             const uint32_t base = (E[j] >> 11) & 0x3FFFFu, wj = woff(j);
-                            x[j] = w8_slot_lds(MODE, j) ? lld(wj + base) : gld(wj, base);
+                            if (FWD && j == DEG - 1 && r > 0) x[j] = pfw;                  // p_{c-1}: handed over by layer r - 1
+                            else x[j] = w8_slot_lds(MODE, j) ? lld(wj + base) : gld(wj, base);
                         }
-                        if (it == 0) {
+                        if (it > 0) {
+                            float o[DEG];
 #pragma unroll
-                            for (int j = 0; j < DEG; j++) dl[j] = 0.f;                      // no messages yet
-                        } else {
+                            for (int j = 0; j < DEG; j++) o[j] = gld(t4, mrow + (uint32_t)j * W8_ROW);     // old message
 #pragma unroll
-                            for (int j = 0; j < DEG; j++) dl[j] = gld(t4, mrow + (uint32_t)j * W8_ROW);     // old message
+                            for (int i = 0; i < LDPC_SPA_MAXC; i++) if (i < ncf) od[i] = gld(t4, mrow + dup_slot(i) * (uint32_t)W8_ROW);
+                            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                            for (int j = 0; j < DEG; j++) x[j] = x[j] - o[j];
                         }
                         __builtin_amdgcn_s_setprio(0);
+                        if (mask0) x[DEG - 1] = INFINITY;
+                        float mn2 = INFINITY;
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
-                            x[j] = x[j] - dl[j];
-                            if (j == DEG - 1 && mask0) x[j] = INFINITY;
+                            const float a = fabsf(x[j]);
+                            mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);
+                            mn1 = fminf(mn1, a);
+                            sx ^= __float_as_uint(x[j]);
                         }
-                        // new_j = ([+] of the slots before j) [+] ([+] of the slots after j); the neutral +inf at the two ends is not paired
-                        constexpr bool CK = DEG == 13;            // the padded (irregular) instantiation
-                        float acc = x[0];
-                        nw[0] = INFINITY;
+                        const float s2 = fmaxf(0.f, (mn2 - 16.f) * 1.44269504088896341f);
+                        kap = __builtin_amdgcn_exp2f(-s2);
+                        cln = s2 * 0.693147180559945309f;
+                        const float s2p1 = s2 + 1.f, hk = 0.5f * kap;
+                        key = (mn2 - mn1 > 60.f) ? mn1 : __builtin_nanf("");      // a_j <> key: "this edge is not the weakest one and the weakest one overflows"
 #pragma unroll
-                        for (int j = 1; j < DEG; j++) { nw[j] = acc; if (j + 1 < DEG) acc = w8_boxplus<CK>(acc, x[j]); }
-                        acc = x[DEG - 1];
+                        for (int j = 0; j < DEG; j++) {
+                            const float es2 = __builtin_amdgcn_exp2f(__builtin_fmaf(fabsf(x[j]), -1.44269504088896341f, s2p1));      // 2 . 2^s2 e^-a
+                            u[j] = es2 * __builtin_amdgcn_rcpf(__builtin_fmaf(es2, hk, 1.f));                                      // / (1 + e^-a)
+                        }
+                        {
+                            float b = 0.f;      // B_j = Q' of the slots behind j; B[k] = B_{BS k + BS - 1} (clipped to the last slot)
 #pragma unroll
-                        for (int j = DEG - 2; j >= 0; j--) { nw[j] = j == 0 ? acc : w8_boxplus<CK>(nw[j], acc); if (j > 0) acc = w8_boxplus<CK>(acc, x[j]); }
-#pragma unroll
-                        for (int j = 0; j < DEG; j++) dl[j] = nw[j] - dl[j];
+                            for (int j = DEG - 1; j >= 0; j--) {
+                                if (j % BS == BS - 1 || j == DEG - 1) B[j / BS] = b;
+                                b = comb(b, u[j]);
+                            }
+                        }
                     }
                     if (ncf > 0) __syncthreads();         // every read of the layer precedes its writes
                     if (act) {
+                        float A = 0.f;
+                        asm volatile("" : "+v"(t4s));
                         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
+                            const float wA = __builtin_fmaf(-kap, A, 1.f);
+                            float Bj;
+                            {
+                                const int js = (j / BS) * BS + BS - 1 < DEG - 1 ? (j / BS) * BS + BS - 1 : DEG - 1;      // the kept slot at or behind j
+                                Bj = B[j / BS];
+#pragma unroll
+                                for (int i = js; i > j; i--) Bj = comb(Bj, u[i]);
+                            }
+                            const float Q = __builtin_fmaf(Bj, wA, A);
+                            const float lg = __builtin_amdgcn_logf(2.f - Q * kap) - __builtin_amdgcn_logf(Q);
+                            float o = __builtin_fmaf(lg, 0.693147180559945309f, cln);
+                            o = (fabsf(x[j]) < key || fabsf(x[j]) > key) ? mn1 : o;
+                            const float nw = __uint_as_float((__float_as_uint(o) & 0x7FFFFFFFu) | ((sx ^ __float_as_uint(x[j])) & 0x80000000u));
+                            A = __builtin_fmaf(u[j], wA, A);
                             const bool pr = ((prim >> j) & 1u) != 0u;
-                            const uint32_t base = (E[j] >> 11) & 0x3FFFFu, wj = woff(j);
+                            const uint32_t base = (E[j] >> 11) & 0x3FFFFu, wj = woff_s(j);
                             if (w8_slot_lds(MODE, j)) {
                                 uint32_t a = wj + (pr ? base : ljunk);
                                 if (j == DEG - 1 && mask0) a = ljunk;
-                                lst(a, x[j] + nw[j]);
+                                lst(a, x[j] + nw);
                             } else {
                                 const uint32_t sb = (MODE == 3 || pr) ? base : 0u;
-                                gst((j == DEG - 1 && mask0) ? W8_OOB : wj, sb, x[j] + nw[j]);
+                                const uint32_t vo = (j == DEG - 1 && mask0) ? W8_OOB : wj;
+                                if (FWD && j == DEG - 2 && r + 1 < q) pfw = x[j] + nw;      // p_c: kept for layer r + 1
+                                else gst(vo, sb, x[j] + nw);
                             }
-                            gst(t4, mrow + (uint32_t)j * W8_ROW, nw[j]);
+                            gst(t4s, mrow + (uint32_t)j * W8_ROW, nw);
+                            if ((dupmask >> j) & 1u) {          // wave-uniform
+#pragma unroll
+                                for (int i = 0; i < LDPC_SPA_MAXC; i++) if (i < ncf && dup_slot(i) == (uint32_t)j) od[i] = nw - od[i];
+                            }
                         }
                         __builtin_amdgcn_s_setprio(0);
                     }
-                    // duplicate edges: level by level, slot index wave-uniform -> a uniform branch picks the register
+                    // duplicate edges: level by level behind a barrier, as in the min-sum layer
                     uint32_t prev_lvl = 0u;
-                    for (int i = 0; i < ncf; i++) {
+#pragma unroll
+                    for (int i = 0; i < LDPC_SPA_MAXC; i++) {
+                        if (i >= ncf) break;
                         const uint32_t e = i == 0 ? ce0 : i == 1 ? ce1 : T[32 + i];
-                        const uint32_t meta = i == 0 ? ((cinfo >> 8) & 31u) | (1u << 8) : i == 1 ? ((cinfo >> 16) & 31u) | (((cinfo >> 21) & 3u) << 8) : T[48 + i];
-                        const uint32_t jj = meta & 31u, lvl = meta >> 8;
+                        const uint32_t lvl = i == 0 ? 1u : i == 1 ? (cinfo >> 21) & 3u : T[48 + i] >> 8;
                         if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
                         if (act) {
-                            float dv = 0.f;
-#pragma unroll
-                            for (int j = 0; j < DEG; j++) if ((uint32_t)j == jj) dv = dl[j];
                             const uint32_t d = t4 - (e & 0x7FFu);
                             const uint32_t off = min(d, d + (uint32_t)W8_ROW), base = (e >> 11) & 0x3FFFFu;
-                            if (MODE != 1) { const float Lv = lld(off + base); lst(off + base, Lv + dv); }
-                            else { const float Lv = gld(off, base); gst(off, base, Lv + dv); }
+                            if (MODE != 1) { const float Lv = lld(off + base); lst(off + base, Lv + od[i]); }
+                            else { const float Lv = gld(off, base); gst(off, base, Lv + od[i]); }
                         }
                     }
                     {

@@ -10,6 +10,11 @@
   src_K_14232.npy        conf/src/K_14232.src fixed payload (data file), packed bits
   kat_*.npz              known-answer vectors produced by the CPU oracle (seeded), small frames
                          (`python make_golden.py sync` remakes only kat_sync_frame_32apsk.npz)
+  kat_ldpc_normal_8_9.npz, kat_chain_16apsk_normal_20ite.npz
+                         the headline code at size (N = 64800, rate 8/9): two frames at 3.0 / 4.2 dB, NMS 10 iterations, alpha 1.0, QC and
+                         NATURAL order (hard bits, CWD, iteration counts, posteriors as fp32), and BASELINE configs[3]'s chain (16APSK, NMS 20
+                         iterations) for one PL frame -- so the headline parity of the GPU tests does not hang on rebuilding the oracle on the
+                         GPU box (`python make_golden.py normal` remakes only these two)
 """
 import json, os, re, sys
 import numpy as np
@@ -91,6 +96,30 @@ def kats():
     y1 = O.fir(taps, hist, x1); y2 = O.fir(taps, hist, x2)
     np.savez_compressed(os.path.join(HERE, "kat_fir_rrc81.npz"), taps=taps, x1=x1, x2=x2, y1=y1, y2=y2)
 
+def kats_normal():
+    from oracle import oracle as O
+    from helpers import chain, make_llrs, make_pl_frames
+    ch = chain(O, "QPSK-N_8/9")
+    _, l0, c0 = make_llrs(O, "QPSK-N_8/9", 1, 3.0, seed=201)
+    _, l1, c1 = make_llrs(O, "QPSK-N_8/9", 1, 4.2, seed=202)
+    llr = np.concatenate([l0, l1]); cw = np.concatenate([c0, c1])
+    out = dict(llr=llr, cw=np.packbits(cw.astype(np.uint8), axis=1), n_ite=10, alpha=1.0)
+    for tag, sched in (("qc", O.QC), ("nat", O.NATURAL)):
+        for es in (0, 1):
+            b, p_, c, it = ch.ldpc.decode(llr, 10, 1.0, sched=sched, early_stop=bool(es))
+            sfx = "%s%s" % (tag, "_es" if es else "")
+            out["bits_" + sfx] = np.packbits(b.astype(np.uint8), axis=1); out["cwd_" + sfx] = c; out["ites_" + sfx] = np.asarray(it, np.int32)
+            if not es:
+                out["post_" + sfx] = p_
+    assert out["cwd_qc"].tolist() == [0, 1] and out["ites_qc_es"][1] < 10          # one frame that does not converge, one that does
+    np.savez_compressed(os.path.join(HERE, "kat_ldpc_normal_8_9.npz"), **out)
+    ch2 = chain(O, "16APSK-N_8/9")
+    info2, pl, cw2, sigma = make_pl_frames(O, "16APSK-N_8/9", 1, 8.1, seed=203)
+    r = ch2.rx(pl[0], sigma=np.float32(sigma), n_ite=20, alpha=1.0, sched=O.QC, early_stop=False)
+    assert np.array_equal(r["info"], info2[0])
+    np.savez_compressed(os.path.join(HERE, "kat_chain_16apsk_normal_20ite.npz"), pl=pl[0], sigma=np.float32(sigma),
+                        info=np.packbits(info2[0].astype(np.uint8)), llr=r["llr"], out=np.packbits(r["info"].astype(np.uint8)), n_ite=20, alpha=1.0)
+
 def kat_sync():
     """Frame synchronizer (row N4): a noise-free 32APSK-S_3/4 PL stream that starts 321 symbols late."""
     from oracle import oracle as O
@@ -113,7 +142,9 @@ def kat_sync():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "sync":
         kat_sync()
+    elif len(sys.argv) > 1 and sys.argv[1] == "normal":
+        kats_normal()
     else:
-        pl_seq(); refs(); src(); kats(); kat_sync()
+        pl_seq(); refs(); src(); kats(); kat_sync(); kats_normal()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -31,6 +31,40 @@ def test_ldpc_golden(Rx):
     rx.close()
 
 
+def test_ldpc_normal_golden(Rx):
+    """The headline code at size from COMMITTED data (N = 64800 rate 8/9, NMS, 10 iterations, alpha 1.0; one frame at 3.0 dB that does not
+    converge, one at 4.2 dB that does): hard bits, CWD, iteration counts and the posteriors' bit patterns, QC and NATURAL order, fixed
+    iterations and the stopping rule."""
+    from dvbs2_amd import lib_binding as B
+    k = np.load(os.path.join(GOLD, "kat_ldpc_normal_8_9.npz"))
+    rx = Rx("QPSK-N_8/9", max_frames=2, n_ite=int(k["n_ite"]), alpha=float(k["alpha"]), early_stop=False)
+    for tag, sched in (("qc", B.SCHED_QC), ("nat", B.SCHED_NATURAL)):
+        rx.set_ldpc_schedule(sched)
+        rx.set_ldpc_params(int(k["n_ite"]), float(k["alpha"]), False)
+        V, CWD, post, ites = rx.decode_siho(k["llr"], with_post=True)
+        assert np.array_equal(np.packbits(V.astype(np.uint8), axis=1), k["bits_" + tag]) and np.array_equal(CWD, k["cwd_" + tag])
+        assert np.max(np.abs(post - k["post_" + tag])) <= 1e-4 and np.array_equal(post, k["post_" + tag])
+        assert (ites == int(k["n_ite"])).all()
+        rx.set_ldpc_params(int(k["n_ite"]), float(k["alpha"]), True)
+        V, CWD, _, ites = rx.decode_siho(k["llr"], with_post=True)
+        assert np.array_equal(np.packbits(V.astype(np.uint8), axis=1), k["bits_" + tag + "_es"]) and np.array_equal(CWD, k["cwd_" + tag + "_es"])
+        assert np.array_equal(ites, k["ites_" + tag + "_es"])
+    assert k["cwd_qc"].tolist() == [0, 1]
+    rx.close()
+
+
+def test_chain_normal_golden(Rx):
+    """BASELINE configs[3]'s chain (16APSK, N = 64800 8/9, NMS 20 iterations) on one committed PL frame: demapper LLRs and information bits."""
+    k = np.load(os.path.join(GOLD, "kat_chain_16apsk_normal_20ite.npz"))
+    rx = Rx("16APSK-N_8/9", max_frames=1, n_ite=int(k["n_ite"]), alpha=float(k["alpha"]), early_stop=False)
+    out, c0, c1 = rx.rx_bb(k["pl"], sigma=k["sigma"])
+    assert np.array_equal(np.packbits(out[0].astype(np.uint8)), k["out"]) and np.array_equal(k["out"], k["info"]) and c0[0] == 1 and c1[0] == 1
+    x = rx.remove_plh(rx.pl_descramble(k["pl"]))
+    llr = rx.demodulate(k["sigma"], x, deinterleave=True)
+    assert np.all(np.abs(llr[0] - k["llr"]) <= 1e-4 * np.maximum(1.0, np.abs(k["llr"])))
+    rx.close()
+
+
 def test_bch_golden(Rx):
     k = np.load(os.path.join(GOLD, "kat_bch_short.npz"))
     rx = Rx("QPSK-S_8/9", max_frames=6)
