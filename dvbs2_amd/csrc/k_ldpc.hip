@@ -294,7 +294,21 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 pl.w8_lds_junk = (uint32_t)(pl.w8_nl * LDPC_Z * 4);
                 pl.w8_lds_bytes = (pl.w8_nl + 1 + (pl.fast_pad && pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z * 4 + 64;
                 pl.w8_st_base = (uint32_t)((2 + pl.w8_ng) * LDPC_Z * 4);
-                pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + (spa ? pl.fast_deg * M : 3 * M);      // SPA: one fp32 message per edge slot
+                pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + 3 * M;
+                if (spa) {      // SPA: one fp32 message per edge slot, [layer][slot][360]; rows on 128-byte lines (DVBS2HIP_SPA_MPITCH=1440: packed)
+                    const char *ep = getenv("DVBS2HIP_SPA_MPITCH");
+                    pl.w8_mpitch = ep ? (uint32_t)atoi(ep) : (uint32_t)LDPC_Z * 4u;
+                    if (pl.w8_mpitch < (uint32_t)LDPC_Z * 4u || (pl.w8_mpitch & 3u)) return "LDPC: DVBS2HIP_SPA_MPITCH must be a multiple of 4 >= 1440";
+                    if (pl.w8_mpitch % 128u == 0) pl.w8_st_base = (pl.w8_st_base + 127u) & ~127u;
+                    pl.w8_gwork_words = (int)((size_t)pl.w8_st_base / 4 + (size_t)q * pl.fast_deg * (pl.w8_mpitch / 4));
+                }
+                {   // every workgroup's slot starts on a cache-line boundary (a slot of 269 280 or 960 480 bytes left three of four workgroups with
+                    // rows straddling lines differently from their neighbours'); DVBS2HIP_LDPC_SLOT_ALIGN / _PAD (bytes) for experiments
+                    const char *ea = getenv("DVBS2HIP_LDPC_SLOT_ALIGN"), *ep = getenv("DVBS2HIP_LDPC_SLOT_PAD");
+                    const size_t al = ea ? (size_t)atoi(ea) / 4 : 1, pad = ep ? (size_t)atoi(ep) / 4 : 0;
+                    if (al > 1) pl.w8_gwork_words = (int)(((size_t)pl.w8_gwork_words + al - 1) / al * al);
+                    pl.w8_gwork_words += (int)pad;
+                }
             }
             // workspace of one workgroup: [posteriors kept in global memory | packed c->v state 3 M words]
             pl.glb_post_words = pl.fast_mode == 1 ? (pl.n_groups + xrows) * LDPC_Z : pl.fast_mode == 3 ? n_g * LDPC_Z : 0;

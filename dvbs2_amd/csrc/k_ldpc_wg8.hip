@@ -46,6 +46,21 @@ constexpr int W8_IO = 16;                  // independent loads per lane in flig
 constexpr uint32_t W8_OOB = 0x7FFFF000u;    // voffset beyond every workspace: the store is dropped
 __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode == 0 || (mode == 3 && j < W8_NL); }
 
+// development knobs of the SPA layer (tools/build_variant.sh): suffix values kept every SPA_BS-th slot; next layer's messages
+// requested under the current layer's stores; cache policy of the message traffic
+#ifndef SPA_BS
+#define SPA_BS 3
+#endif
+#ifndef SPA_PREFETCH
+#define SPA_PREFETCH 1
+#endif
+#ifndef SPA_AUX
+#define SPA_AUX 0
+#endif
+#ifndef SPA_ABL          // timing-only ablations (wrong results): 1 no message stores, 2 no message loads, 4 no posterior stores to global memory, 8 no check-node arithmetic
+#define SPA_ABL 0
+#endif
+
 #ifdef LDPC_PHASE_PROF
 #define PROF_MARK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[i] += (uint32_t)(n_ - pt_); pt_ = n_; } while (0)
 #else
@@ -58,6 +73,14 @@ __device__ __forceinline__ float and_or(uint32_t a, uint32_t m_sgpr, float b)
     float r;
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m_sgpr), "v"(b));
     return r;
+}
+
+// the lane's index, re-formed where it is needed (two instructions) instead of kept in a register across the layer loop
+__device__ __forceinline__ int w8_lane_now()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
 }
 
 // message on slot j from the packed per-check state: magnitude c1 at the recorded minimum, c2 elsewhere
@@ -104,7 +127,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
         const uint32_t xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);        // HW_REG_XCC_ID
         const uint32_t key = (xcc & 15u) << 8 | ((hw >> 13) & 7u) << 5 | ((hw >> 12) & 1u) << 4 | ((hw >> 8) & 15u);
         s_misc[8] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[key], 1u) & 1u) : 0;
+        s_misc[10] = 0; s_misc[11] = 0; s_misc[12] = 0;      // SPA: the three vote words
     }
+    int nvote = 0;                                           // SPA: votes taken so far (rotation of the vote words)
     __syncthreads();
     int role;
     {
@@ -134,6 +159,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
     asm volatile("" : "+s"(SB));                             // the sign mask as an SGPR operand (VOP3 takes no literal)
     auto gld = [&](uint32_t voff, uint32_t soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0)); };
     auto gst = [&](uint32_t voff, uint32_t soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, 0); };
+    auto mld = [&](uint32_t voff, uint32_t soff) { if (SPA_ABL & 2) return __uint_as_float(voff & 0x3F000000u); return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, SPA_AUX)); };      // SPA messages
+    auto mst = [&](uint32_t voff, uint32_t soff, float v) { if (SPA_ABL & 1) { asm volatile("" :: "v"(v)); return; } __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, SPA_AUX); };
     auto lld = [&](uint32_t a) -> float { return *(lds_float *)(L + a); };
     auto lst = [&](uint32_t a, float v) { *(lds_float *)(L + a) = v; };
     auto st_off = [&](int arr, int r) { return st_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u; };
@@ -153,22 +180,26 @@ ldpc_wg8_kernel(const LdpcKParams p)
     for (int f = blockIdx.x; f < p.n_frames; ) {
         // ---- channel LLRs -> posterior image, W8_IO independent loads per lane in flight; packed state := 0
         const float *Y = p.llr + (size_t)f * p.N;
+        // the frame I/O addresses are formed per frame from an opaque copy of the lane's index: hoisted out of the frame loop they are
+        // ~10 64-bit pointers per lane that the layer loop has no registers for (they were spilled)
+        const int lio = SPA ? w8_lane_now() : lane, tio = SPA ? role * 64 + lio : t;
+        const uint32_t tio4 = SPA ? (uint32_t)tio * 4u : t4;
         __builtin_amdgcn_s_setprio(3);                       // frame I/O: short bursts of loads that the other workgroup's arithmetic should not delay
         if (act) {
             // info groups: coalesced rows of 360, streamed in once (non-temporal)
             for (int l0 = 0; l0 < nl_info; l0 += W8_IO) {
                 float v[W8_IO];
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) v[k] = __builtin_nontemporal_load(&Y[(int)rows[l0 + k < nl_info ? l0 + k : nl_info - 1] * LDPC_Z + t]);
+                for (int k = 0; k < W8_IO; k++) v[k] = __builtin_nontemporal_load(&Y[(int)rows[l0 + k < nl_info ? l0 + k : nl_info - 1] * LDPC_Z + tio]);
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) if (l0 + k < nl_info) lst((uint32_t)(l0 + k) * W8_ROW + t4, v[k]);
+                for (int k = 0; k < W8_IO; k++) if (l0 + k < nl_info) lst((uint32_t)(l0 + k) * W8_ROW + tio4, v[k]);
             }
             for (int l0 = 0; l0 < ng_info; l0 += W8_IO) {
                 float v[W8_IO];
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) v[k] = __builtin_nontemporal_load(&Y[(int)rows[nl + (l0 + k < ng_info ? l0 + k : ng_info - 1)] * LDPC_Z + t]);
+                for (int k = 0; k < W8_IO; k++) v[k] = __builtin_nontemporal_load(&Y[(int)rows[nl + (l0 + k < ng_info ? l0 + k : ng_info - 1)] * LDPC_Z + tio]);
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) if (l0 + k < ng_info) gst(t4, grow0 + (uint32_t)(l0 + k) * W8_ROW, v[k]);
+                for (int k = 0; k < W8_IO; k++) if (l0 + k < ng_info) gst(tio4, grow0 + (uint32_t)(l0 + k) * W8_ROW, v[k]);
             }
         }
         if (role >= 0) {
@@ -180,15 +211,15 @@ ldpc_wg8_kernel(const LdpcKParams p)
             const const_u32 prow = rows + nl + ng;
             // element e = 64 i + lane of the wave's region is (check tl = e / q, parity group r = e mod q): stepped, not divided
             const int dq = 64 / q, dr = 64 - dq * q;
-            int tl = lane / q, r = lane - tl * q;
+            int tl = lio / q, r = lio - tl * q;
             constexpr int PIO = 8;
             for (int i0 = 0; i0 < q; i0 += PIO) {
                 float v[PIO];
 #pragma unroll
-                for (int k = 0; k < PIO; k++) { const int e = (i0 + k) * 64 + lane; v[k] = e < cnt ? Yp[e] : 0.f; }
+                for (int k = 0; k < PIO; k++) { const int e = (i0 + k) * 64 + lio; v[k] = e < cnt ? Yp[e] : 0.f; }
 #pragma unroll
                 for (int k = 0; k < PIO; k++) {
-                    if ((i0 + k) * 64 + lane < cnt) {
+                    if ((i0 + k) * 64 + lio < cnt) {
                         const uint32_t loc = prow[r], off = (loc & 0x7FFFFFFFu) + (uint32_t)(tl0 + tl) * 4u;
                         if (loc >> 31) gst(off, 0u, v[k]); else lst(off, v[k]);
                     }
@@ -202,7 +233,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
             // reads of the first iteration are replaced by zeros where they happen (nx* / dl[] below)
             if (p.w8.pad) { if (MODE == 0) lst(ljunk + W8_ROW + t4, INFINITY); else gst(t4, W8_ROW, INFINITY); }     // what NULL slots read
         }
-        if (p.packed && threadIdx.x == 0 && (p.K & 31)) p.packed[(size_t)f * ((p.K + 31) / 32) + p.K / 32] = 0u;     // the bits behind K in the last word
+        if (p.packed && (SPA ? wave == 0 && lio == 0 : threadIdx.x == 0) && (p.K & 31)) p.packed[(size_t)f * ((p.K + 31) / 32) + p.K / 32] = 0u;     // the bits behind K in the last word
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         PROF_MARK(8);
@@ -211,6 +242,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
         bool ok = false;
         float nx1 = 0.f, nx2 = 0.f, nxk = 0.f;           // packed state of the next layer (prefetched)
         float pfw = 0.f;                                 // posterior of parity bit q t + r after layer r, on its way to layer r + 1
+        float onx[SPA ? DEG : 1];                        // SPA: old messages of the NEXT layer, requested while this layer's stores drain
+#pragma unroll
+        for (int j = 0; j < (SPA ? DEG : 1); j++) onx[j] = 0.f;
         // layer table of the NEXT layer, fetched under the end-of-layer barrier: 27 slots | prim | conflict info | 2 conflict entries
         uint32_t TE[32];
 #pragma unroll
@@ -236,7 +270,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     // magnitude so that the sum seen by the WEAKEST edge is representable; should the weakest edge itself then overflow
                     // (min2 - min1 > 60), the other edges' outputs are min1 to within e^-60.  Per edge: 2 exp + 1 rcp on the way in, 2 log
                     // on the way out and ~20 full-rate operations, against 2.8 boxplus x (2 exp + 2 log + 12) of the forward / backward form.
-                    const uint32_t mrow = st_base + (uint32_t)(r * DEG) * W8_ROW;       // messages of this layer: [slot][360]
+                    const uint32_t mpitch = p.w8.mpitch;
+                    const uint32_t mrow = st_base + (uint32_t)(r * DEG) * mpitch;       // messages of this layer: [slot][360 of mpitch / 4]
                     const uint32_t dupmask = TE[31];
                     // the circulant offsets are formed twice, for the loads and again for the stores (an opaque copy of t4 keeps the compiler
                     // from holding 27 of them across the arithmetic: registers, not instructions, are what this layer is short of)
@@ -246,7 +281,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     auto dup_slot = [&](int i) -> uint32_t { return i == 0 ? (cinfo >> 8) & 31u : i == 1 ? (cinfo >> 16) & 31u : T[48 + i] & 31u; };
                     // suffix values are kept for every BS-th slot only and rebuilt from there on the way forward (one or two steps off the
                     // critical path): the full array does not fit the 128-VGPR budget of two workgroups per CU beside x[] and u[]
-                    constexpr int BS = 3, NB = (DEG + BS - 1) / BS;
+                    constexpr int BS = SPA_BS, NB = (DEG + BS - 1) / BS;
                     float x[DEG], u[DEG], B[NB];                    // v->c ; 2^s2 (1 - tanh(|v->c| / 2)) ; suffix recursion
                     float od[LDPC_SPA_MAXC];                        // old c->v of the duplicate edges, then new - old (what such an edge adds)
                     float mn1 = INFINITY, kap = 1.f, cln = 0.f, key = 0.f;
@@ -263,16 +298,16 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             else x[j] = w8_slot_lds(MODE, j) ? lld(wj + base) : gld(wj, base);
                         }
                         if (it > 0) {
-                            float o[DEG];
+#if !SPA_PREFETCH
 #pragma unroll
-                            for (int j = 0; j < DEG; j++) o[j] = gld(t4, mrow + (uint32_t)j * W8_ROW);     // old message
+                            for (int j = 0; j < DEG; j++) onx[j] = mld(t4, mrow + (uint32_t)j * mpitch);     // old message
+#endif
 #pragma unroll
-                            for (int i = 0; i < LDPC_SPA_MAXC; i++) if (i < ncf) od[i] = gld(t4, mrow + dup_slot(i) * (uint32_t)W8_ROW);
-                            __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-                            for (int j = 0; j < DEG; j++) x[j] = x[j] - o[j];
+                            for (int i = 0; i < LDPC_SPA_MAXC; i++) if (i < ncf) od[i] = mld(t4, mrow + dup_slot(i) * mpitch);
                         }
                         __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                        for (int j = 0; j < DEG; j++) x[j] = x[j] - onx[j];      // zeros in the first iteration
                         if (mask0) x[DEG - 1] = INFINITY;
                         float mn2 = INFINITY;
 #pragma unroll
@@ -289,8 +324,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         key = (mn2 - mn1 > 60.f) ? mn1 : __builtin_nanf("");      // a_j <> key: "this edge is not the weakest one and the weakest one overflows"
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
-                            const float es2 = __builtin_amdgcn_exp2f(__builtin_fmaf(fabsf(x[j]), -1.44269504088896341f, s2p1));      // 2 . 2^s2 e^-a
-                            u[j] = es2 * __builtin_amdgcn_rcpf(__builtin_fmaf(es2, hk, 1.f));                                      // / (1 + e^-a)
+                            const float ea = __builtin_fmaf(fabsf(x[j]), -1.44269504088896341f, s2p1);
+                            const float es2 = (SPA_ABL & 8) ? ea : __builtin_amdgcn_exp2f(ea);                                     // 2 . 2^s2 e^-a
+                            u[j] = es2 * ((SPA_ABL & 8) ? hk : __builtin_amdgcn_rcpf(__builtin_fmaf(es2, hk, 1.f)));               // / (1 + e^-a)
                         }
                         {
                             float b = 0.f;      // B_j = Q' of the slots behind j; B[k] = B_{BS k + BS - 1} (clipped to the last slot)
@@ -317,7 +353,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                                 for (int i = js; i > j; i--) Bj = comb(Bj, u[i]);
                             }
                             const float Q = __builtin_fmaf(Bj, wA, A);
-                            const float lg = __builtin_amdgcn_logf(2.f - Q * kap) - __builtin_amdgcn_logf(Q);
+                            const float lg = (SPA_ABL & 8) ? Q : __builtin_amdgcn_logf(2.f - Q * kap) - __builtin_amdgcn_logf(Q);
                             float o = __builtin_fmaf(lg, 0.693147180559945309f, cln);
                             o = (fabsf(x[j]) < key || fabsf(x[j]) > key) ? mn1 : o;
                             const float nw = __uint_as_float((__float_as_uint(o) & 0x7FFFFFFFu) | ((sx ^ __float_as_uint(x[j])) & 0x80000000u));
@@ -332,14 +368,28 @@ ldpc_wg8_kernel(const LdpcKParams p)
                                 const uint32_t sb = (MODE == 3 || pr) ? base : 0u;
                                 const uint32_t vo = (j == DEG - 1 && mask0) ? W8_OOB : wj;
                                 if (FWD && j == DEG - 2 && r + 1 < q) pfw = x[j] + nw;      // p_c: kept for layer r + 1
+                                else if (SPA_ABL & 4) asm volatile("" :: "v"(x[j] + nw), "v"(vo), "s"(sb));
                                 else gst(vo, sb, x[j] + nw);
                             }
-                            gst(t4s, mrow + (uint32_t)j * W8_ROW, nw);
+                            mst(t4s, mrow + (uint32_t)j * mpitch, nw);
                             if ((dupmask >> j) & 1u) {          // wave-uniform
 #pragma unroll
                                 for (int i = 0; i < LDPC_SPA_MAXC; i++) if (i < ncf && dup_slot(i) == (uint32_t)j) od[i] = nw - od[i];
                             }
                         }
+#if SPA_PREFETCH
+                        // the messages of the next layer do not depend on this one: their loads (HBM misses, the message store is
+                        // streamed through once per iteration) go out now and travel while this layer's stores drain at the barriers
+                        __builtin_amdgcn_sched_barrier(0);      // not earlier: x[], u[], B[] have to be dead first (registers)
+                        if ((it > 0 || r + 1 == q) && !(r + 1 == q && it + 1 >= p.n_ite)) {
+                            const uint32_t mnext = st_base + (uint32_t)((r + 1 < q ? r + 1 : 0) * DEG) * mpitch;
+#pragma unroll
+                            for (int j = 0; j < DEG; j++) onx[j] = mld(t4s, mnext + (uint32_t)j * mpitch);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < DEG; j++) onx[j] = 0.f;
+                        }
+#endif
                         __builtin_amdgcn_s_setprio(0);
                     }
                     // duplicate edges: level by level behind a barrier, as in the min-sum layer
@@ -514,6 +564,18 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 //      one vote, after the last layer, as before (a vote per layer in that mode too made the bench 0.4 % slower)
                 ok = true;
                 int bad = 0;
+                // SPA: the workgroup's vote as a ballot per wave + one LDS word out of three in rotation (zeroed two votes ahead), one
+                // barrier per vote; __syncthreads_or keeps the 64-bit thread index alive across the layer loop, which this kernel spills
+                auto vote = [&](int b) -> bool {
+                    if (!SPA) return __syncthreads_or(b) != 0;
+                    const bool any = __ballot(b != 0) != 0ull;
+                    lds_int *const w = s_misc + 10;
+                    const int k = nvote % 3;
+                    nvote++;
+                    if (w8_lane_now() == 0) { if (any) w[k] = 1; if (wave == 0) w[(k + 1) % 3] = 0; }
+                    __syncthreads();
+                    return w[k] != 0;
+                };
                 for (int r = 0; r < q; r++) {
                     if (act) {
                         const const_u32 T = tab + r * LDPC_FAST_STRIDE;
@@ -531,7 +593,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         for (int j = 0; j < DEG; j++) x ^= __float_as_uint(Lv[j]);             // NULL slots read +inf
                         bad |= (int)(x >> 31);
                     }
-                    if ((p.early_stop || r == q - 1) && __syncthreads_or(bad)) { ok = false; break; }
+                    if ((p.early_stop || r == q - 1) && vote(bad)) { ok = false; break; }
                 }
                 PROF_MARK(6);
                 if (ok) break;
@@ -539,7 +601,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
         }
 
         // ---- outputs: hard decisions of the info bits (image rows in storage order, W8_IO loads in flight)
-        if (threadIdx.x == 0) {
+        const int lo = SPA ? w8_lane_now() : lane, to = SPA ? role * 64 + lo : t;
+        const bool first = SPA ? wave == 0 && lo == 0 : threadIdx.x == 0;
+        if (first) {
             if (p.cwd) p.cwd[f] = ok ? 1 : 0;
             if (p.ites) p.ites[f] = it;
         }
@@ -553,15 +617,15 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 const int kb = g * LDPC_Z + role * 64;
                 const const_u32 pq = prbs_c + 2 * (g * 6 + role);
                 const unsigned long long m64 = (unsigned long long)pq[0] | ((unsigned long long)pq[1] << 32);
-                const int k = kb + lane;
+                const int k = kb + lo;
                 if (act && k < p.K_info)
-                    __builtin_nontemporal_store((int32_t)((Lv < 0.f ? 1u : 0u) ^ (uint32_t)((m64 >> lane) & 1ull)), &p.info_out[(size_t)f * p.K_info + k]);
+                    __builtin_nontemporal_store((int32_t)((Lv < 0.f ? 1u : 0u) ^ (uint32_t)((m64 >> lo) & 1ull)), &p.info_out[(size_t)f * p.K_info + k]);
             }
             if (act) {
                 if (g < p.n_info) {
-                    if (p.bits) __builtin_nontemporal_store((int32_t)(Lv < 0.f ? 1 : 0), &p.bits[(size_t)f * p.K + g * LDPC_Z + t]);
-                    if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + t] = Lv;
-                } else if (p.post) p.post[(size_t)f * p.N + p.K + q * t + (g - p.n_info)] = Lv;
+                    if (p.bits) __builtin_nontemporal_store((int32_t)(Lv < 0.f ? 1 : 0), &p.bits[(size_t)f * p.K + g * LDPC_Z + to]);
+                    if (p.post) p.post[(size_t)f * p.N + g * LDPC_Z + to] = Lv;
+                } else if (p.post) p.post[(size_t)f * p.N + p.K + q * to + (g - p.n_info)] = Lv;
             }
             if (p.packed && role >= 0 && g < p.n_info) {
                 // 64 lanes = 64 consecutive info bits starting at bit o = 360 g + 64 role of the frame: o is a multiple of 8, so the
@@ -569,7 +633,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 // no atomics and no zeroing of the image
                 const unsigned long long m = __ballot(act && Lv < 0.f);
                 const int o8 = g * (LDPC_Z / 8) + role * 8, nb = role * 64 + 64 <= LDPC_Z ? 8 : (LDPC_Z - role * 64) / 8;
-                if (lane < nb) reinterpret_cast<uint8_t *>(p.packed + (size_t)f * n_words)[o8 + lane] = (uint8_t)(m >> (8 * lane));
+                if (lo < nb) reinterpret_cast<uint8_t *>(p.packed + (size_t)f * n_words)[o8 + lo] = (uint8_t)(m >> (8 * lo));
             }
         };
         const int nl_out = p.post ? nl : nl_info, ng_out = p.post ? ng : ng_info;
@@ -589,9 +653,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 for (int k = 0; k < W8_IO; k++) if (l0 + k < ng_out) emit((int)rows[nl + l0 + k], v[k]);
             }
         }
-        if (threadIdx.x == 0) s_misc[9] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[LDPC_FRAME_CTR], 1u) + gridDim.x) : f + (int)gridDim.x;
+        if (first) s_misc[9] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[LDPC_FRAME_CTR], 1u) + gridDim.x) : f + (int)gridDim.x;
         __syncthreads();     // the posterior image is reused by the next frame of this workgroup
-        f = s_misc[9];
+        f = SPA ? __builtin_amdgcn_readfirstlane(s_misc[9]) : s_misc[9];      // (uniform: the frame's base addresses stay on the scalar unit)
         PROF_MARK(7);
 #ifdef LDPC_PHASE_PROF
         prof[9]++;                                            // frames this workgroup decoded
@@ -674,6 +738,7 @@ hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
     p.cu_ctr = pl.d_cu_ctr;
     p.w8.tab = pl.d_w8_tab; p.w8.rows = pl.d_w8_rows;
     p.w8.st_base = pl.w8_st_base; p.w8.lds_junk = pl.w8_lds_junk; p.w8.lds_bytes = pl.w8_lds_bytes; p.w8.pad = pl.fast_pad ? 1 : 0;
+    p.w8.mpitch = pl.w8_mpitch;
     p.w8.nl_info = pl.w8_nl_info; p.w8.nl = pl.w8_nl; p.w8.ng_info = pl.w8_ng_info; p.w8.ng = pl.w8_ng;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.gwork_words = pl.w8_gwork_words;

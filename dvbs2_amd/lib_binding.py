@@ -152,7 +152,7 @@ def load(build_if_missing: bool = True):
                 import torch  # noqa: F401
             except ImportError:
                 pass
-        path = _build.LIB
+        path = os.environ.get("DVBS2HIP_LIB", _build.LIB)      # development: another build of the same sources (tools/build_variant.sh)
         if not os.path.exists(path):
             if not build_if_missing:
                 raise Dvbs2HipError(-5, "libdvbs2hip.so not built (%s); there is no CPU fallback" % path)
