@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra launches (3.0 dB batch, early-stop rates): under rocprofv3 every LDPC launch is then the timed workload")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
+    ap.add_argument("--self-check-steps", type=int, default=200, help="the timed loop once more with this many steps after the timed region (untimed for `value`; ~1.4 s of "
+                    "uninterrupted kernel time, so that an outside observer's SMI samples can see the GPU busy); 0 = off")
     args = ap.parse_args()
 
     import torch
@@ -143,6 +145,15 @@ def main():
     elapsed = reduce_max(elapsed, dev)
     k_ms, k_n = rx.timing_get(B.K_LDPC)          # HIP events on the launch stream, per launch
     rx.timing_enable(False)
+    self_check = None
+    if args.self_check_steps > 0:
+        t1 = time.perf_counter()
+        for _ in range(args.self_check_steps):
+            step()
+        rx.synchronize()
+        sc = time.perf_counter() - t1
+        self_check = {"steps": args.self_check_steps, "ms_per_step": 1e3 * sc / args.self_check_steps, "seconds": sc,
+                      "what": "the timed loop again, longer and untimed for `value`: the same step() back to back on this rank"}
 
     # ---- correctness of what was timed (untimed): BER/FER of the decoded batch, summed over ranks
     ref = torch.from_numpy(info).to(dev)[sel]
@@ -163,6 +174,7 @@ def main():
     Fh = int(llr_hard.shape[0])
     hard, es, copy_gbps, chain = None, {}, None, None
     if not args.no_extras:
+      timed(llr_hard, Fh, 1)          # warm-up launch (first use of this tensor and batch size), as for the early-stop points below
       dt_hard = timed(llr_hard, Fh, 3)
       ref_h = torch.from_numpy(info).to(dev)[sel_h]
       be_h = (bits[:Fh] != ref_h).sum(dim=1)
@@ -236,6 +248,8 @@ def main():
         # (fabric traffic against the Infinity-Cache rate) and the bytes that must cross HBM in `hbm_true`.
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     # what physically binds the kernel, for anything that parses a fraction of a real ceiling: the fabric figure of `bounded`
+                     "binding_resource": "fabric", "algorithmic_frac": achieved / HBM_PEAK_GBPS, "bounded_frac": bounded["frac"] if bounded else None,
                      "kernel": kname, "kernel_sha": kernel_sha(), "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_n,
                      "algorithmic_bytes_per_launch": bytes_per_frame * F, "algorithmic_GBps": achieved,
                      "bounded": bounded,
@@ -243,6 +257,7 @@ def main():
                                   "frac": io_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBPS if k_n else 0.0,
                                   "what": "(4 N + 4 K) bytes per frame: the LLRs in and the hard decisions out, the only bytes that have to cross HBM"},
                      "hbm_copy_GBps_measured": copy_gbps},
+        "self_check": self_check,
         "extra": {"hard_batch_fixed_10_ite": hard, "fused_rx_chain": chain,
                   "early_stop_fps": {k: v["fec_frames_per_s"] for k, v in es.items()}, "early_stop": es,
                   "early_stop_note": "the reference's default rule (syndrome check after every iteration, enable_syndrome); untimed for `value`, 3 launches each"},
@@ -288,21 +303,31 @@ def _copy_bandwidth(torch, dev):
 
 
 def cpu_baseline(mc, llr, target_s):
-    """CPU leg: the oracle's AFF3CT-style decoder (natural row order, fp32, NMS 10 ite) timed on the
-    host cores on a bounded sample of the same LLRs, in the two flavours the reference offers:
-    scalar (`--dec-simd ""`) and inter-frame SIMD (`--dec-simd INTER`, 16 frames per vector); the
-    faster one is `value`.  Checker code used as a reported baseline only -- never on the product path."""
+    """CPU leg: the oracle's AFF3CT-style decoder (natural row order, fp32, NMS 10 ite) timed on the host cores on a bounded sample of
+    the same LLRs, in the two flavours the reference offers: scalar (`--dec-simd ""`) and inter-frame SIMD (`--dec-simd INTER`, one frame
+    per lane of a vector register); the faster one is `value`.  The library that is timed is compiled HERE, on the host it runs on, with
+    the reference's own flags (-O3 -march=native -funroll-loops, README.md:103; 512-bit vectors where the host has them: oracle/Makefile
+    `native`) -- the portable x86-64-v3 build stays the tests' checker.  Checker code used as a reported baseline only, never on the
+    product path."""
     from oracle import oracle as O
     from dvbs2_amd import params as P
     rp, ad = P.load_ldpc_table(mc.ldpc_table)
-    code = O.Ldpc(mc.N_ldpc, mc.K_ldpc, rp, ad)
+    try:
+        code = O.NativeLdpc(mc.N_ldpc, mc.K_ldpc, rp, ad)
+        build, isa, width = "-O3 -march=native -mprefer-vector-width=512 -funroll-loops (built on this host)", O.native_isa(), code.inter_width
+    except Exception as e:      # no compiler on this host: the portable build the snapshot carries
+        code = O.Ldpc(mc.N_ldpc, mc.K_ldpc, rp, ad)
+        build, isa, width = "-O3 -march=x86-64-v3 -funroll-loops (portable build; native build failed: %s)" % type(e).__name__, "ymm", O.lib().orc_ldpc_inter_width()
     ncpu = os.cpu_count() or 1
-    res = {}
-    for kind, quantum in (("scalar", 1), ("inter16", 16)):
+    res, one = {}, {}
+    for kind, quantum in (("scalar", 1), ("inter", width)):
         def fn(x, thr):
             if kind == "scalar":
                 return code.decode_batch_timed(x, n_ite=N_ITE, alpha=1.0, sched=O.NATURAL, threads=thr)
             return code.decode_batch_inter_timed(x, n_ite=N_ITE, alpha=1.0, threads=thr)
+        x1 = llr[:2 * quantum].cpu().numpy()
+        fn(x1, 1)
+        one[kind] = x1.shape[0] / fn(x1, 1)[1]                 # frames/s of ONE thread: what the vector flavour buys per core
         # the box may give this job fewer cores than it shows (and SMT pairs share the 1 MB L2 a frame's 1.8 MB of
         # state already overflows): probe a few thread counts on a small sample and keep the fastest
         best_thr, best_rate = 1, 0.0
@@ -322,6 +347,8 @@ def cpu_baseline(mc, llr, target_s):
             "sample": "%d frames of the same batch, oracle layered NMS (natural row order, fp32, 10 ite, %s flavour, frames "
                       "sharded over %d threads -- the fastest of %d/8, /4, /2 and all %d hardware threads), %.1f s"
                       % (n, best, cores, ncpu, ncpu, sec),
+            "build": build, "isa": isa, "frames_per_vector": width,
+            "one_thread_frames_per_s": one, "inter_over_scalar_per_core": one["inter"] / one["scalar"],
             "flavours_frames_per_s": {k: v[0] / v[1] for k, v in res.items()}, "flavours_threads": {k: v[2] for k, v in res.items()}}
 
 

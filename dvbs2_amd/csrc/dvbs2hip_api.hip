@@ -4,6 +4,8 @@
 #include "dvbs2_tables_gen.h"
 #include <dlfcn.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <time.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -847,9 +849,15 @@ int dvbs2hip_filter2_dev(dvbs2hip_t *h, const float *X, const float *Yh, float *
     const int split = dvbs2hip_filter_split(h, n_cplx);
     if (split < 0) return fail(h, DVBS2HIP_EINVAL, "filter1 / filter2: half a frame has to hold the filter's memory (n_cplx / 2 >= n_taps - 1)");
     const size_t hb = sizeof(float) * 2 * (size_t)(h->fir_T > 1 ? h->fir_T - 1 : 1);
-    if (!h->d_hist_zero) {
-        HIPCHK(h, hipMalloc((void **)&h->d_hist_zero, hb)); HIPCHK(h, hipMalloc((void **)&h->d_hist_junk, hb));
-        HIPCHK(h, hipMemsetAsync(h->d_hist_zero, 0, hb, h->stream));
+    if (!h->d_hist_zero || !h->d_hist_junk) {      // both buffers, zeroed, or neither: the handle only ever sees the complete pair
+        float *z = nullptr, *j = nullptr;
+        hipError_t e = hipMalloc((void **)&z, hb);
+        if (e == hipSuccess) e = hipMalloc((void **)&j, hb);
+        if (e == hipSuccess) e = hipMemsetAsync(z, 0, hb, h->stream);
+        if (e != hipSuccess) { if (z) (void)hipFree(z); if (j) (void)hipFree(j); HIPCHK(h, e); }
+        if (h->d_hist_zero) (void)hipFree(h->d_hist_zero);
+        if (h->d_hist_junk) (void)hipFree(h->d_hist_junk);
+        h->d_hist_zero = z; h->d_hist_junk = j;
     }
     void *tmp;
     const size_t row = sizeof(float) * 2 * (size_t)n_cplx;
@@ -1356,26 +1364,96 @@ const char *rccl_load()
 std::string rccl_err(int e) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : ("rccl error " + std::to_string(e)); }
 }  // namespace
 
-// rank 0 publishes `bytes` bytes in the file `path` (written beside, then renamed: a reader never sees a partial file), every other rank polls
-// for it.  No GPU involved: this is the out-of-band step of the RCCL bootstrap, exported so that it can be exercised by two CPU processes.
-int dvbs2hip_rendezvous(int32_t rank, const char *path, void *blob, size_t bytes, int32_t timeout_ms)
+// The out-of-band step of the RCCL bootstrap (no GPU involved; exported so that CPU processes can exercise it): rank 0 hands `bytes`
+// bytes to every other rank through files named after `path`.  A file found under that name is never trusted for being there (a run
+// that crashed leaves files behind, and a fixed name under /tmp can be squatted): every reader publishes a fresh random nonce in
+// `path.hello.<rank>` and accepts only a `path.ack.<rank>` that carries the same nonce in front of the payload; rank 0 answers every
+// hello it sees, answers again when a hello's nonce changes (a stale hello being replaced by the live reader's), and is done with a
+// rank once that rank has consumed (removed) its ack.  Nothing is left behind by a successful exchange.  Files are created beside and
+// renamed (nobody reads a partial file), with O_EXCL | O_NOFOLLOW and mode 0600; a private directory is still the better place.
+namespace {
+constexpr size_t RDV_NONCE = 16;
+bool rdv_write(const std::string &name, const void *a, size_t na, const void *b, size_t nb)
 {
-    if (rank < 0 || !path || !*path || !blob || !bytes) return DVBS2HIP_EINVAL;
-    if (rank == 0) {
-        const std::string tmp = std::string(path) + ".tmp";
-        FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(blob, bytes, 1, f) != 1) { if (f) fclose(f); return fail(nullptr, DVBS2HIP_EINVAL, "cannot write the rendezvous file " + tmp); }
-        fclose(f);
-        if (rename(tmp.c_str(), path)) return fail(nullptr, DVBS2HIP_EINVAL, std::string("cannot publish the rendezvous file ") + path);
-        return 0;
+    const std::string tmp = name + ".tmp." + std::to_string((long long)getpid());
+    (void)unlink(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+    if (fd < 0) return false;
+    bool ok = (size_t)write(fd, a, na) == na && (nb == 0 || (size_t)write(fd, b, nb) == nb);
+    ok = close(fd) == 0 && ok;
+    if (ok) ok = rename(tmp.c_str(), name.c_str()) == 0;
+    if (!ok) (void)unlink(tmp.c_str());
+    return ok;
+}
+bool rdv_read(const std::string &name, void *buf, size_t n)      // true only for a regular file that holds exactly n bytes
+{
+    const int fd = open(name.c_str(), O_RDONLY | O_NOFOLLOW);
+    if (fd < 0) return false;
+    std::vector<unsigned char> tmp(n + 1);
+    size_t got = 0;
+    for (;;) { const ssize_t r = read(fd, tmp.data() + got, n + 1 - got); if (r <= 0) break; got += (size_t)r; if (got > n) break; }
+    close(fd);
+    if (got != n) return false;
+    memcpy(buf, tmp.data(), n);
+    return true;
+}
+void rdv_nonce(unsigned char *n)
+{
+    bool ok = false;
+    const int fd = open("/dev/urandom", O_RDONLY);
+    if (fd >= 0) { ok = read(fd, n, RDV_NONCE) == (ssize_t)RDV_NONCE; close(fd); }
+    if (!ok) {
+        struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+        unsigned long long v[2] = {(unsigned long long)ts.tv_nsec ^ ((unsigned long long)getpid() << 32), (unsigned long long)ts.tv_sec ^ (unsigned long long)(uintptr_t)n};
+        memcpy(n, v, RDV_NONCE);
     }
+}
+}  // namespace
+
+int dvbs2hip_rendezvous(int32_t rank, int32_t world, const char *path, void *blob, size_t bytes, int32_t timeout_ms)
+{
+    if (world < 1 || rank < 0 || rank >= world || !path || !*path || !blob || !bytes) return DVBS2HIP_EINVAL;
+    if (world == 1) return 0;
+    const std::string base(path);
     const int step_ms = 20;
-    for (int waited = 0;; waited += step_ms) {
-        FILE *f = fopen(path, "rb");
-        if (f) { const size_t n = fread(blob, 1, bytes, f); fclose(f); if (n == bytes) return 0; }
-        if (timeout_ms >= 0 && waited >= timeout_ms) return fail(nullptr, DVBS2HIP_EHIP, std::string("timed out waiting for the rendezvous file ") + path);
-        usleep(step_ms * 1000);
+    if (rank > 0) {
+        unsigned char nonce[RDV_NONCE];
+        rdv_nonce(nonce);
+        const std::string hello = base + ".hello." + std::to_string(rank), ack = base + ".ack." + std::to_string(rank);
+        if (!rdv_write(hello, nonce, RDV_NONCE, nullptr, 0)) return fail(nullptr, DVBS2HIP_EINVAL, "cannot write the rendezvous file " + hello);
+        std::vector<unsigned char> buf(RDV_NONCE + bytes);
+        for (int waited = 0;; waited += step_ms) {
+            if (rdv_read(ack, buf.data(), buf.size()) && !memcmp(buf.data(), nonce, RDV_NONCE)) {
+                memcpy(blob, buf.data() + RDV_NONCE, bytes);
+                (void)unlink(ack.c_str()); (void)unlink(hello.c_str());
+                return 0;
+            }
+            if (timeout_ms >= 0 && waited >= timeout_ms) { (void)unlink(hello.c_str()); return fail(nullptr, DVBS2HIP_EHIP, "timed out waiting for rank 0 at the rendezvous " + base); }
+            usleep(step_ms * 1000);
+        }
     }
+    std::vector<char> acked(world, 0), done(world, 0);
+    std::vector<unsigned char> nonces((size_t)world * RDV_NONCE, 0);
+    int left = world - 1;
+    for (int waited = 0; left > 0; waited += step_ms) {
+        for (int r = 1; r < world; r++) {
+            if (done[r]) continue;
+            const std::string hello = base + ".hello." + std::to_string(r), ack = base + ".ack." + std::to_string(r);
+            unsigned char n[RDV_NONCE];
+            if (rdv_read(hello, n, RDV_NONCE) && (!acked[r] || memcmp(n, &nonces[(size_t)r * RDV_NONCE], RDV_NONCE))) {
+                if (!rdv_write(ack, n, RDV_NONCE, blob, bytes)) return fail(nullptr, DVBS2HIP_EINVAL, "cannot write the rendezvous file " + ack);
+                memcpy(&nonces[(size_t)r * RDV_NONCE], n, RDV_NONCE); acked[r] = 1;
+            } else if (acked[r] && access(ack.c_str(), F_OK) != 0) { done[r] = 1; left--; }      // consumed by its reader
+        }
+        if (left > 0) {
+            if (timeout_ms >= 0 && waited >= timeout_ms) {
+                for (int r = 1; r < world; r++) if (acked[r] && !done[r]) (void)unlink((base + ".ack." + std::to_string(r)).c_str());
+                return fail(nullptr, DVBS2HIP_EHIP, "timed out waiting for " + std::to_string(left) + " rank(s) at the rendezvous " + base);
+            }
+            usleep(step_ms * 1000);
+        }
+    }
+    return 0;
 }
 
 int dvbs2hip_monitor_reduce_init(dvbs2hip_t *h, int32_t rank, int32_t world, const char *rendezvous, int32_t timeout_ms)
@@ -1392,7 +1470,7 @@ int dvbs2hip_monitor_reduce_init(dvbs2hip_t *h, int32_t rank, int32_t world, con
         if (e) return fail(h, DVBS2HIP_EHIP, "ncclGetUniqueId: " + rccl_err(e));
     }
     if (world > 1) {
-        const int rr = dvbs2hip_rendezvous(rank, rendezvous, &id, sizeof id, timeout_ms);
+        const int rr = dvbs2hip_rendezvous(rank, world, rendezvous, &id, sizeof id, timeout_ms);
         if (rr) return fail(h, rr, dvbs2hip_last_error(nullptr));
     }
     void *comm = nullptr;

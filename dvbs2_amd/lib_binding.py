@@ -110,7 +110,7 @@ ABI = {
     "dvbs2hip_monitor_check_errors2": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_monitor_check_errors2_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_monitor_reduce_init": (C.c_int, [_vp, _i, _i, C.c_char_p, _i]),
-    "dvbs2hip_rendezvous": (C.c_int, [_i, C.c_char_p, _vp, C.c_size_t, _i]),
+    "dvbs2hip_rendezvous": (C.c_int, [_i, _i, C.c_char_p, _vp, C.c_size_t, _i]),
     "dvbs2hip_monitor_reduce": (C.c_int, [_vp, _vp]),
     "dvbs2hip_monitor_reduce_finalize": (C.c_int, [_vp]),
     "dvbs2hip_rx_bb": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),

@@ -13,7 +13,8 @@
 // (seed = base + rank, like the reference's per-clone seeds, main.cpp:118-120); the monitors are reduced by
 // dvbs2hip_monitor_reduce = one RCCL all-reduce of {FRA, BE, FE} per batch, which is what tools::Monitor_reduction does
 // across the reference's threads (main.cpp:123-125,155-161); every rank stops on the REDUCED frame-error count; rank 0
-// prints the table.
+// prints the table.  A rank that fails leaves with a non-zero exit code; the collectives of the others do not time out, so the
+// launcher has to end the job when one process dies (torchrun does).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -103,7 +104,6 @@ int main(int argc, char **argv)
         std::fflush(stdout);
     }
     if (chief) std::printf("# End of the simulation\n");
-    if (chief && world > 1 && !rendezvous.empty()) std::remove(rendezvous.c_str());
     dvbs2hip_free(h, d_pl); dvbs2hip_free(h, d_sent); dvbs2hip_free(h, d_got); dvbs2hip_free(h, d_sig);
     dvbs2hip_destroy(h);
     return 0;

@@ -255,14 +255,17 @@ int dvbs2hip_monitor_check_errors2_dev(dvbs2hip_t *h, const int32_t *U, const in
  * :155-161 is_done_all / final reduction) for ONE PROCESS PER GPU: the sum of {FRA, BE, FE} over the ranks, one RCCL
  * all-reduce of 3 x uint64 on the handle's stream (over xGMI inside a node).  COLLECTIVE: every rank calls _reduce the same
  * number of times (call it once per batch, as is_done_all is).  librccl.so is opened at run time on the first _init.
- *   init    : rank 0 creates the communicator id and publishes it in the file `rendezvous_path` (written beside, then
- *             renamed); the others poll for it for at most timeout_ms (< 0: for ever).  world_size 1 needs no file.
+ *   init    : rank 0 creates the communicator id and hands it to the other ranks through files named after `rendezvous_path`
+ *             (dvbs2hip_rendezvous below); each side waits for at most timeout_ms (< 0: for ever).  world_size 1 needs no file.
+ *             ncclCommInitRank itself has no timeout: a launcher has to end the whole job when one rank dies.
  *   reduce  : the reduced counters; on a handle without _init it is dvbs2hip_monitor_get (a single process).
  *   finalize: destroys the communicator (also done by dvbs2hip_destroy).                                              */
 int dvbs2hip_monitor_reduce_init(dvbs2hip_t *h, int32_t rank, int32_t world_size, const char *rendezvous_path, int32_t timeout_ms);
-/* the out-of-band step of _reduce_init on its own (no GPU needed): rank 0 publishes `bytes` bytes of `blob` in the file, every other rank
- * waits for the complete file and reads them into `blob`.  0, DVBS2HIP_EINVAL (cannot write) or DVBS2HIP_EHIP (timed out).              */
-int dvbs2hip_rendezvous(int32_t rank, const char *rendezvous_path, void *blob, size_t bytes, int32_t timeout_ms);
+/* the out-of-band step of _reduce_init on its own (no GPU needed): rank 0 hands `bytes` bytes of `blob` to every other rank, which
+ * receives them in `blob`.  Files left by an earlier run are harmless: rank r publishes a fresh random nonce in `<path>.hello.<r>` and takes
+ * the payload only from a `<path>.ack.<r>` that repeats it; a completed exchange leaves no file behind.  Give every job a path of its own
+ * in a directory only its user can write.  0, DVBS2HIP_EINVAL (bad arguments, cannot write) or DVBS2HIP_EHIP (timed out).                */
+int dvbs2hip_rendezvous(int32_t rank, int32_t world_size, const char *rendezvous_path, void *blob, size_t bytes, int32_t timeout_ms);
 int dvbs2hip_monitor_reduce(dvbs2hip_t *h, uint64_t fra_be_fe[3]);
 int dvbs2hip_monitor_reduce_finalize(dvbs2hip_t *h);
 

@@ -284,10 +284,14 @@ double orc_ldpc_decode_batch(const orc_ldpc *c, const float *llr, int F, int sch
 
 /* ---- inter-frame SIMD flavour of the CPU baseline: what `--dec-simd INTER` does in the reference
  * (README.md:171-178): W frames are decoded together, frame index fastest in memory, every
- * per-edge operation is one vector operation across the W frames (gcc auto-vectorises the
- * `omp simd` loops to AVX2 / AVX-512).  Natural row order, NMS, fixed n_ite.  Same arithmetic as
+ * per-edge operation is one vector operation across the W frames (GCC vector types: AVX2 or
+ * AVX-512 registers, whichever the build's -march has).  Natural row order, NMS, fixed n_ite.  Same arithmetic as
  * orc_ldpc_decode(.., ORC_NMS, ORC_SCHED_NATURAL, ..): results are bit-identical (tests). */
-#define ORC_W 16
+#ifdef __AVX512F__
+#define ORC_W 16       /* frames per vector = floats per register, as mipp::N<float>() in the reference */
+#else
+#define ORC_W 8
+#endif
 typedef struct { float *L, *msg, *v2c; } inter_ws;       /* one per thread, reused across blocks */
 static void inter_ws_alloc(const orc_ldpc *c, inter_ws *w)
 {
@@ -297,56 +301,52 @@ static void inter_ws_alloc(const orc_ldpc *c, inter_ws *w)
 }
 static void inter_ws_free(inter_ws *w) { free(w->L); free(w->msg); free(w->v2c); }
 
-static void decode_inter_block(const orc_ldpc *c, const float *llr, int nf, int n_ite, float alpha, int32_t *bits, inter_ws *ws)
+/* one vector = the ORC_W frames of a block (GCC vector extensions: one zmm register with AVX-512, two ymm with AVX2); the running
+ * minima and the sign word stay in registers across a check's edges */
+typedef float vf32 __attribute__((vector_size(4 * ORC_W), aligned(64)));
+typedef int32_t vi32 __attribute__((vector_size(4 * ORC_W), aligned(64)));
+#define v_sel(m, a, b) ((vf32)(((vi32)(a) & (m)) | ((vi32)(b) & ~(m))))      /* m ? a : b, lane by lane (a macro: a 64-byte vector argument would go through memory in an AVX2 build) */
+
+static __attribute__((noinline)) void decode_inter_block(const orc_ldpc *c, const float *llr, int nf, int n_ite, float alpha, int32_t *bits, inter_ws *ws)
 {
     const int N = c->N, M = c->M;
-    float *L = ws->L, *msg = ws->msg, *v2c = ws->v2c;
+    float *L = ws->L, *msg = ws->msg;
+    vf32 *v2c = (vf32 *)ws->v2c;
+    const vi32 absm = (vi32){0} + 0x7FFFFFFF, sgnm = (vi32){0} + (int32_t)0x80000000u;
+    const vf32 fmax = (vf32){0} + FLT_MAX, va = (vf32){0} + alpha;
     memset(msg, 0, sizeof(float) * (size_t)c->E * ORC_W);
     for (int v = 0; v < N; v++)
         for (int w = 0; w < ORC_W; w++) L[(size_t)v * ORC_W + w] = w < nf ? llr[(size_t)w * N + v] : 1.0f;
     for (int it = 0; it < n_ite; it++)
         for (int k = 0; k < M; k++) {
             const int b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
-            float min1[ORC_W], min2[ORC_W];
-            uint32_t sg[ORC_W];
-#pragma omp simd
-            for (int w = 0; w < ORC_W; w++) { min1[w] = FLT_MAX; min2[w] = FLT_MAX; sg[w] = 0u; }
+            vf32 min1 = fmax, min2 = fmax;
+            vi32 sg = (vi32){0};
             for (int j = 0; j < d; j++) {
-                const float *Lv = L + (size_t)c->chk_var[b + j] * ORC_W;
-                const float *mj = msg + (size_t)(b + j) * ORC_W;
-                float *vj = v2c + (size_t)j * ORC_W;
-#pragma omp simd
-                for (int w = 0; w < ORC_W; w++) {
-                    const float x = Lv[w] - mj[w];
-                    vj[w] = x;
-                    const float a = fabsf(x);
-                    uint32_t u; memcpy(&u, &x, 4);
-                    sg[w] ^= u;
-                    const float t = a > min1[w] ? a : min1[w];
-                    min2[w] = min2[w] < t ? min2[w] : t;
-                    min1[w] = min1[w] < a ? min1[w] : a;
-                }
+                const vf32 x = *(const vf32 *)(L + (size_t)c->chk_var[b + j] * ORC_W) - *(const vf32 *)(msg + (size_t)(b + j) * ORC_W);
+                v2c[j] = x;
+                const vf32 a = (vf32)((vi32)x & absm);
+                sg ^= (vi32)x;
+                const vf32 t = v_sel(a > min1, a, min1);          /* max(a, min1) */
+                min2 = v_sel(min2 < t, min2, t);
+                min1 = v_sel(min1 < a, min1, a);
             }
+            const vf32 cst1 = min2 * va, cst2 = min1 * va;
             for (int j = 0; j < d; j++) {
-                float *Lv = L + (size_t)c->chk_var[b + j] * ORC_W;
-                float *mj = msg + (size_t)(b + j) * ORC_W;
-                const float *vj = v2c + (size_t)j * ORC_W;
-#pragma omp simd
-                for (int w = 0; w < ORC_W; w++) {
-                    const float x = vj[w];
-                    const float mag = (fabsf(x) == min1[w]) ? min2[w] * alpha : min1[w] * alpha;
-                    uint32_t u, um; memcpy(&u, &x, 4); memcpy(&um, &mag, 4);
-                    um |= (sg[w] ^ u) & 0x80000000u;
-                    float nw; memcpy(&nw, &um, 4);
-                    mj[w] = nw;
-                    Lv[w] = x + nw;
-                }
+                const vf32 x = v2c[j];
+                const vf32 a = (vf32)((vi32)x & absm);
+                const vf32 mag = v_sel(a == min1, cst1, cst2);
+                const vf32 nw = (vf32)((vi32)mag | ((sg ^ (vi32)x) & sgnm));
+                *(vf32 *)(msg + (size_t)(b + j) * ORC_W) = nw;
+                *(vf32 *)(L + (size_t)c->chk_var[b + j] * ORC_W) = x + nw;
             }
         }
     if (bits)
         for (int w = 0; w < nf; w++)
             for (int i = 0; i < c->K; i++) bits[(size_t)w * c->K + i] = L[(size_t)i * ORC_W + w] < 0.0f;
 }
+
+int orc_ldpc_inter_width(void) { return ORC_W; }
 
 double orc_ldpc_decode_batch_inter(const orc_ldpc *c, const float *llr, int F, int n_ite, float alpha, int32_t *bits, int threads)
 {

@@ -141,8 +141,10 @@ void orc_fp_synchronize(int n_cplx, const float *X, float *Y, float *out2);
 /* decode F frames with `threads` threads (frames sharded); returns seconds */
 double orc_ldpc_decode_batch(const orc_ldpc *c, const float *llr, int F, int sched, int n_ite,
                              float alpha, int32_t *bits, int threads);
-/* inter-frame SIMD flavour (16 frames per vector, `--dec-simd INTER` of the reference): NMS, natural
- * row order, fixed n_ite, bit-identical to the scalar decoder; returns seconds */
+/* inter-frame SIMD flavour (`--dec-simd INTER` of the reference: one frame per lane of a vector register, 16 with AVX-512, 8 with
+ * AVX2 -- orc_ldpc_inter_width() says which this build uses): NMS, natural row order, fixed n_ite, bit-identical to the scalar
+ * decoder; returns seconds */
+int orc_ldpc_inter_width(void);
 double orc_ldpc_decode_batch_inter(const orc_ldpc *c, const float *llr, int F, int n_ite, float alpha,
                                    int32_t *bits, int threads);
 #ifdef __cplusplus

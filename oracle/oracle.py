@@ -23,7 +23,79 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+_NATIVE_SO = os.path.join(_HERE, "_native", "libdvbs2_oracle_native.so")
+
+
+def build_native() -> str:
+    """The CPU baseline's -march=native build (bench.py's cpu_baseline leg): always rebuilt by make on the host that runs it when the
+    source is newer; raises when the host has no compiler."""
+    subprocess.check_call(["make", "-C", _HERE, "-s", "native"])
+    return _NATIVE_SO
+
+
+def native_isa() -> str:
+    """widest vector registers the native build's inter-frame loop uses: 'zmm' / 'ymm' / 'xmm' / '?' (objdump of decode_inter_block)"""
+    import shutil
+    if not shutil.which("objdump") or not os.path.exists(_NATIVE_SO):
+        return "?"
+    dis = subprocess.run(["objdump", "-d", "--no-show-raw-insn", _NATIVE_SO], capture_output=True, text=True).stdout
+    body, on = [], False
+    for line in dis.splitlines():
+        if line.endswith("<decode_inter_block>:"):
+            on = True
+        elif on and line.strip() == "":
+            break
+        elif on:
+            body.append(line)
+    for reg in ("zmm", "ymm", "xmm"):
+        if any(reg in l and ("vsubps" in l or "vaddps" in l or "vcmp" in l) for l in body):
+            return reg
+    return "?"
+
+
 _lib = None
+_libs = {}
+
+
+def _bind(path):
+    if path not in _libs:
+        L = C.CDLL(path)
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.orc_ldpc_create.restype = vp
+        L.orc_ldpc_create.argtypes = [ci, ci, ci, vp, vp]
+        L.orc_ldpc_destroy.argtypes = [vp]
+        L.orc_ldpc_decode_batch.restype = C.c_double
+        L.orc_ldpc_decode_batch.argtypes = [vp, vp, ci, ci, ci, cf, vp, ci]
+        L.orc_ldpc_decode_batch_inter.restype = C.c_double
+        L.orc_ldpc_decode_batch_inter.argtypes = [vp, vp, ci, ci, cf, vp, ci]
+        L.orc_ldpc_inter_width.restype = ci
+        _libs[path] = L
+    return _libs[path]
+
+
+class NativeLdpc:
+    """The batch decoders of the -march=native build (CPU baseline only): same source, same results as Ldpc.decode_batch*_timed."""
+    def __init__(self, N, K, row_ptr, addr):
+        self.L = _bind(build_native())
+        self.N, self.K = N, K
+        self.inter_width = self.L.orc_ldpc_inter_width()
+        self._rp, self._ad = _i32(row_ptr), _i32(addr)
+        self.h = self.L.orc_ldpc_create(N, K, len(self._rp) - 1, _p(self._rp), _p(self._ad))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_ldpc_destroy(self.h)
+            self.h = None
+
+    def decode_batch_timed(self, llr, n_ite=10, alpha=1.0, sched=0, threads=1):
+        llr = _f32(llr).reshape(-1, self.N)
+        bits = np.empty((llr.shape[0], self.K), dtype=np.int32)
+        return bits, self.L.orc_ldpc_decode_batch(self.h, _p(llr), llr.shape[0], sched, n_ite, alpha, _p(bits), threads)
+
+    def decode_batch_inter_timed(self, llr, n_ite=10, alpha=1.0, threads=1):
+        llr = _f32(llr).reshape(-1, self.N)
+        bits = np.empty((llr.shape[0], self.K), dtype=np.int32)
+        return bits, self.L.orc_ldpc_decode_batch_inter(self.h, _p(llr), llr.shape[0], n_ite, alpha, _p(bits), threads)
 
 
 def lib():
@@ -166,7 +238,7 @@ class Ldpc:
 
 
     def decode_batch_inter_timed(self, llr, n_ite=10, alpha=1.0, threads=1):
-        """inter-frame SIMD CPU flavour (16 frames per vector), natural order NMS"""
+        """inter-frame SIMD CPU flavour (8 or 16 frames per vector), natural order NMS"""
         llr = _f32(llr).reshape(-1, self.N)
         bits = np.empty((llr.shape[0], self.K), dtype=np.int32)
         sec = lib().orc_ldpc_decode_batch_inter(self.h, _p(llr), llr.shape[0], n_ite, alpha, _p(bits), threads)

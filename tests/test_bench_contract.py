@@ -28,7 +28,7 @@ def test_committed_pmc_traffic_belongs_to_the_kernel_in_the_tree():
 
 @pytest.mark.gpu
 def test_bench_line_on_the_gpu():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--self-check-steps", "20"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
@@ -42,12 +42,32 @@ def test_bench_line_on_the_gpu():
     assert ro["bound"] == "hbm" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
     assert ro["avg_launch_ms"] <= d["ms_per_step"] * 1.02
     assert 0.0 < ro["hbm_true"]["frac"] < 0.1
+    assert ro["binding_resource"] == "fabric" and ro["algorithmic_frac"] == ro["frac"]
+    assert d["self_check"]["steps"] == 20 and 0.5 * d["ms_per_step"] < d["self_check"]["ms_per_step"] < 1.5 * d["ms_per_step"]
     if ro["traffic"] is not None:                                          # the committed PMC file matches the running kernel
         b = ro["bounded"]
+        assert ro["bounded_frac"] == b["frac"]
         assert 0.0 < b["frac"] <= 1.0 and abs(b["achieved"] - ro["traffic"] / (ro["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * b["achieved"]
         assert 0.0 < b["valu"]["frac"] <= 1.0
     else:
-        assert ro["bounded"] is None
+        assert ro["bounded"] is None and ro["bounded_frac"] is None
     ex = d["extra"]
     assert set(ex["early_stop_fps"]) == {"4.0 dB", "3.0 dB"} and ex["early_stop_fps"]["4.0 dB"] > d["fec_frames_per_s"]       # converging frames stop early
     assert ex["hard_batch_fixed_10_ite"]["cwd"] == 0 and ex["hard_batch_fixed_10_ite"]["FE"] == ex["hard_batch_fixed_10_ite"]["frames"]
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_one_rank():
+    """The launch line the driver uses for N > 1, with one rank (this pool has one GPU per box): `python -m torch.distributed.run ... bench.py --gpus 1`
+    as a FRESH child process (never a re-exec of one that has touched the GPU): RCCL process group, the counters' all-reduce, the max over ranks
+    of the timing, one JSON line from rank 0.  What it cannot show is scaling: N > 1 is unmeasured on this pool."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29517",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--self-check-steps", "0"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["ber"]["FRA"] == 4096 and d["ber"]["FE"] == 0
+    assert "cpu_baseline" not in d and d["self_check"] is None

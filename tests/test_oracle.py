@@ -94,7 +94,7 @@ def test_ldpc_kat_and_self_checks(O):
 
 
 def test_inter_frame_simd_flavour_is_bit_identical(O):
-    """The CPU baseline's `--dec-simd INTER` flavour (16 frames per vector) = the scalar decoder."""
+    """The CPU baseline's `--dec-simd INTER` flavour (one frame per vector lane) = the scalar decoder."""
     ch = chain(O, "QPSK-S_8/9")
     _, llr, _ = make_llrs(O, "QPSK-S_8/9", 21, 3.7, seed=9)
     b1, _ = ch.ldpc.decode_batch_timed(llr, 6, 0.875, O.NATURAL, threads=2)
@@ -104,25 +104,34 @@ def test_inter_frame_simd_flavour_is_bit_identical(O):
 
 
 def test_inter_frame_baseline_is_really_vector_code(O):
-    """The CPU baseline's inter-frame flavour counts on gcc vectorising its `omp simd` loops over the 16 frames of a block: check the
-    built library -- packed-single AVX instructions on ymm registers inside decode_inter_block (x86-64-v3 = AVX2: 2 x 8 frames per step)."""
+    """The CPU baseline's inter-frame flavour is written with GCC vector types, one lane per frame: check the built libraries -- the
+    portable checker build (x86-64-v3 = AVX2: 8 frames per ymm register) and, where this host has AVX-512, the -march=native build the
+    bench's CPU leg times (16 frames per zmm register)."""
     import shutil
     import subprocess
     if not shutil.which("objdump"):
         pytest.skip("no objdump in this image")
     O.build()
-    dis = subprocess.run(["objdump", "-d", "--no-show-raw-insn", O._SO], capture_output=True, text=True).stdout
-    body, on = [], False
-    for line in dis.splitlines():
-        if line.endswith("<decode_inter_block>:"):
-            on = True
-        elif on and line.strip() == "":
-            break
-        elif on:
-            body.append(line)
-    assert body, "decode_inter_block not found (inlined?)"
-    ops = [l.split()[1] for l in body if "ymm" in l and len(l.split()) > 1]
-    assert any(o.startswith("vsubps") for o in ops) and any(o.startswith("vcmp") for o in ops) and any(o.startswith("vblendvps") for o in ops), sorted(set(ops))
+
+    def regs(so):
+        dis = subprocess.run(["objdump", "-d", "--no-show-raw-insn", so], capture_output=True, text=True).stdout
+        body, on = [], False
+        for line in dis.splitlines():
+            if line.endswith("<decode_inter_block>:"):
+                on = True
+            elif on and line.strip() == "":
+                break
+            elif on:
+                body.append(line)
+        assert body, "decode_inter_block not found (inlined?)"
+        return {r: sorted({l.split()[1] for l in body if r in l and len(l.split()) > 1}) for r in ("zmm", "ymm")}
+    ops = regs(O._SO)["ymm"]
+    assert any(o.startswith("vsubps") for o in ops) and any(o.startswith("vcmp") for o in ops) and any(o.startswith("vaddps") for o in ops), ops
+    if "avx512f" in open("/proc/cpuinfo").read():
+        so = O.build_native()
+        ops = regs(so)["zmm"]
+        assert any(o.startswith("vsubps") for o in ops) and any(o.startswith("vcmp") for o in ops), ops
+        assert O.native_isa() == "zmm" and O.NativeLdpc(16200, 14400, *__import__("dvbs2_amd.params", fromlist=["x"]).load_ldpc_table("N16200_8_9.txt")).inter_width == 16
 
 
 def test_two_schedules_agree_statistically(O):

@@ -62,33 +62,38 @@ def test_reductions_are_identity_without_process_group():
     assert reduce_counters([3, 2, 1]) == [3, 2, 1] and reduce_max(2.5) == 2.5
 
 
-def _rdv_worker(rank, path, delay_s, q):
+def _rdv_worker(rank, world, path, delay_s, q):
     import ctypes as C
     import time
     sys.path.insert(0, ROOT)
     from dvbs2_amd import lib_binding as B
     L = C.CDLL(B.lib_path())
     L.dvbs2hip_rendezvous.restype = C.c_int
-    L.dvbs2hip_rendezvous.argtypes = [C.c_int32, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int32]
+    L.dvbs2hip_rendezvous.argtypes = [C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int32]
     buf = (C.c_ubyte * 128)()
+    time.sleep(delay_s)
     if rank == 0:
-        time.sleep(delay_s)                                  # the readers are already polling when the file appears
         for i in range(128):
             buf[i] = (7 * i + 3) & 255
-    rc = L.dvbs2hip_rendezvous(rank, path.encode(), buf, 128, 20000)
+    rc = L.dvbs2hip_rendezvous(rank, world, path.encode(), buf, 128, 20000)
     q.put((rank, rc, bytes(buf)))
 
 
 def test_rccl_bootstrap_rendezvous_through_a_file(tmp_path):
-    """dvbs2hip_monitor_reduce_init's out-of-band step (the communicator id from rank 0 to the other ranks through a file) between three CPU
-    processes: the readers start first and poll, rank 0 publishes late (write beside + rename: nobody reads a partial file), everybody ends
-    up with rank 0's 128 bytes; a reader without a writer times out with an error instead of hanging."""
+    """dvbs2hip_monitor_reduce_init's out-of-band step (the communicator id from rank 0 to the other ranks through files) between three CPU
+    processes, in a directory that still holds what a crashed earlier run left there -- an id file of the old format, a complete ack and a
+    hello with another nonce: nobody may take the stale payload.  Readers that start before rank 0 and one that starts after it all end up
+    with rank 0's 128 bytes, nothing is left behind, and a side whose partner never shows up times out with an error instead of hanging."""
     import ctypes as C
     from dvbs2_amd import lib_binding as B
     path = str(tmp_path / "rdv")
+    stale = bytes(range(128))
+    open(path, "wb").write(stale)                                            # what round 2's protocol would have read and trusted
+    open(path + ".ack.1", "wb").write(b"N" * 16 + stale)                     # a complete answer to somebody else's nonce
+    open(path + ".hello.2", "wb").write(b"O" * 16)                           # a reader that died: rank 0 answers it, the live rank 2 replaces it
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rdv_worker, args=(r, path, 0.5, q)) for r in (1, 2, 0)]
+    procs = [ctx.Process(target=_rdv_worker, args=(r, 3, path, d, q)) for r, d in ((1, 0.0), (0, 0.5), (2, 1.2))]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=60) for _ in procs)
@@ -96,8 +101,13 @@ def test_rccl_bootstrap_rendezvous_through_a_file(tmp_path):
         p.join(timeout=30)
     want = bytes((7 * i + 3) & 255 for i in range(128))
     assert [g[0] for g in got] == [0, 1, 2] and all(g[1] == 0 and g[2] == want for g in got)
+    assert sorted(os.listdir(tmp_path)) == ["rdv"]                           # the exchange cleaned up after itself (the old-format file is not its own)
     L = C.CDLL(B.lib_path())
-    L.dvbs2hip_rendezvous.argtypes = [C.c_int32, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int32]
+    L.dvbs2hip_rendezvous.argtypes = [C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int32]
     buf = (C.c_ubyte * 128)()
-    assert L.dvbs2hip_rendezvous(1, str(tmp_path / "nobody").encode(), buf, 128, 100) == -3      # DVBS2HIP_EHIP: timed out
-    assert L.dvbs2hip_rendezvous(0, str(tmp_path / "no_such_dir" / "x").encode(), buf, 128, 100) == -1
+    assert L.dvbs2hip_rendezvous(1, 2, str(tmp_path / "nobody").encode(), buf, 128, 100) == -3      # DVBS2HIP_EHIP: timed out (no rank 0)
+    assert L.dvbs2hip_rendezvous(0, 2, str(tmp_path / "nobody").encode(), buf, 128, 100) == -3      # ... and no rank 1
+    assert L.dvbs2hip_rendezvous(1, 2, str(tmp_path / "no_such_dir" / "x").encode(), buf, 128, 100) == -1
+    assert L.dvbs2hip_rendezvous(0, 1, str(tmp_path / "alone").encode(), buf, 128, 100) == 0        # one rank: nothing to exchange
+    assert L.dvbs2hip_rendezvous(2, 2, path.encode(), buf, 128, 100) == -1                          # rank outside the world
+    assert sorted(os.listdir(tmp_path)) == ["rdv"]
