@@ -41,6 +41,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    for stale in set(glob.glob(os.path.join(LIBDIR, "*.hip.o"))) - {os.path.join(LIBDIR, os.path.basename(src) + ".o") for src in sources()}:
+        os.remove(stale)          # the object of a translation unit that no longer exists
     objs = []
     cc = _hipcc()
     procs = []

@@ -131,14 +131,17 @@ fir_mfma_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const floa
         const float2 s0 = fm_fetch_edge(x, hist_in, H, n_total, gi), s1 = fm_fetch_edge(x, hist_in, H, n_total, gi + 1);
         fm_stage(lds, 2 * tid, s0.x, s0.y, s1.x, s1.y);
     }
-    // the Toeplitz fragments of the three tap parts (host-made, 9 KB, L2-resident)
-    fm_bf16x8 A[NPH][3][3];
+    // the Toeplitz fragments of the three tap parts (host-made, 9 KB, L2-resident).  A polyphase branch of the shaping filter has at most
+    // 49 taps (upfir_mfma_usable), right-aligned in the 81-entry band: nothing of it falls into the first 32-wide K step, which NPH = 2
+    // therefore leaves out -- a third of its products multiplied zeros, and the 24 registers of those fragments were what it spilled for
+    constexpr int S0 = NPH == 2 ? 1 : 0, NS = 3 - S0;
+    fm_bf16x8 A[NPH][3][NS];
 #pragma unroll
     for (int ph = 0; ph < NPH; ph++)
 #pragma unroll
         for (int p = 0; p < 3; p++)
 #pragma unroll
-            for (int s = 0; s < 3; s++) A[ph][p][s] = __builtin_bit_cast(fm_bf16x8, afrag[((ph * 3 + p) * 3 + s) * 64 + lane]);
+            for (int s = 0; s < NS; s++) A[ph][p][s] = __builtin_bit_cast(fm_bf16x8, afrag[((ph * 3 + p) * 3 + s + S0) * 64 + lane]);
     const int c = lane & 15, g = lane >> 4;
     // lane's share of the overlap that is carried from tile to tile inside LDS: 6 planes x 40 pairs
     const int ov_dst = (tid / (FM_H / 2)) * FM_PLANE + 2 * (tid % (FM_H / 2)), ov_src = ov_dst + FM_TILE;
@@ -167,12 +170,12 @@ fir_mfma_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const floa
             fm_f32x4 acc[NPH][2];
 #pragma unroll
             for (int pl = 0; pl < 2; pl++) {
-                fm_bf16x8 B[3][3];
+                fm_bf16x8 B[3][NS];
 #pragma unroll
                 for (int p = 0; p < 3; p++)
 #pragma unroll
-                    for (int s = 0; s < 3; s++) {
-                        const int idx = 16 * (c + 2 * s + 16 * tt) + 8 * g;
+                    for (int s = 0; s < NS; s++) {
+                        const int idx = 16 * (c + 2 * (s + S0) + 16 * tt) + 8 * g;
                         B[p][s] = __builtin_bit_cast(fm_bf16x8, *reinterpret_cast<const uint4 *>(lds + (2 * p + pl) * FM_PLANE + idx));
                     }
                 // (tap part, sample part), smallest products first
@@ -183,7 +186,7 @@ fir_mfma_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, const floa
 #pragma unroll
                     for (int q = 0; q < 6; q++)
 #pragma unroll
-                        for (int s = 0; s < 3; s++) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[TB[q]][s], A[ph][TA[q]][s], d, 0, 0, 0);
+                        for (int s = 0; s < NS; s++) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[TB[q]][s], A[ph][TA[q]][s], d, 0, 0, 0);
                     acc[ph][pl] = d;
                 }
             }
@@ -276,7 +279,8 @@ std::vector<uint16_t> upfir_mfma_afrag(const float *taps, int T)
 
 bool upfir_mfma_usable(const float *x, const float *y, int T, int osf, long long n_in)
 {
-    return osf == 2 && T >= 1 && (T - 1) / 2 <= FM_H && n_in >= 2 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    // a branch of at most 49 taps: the kernel skips the band's first K step
+    return osf == 2 && T >= 1 && (T - 1) / 2 + 1 <= FM_H + 1 - 32 && n_in >= 2 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
 }
 
 // hist = the last (T - 1) / 2 input samples

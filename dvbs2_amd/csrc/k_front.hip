@@ -150,17 +150,21 @@ __device__ __forceinline__ float block_sum(float v, float *red)
     return s;
 }
 
-// Estimator_DVBS2.hxx:44-56 from the two moment sums
+// Estimator_DVBS2.hxx:44-56 from the two moment sums.  The divisions, square roots, log10 and 10^x are single hardware instructions
+// (v_rcp / v_sqrt / v_log / v_exp, 1 ulp each): the library forms (IEEE division, sqrtf, log10f, powf) expand into sequences that need
+// up to ~40 registers of their own at a point where the register-resident kernels hold a whole frame -- they spilled frame symbols for it.
+// The estimates end up within ~1e-6 relative of the reference's expressions (compared at 1e-4).
 __device__ __forceinline__ void m2m4_finish(float m2, float m4, int n_sym, float code_rate, int bps,
                                             float &sigma, float &ebn0, float &esn0)
 {
-    m2 /= (float)n_sym; m4 /= (float)n_sym;
-    const float Se = sqrtf(fabsf(2 * m2 * m2 - m4));
+    const float rn = __builtin_amdgcn_rcpf((float)n_sym);
+    m2 *= rn; m4 *= rn;
+    const float Se = __builtin_amdgcn_sqrtf(fabsf(2 * m2 * m2 - m4));
     const float Ne = fabsf(m2 - Se);
-    esn0 = 10 * log10f(Se / Ne);
-    if (isinf(esn0)) esn0 = 100.f;
-    sigma = sqrtf(1.0f / (2.0f * powf(10.0f, esn0 / 10.0f)));
-    ebn0 = esn0 - 10.0f * log10f(code_rate * (float)bps);
+    esn0 = 10.f * 0.301029995663981f * __builtin_amdgcn_logf(Se * __builtin_amdgcn_rcpf(Ne));      // 10 log10(Se / Ne); Ne = 0: +inf
+    if (fabsf(esn0) == INFINITY) esn0 = 100.f;
+    sigma = __builtin_amdgcn_sqrtf(__builtin_amdgcn_rcpf(2.0f * __builtin_amdgcn_exp2f(esn0 * 0.332192809488736f)));      // sqrt(1 / (2 10^(esn0 / 10)))
+    ebn0 = esn0 - 10.f * 0.301029995663981f * __builtin_amdgcn_logf(code_rate * (float)bps);
 }
 
 // separable 2-bit constellation (every reference QPSK mapping): bit b is carried by one axis alone with two levels
@@ -258,12 +262,12 @@ front_kernel(const FrontKParams p)
 // are all in flight together, and QPSK LLR pairs leave as one 8-byte store per lane.
 constexpr int FRONT_WIDE = 1024;
 typedef float front_f2 __attribute__((ext_vector_type(2)));      // a type the non-temporal builtins accept
-template <int BPS, int SPT, bool SEP>            // SEP: separable 2-bit constellation, linear LLRs (no general demapper compiled in)
-__global__ void __launch_bounds__(FRONT_WIDE)
+template <int BPS, int SPT, bool SEP, int WIDE = FRONT_WIDE>      // SEP: separable 2-bit constellation, linear LLRs (no general demapper compiled in); WIDE lanes per frame
+__global__ void __launch_bounds__(WIDE, 4)      // four waves per SIMD: one 1024-lane or two 512-lane workgroups per CU, 128 registers
 front_reg_kernel(const FrontKParams p)
 {
     __shared__ float4 tab[1 << BPS];
-    __shared__ float red[2][FRONT_WIDE / 64];
+    __shared__ float red[2][WIDE / 64];
     const int tid = threadIdx.x, f = blockIdx.x;
     const int n_sym = p.n_sym, n_pil = n_sym / (PL_SLOTS * PL_M);
     const float2 *in = reinterpret_cast<const float2 *>(p.in + (size_t)f * 2 * (size_t)p.pl_frame);
@@ -272,23 +276,27 @@ front_reg_kernel(const FrontKParams p)
     // an offset past the frame returns zero, which is what the padding lanes have to hold
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(in), 0, 8 * p.pl_frame, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.pl_seq), 0, p.pl_frame, 0x00020000);
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int i = 0; i < SPT; i++) {
-        const int k = tid + i * FRONT_WIDE;
+        const int k = tid + i * WIDE;
         const int pi = k < n_sym ? pl_index(k, n_pil) : p.pl_frame;
         const front_f2 v = __builtin_bit_cast(front_f2, __builtin_amdgcn_raw_buffer_load_b64(rin, 8 * pi, 0, 2));      // nt: read once
         y[i] = make_float2(v.x, v.y);
+        if (SPT > 8 && (i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // offsets formed four at a time, not all SPT of them ahead of the first load (registers)
     }
     float sigma;
     if (p.sigma_in == nullptr) {
         float m2 = 0.f, m4 = 0.f;                  // |y| is invariant under the PL derotation; padding lanes hold zeros
-#pragma unroll
-        for (int i = 0; i < SPT; i++) { const float e = y[i].x * y[i].x + y[i].y * y[i].y; m2 += e; m4 += e * e; }
+#pragma clang loop unroll(full)
+        for (int i = 0; i < SPT; i++) {
+            const float e = y[i].x * y[i].x + y[i].y * y[i].y; m2 += e; m4 += e * e;
+            if (SPT > 8 && (i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four squares at a time, not SPT of them beside the frame (registers)
+        }
         for (int o = 32; o > 0; o >>= 1) { m2 += __shfl_xor(m2, o); m4 += __shfl_xor(m4, o); }
         if ((tid & 63) == 0) { red[0][tid >> 6] = m2; red[1][tid >> 6] = m4; }
         __syncthreads();
         m2 = 0.f; m4 = 0.f;
-        for (int i = 0; i < FRONT_WIDE / 64; i++) { m2 += red[0][i]; m4 += red[1][i]; }
+        for (int i = 0; i < WIDE / 64; i++) { m2 += red[0][i]; m4 += red[1][i]; }
         float ebn0, esn0;
         m2m4_finish(m2, m4, n_sym, p.code_rate, p.bps, sigma, ebn0, esn0);
         if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = ebn0; p.est[3 * f + 2] = esn0; }
@@ -296,7 +304,7 @@ front_reg_kernel(const FrontKParams p)
         sigma = p.sigma_in[f];
         if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = 0.f; p.est[3 * f + 2] = 0.f; }
     }
-    const float inv2s2 = 1.0f / (2.0f * sigma * sigma);
+    const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sigma * sigma);
     if (!SEP) {
         if (tid < (1 << BPS)) tab[tid] = demap_table_entry(p.cstl, tid, inv2s2);
         __syncthreads();
@@ -307,29 +315,29 @@ front_reg_kernel(const FrontKParams p)
     constexpr bool sep = SEP;
     constexpr int U = 1;                           // the frame itself fills the registers
     static_assert(SPT % U == 0, "symbols per lane come in groups of U");
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int i0 = 0; i0 < SPT; i0 += U) {
         asm volatile("" ::: "memory");             // one group at a time: nothing of the next one is hoisted into registers
-        if (tid + i0 * FRONT_WIDE >= n_sym) continue;
+        if (tid + i0 * WIDE >= n_sym) continue;
         float2 yy[U];
         float out[U][BPS];
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int i = 0; i < U; i++) {
-            const int k = tid + (i0 + i) * FRONT_WIDE;
+            const int k = tid + (i0 + i) * WIDE;
             const int R = (int)__builtin_amdgcn_raw_buffer_load_b8(rsq, (k < n_sym ? pl_index(k, n_pil) : PL_M) - PL_M, 0, 0);      // L2-resident table
             yy[i] = pl_derotate(y[i0 + i], R);
         }
         if constexpr (sep) {
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int i = 0; i < U; i++) demap_sep2(yy[i], inv2s2, p, out[i]);
         } else demap_symbols<BPS, U>(yy, tab, out);
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int i = 0; i < U; i++) {
-            const int k = tid + (i0 + i) * FRONT_WIDE;
+            const int k = tid + (i0 + i) * WIDE;
             if (k >= n_sym) continue;
             if (pairs) { front_f2 v; v.x = out[i][0]; v.y = out[i][BPS - 1]; __builtin_nontemporal_store(v, reinterpret_cast<front_f2 *>(llr) + k); }
             else {
-#pragma unroll
+#pragma clang loop unroll(full)
                 for (int b = 0; b < BPS; b++) llr[deitl_index(k, b, BPS, p.itl_cols, p.itl_order, n_rows)] = out[i][b];
             }
         }
@@ -381,7 +389,7 @@ front_reg2_kernel(const FrontKParams p)
         sigma = p.sigma_in[f];
         if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = 0.f; p.est[3 * f + 2] = 0.f; }
     }
-    const float inv2s2 = 1.0f / (2.0f * sigma * sigma);
+    const float inv2s2 = __builtin_amdgcn_rcpf(2.0f * sigma * sigma);
     front_f4 *llr = reinterpret_cast<front_f4 *>(p.llr + (size_t)f * n_sym * 2);
 #pragma unroll
     for (int i = 0; i < PPT; i++) {
@@ -400,17 +408,19 @@ static bool front_reg_try(const FrontKParams &p, hipStream_t s)
 {
     if (getenv("DVBS2HIP_FRONT_TWO_SWEEP")) return false;
     dim3 g(p.n_frames), b(FRONT_WIDE);
-    const bool small = p.n_sym <= 8 * FRONT_WIDE, big = p.n_sym <= 32 * FRONT_WIDE;
+    const bool small = p.n_sym <= 8 * FRONT_WIDE, mid = p.n_sym <= 22 * FRONT_WIDE, big = p.n_sym <= 32 * FRONT_WIDE;
     const bool pair_ok = p.bps == 2 && p.sep && p.itl_cols <= 1 && p.n_sym % 2 == 0 && p.pl_frame % 2 == 0 && !getenv("DVBS2HIP_FRONT_SINGLE") &&
                          ((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.llr)) & 15) == 0;
     if (pair_ok && small) hipLaunchKernelGGL((front_reg2_kernel<4>), g, b, 0, s, p);
     else if (pair_ok && big) hipLaunchKernelGGL((front_reg2_kernel<16>), g, b, 0, s, p);
+    // one symbol per lane and access: short frames (8 symbols per lane) and the 8PSK normal frame (21600 symbols: 22 per lane = 44 registers
+    // of frame, which leaves the demapper its own; the 32-per-lane forms of round 2 spilled frame symbols and are gone -- a QPSK normal frame
+    // that cannot take the pair kernel, i.e. unaligned sockets or a non-separable mapping, goes to the two-sweep kernel)
     else if (p.bps == 2 && p.sep && small) hipLaunchKernelGGL((front_reg_kernel<2, 8, true>), g, b, 0, s, p);
     else if (p.bps == 2 && p.sep && big) hipLaunchKernelGGL((front_reg_kernel<2, 32, true>), g, b, 0, s, p);
     else if (p.bps == 2 && small) hipLaunchKernelGGL((front_reg_kernel<2, 8, false>), g, b, 0, s, p);
-    else if (p.bps == 2 && big) hipLaunchKernelGGL((front_reg_kernel<2, 32, false>), g, b, 0, s, p);
     else if (p.bps == 3 && small) hipLaunchKernelGGL((front_reg_kernel<3, 8, false>), g, b, 0, s, p);
-    else if (p.bps == 3 && big) hipLaunchKernelGGL((front_reg_kernel<3, 32, false>), g, b, 0, s, p);
+    else if (p.bps == 3 && mid) hipLaunchKernelGGL((front_reg_kernel<3, 22, false>), g, b, 0, s, p);
     else return false;
     return true;
 }

@@ -444,7 +444,7 @@ __device__ __forceinline__ float c2v_unpack(float c1, float c2, uint32_t pk, int
 }
 
 template <int DEG, bool HYBRID, bool C2V_LDS>
-__global__ void __launch_bounds__(LDPC_THREADS, 3)
+__global__ void __launch_bounds__(LDPC_THREADS, (DEG > 13 && HYBRID) ? 2 : 3)      // (the 27-slot hybrid form needs ~172 registers: two waves per SIMD instead of three, no spills)
 ldpc_layered_nms_kernel(const LdpcKParams p)
 {
     extern __shared__ float smem[];

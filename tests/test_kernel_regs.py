@@ -1,0 +1,27 @@
+"""No kernel of libdvbs2hip.so spills vector registers (VERDICT r2 found 15-17 spilled VGPRs in the SPA decoder, 6-11 in the register-resident
+front ends, 8 in the shaping filter): read from the code objects' metadata (llvm-readelf --notes of every translation unit, tools/kernel_regs.py),
+so it holds for the library that is in the tree, on CPU."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_no_kernel_spills_vector_registers():
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("no ROCm LLVM tools in this image")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dvbs2_amd import build
+    build.build_lib()
+    import kernel_regs
+    ks = kernel_regs.kernels()
+    names = {k["name"] for k in ks}
+    assert len(ks) >= 80 and any("ldpc_wg8_kernel<27, 3, true>" in n for n in names) and any("fir_mfma_kernel<2>" in n for n in names)
+    assert not any("ldpc_fast2" in n for n in names), "stale object of a removed translation unit in dvbs2_amd/lib"
+    bad = [(k["name"], k["vgpr_spill"]) for k in ks if k["vgpr_spill"] > 0]
+    assert not bad, bad
+    # private memory only where a kernel calls a non-inlined device function (the delay line's general walk)
+    scratch = [(k["name"], k["scratch"]) for k in ks if k["scratch"] > 0]
+    assert all("sync_vdelay_batch_kernel" in n for n, _ in scratch), scratch
