@@ -26,6 +26,20 @@ def test_committed_pmc_traffic_belongs_to_the_kernel_in_the_tree():
     assert bench._pmc_traffic(d["kernel"], bench.FRAMES_PER_GPU + 1, bench.N_ITE)[0] is None          # another workload: no figure
 
 
+def test_committed_kernel_counters_belong_to_the_kernels_in_the_tree():
+    """profiles/<round>_kernels_pmc.md (rocprofv3 counters of every non-LDPC kernel, tools/profile_kernels.sh + tools/summarize_kernels_pmc.py) is
+    stamped with the hash of the kernel sources it was measured on (profiles/kernels_pmc_stamp.json): editing k_front / k_bch / k_sync* / k_fir* /
+    k_tx without re-profiling fails here -- round 2's APSK front-end counters had silently gone stale."""
+    import hashlib
+    d = json.load(open(os.path.join(ROOT, "profiles", "kernels_pmc_stamp.json")))
+    h = hashlib.sha256()
+    for f in d["sources"]:
+        h.update(open(os.path.join(ROOT, "dvbs2_amd", "csrc", f), "rb").read())
+    assert set(d["sources"]) >= {"k_front.hip", "k_bch.hip", "k_sync.hip", "k_sync_mfma.hip", "k_fir.hip", "k_fir_mfma.hip", "k_tx.hip"}
+    assert d["sha"] == h.hexdigest()[:16], "re-profile: a non-LDPC kernel changed since %s was measured" % d["file"]
+    assert os.path.exists(os.path.join(ROOT, d["file"])) and d["sha"] in open(os.path.join(ROOT, d["file"])).read()
+
+
 @pytest.mark.gpu
 def test_bench_line_on_the_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--self-check-steps", "20"], capture_output=True, text=True, cwd=ROOT)

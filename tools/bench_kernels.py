@@ -69,6 +69,9 @@ res["config3_QPSK-N_8/9_F4096_10ite"] = chain_case("QPSK-N_8/9", 4096, 10, 4.2)
 res["config1_QPSK-S_8/9_F8192_10ite"] = chain_case("QPSK-S_8/9", 8192, 10, 4.4)
 res["config4_16APSK-N_8/9_F4096_20ite"] = chain_case("16APSK-N_8/9", 4096, 20, 8.2)
 res["config5_32APSK-S_3/4_F4096_10ite"] = chain_case("32APSK-S_3/4", 4096, 10, 10.5)
+res["ext_8PSK-N_8/9_F4096_10ite"] = chain_case("8PSK-N_8/9", 4096, 10, 7.5)
+res["ref_8PSK-S_8/9_F8192_10ite"] = chain_case("8PSK-S_8/9", 8192, 10, 7.5)
+res["ref_16APSK-S_8/9_F8192_10ite"] = chain_case("16APSK-S_8/9", 8192, 10, 8.4)
 def upfir_case(n_in, F, reps=20):
     """row N2: TX shaping filter (polyphase up-sampling SRRC, osf 2): 8 B in + 16 B out per input sample, 2 x 41 taps"""
     rx = Dvbs2Hip("32APSK-S_3/4", max_frames=max(F, 1))

@@ -57,7 +57,21 @@ def sync(modcod, F):
     rx.synchronize(); rx.close()
 
 
+def fir(n_cplx, F, n_in, F_in):
+    """a5 matched filter on a stream of F frames of n_cplx samples; N2 shaping filter on F_in frames of n_in symbols (osf 2)"""
+    rx = Dvbs2Hip("32APSK-S_3/4", max_frames=max(F, F_in))
+    x = torch.randn((F, 2 * n_cplx), dtype=torch.float32, device=dev); y = torch.empty_like(x)
+    xs = torch.randn((F_in, 2 * n_in), dtype=torch.float32, device=dev); ys = torch.empty((F_in, 4 * n_in), dtype=torch.float32, device=dev)
+    for _ in range(REPS):
+        rx.filter_dev(x.data_ptr(), y.data_ptr(), n_cplx, F)
+        rx.shape_filter_dev(xs.data_ptr(), ys.data_ptr(), n_in, F_in)
+    rx.synchronize(); rx.close()
+
+
 if "sync" not in sys.argv[1:]:             # `pmc_workload.py sync`: the synchronizers only (quick kernel-trace passes)
+    fir(66564, 1024, 33282, 1024)
+    fir(6804, 4096, 3402, 4096)
+    chain("8PSK-N_8/9", 4096, 10, 7.5)
     chain("QPSK-N_8/9", 4096, 10, 4.2)
     chain("QPSK-S_8/9", 8192, 10, 4.4)
     chain("16APSK-N_8/9", 4096, 20, 8.2)

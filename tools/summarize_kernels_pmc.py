@@ -3,7 +3,7 @@
 path (other than the LDPC decoder) and per workload size -- launches of one kernel name are split by grid size -- the average
 duration, calibrated fabric bytes (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; MI355X_MICROARCH.md HBM section), instruction
 counts and the busy / wait shares that say what bounds it."""
-import collections, csv, glob, os, sys
+import collections, csv, glob, hashlib, json, os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 OUT = os.path.join(ROOT, "gpurun_out")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
@@ -36,13 +36,26 @@ for d in ("pk_fetch", "pk_write", "pk_sq1", "pk_sq2", "pk_sq3"):
         k = short(r["Kernel_Name"])
         if any(w in k for w in want):
             pmc[(k, r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+STAMPED = ("k_front.hip", "k_bch.hip", "k_sync.hip", "k_sync_mfma.hip", "k_fir.hip", "k_fir_mfma.hip", "k_tx.hip")
+
+
+def sources_sha():
+    h = hashlib.sha256()
+    for f in STAMPED:
+        h.update(open(os.path.join(ROOT, "dvbs2_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 lines = ["# rocprofv3 counters of the non-LDPC kernels (%s) -- `python3 tools/pmc_workload.py`, passes of tools/profile_kernels.sh" % tag, "",
+         "Sources measured: %s, sha-256 `%s` (profiles/kernels_pmc_stamp.json; tests/test_bench_contract.py fails when they change without a new profile)." % (", ".join(STAMPED), sources_sha()), "",
          "Per kernel and grid size (= workload): average over its launches.  fabric GB = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; FETCH_SIZE",
          "reports half of the bytes of a coalesced stream on gfx950, WRITE_SIZE the bytes: calibrated in profiles/r02_ldpc_rocprof.md).",
          "VALU busy = SQ_ACTIVE_INST_VALU / (4 SIMDs x SQ_BUSY_CYCLES summed over the chip's SQs) is shown as the share of wave-cycles instead:",
          "valu/wave-cyc = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES, trans = v_exp / v_log / v_rcp / v_sqrt instructions.", "",
-         "| kernel | grid | launches | avg us | fabric GB | fabric TB/s | VALU inst | trans inst | LDS inst | VMEM rd / wr | valu / wave-cyc | wait / wave-cyc | LDS bank-conflict / LDS active | L2 hit |",
-         "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+         "VALU issue = (SQ_INSTS_VALU x 4 + trans x 4 more: transcendentals issue in 8 cycles) / (1024 SIMDs x SQ_BUSY_CYCLES / 32): the share of the chip's vector issue slots.", "",
+         "| kernel | grid | launches | avg us | fabric GB | fabric TB/s | VALU inst | trans inst | VALU issue | LDS inst | VMEM rd / wr | valu / wave-cyc | wait / wave-cyc | LDS bank-conflict / LDS active | L2 hit |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+rows_json = []
 for key in sorted(dur, key=lambda k: -sum(dur[k])):
     c = {n: sum(v) / len(v) for n, v in pmc.get(key, {}).items()}
     us = sum(dur[key]) / len(dur[key])
@@ -50,10 +63,15 @@ for key in sorted(dur, key=lambda k: -sum(dur[k])):
     wc = c.get("SQ_WAVE_CYCLES", 0)
     def ratio(a, b): return "%.2f" % (a / b) if b else "-"
     hit = c.get("TCC_HIT_sum", 0); miss = c.get("TCC_MISS_sum", 0)
-    lines.append("| `%s` | %s | %d | %.1f | %.3f | %.2f | %.3g | %.3g | %.3g | %.3g / %.3g | %s | %s | %s | %s |" % (
+    busy = c.get("SQ_BUSY_CYCLES", 0) / 32.0
+    issue = (c.get("SQ_INSTS_VALU", 0) * 4.0 + c.get("SQ_INSTS_VALU_TRANS_F32", 0) * 4.0) / (1024.0 * busy) if busy else None
+    rows_json.append(dict(kernel=key[0], grid=key[1], launches=len(dur[key]), avg_us=us, fabric_bytes=fab, valu_issue=issue, counters=c))
+    lines.append("| `%s` | %s | %d | %.1f | %.3f | %.2f | %.3g | %.3g | %s | %.3g | %.3g / %.3g | %s | %s | %s | %s |" % (
         key[0], key[1], len(dur[key]), us, fab / 1e9, fab / (us * 1e-6) / 1e12 if us else 0, c.get("SQ_INSTS_VALU", 0), c.get("SQ_INSTS_VALU_TRANS_F32", 0),
-        c.get("SQ_INSTS_LDS", 0), c.get("SQ_INSTS_VMEM_RD", 0), c.get("SQ_INSTS_VMEM_WR", 0), ratio(c.get("SQ_ACTIVE_INST_VALU", 0), wc), ratio(c.get("SQ_WAIT_ANY", 0), wc),
+        ("%.2f" % issue) if issue is not None else "-", c.get("SQ_INSTS_LDS", 0), c.get("SQ_INSTS_VMEM_RD", 0), c.get("SQ_INSTS_VMEM_WR", 0), ratio(c.get("SQ_ACTIVE_INST_VALU", 0), wc), ratio(c.get("SQ_WAIT_ANY", 0), wc),
         ratio(c.get("SQ_LDS_BANK_CONFLICT", 0), c.get("SQ_LDS_IDX_ACTIVE", 0)), ratio(hit, hit + miss)))
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 open(os.path.join(ROOT, "profiles", "%s_kernels_pmc.md" % tag), "w").write("\n".join(lines) + "\n")
+json.dump(dict(tag=tag, sources=list(STAMPED), sha=sources_sha(), rows=rows_json), open(os.path.join(ROOT, "profiles", "%s_kernels_pmc.json" % tag), "w"), indent=1)
+json.dump(dict(tag=tag, sources=list(STAMPED), sha=sources_sha(), file="profiles/%s_kernels_pmc.md" % tag), open(os.path.join(ROOT, "profiles", "kernels_pmc_stamp.json"), "w"), indent=1)
 print("\n".join(lines))
