@@ -276,6 +276,15 @@ int dvbs2hip_cfg_from_modcod(const char *modcod, dvbs2hip_cfg *cfg)
     return DVBS2HIP_EINVAL;
 }
 
+int dvbs2hip_device_count(int32_t *count)
+{
+    if (!count) return DVBS2HIP_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return 0;
+}
+
 int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
 {
     if (!cfg || !out) return fail(nullptr, DVBS2HIP_EINVAL, "null argument");

@@ -71,7 +71,6 @@ struct LdpcKParams {
         uint32_t lds_junk;     // byte offset of the write-only LDS row (the +inf row of padded codes follows it)
         int32_t lds_bytes, pad;
         int32_t nl_info, nl, ng_info, ng;
-        uint32_t mpitch;       // SPA: bytes between the message rows of consecutive slots (1536: whole 128-byte lines)
     } w8;
 };
 
@@ -103,7 +102,7 @@ struct LdpcPlan {             // host-side description, built once per handle
     bool w8_dups_in_lds = false;  // static hybrid: every bit-group with two edges in one layer is LDS-resident
     std::vector<uint32_t> w8_tab, w8_rows;
     uint32_t *d_w8_tab = nullptr, *d_w8_rows = nullptr;
-    uint32_t w8_st_base = 0, w8_lds_junk = 0, w8_mpitch = 0;
+    uint32_t w8_st_base = 0, w8_lds_junk = 0;
     int w8_lds_bytes = 0, w8_gwork_words = 0, w8_nl_info = 0, w8_nl = 0, w8_ng_info = 0, w8_ng = 0;
     uint32_t *d_cu_ctr = nullptr; // [LDPC_CU_CTR_WORDS]
 };

@@ -30,7 +30,7 @@
 //   DVBS2HIP_LDPC_PATH=generic        force the generic kernel
 //   DVBS2HIP_LDPC_WG=12               the two-frames-per-12-wave-workgroup NMS kernel of k_ldpc_fast.hip instead of k_ldpc_wg8.hip
 //   DVBS2HIP_LDPC_FAST_MODE=lds|global|static   posterior image of the fast kernels (default: lds for N = 16200, static hybrid for N = 64800)
-//   DVBS2HIP_LDPC_LOCK_DUPS=0         static hybrid without forcing the duplicate-edge bit-groups into LDS (then the 12-wave kernel runs)
+//   DVBS2HIP_LDPC_LOCK_DUPS=0         static hybrid without forcing the duplicate-edge bit-groups into LDS (then the generic kernel runs)
 //   DVBS2HIP_LDPC_C2V=lds|global, DVBS2HIP_LDPC_LDS_GROUPS=n   generic kernel storage policy
 //   DVBS2HIP_LDPC_BLOCKS_PER_CU, DVBS2HIP_LDPC_GRID_MAX, DVBS2HIP_LDS_LIMIT   occupancy / scaling experiments
 #include "dvbs2hip_internal.h"
@@ -295,15 +295,8 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 pl.w8_lds_bytes = (pl.w8_nl + 1 + (pl.fast_pad && pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z * 4 + 64;
                 pl.w8_st_base = (uint32_t)((2 + pl.w8_ng) * LDPC_Z * 4);
                 pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + 3 * M;
-                if (spa) {      // SPA: one fp32 message per edge slot, [layer][slot][360]; rows on 128-byte lines (DVBS2HIP_SPA_MPITCH=1440: packed)
-                    const char *ep = getenv("DVBS2HIP_SPA_MPITCH");
-                    pl.w8_mpitch = ep ? (uint32_t)atoi(ep) : (uint32_t)LDPC_Z * 4u;
-                    if (pl.w8_mpitch < (uint32_t)LDPC_Z * 4u || (pl.w8_mpitch & 3u)) return "LDPC: DVBS2HIP_SPA_MPITCH must be a multiple of 4 >= 1440";
-                    if (pl.w8_mpitch % 128u == 0) pl.w8_st_base = (pl.w8_st_base + 127u) & ~127u;
-                    pl.w8_gwork_words = (int)((size_t)pl.w8_st_base / 4 + (size_t)q * pl.fast_deg * (pl.w8_mpitch / 4));
-                }
-                {   // every workgroup's slot starts on a cache-line boundary (a slot of 269 280 or 960 480 bytes left three of four workgroups with
-                    // rows straddling lines differently from their neighbours'); DVBS2HIP_LDPC_SLOT_ALIGN / _PAD (bytes) for experiments
+                if (spa) pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + pl.fast_deg * M;      // SPA: one fp32 message per edge slot, [layer][slot][360]
+                {   // DVBS2HIP_LDPC_SLOT_ALIGN / _PAD (bytes): where a workgroup's slot starts -- measured without effect, kept for experiments
                     const char *ea = getenv("DVBS2HIP_LDPC_SLOT_ALIGN"), *ep = getenv("DVBS2HIP_LDPC_SLOT_PAD");
                     const size_t al = ea ? (size_t)atoi(ea) / 4 : 1, pad = ep ? (size_t)atoi(ep) / 4 : 0;
                     if (al > 1) pl.w8_gwork_words = (int)(((size_t)pl.w8_gwork_words + al - 1) / al * al);

@@ -270,12 +270,13 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     // magnitude so that the sum seen by the WEAKEST edge is representable; should the weakest edge itself then overflow
                     // (min2 - min1 > 60), the other edges' outputs are min1 to within e^-60.  Per edge: 2 exp + 1 rcp on the way in, 2 log
                     // on the way out and ~20 full-rate operations, against 2.8 boxplus x (2 exp + 2 log + 12) of the forward / backward form.
-                    const uint32_t mpitch = p.w8.mpitch;
+                    constexpr uint32_t mpitch = W8_ROW;      // message rows packed like the image's (a run-time pitch costs two scalar instructions per access; 1536-byte rows -- whole lines -- measured SLOWER)
                     const uint32_t mrow = st_base + (uint32_t)(r * DEG) * mpitch;       // messages of this layer: [slot][360 of mpitch / 4]
                     const uint32_t dupmask = TE[31];
                     // the circulant offsets are formed twice, for the loads and again for the stores (an opaque copy of t4 keeps the compiler
                     // from holding 27 of them across the arithmetic: registers, not instructions, are what this layer is short of)
-                    uint32_t t4s = t4;
+                    uint32_t t4s = t4, MAGM = 0x7FFFFFFFu;
+                    asm volatile("" : "+s"(MAGM));                // the magnitude mask as an SGPR operand (VOP3 takes no literal)
                     auto woff = [&](int j) { const uint32_t d = t4 - (E[j] & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
                     auto woff_s = [&](int j) { const uint32_t d = t4s - (E[j] & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
                     auto dup_slot = [&](int i) -> uint32_t { return i == 0 ? (cinfo >> 8) & 31u : i == 1 ? (cinfo >> 16) & 31u : T[48 + i] & 31u; };
@@ -356,7 +357,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             const float lg = (SPA_ABL & 8) ? Q : __builtin_amdgcn_logf(2.f - Q * kap) - __builtin_amdgcn_logf(Q);
                             float o = __builtin_fmaf(lg, 0.693147180559945309f, cln);
                             o = (fabsf(x[j]) < key || fabsf(x[j]) > key) ? mn1 : o;
-                            const float nw = __uint_as_float((__float_as_uint(o) & 0x7FFFFFFFu) | ((sx ^ __float_as_uint(x[j])) & 0x80000000u));
+                            float nw;                                 // magnitude bits of o under the sign of (all signs) ^ (own sign): one v_bfi_b32
+                            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(nw) : "s"(MAGM), "v"(o), "v"(sx ^ __float_as_uint(x[j])));
                             A = __builtin_fmaf(u[j], wA, A);
                             const bool pr = ((prim >> j) & 1u) != 0u;
                             const uint32_t base = (E[j] >> 11) & 0x3FFFFu, wj = woff_s(j);
@@ -738,7 +740,6 @@ hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
     p.cu_ctr = pl.d_cu_ctr;
     p.w8.tab = pl.d_w8_tab; p.w8.rows = pl.d_w8_rows;
     p.w8.st_base = pl.w8_st_base; p.w8.lds_junk = pl.w8_lds_junk; p.w8.lds_bytes = pl.w8_lds_bytes; p.w8.pad = pl.fast_pad ? 1 : 0;
-    p.w8.mpitch = pl.w8_mpitch;
     p.w8.nl_info = pl.w8_nl_info; p.w8.nl = pl.w8_nl; p.w8.ng_info = pl.w8_ng_info; p.w8.ng = pl.w8_ng;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.gwork_words = pl.w8_gwork_words;

@@ -49,6 +49,7 @@ _SOCK2 = [_vp, _vp, _vp, _i]
 ABI = {
     "dvbs2hip_cfg_from_modcod": (C.c_int, [C.c_char_p, C.POINTER(Cfg)]),
     "dvbs2hip_create": (C.c_int, [C.POINTER(Cfg), C.POINTER(_vp)]),
+    "dvbs2hip_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
     "dvbs2hip_destroy": (None, [_vp]),
     "dvbs2hip_last_error": (C.c_char_p, [_vp]),
     "dvbs2hip_ldpc_kernel_name": (C.c_char_p, [_vp]),

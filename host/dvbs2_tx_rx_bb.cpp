@@ -60,7 +60,9 @@ int main(int argc, char **argv)
     dvbs2hip_cfg cfg;
     if (dvbs2hip_cfg_from_modcod(modcod.c_str(), &cfg)) { std::fprintf(stderr, "%s\n", dvbs2hip_last_error(nullptr)); return 3; }
     cfg.max_frames = F; cfg.ldpc_n_ite = n_ite; cfg.ldpc_alpha = alpha; cfg.ldpc_early_stop = 1;
-    cfg.device = local_rank >= 0 ? local_rank : rank;
+    int32_t n_gpus = 0;
+    (void)dvbs2hip_device_count(&n_gpus);
+    cfg.device = local_rank >= 0 ? local_rank : (n_gpus > 0 ? rank % n_gpus : rank);      // a global rank only: ranks are dealt to the node's GPUs in order
     cfg.ldpc_implem = implem == "SPA" ? DVBS2HIP_IMPLEM_SPA : implem == "MS" ? DVBS2HIP_IMPLEM_MS : DVBS2HIP_IMPLEM_NMS;
     if (implem != "SPA" && implem != "MS" && implem != "NMS") { std::fprintf(stderr, "--dec-implem has to be SPA, MS or NMS\n"); return 2; }
     if (dvbs2hip_create(&cfg, &h)) { std::fprintf(stderr, "%s\n", dvbs2hip_last_error(nullptr)); return 3; }

@@ -103,6 +103,10 @@ typedef struct dvbs2hip_cfg {
  * DVBS2.cpp:135-142). */
 int dvbs2hip_cfg_from_modcod(const char *modcod, dvbs2hip_cfg *cfg);
 int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out);
+/* GPUs this process sees (0 without one): what a one-process-per-GPU launcher takes `cfg.device = local_rank % count` from when the
+ * environment gives it a global rank only (host/dvbs2_tx_rx_bb.cpp); the reference's analogue is the thread count of Sequence(first, n_threads),
+ * TX_RX_BB/main.cpp:96. */
+int dvbs2hip_device_count(int32_t *count);
 void dvbs2hip_destroy(dvbs2hip_t *h);
 /* text of the last error on this handle (or of the last failed create when h == NULL) */
 const char *dvbs2hip_last_error(const dvbs2hip_t *h);
