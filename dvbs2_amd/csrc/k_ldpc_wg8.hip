@@ -268,7 +268,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     // To keep Q inside the fp32 range for LLRs of hundreds, the lane carries Q' = 2^s2 Q with s2 = max(0, (min2 - 16) log2 e):
                     // an exact change of variable (Q'_ab = Q'_a + Q'_b (1 - kap Q'_a), kap = 2^-s2), chosen from the second smallest
                     // magnitude so that the sum seen by the WEAKEST edge is representable; should the weakest edge itself then overflow
-                    // (min2 - min1 > 60), the other edges' outputs are min1 to within e^-60.  Per edge: 2 exp + 1 rcp on the way in, 2 log
+                    // (min2 - min1 > 60), the other edges' outputs are min1 to within e^-57.  Per edge: 1 exp + 1 rcp on the way in, 2 log
                     // on the way out and ~20 full-rate operations, against 2.8 boxplus x (2 exp + 2 log + 12) of the forward / backward form.
                     constexpr uint32_t mpitch = W8_ROW;      // message rows packed like the image's (a run-time pitch costs two scalar instructions per access; 1536-byte rows -- whole lines -- measured SLOWER)
                     const uint32_t mrow = st_base + (uint32_t)(r * DEG) * mpitch;       // messages of this layer: [slot][360 of mpitch / 4]
@@ -325,9 +325,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         key = (mn2 - mn1 > 60.f) ? mn1 : __builtin_nanf("");      // a_j <> key: "this edge is not the weakest one and the weakest one overflows"
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
-                            const float ea = __builtin_fmaf(fabsf(x[j]), -1.44269504088896341f, s2p1);
-                            const float es2 = (SPA_ABL & 8) ? ea : __builtin_amdgcn_exp2f(ea);                                     // 2 . 2^s2 e^-a
-                            u[j] = es2 * ((SPA_ABL & 8) ? hk : __builtin_amdgcn_rcpf(__builtin_fmaf(es2, hk, 1.f)));               // / (1 + e^-a)
+                            // u' = 2^s2 . 2 / (e^a + 1) = 1 / (2^(a log2 e - s2 - 1) + 2^-(s2 + 1)): fma, exp, add, rcp; a = +inf (absent edge) -> 0
+                            const float ea = __builtin_fmaf(fabsf(x[j]), 1.44269504088896341f, -s2p1);
+                            u[j] = (SPA_ABL & 8) ? ea : __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(ea) + hk);
                         }
                         {
                             float b = 0.f;      // B_j = Q' of the slots behind j; B[k] = B_{BS k + BS - 1} (clipped to the last slot)
@@ -354,7 +354,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                                 for (int i = js; i > j; i--) Bj = comb(Bj, u[i]);
                             }
                             const float Q = __builtin_fmaf(Bj, wA, A);
-                            const float lg = (SPA_ABL & 8) ? Q : __builtin_amdgcn_logf(2.f - Q * kap) - __builtin_amdgcn_logf(Q);
+                            const float lg = (SPA_ABL & 8) ? Q : __builtin_amdgcn_logf(__builtin_fmaf(-kap, Q, 2.f)) - __builtin_amdgcn_logf(Q);
                             float o = __builtin_fmaf(lg, 0.693147180559945309f, cln);
                             o = (fabsf(x[j]) < key || fabsf(x[j]) > key) ? mn1 : o;
                             float nw;                                 // magnitude bits of o under the sign of (all signs) ^ (own sign): one v_bfi_b32

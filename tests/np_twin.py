@@ -74,8 +74,8 @@ def spa_check_complement(v2c):
         kap = np.exp2(-s2, dtype=f32)
         cln = (s2 * LN2).astype(f32)
         hk = (f32(0.5) * kap).astype(f32)
-        es2 = np.exp2((a * (-LOG2E) + (s2 + f32(1))[:, None]).astype(f32), dtype=f32)
-        u = (es2 * (f32(1) / (es2 * hk[:, None] + f32(1)).astype(f32)).astype(f32)).astype(f32)
+        # u' = 2^s2 . 2 / (e^a + 1) = 1 / (2^(a log2 e - s2 - 1) + 2^-(s2 + 1))
+        u = (f32(1) / (np.exp2((a * LOG2E - (s2 + f32(1))[:, None]).astype(f32), dtype=f32) + hk[:, None]).astype(f32)).astype(f32)
         comb = lambda A, b: (b * (f32(1) - kap * A).astype(f32) + A).astype(f32)
         B = np.zeros((n, d), f32)
         for j in range(d - 2, -1, -1):
@@ -85,7 +85,7 @@ def spa_check_complement(v2c):
         out = np.empty((n, d), f32)
         for j in range(d):
             Q = comb(A, B[:, j])
-            lg = (np.log2(f32(2) - Q * kap, dtype=f32) - np.log2(Q, dtype=f32)).astype(f32)
+            lg = (np.log2((f32(2) - kap * Q).astype(f32), dtype=f32) - np.log2(Q, dtype=f32)).astype(f32)
             o = (lg * LN2 + cln).astype(f32)
             out[:, j] = np.where((a[:, j] < key) | (a[:, j] > key), min1, o)
             A = comb(A, u[:, j])
