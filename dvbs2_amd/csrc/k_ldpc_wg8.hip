@@ -57,6 +57,9 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #ifndef SPA_AUX
 #define SPA_AUX 0
 #endif
+#ifndef SPA_MSG4         // 1: a lane keeps the messages of four consecutive slots as one 16-byte piece ([layer][slot / 4][360][4]); 0: [layer][slot][360]
+#define SPA_MSG4 1
+#endif
 #ifndef SPA_ABL          // timing-only ablations (wrong results): 1 no message stores, 2 no message loads, 4 no posterior stores to global memory, 8 no check-node arithmetic
 #define SPA_ABL 0
 #endif
@@ -161,6 +164,31 @@ ldpc_wg8_kernel(const LdpcKParams p)
     auto gst = [&](uint32_t voff, uint32_t soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, 0); };
     auto mld = [&](uint32_t voff, uint32_t soff) { if (SPA_ABL & 2) return __uint_as_float(voff & 0x3F000000u); return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, SPA_AUX)); };      // SPA messages
     auto mst = [&](uint32_t voff, uint32_t soff, float v) { if (SPA_ABL & 1) { asm volatile("" :: "v"(v)); return; } __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, SPA_AUX); };
+    // SPA_MSG4: the messages of a layer as [slot / 4][360][4 slots] (the last group holds DEG mod 4 of them): a lane's messages of four consecutive slots are 16
+    // consecutive bytes, a wave's access 1 KB -- whole lines written and read by ONE instruction instead of four 256-byte pieces of four rows
+    // (the per-edge message stream, HBM by construction, is what the sum-product kernel is bound by: section 6's ablations).  Same bytes per layer.
+    typedef uint32_t m_u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t m_u32x3 __attribute__((ext_vector_type(3)));
+    typedef uint32_t m_u32x2 __attribute__((ext_vector_type(2)));
+    constexpr int MG4 = DEG / 4, MR = DEG % 4;                                            // whole groups of four slots, slots in the last group
+    auto mgrp_ld = [&](float *dst, uint32_t tb, uint32_t lbase) {                         // all DEG messages of this lane; tb = 4 t (bytes of one dword per lane)
+#pragma unroll
+        for (int g = 0; g < MG4; g++) {
+            m_u32x4 v = {0u, 0u, 0u, 0u};
+            if (!(SPA_ABL & 2)) v = __builtin_amdgcn_raw_buffer_load_b128(rs, tb * 4u, lbase + (uint32_t)g * (W8_ROW * 4u), SPA_AUX);
+            dst[4 * g] = __uint_as_float(v.x); dst[4 * g + 1] = __uint_as_float(v.y); dst[4 * g + 2] = __uint_as_float(v.z); dst[4 * g + 3] = __uint_as_float(v.w);
+        }
+        const uint32_t tbase = lbase + (uint32_t)MG4 * (W8_ROW * 4u);
+        if (MR == 3) { m_u32x3 v = {0u, 0u, 0u}; if (!(SPA_ABL & 2)) v = __builtin_amdgcn_raw_buffer_load_b96(rs, tb * 3u, tbase, SPA_AUX);
+                       dst[4 * MG4] = __uint_as_float(v.x); dst[4 * MG4 + 1] = __uint_as_float(v.y); dst[4 * MG4 + 2] = __uint_as_float(v.z); }
+        if (MR == 2) { m_u32x2 v = {0u, 0u}; if (!(SPA_ABL & 2)) v = __builtin_amdgcn_raw_buffer_load_b64(rs, tb * 2u, tbase, SPA_AUX);
+                       dst[4 * MG4] = __uint_as_float(v.x); dst[4 * MG4 + 1] = __uint_as_float(v.y); }
+        if (MR == 1) dst[4 * MG4] = mld(tb, tbase);
+    };
+    auto mone_ld = [&](uint32_t slot, uint32_t tb, uint32_t lbase) -> float {             // one message (wave-uniform slot): the duplicate edges' old values
+        const uint32_t g = slot >> 2, k = slot & 3u;
+        return g < (uint32_t)MG4 ? mld(tb * 4u, lbase + g * (W8_ROW * 4u) + k * 4u) : mld(tb * (uint32_t)(MR ? MR : 1), lbase + (uint32_t)MG4 * (W8_ROW * 4u) + k * 4u);
+    };
     auto lld = [&](uint32_t a) -> float { return *(lds_float *)(L + a); };
     auto lst = [&](uint32_t a, float v) { *(lds_float *)(L + a) = v; };
     auto st_off = [&](int arr, int r) { return st_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u; };
@@ -300,11 +328,15 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         }
                         if (it > 0) {
 #if !SPA_PREFETCH
+#if SPA_MSG4
+                            mgrp_ld(onx, t4, mrow);
+#else
 #pragma unroll
                             for (int j = 0; j < DEG; j++) onx[j] = mld(t4, mrow + (uint32_t)j * mpitch);     // old message
 #endif
+#endif
 #pragma unroll
-                            for (int i = 0; i < LDPC_SPA_MAXC; i++) if (i < ncf) od[i] = mld(t4, mrow + dup_slot(i) * mpitch);
+                            for (int i = 0; i < LDPC_SPA_MAXC; i++) if (i < ncf) od[i] = SPA_MSG4 ? mone_ld(dup_slot(i), t4, mrow) : mld(t4, mrow + dup_slot(i) * mpitch);
                         }
                         __builtin_amdgcn_s_setprio(0);
 #pragma unroll
@@ -341,6 +373,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     if (ncf > 0) __syncthreads();         // every read of the layer precedes its writes
                     if (act) {
                         float A = 0.f;
+                        float mq[4] = {0.f, 0.f, 0.f, 0.f};
                         asm volatile("" : "+v"(t4s));
                         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
@@ -373,7 +406,22 @@ ldpc_wg8_kernel(const LdpcKParams p)
                                 else if (SPA_ABL & 4) asm volatile("" :: "v"(x[j] + nw), "v"(vo), "s"(sb));
                                 else gst(vo, sb, x[j] + nw);
                             }
+#if SPA_MSG4
+                            mq[j & 3] = nw;                     // four slots' messages leave as one 16-byte piece (the last group: what is left)
+                            if (!(SPA_ABL & 1)) {
+                                if ((j & 3) == 3)
+                                    __builtin_amdgcn_raw_buffer_store_b128(m_u32x4{__float_as_uint(mq[0]), __float_as_uint(mq[1]), __float_as_uint(mq[2]), __float_as_uint(mq[3])}, rs, t4s * 4u,
+                                                                           mrow + (uint32_t)(j >> 2) * (W8_ROW * 4u), SPA_AUX);
+                                else if (j == DEG - 1) {
+                                    const uint32_t tbase = mrow + (uint32_t)MG4 * (W8_ROW * 4u);
+                                    if (MR == 3) __builtin_amdgcn_raw_buffer_store_b96(m_u32x3{__float_as_uint(mq[0]), __float_as_uint(mq[1]), __float_as_uint(mq[2])}, rs, t4s * 3u, tbase, SPA_AUX);
+                                    if (MR == 2) __builtin_amdgcn_raw_buffer_store_b64(m_u32x2{__float_as_uint(mq[0]), __float_as_uint(mq[1])}, rs, t4s * 2u, tbase, SPA_AUX);
+                                    if (MR == 1) mst(t4s, tbase, mq[0]);
+                                }
+                            } else asm volatile("" :: "v"(nw));
+#else
                             mst(t4s, mrow + (uint32_t)j * mpitch, nw);
+#endif
                             if ((dupmask >> j) & 1u) {          // wave-uniform
 #pragma unroll
                                 for (int i = 0; i < LDPC_SPA_MAXC; i++) if (i < ncf && dup_slot(i) == (uint32_t)j) od[i] = nw - od[i];
@@ -385,8 +433,12 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         __builtin_amdgcn_sched_barrier(0);      // not earlier: x[], u[], B[] have to be dead first (registers)
                         if ((it > 0 || r + 1 == q) && !(r + 1 == q && it + 1 >= p.n_ite)) {
                             const uint32_t mnext = st_base + (uint32_t)((r + 1 < q ? r + 1 : 0) * DEG) * mpitch;
+#if SPA_MSG4
+                            mgrp_ld(onx, t4s, mnext);
+#else
 #pragma unroll
                             for (int j = 0; j < DEG; j++) onx[j] = mld(t4s, mnext + (uint32_t)j * mpitch);
+#endif
                         } else {
 #pragma unroll
                             for (int j = 0; j < DEG; j++) onx[j] = 0.f;
