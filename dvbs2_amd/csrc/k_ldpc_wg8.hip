@@ -57,6 +57,12 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #ifndef SPA_AUX
 #define SPA_AUX 0
 #endif
+// Cache policy of the message STORES alone.  Default: non-temporal (aux = 2) where the image does not fit LDS, i.e. for the long codes, whose message
+// store (512 x 778 KB for N = 64800) is larger than the Infinity Cache and is read back one whole iteration later -- same-box A/B 64.9 -> 61.1 ms per 16384
+// normal frames, 16.6 -> 15.0 ms per 4096; for N = 16200 (512 x 194 KB: cache-resident) the default policy is 7 % faster, and non-temporal LOADS lose on both.
+#ifndef SPA_AUX_ST
+#define SPA_AUX_ST (MODE == 0 ? SPA_AUX : 2)
+#endif
 #ifndef SPA_MSG4         // 1: a lane keeps the messages of four consecutive slots as one 16-byte piece ([layer][slot / 4][360][4]); 0: [layer][slot][360]
 #define SPA_MSG4 1
 #endif
@@ -310,7 +316,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     auto dup_slot = [&](int i) -> uint32_t { return i == 0 ? (cinfo >> 8) & 31u : i == 1 ? (cinfo >> 16) & 31u : T[48 + i] & 31u; };
                     // suffix values are kept for every BS-th slot only and rebuilt from there on the way forward (one or two steps off the
                     // critical path): the full array does not fit the 128-VGPR budget of two workgroups per CU beside x[] and u[]
-                    constexpr int BS = SPA_BS, NB = (DEG + BS - 1) / BS;
+                    constexpr int BS = DEG > 13 ? SPA_BS : 1, NB = (DEG + BS - 1) / BS;      // (the 11- and 13-slot codes have the registers for every suffix value)
                     float x[DEG], u[DEG], B[NB];                    // v->c ; 2^s2 (1 - tanh(|v->c| / 2)) ; suffix recursion
                     float od[LDPC_SPA_MAXC];                        // old c->v of the duplicate edges, then new - old (what such an edge adds)
                     float mn1 = INFINITY, kap = 1.f, cln = 0.f, key = 0.f;
@@ -374,7 +380,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     if (act) {
                         float A = 0.f;
                         float mq[4] = {0.f, 0.f, 0.f, 0.f};
-                        asm volatile("" : "+v"(t4s));
+                        if (DEG > 13) asm volatile("" : "+v"(t4s));      // (the short codes keep their offsets: 70 registers in all)
                         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
@@ -411,11 +417,11 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             if (!(SPA_ABL & 1)) {
                                 if ((j & 3) == 3)
                                     __builtin_amdgcn_raw_buffer_store_b128(m_u32x4{__float_as_uint(mq[0]), __float_as_uint(mq[1]), __float_as_uint(mq[2]), __float_as_uint(mq[3])}, rs, t4s * 4u,
-                                                                           mrow + (uint32_t)(j >> 2) * (W8_ROW * 4u), SPA_AUX);
+                                                                           mrow + (uint32_t)(j >> 2) * (W8_ROW * 4u), SPA_AUX_ST);
                                 else if (j == DEG - 1) {
                                     const uint32_t tbase = mrow + (uint32_t)MG4 * (W8_ROW * 4u);
-                                    if (MR == 3) __builtin_amdgcn_raw_buffer_store_b96(m_u32x3{__float_as_uint(mq[0]), __float_as_uint(mq[1]), __float_as_uint(mq[2])}, rs, t4s * 3u, tbase, SPA_AUX);
-                                    if (MR == 2) __builtin_amdgcn_raw_buffer_store_b64(m_u32x2{__float_as_uint(mq[0]), __float_as_uint(mq[1])}, rs, t4s * 2u, tbase, SPA_AUX);
+                                    if (MR == 3) __builtin_amdgcn_raw_buffer_store_b96(m_u32x3{__float_as_uint(mq[0]), __float_as_uint(mq[1]), __float_as_uint(mq[2])}, rs, t4s * 3u, tbase, SPA_AUX_ST);
+                                    if (MR == 2) __builtin_amdgcn_raw_buffer_store_b64(m_u32x2{__float_as_uint(mq[0]), __float_as_uint(mq[1])}, rs, t4s * 2u, tbase, SPA_AUX_ST);
                                     if (MR == 1) mst(t4s, tbase, mq[0]);
                                 }
                             } else asm volatile("" :: "v"(nw));

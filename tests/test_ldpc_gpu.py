@@ -176,6 +176,27 @@ def test_ldpc_spa_matches_oracle(O, Rx, modcod, ebn0):
     rx.close()
 
 
+@pytest.mark.parametrize("modcod,ebn0,n_ite,scale", [("QPSK-S_8/9", 5.0, 10, 1.0), ("QPSK-S_8/9", 9.0, 20, 4.0), ("QPSK-S_3/5", 6.0, 10, 1.0), ("32APSK-S_3/4", 8.0, 10, 1.0),
+                                                     ("QPSK-N_8/9", 6.0, 10, 1.0), ("QPSK-N_8/9", 9.0, 10, 3.0)])
+def test_ldpc_spa_far_beyond_the_saturation_of_tanh(O, Rx, modcod, ebn0, n_ite, scale):
+    """The sum-product kernel evaluates the check node in the complement-product domain with a per-check scale (k_ldpc_wg8.hip): fixed iterations far
+    above the waterfall drive the posteriors to hundreds and thousands (11 800 in the second case) -- where tanh(a / 2) is 1 in fp32, e^-a leaves
+    the fp32 range, and a check's weakest edge can lie 60 and more below its second weakest -- and the GPU still has to follow the oracle's boxplus
+    recursions: posteriors within 1e-4 max(1, abs(L)) (measured: 3e-6), no NaN, identical hard decisions and CWD."""
+    ch = chain(O, modcod)
+    F = 2
+    _, llr, cw = make_llrs(O, modcod, F, ebn0, seed=23)
+    llr = (llr * scale).astype(np.float32)
+    rx = Rx(modcod, max_frames=F, n_ite=n_ite, early_stop=False, implem="SPA")
+    V, CWD, post, _ = rx.decode_siho(llr, with_post=True)
+    Vo, posto, cwdo, _ = ch.ldpc.decode(llr, n_ite=n_ite, implem=O.SPA, sched=O.QC, early_stop=False)
+    assert not np.isnan(post).any() and np.isfinite(post).all()
+    assert float(np.abs(posto).max()) > 400.0                                    # the regime the test is about
+    assert np.all(np.abs(post - posto) <= 1e-4 * np.maximum(1.0, np.abs(posto))), float((np.abs(post - posto) / np.maximum(1.0, np.abs(posto))).max())
+    assert np.array_equal(V, Vo) and np.array_equal(CWD, cwdo) and CWD.all()
+    rx.close()
+
+
 NAT_CASES = [("QPSK-S_8/9", 4.4, 5), ("QPSK-S_8/9", 3.2, 70), ("QPSK-S_3/5", 1.2, 3), ("32APSK-S_3/4", 3.4, 4), ("QPSK-N_8/9", 3.6, 2)]
 
 
