@@ -46,6 +46,162 @@ namespace dvbs2 {
 // ------------------------------------------------------------------------------------------
 static const char *const PLAN_RETRY_GENERIC = "\x01generic";
 
+// ------------------------------------------------------------------------------------------
+// MODE 4 ("parked rows", k_ldpc_wg8.hip): on-chip bit-groups = LDS rows + rows PARKED in the registers of the workgroup's two
+// idle waves while no layer needs them.  The schedule is static and cyclic over the q layers of an iteration:
+//   * the on-chip set S gives every layer exactly LDPC_PARK_NL of its slots (k_ldpc_wg8.hip knows at compile time which slots
+//     are LDS accesses);
+//   * n_pos LDS positions, NR = |S| - n_pos of them each shared by a PAIR of rows (X, Y) with register slot k: while X is in the
+//     position Y sits in the slot, and twice per iteration the idle waves swap them ("during layer s": between the end-of-layer
+//     barriers s-1 and s).  A pair is compatible when two layers s1, s2 that use neither row separate the layers that use X
+//     (all inside (s1, s2)) from those that use Y (all inside (s2, s1)): X is swapped in during s1 -- it is first needed by s1 + 1
+//     at the earliest -- and out during s2, after its last use;
+//   * the other rows of S own a position for good.  Pairs = a matching in the compatibility graph (randomised greedy, restarts).
+// Everything here is host code; the result is verified by simulating one full cycle before it is used.
+struct ParkPlan {
+    std::vector<char> in_chip;              // [n_groups]
+    std::vector<std::vector<int>> pos;      // [n_groups][q]: LDS position of the row during layer r (-1: not in LDS then)
+    std::vector<uint32_t> srv;              // [q][LDPC_PARK_NR]: LDS position slot k swaps with during layer r (0xFF: none)
+    std::vector<int> lds0, reg0;            // state at the start of layer 0: bit-group at LDS position / in register slot (-1: empty)
+    int n_pos = 0, nl0 = 0, n_moves = 0, n_pairs = 0;
+};
+
+static bool plan_parked(const std::vector<std::vector<int>> &mult, const std::vector<char> &banned, int q, int NL, int n_pos, int NRmax,
+                        ParkPlan &out, std::string &why)
+{
+    const int n_groups = (int)mult.size();
+    uint32_t rng = 2463534242u;
+    auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return rng >> 4; };
+    std::vector<int> touches(n_groups, 0);
+    std::vector<char> dup(n_groups, 0);
+    for (int g = 0; g < n_groups; g++) for (int r = 0; r < q; r++) { touches[g] += mult[g][r]; dup[g] |= mult[g][r] > 1; }
+    for (int round = 0; round < 8; round++) {
+        // ---- (A) the on-chip set: exactly NL slots of every layer, at most n_pos + NRmax rows, the doubly connected groups among them
+        const int cap = n_pos + NRmax;
+        std::vector<char> inS(n_groups, 0);
+        std::vector<int> cnt(q, 0);
+        int size = 0;
+        auto fits = [&](int g) { for (int r = 0; r < q; r++) if (cnt[r] + mult[g][r] > NL) return false; return true; };
+        auto add = [&](int g, int s) { inS[g] = s > 0; size += s; for (int r = 0; r < q; r++) cnt[r] += s * mult[g][r]; };
+        for (int g = 0; g < n_groups; g++) if (dup[g]) {
+            if (banned[g] || !fits(g) || size >= cap) { why = "doubly connected bit-groups do not fit"; return false; }
+            add(g, +1);
+        }
+        for (;;) {
+            int best = 0, bg = -1;
+            for (int g = 0; g < n_groups && size < cap; g++) if (!inS[g] && !banned[g] && fits(g) && touches[g] * 16 + (int)(rnd() % 16) > best) { best = touches[g] * 16 + 15; bg = g; }
+            if (bg < 0) break;
+            add(bg, +1);
+        }
+        auto cost = [&]() { int c = 0; for (int r = 0; r < q; r++) c += (NL - cnt[r]) * (NL - cnt[r]); return c; };
+        int c0 = cost();
+        for (int it = 0; it < 600000 && c0 > 0; it++) {
+            int g_out = -1, g_in = -1;
+            if (rnd() & 1) { do { g_out = (int)(rnd() % n_groups); } while (!inS[g_out]); if (dup[g_out]) g_out = -1; }
+            if (rnd() % 10 != 0) { do { g_in = (int)(rnd() % n_groups); } while (inS[g_in] || banned[g_in]); }
+            if (g_out >= 0) add(g_out, -1);
+            bool ok = true;
+            if (g_in >= 0) { ok = fits(g_in) && size < cap; if (ok) add(g_in, +1); }
+            const int c1 = ok ? cost() : 1 << 30;
+            if (ok && (c1 <= c0 || rnd() % 500 == 0)) c0 = c1;
+            else { if (ok && g_in >= 0) add(g_in, -1); if (g_out >= 0) add(g_out, +1); }
+        }
+        if (c0 != 0) { why = "no on-chip set with the same number of slots in every layer"; continue; }
+        std::vector<int> S;
+        for (int g = 0; g < n_groups; g++) if (inS[g]) S.push_back(g);
+        const int need = (int)S.size() - n_pos;                 // pairs (= register slots) needed
+        if (need > NRmax) { why = "on-chip set too large"; continue; }
+        // ---- (B) compatible pairs and their swap layers
+        struct Edge { int x, y, s1, s2; };                      // x in LDS during (s1, s2), y during (s2, s1)
+        std::vector<Edge> edges;
+        auto used_by = [&](int g, int l) { return mult[g][((l % q) + q) % q] > 0; };
+        for (size_t i = 0; i < S.size(); i++) for (size_t j = i + 1; j < S.size(); j++) {
+            const int x = S[i], y = S[j];
+            int bs1 = -1, bs2 = -1, bsc = -1;
+            for (int s1 = 0; s1 < q; s1++) {
+                if (used_by(x, s1) || used_by(y, s1) || used_by(y, s1 + 1)) continue;          // y leaves during s1: not needed in s1 nor s1 + 1 .. ; x arrives
+                for (int d = 1; d < q; d++) {
+                    const int s2 = (s1 + d) % q;
+                    if (used_by(x, s2) || used_by(y, s2) || used_by(x, s2 + 1)) continue;
+                    bool okp = true;
+                    for (int l = 0; l < q && okp; l++) {
+                        const bool inside = ((l - s1) % q + q) % q < d;                      // l in [s1, s2)
+                        if (used_by(x, l) && !inside) okp = false;
+                        if (used_by(y, l) && inside) okp = false;
+                    }
+                    if (!okp) continue;
+                    // slack: layers between the swap and the first use after it (the more, the less a late swap can delay a layer)
+                    int f1 = 1, f2 = 1;
+                    while (!used_by(x, s1 + f1)) f1++;
+                    while (!used_by(y, s2 + f2)) f2++;
+                    const int sc = std::min(f1, f2);
+                    if (sc > bsc) { bsc = sc; bs1 = s1; bs2 = s2; }
+                }
+            }
+            if (bs1 >= 0) edges.push_back({x, y, bs1, bs2});
+        }
+        // ---- (C) matching: randomised greedy, low-degree rows first
+        std::vector<int> best_match;
+        for (int attempt = 0; attempt < 3000 && (int)best_match.size() < need; attempt++) {
+            std::vector<int> deg(n_groups, 0), order(edges.size());
+            std::vector<uint32_t> key(edges.size());
+            for (const Edge &e : edges) { deg[e.x]++; deg[e.y]++; }
+            for (size_t i = 0; i < edges.size(); i++) { order[i] = (int)i; key[i] = (uint32_t)(deg[edges[i].x] + deg[edges[i].y]) * 64u + rnd() % (attempt == 0 ? 1u : 512u); }
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+            std::vector<char> taken(n_groups, 0);
+            std::vector<int> m;
+            for (int i : order) if (!taken[edges[i].x] && !taken[edges[i].y]) { taken[edges[i].x] = taken[edges[i].y] = 1; m.push_back(i); }
+            if (m.size() > best_match.size()) best_match = m;
+        }
+        if ((int)best_match.size() < need) { why = "not enough compatible pairs of rows"; continue; }
+        best_match.resize((size_t)need);
+        // ---- (D) tables: positions 0 .. need-1 are the shared ones (slot k <-> position k), then the rows that own theirs
+        out.in_chip = inS; out.n_pos = n_pos; out.n_pairs = need; out.n_moves = 4 * need;
+        out.pos.assign(n_groups, std::vector<int>(q, -1));
+        out.srv.assign((size_t)q * NRmax, 0xFFu);
+        out.lds0.assign(n_pos, -1); out.reg0.assign(NRmax, -1);
+        std::vector<char> paired(n_groups, 0);
+        for (int k = 0; k < need; k++) {
+            const Edge &e = edges[best_match[k]];
+            paired[e.x] = paired[e.y] = 1;
+            const int d = ((e.s2 - e.s1) % q + q) % q;
+            for (int l = 0; l < q; l++) {
+                const int off = ((l - e.s1) % q + q) % q;
+                if (off >= 1 && off < d) out.pos[e.x][l] = k;            // x: layers strictly between s1 and s2
+                if (off > d) out.pos[e.y][l] = k;                       // y: strictly between s2 and s1
+            }
+            out.srv[(size_t)e.s1 * NRmax + k] = (uint32_t)k;
+            out.srv[(size_t)e.s2 * NRmax + k] = (uint32_t)k;
+            // start of layer 0 (before its swaps): x holds the position iff 0 is in (s1, s2]
+            const int o0 = ((0 - e.s1) % q + q) % q;
+            const bool x_in = o0 >= 1 && o0 <= d;
+            out.lds0[k] = x_in ? e.x : e.y; out.reg0[k] = x_in ? e.y : e.x;
+        }
+        int P = need;
+        for (int g : S) if (!paired[g]) { for (int l = 0; l < q; l++) out.pos[g][l] = P; out.lds0[P] = g; P++; }
+        if (P > n_pos) { why = "internal: positions"; return false; }
+        out.nl0 = P;
+        // ---- (E) one full cycle simulated from that state: every access finds its row, no swap touches a row in use, the state closes
+        {
+            std::vector<int> lds = out.lds0, reg = out.reg0;
+            for (int r = 0; r < q; r++) {
+                for (int g : S) if (mult[g][r]) { const int Pg = out.pos[g][r]; if (Pg < 0 || lds[Pg] != g) { why = "simulation: row not where the table says"; return false; } }
+                for (int k = 0; k < NRmax; k++) {
+                    const uint32_t e = out.srv[(size_t)r * NRmax + k];
+                    if (e == 0xFFu) continue;
+                    const int a = lds[e], b = reg[k];
+                    if (a < 0 || b < 0) { why = "simulation: swap with an empty place"; return false; }
+                    if (mult[a][r] || mult[a][(r + 1) % q] || mult[b][r]) { why = "simulation: swap of a row in use"; return false; }
+                    lds[e] = b; reg[k] = a;
+                }
+            }
+            if (lds != out.lds0 || reg != out.reg0) { why = "simulation: the cycle does not close"; return false; }
+        }
+        return true;
+    }
+    return false;
+}
+
 static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,
                                    const int32_t *addr, int lds_groups_req, size_t lds_limit, bool spa, bool allow_fast)
 {
@@ -149,6 +305,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             // exactly NL = 9 of its 27 slots in LDS; the kernel then knows at compile time which slots are LDS
             // accesses.  Greedy fill + randomised local search on sum_r (NL - count_r)^2 (deterministic seed).
             std::vector<char> in_lds(pl.n_groups, 0);
+            ParkPlan park;
             {
                 const int NL = 9;
                 const bool want = (env_mode && !strcmp(env_mode, "static")) || (!env_mode && pl.fast_mode == 1);
@@ -206,11 +363,23 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     }
                     if (c0 == 0) pl.fast_mode = 3;
                     else { std::fill(in_lds.begin(), in_lds.end(), 0); pl.w8_dups_in_lds = false; }
+                    // mode 4: rows parked in the idle waves' registers on top of the LDS rows (min-sum kernel; DVBS2HIP_LDPC_FAST_MODE=static keeps mode 3)
+                    if (pl.fast_mode == 3 && pl.w8_dups_in_lds && !spa && !(env_mode && !strcmp(env_mode, "static"))) {
+                        std::vector<char> banned(pl.n_groups, 0);
+                        for (int g = 0; g < pl.n_groups; g++) banned[g] = banned_g(g);
+                        std::string why;
+                        if (plan_parked(mult, banned, q, LDPC_PARK_NL, cap, LDPC_PARK_NR, park, why)) {
+                            pl.fast_mode = 4;
+                            for (int g = 0; g < pl.n_groups; g++) in_lds[g] = park.in_chip[g];
+                        } else if (getenv("DVBS2HIP_VERBOSE")) fprintf(stderr, "[dvbs2hip] LDPC plan: parked rows not used (%s)\n", why.c_str());
+                    }
                 }
             }
-            if (pl.fast_mode == 3) {
+            const bool hyb = pl.fast_mode == 3 || pl.fast_mode == 4;       // static hybrid: the first NLH slots of every layer are LDS accesses
+            const int NLH = pl.fast_mode == 4 ? LDPC_PARK_NL : 9;
+            if (hyb) {
                 for (int g = 0; g < pl.n_groups; g++) {
-                    if (in_lds[g]) { gbase[g] = (uint32_t)(n_l++ * LDPC_Z); glds[g] = 1u; }
+                    if (in_lds[g]) { gbase[g] = (uint32_t)(n_l++ * LDPC_Z); glds[g] = 1u; }       // (mode 4: the LDS position of a row depends on the layer, park.pos)
                     else gbase[g] = (uint32_t)(n_g++ * LDPC_Z);
                 }
             } else
@@ -220,11 +389,13 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             const uint32_t inf_row_words = (uint32_t)((pl.n_groups + (pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z);
             // k_ldpc_wg8.hip image layout -- LDS: [rows | junk | +inf]; global: [junk | +inf | rows]
             pl.w8_tab.assign((size_t)q * LDPC_FAST_STRIDE, 0u);
-            const int w8_lrows = pl.fast_mode == 0 ? pl.n_groups : pl.fast_mode == 3 ? n_l : 0;
-            auto pack8 = [&](const Slot &sl) -> uint32_t {
+            const int w8_lrows = pl.fast_mode == 0 ? pl.n_groups : pl.fast_mode == 3 ? n_l : pl.fast_mode == 4 ? park.n_pos : 0;
+            bool park_bad = false;
+            auto pack8 = [&](const Slot &sl, int r) -> uint32_t {
                 if (sl.group < 0) return (uint32_t)((pl.fast_mode == 0 ? (w8_lrows + 1) * LDPC_Z * 4 : LDPC_Z * 4)) << 11;      // the +inf row
-                const bool il = pl.fast_mode == 0 || (pl.fast_mode == 3 && glds[sl.group]);
-                const uint32_t base = il ? gbase[sl.group] * 4u : 2u * LDPC_Z * 4u + gbase[sl.group] * 4u;
+                const bool il = pl.fast_mode == 0 || (hyb && glds[sl.group]);
+                uint32_t base = il ? gbase[sl.group] * 4u : 2u * LDPC_Z * 4u + gbase[sl.group] * 4u;
+                if (il && pl.fast_mode == 4) { const int P = park.pos[sl.group][r]; if (P < 0) park_bad = true; base = (uint32_t)(P < 0 ? 0 : P) * LDPC_Z * 4u; }
                 return (uint32_t)(sl.t0 * 4) | (base << 11) | (il ? (1u << 29) : 0u);
             };
             for (int r = 0; r < q; r++) {
@@ -236,9 +407,9 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 std::vector<char> prev_touch(pl.n_groups, 0);
                 for (const Slot &sl : layers[(r + q - 1) % q]) prev_touch[sl.group] = 1;      // (layers[] hold real slots only)
                 std::vector<Slot> ord;
-                if (pl.fast_mode == 3) {      // static hybrid: the LDS-resident slots first (exactly 9 of them), then the others
+                if (hyb) {      // static hybrid: the LDS-resident slots first (exactly 9 of them; 14 with parked rows), then the others
                     for (const Slot &sl : layers[r]) if (in_lds[sl.group]) ord.push_back(sl);
-                    if ((int)ord.size() != 9) return "LDPC: internal: static hybrid balance broken";
+                    if ((int)ord.size() != NLH) return "LDPC: internal: static hybrid balance broken";
                     for (const Slot &sl : layers[r]) if (!in_lds[sl.group]) ord.push_back(sl);
                     const size_t nn = ord.size();
                     if (nn < 2 || ord[nn - 2].group != n_rows + r || ord[nn - 1].group != n_rows + (r + q - 1) % q || ord[nn - 2].t0 != 0 || (r > 0 && ord[nn - 1].t0 != 0))
@@ -254,15 +425,15 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 for (int lvl = 1; lvl <= 3; lvl++)
                     for (size_t j = 0; j < ord.size(); j++)
                         if (ord[j].lvl == lvl && ord[j].group >= 0) {
-                            T8[32 + nc] = pack8(ord[j]);
+                            T8[32 + nc] = pack8(ord[j], r);
                             T8[48 + nc] = (uint32_t)j | ((uint32_t)lvl << 8);
                             dupmask |= 1u << j;
-                            if (pl.fast_mode == 3 && !glds[ord[j].group]) pl.w8_dups_in_lds = false;
+                            if (hyb && !glds[ord[j].group]) pl.w8_dups_in_lds = false;
                             nc++;
                         }
                 for (size_t j = 0; j < ord.size(); j++) {
                     // byte shift (11 bits) | byte offset of the bit-group in its store (18 bits) | LDS flag
-                    T8[j] = pack8(ord[j]);
+                    T8[j] = pack8(ord[j], r);
                     if (ord[j].lvl == 0 && ord[j].group >= 0) prim |= 1u << j;
                 }
                 // ncf | slot of entry 0 << 8 | level << 13 | slot of entry 1 << 16 | level << 21 ; entries 0 and 1 ; slots with a duplicate edge
@@ -275,7 +446,11 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             }
             {   // image rows in storage order: LDS rows then global rows (bit-groups ascend inside each: info first)
                 std::vector<int> lrow, grow;
-                for (int g = 0; g < pl.n_groups; g++) ((pl.fast_mode == 0 || (pl.fast_mode == 3 && glds[g])) ? lrow : grow).push_back(g);
+                for (int g = 0; g < pl.n_groups; g++) ((pl.fast_mode == 0 || (hyb && glds[g])) ? lrow : grow).push_back(g);
+                if (pl.fast_mode == 4) {      // LDS rows = the positions that hold a row at the start of an iteration (layer 0), in position order
+                    if (park_bad) return "LDPC: internal: parked-row table";
+                    lrow.assign(park.lds0.begin(), park.lds0.begin() + park.nl0);
+                }
                 pl.w8_nl = (int)lrow.size(); pl.w8_ng = (int)grow.size();
                 pl.w8_nl_info = (int)std::count_if(lrow.begin(), lrow.end(), [&](int g) { return g < pl.n_info; });
                 pl.w8_ng_info = (int)std::count_if(grow.begin(), grow.end(), [&](int g) { return g < pl.n_info; });
@@ -286,13 +461,21 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 // byte offset of its row in LDS, or bit 31 | byte offset inside the workgroup's global slot ([junk][+inf][rows])
                 for (int r = 0; r < q; r++) {
                     const int g = pl.n_info + r;
-                    const bool in_lds = pl.fast_mode == 0 || (pl.fast_mode == 3 && glds[g]);
+                    const bool in_lds = pl.fast_mode == 0 || (hyb && glds[g]);
+                    if (in_lds && pl.fast_mode == 4) return "LDPC: internal: parity group among the parked rows";
                     pl.w8_rows.push_back(in_lds ? (uint32_t)gbase[g] * 4u : 0x80000000u | (uint32_t)((2 * LDPC_Z + (int)gbase[g]) * 4));
                 }
-                for (size_t i = 0; i < lrow.size(); i++) if ((int)gbase[lrow[i]] != (int)i * LDPC_Z) return "LDPC: internal: LDS row order";
+                if (pl.fast_mode == 4) {      // then the bit-group in register slot k of the idle waves at the start of an iteration (0xFFFFFFFF: empty)
+                    for (int k = 0; k < LDPC_PARK_NR; k++) pl.w8_rows.push_back(park.reg0[k] < 0 ? 0xFFFFFFFFu : (uint32_t)park.reg0[k]);
+                    // and the idle waves' swaps behind the layer tables: [q][LDPC_PARK_NR] x LDS position (0xFF: none)
+                    pl.w8_tab.insert(pl.w8_tab.end(), park.srv.begin(), park.srv.end());
+                } else
+                    for (size_t i = 0; i < lrow.size(); i++) if ((int)gbase[lrow[i]] != (int)i * LDPC_Z) return "LDPC: internal: LDS row order";
                 for (size_t i = 0; i < grow.size(); i++) if ((int)gbase[grow[i]] != (int)i * LDPC_Z) return "LDPC: internal: global row order";
-                pl.w8_lds_junk = (uint32_t)(pl.w8_nl * LDPC_Z * 4);
-                pl.w8_lds_bytes = (pl.w8_nl + 1 + (pl.fast_pad && pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z * 4 + 64;
+                const int n_lds_rows = pl.fast_mode == 4 ? park.n_pos : pl.w8_nl;
+                pl.w8_lds_junk = (uint32_t)(n_lds_rows * LDPC_Z * 4);
+                pl.w8_lds_bytes = (n_lds_rows + 1 + (pl.fast_pad && pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z * 4 + 64;
+                pl.w8_park_moves = pl.fast_mode == 4 ? park.n_moves : 0;
                 pl.w8_st_base = (uint32_t)((2 + pl.w8_ng) * LDPC_Z * 4);
                 pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + 3 * M;
                 if (spa) pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + pl.fast_deg * M;      // SPA: one fp32 message per edge slot, [layer][slot][360]
@@ -304,12 +487,12 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 }
             }
             // workspace of one workgroup: [posteriors kept in global memory | packed c->v state 3 M words]
-            pl.glb_post_words = pl.fast_mode == 1 ? (pl.n_groups + xrows) * LDPC_Z : pl.fast_mode == 3 ? n_g * LDPC_Z : 0;
-            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1 + xrows) * LDPC_Z : pl.fast_mode == 3 ? (n_l + 1) * LDPC_Z : 0;
+            pl.glb_post_words = pl.fast_mode == 1 ? (pl.n_groups + xrows) * LDPC_Z : hyb ? n_g * LDPC_Z : 0;
+            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1 + xrows) * LDPC_Z : pl.fast_mode == 3 ? (n_l + 1) * LDPC_Z : pl.fast_mode == 4 ? (park.n_pos + 1) * LDPC_Z : 0;
             pl.fast_inf_row = pl.fast_pad ? (int)(inf_row_words * 4u) : -1;
             pl.gwork_words = pl.glb_post_words + (spa ? pl.fast_deg * M : 3 * M);      // SPA: one fp32 message per edge slot
             pl.lds_bytes = (size_t)pl.lds_post_words * 4;
-            pl.hybrid = pl.fast_mode == 3; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : n_l;
+            pl.hybrid = hyb; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : n_l;
             {   // k_ldpc_nat.hip (natural row order, one lane per frame): per layer the info slots (NULL-padded), then p_c, then p_{c-1}
                 pl.nat_tab.assign((size_t)q * pl.fast_deg * 2, 0u);
                 for (int r = 0; r < q; r++) {
@@ -351,7 +534,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             // one frame per 8-wave workgroup, two independent workgroups per CU (k_ldpc_wg8.hip); a code it cannot take (a static hybrid
             // whose doubly connected bit-groups do not all fit in LDS) goes to the generic table-driven kernel below
             {
-                const bool w8_ok = pl.fast_mode == 0 || pl.fast_mode == 1 || (pl.fast_mode == 3 && pl.w8_dups_in_lds);
+                const bool w8_ok = pl.fast_mode == 0 || pl.fast_mode == 1 || (hyb && pl.w8_dups_in_lds);
                 if (!(w8_ok && (size_t)pl.w8_lds_bytes <= lds_limit + 512) || (spa && maxc > LDPC_SPA_MAXC)) return PLAN_RETRY_GENERIC;
                 pl.fast_wg8 = true; pl.gwork_words = pl.w8_gwork_words;
             }

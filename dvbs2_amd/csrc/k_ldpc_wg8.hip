@@ -44,7 +44,8 @@ constexpr int W8_NL = 9;                    // MODE 3: LDS-resident slots per la
 constexpr int W8_ROW = LDPC_Z * 4;          // bytes per bit-group row
 constexpr int W8_IO = 16;                  // independent loads per lane in flight during frame I/O
 constexpr uint32_t W8_OOB = 0x7FFFF000u;    // voffset beyond every workspace: the store is dropped
-__host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode == 0 || (mode == 3 && j < W8_NL); }
+__host__ __device__ constexpr bool w8_hybrid(int mode) { return mode == 3 || mode == 4; }      // static hybrid image (4: with rows parked in the idle waves' registers)
+__host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode == 0 || (mode == 3 && j < W8_NL) || (mode == 4 && j < LDPC_PARK_NL); }
 
 // development knobs of the SPA layer (tools/build_variant.sh): suffix values kept every SPA_BS-th slot; next layer's messages
 // requested under the current layer's stores; cache policy of the message traffic
@@ -122,6 +123,104 @@ __device__ __forceinline__ float w8_boxplus(float a, float b)
     return a == INFINITY ? b : (b == INFINITY ? a : r);
 }
 
+// MODE 4: what the two waves of a workgroup that hold no check do instead of idling -- they keep LDPC_PARK_NR bit-group rows of the frame in
+// their registers (3 VGPRs per row and lane: lane e of 128 holds elements e, e + 128, e + 256) and swap rows with LDS by the static, cyclic
+// schedule of k_ldpc.hip (plan_parked): slot k and one LDS position are shared by a pair of rows whose layers do not interleave; twice per
+// iteration, during a layer that uses neither, the slot's row goes to the position and the position's row into the slot.  Every register index
+// is a compile-time constant (the loop over the slots is unrolled; the positions come from a table read on the scalar unit).  The waves
+// follow the working waves barrier for barrier; `nvote` and the vote words are shared with them.
+template <int DEG>
+__device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_char *const L, lds_int *const s_misc, const int wave, const int sidx)
+{
+    constexpr int NR = LDPC_PARK_NR;
+    const int q = p.q;
+    const const_u32 tab = (const_u32)p.w8.tab, srv = tab + q * LDPC_FAST_STRIDE;
+    const const_u32 srow = (const_u32)p.w8.rows + p.w8.nl + p.w8.ng + q;        // bit-group in slot k at the start of an iteration
+    const int lane = (int)threadIdx.x & 63, el = sidx * 64 + lane;
+    // lanes 104 .. 127 have no third element: they mirror element 359 (they read and write back the value lane 103 owns)
+    const int e2 = el + 256 < LDPC_Z ? el + 256 : LDPC_Z - 1;
+    const uint32_t a0 = (uint32_t)el * 4u, a2 = (uint32_t)e2 * 4u;
+    auto lld = [&](uint32_t a) -> float { return *(lds_float *)(L + a); };
+    auto lst = [&](uint32_t a, float v) { *(lds_float *)(L + a) = v; };
+    float R[NR][3];
+    int nvote = 0;
+    auto vote0 = [&]() -> bool {                    // the working waves' vote (ldpc_wg8_kernel), with nothing to report
+        lds_int *const w = s_misc + 10;
+        const int k = nvote % 3;
+        nvote++;
+        if (lane == 0 && wave == 0) w[(k + 1) % 3] = 0;
+        __syncthreads();
+        return w[k] != 0;
+    };
+    auto moves = [&](int r) {                       // the swaps of layer r: slot k <-> LDS position mv[k] (0xFF: none); same lane, same addresses: read, then write
+        const const_u32 mv = srv + r * NR;
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const uint32_t e = mv[k];
+            if (e != 0xFFu) {
+                const uint32_t b = e * (uint32_t)W8_ROW;
+                const float t0 = lld(b + a0), t1 = lld(b + a0 + 512u), t2 = lld(b + a2);
+                lst(b + a0, R[k][0]); lst(b + a0 + 512u, R[k][1]); lst(b + a2, R[k][2]);
+                R[k][0] = t0; R[k][1] = t1; R[k][2] = t2;
+            }
+        }
+    };
+    auto layer_barriers = [&](int r) {              // the barriers of one min-sum layer, as the working waves take them
+        const const_u32 T = tab + r * LDPC_FAST_STRIDE;
+        const uint32_t cinfo = T[28];
+        const int ncf = (int)(cinfo & 0xFFu);
+        if (ncf > 0) {
+            __syncthreads();                        // every read of the layer precedes its writes
+            __syncthreads();                        // the primary writes are in place
+            uint32_t prev_lvl = 1u;
+            for (int i = (ncf > 1 && ((cinfo >> 21) & 3u) == 1u) ? 2 : 1; i < ncf; i++) {
+                const uint32_t lvl = T[48 + i] >> 8;
+                if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
+            }
+        }
+        __syncthreads();                            // end of the layer
+    };
+    const bool es = p.early_stop != 0;
+    for (int f = blockIdx.x; f < p.n_frames; ) {
+        const float *Y = p.llr + (size_t)f * p.N;
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const uint32_t g = srow[k];
+            const float *Yg = Y + (g == 0xFFFFFFFFu ? 0u : g) * (uint32_t)LDPC_Z;
+            R[k][0] = __builtin_nontemporal_load(&Yg[el]); R[k][1] = __builtin_nontemporal_load(&Yg[el + 128]); R[k][2] = __builtin_nontemporal_load(&Yg[e2]);
+        }
+        __syncthreads();                            // the image is in place
+        // ph 0: layer r of an iteration; 1: layer r of the syndrome sweep; 2: catching up with the schedule after a sweep that stopped early
+        int ph = 0, r = 0, it = 0;
+        bool ok = false, fin = false;
+        while (!fin) {
+            bool mv = true;
+            if (ph == 1 && es && r == 0 && vote0()) { ok = false; mv = false; ph = 3; }       // stopping rule: the vote on layer 0 comes before anything moves
+            if (mv) moves(r);
+            if (ph == 0) {
+                layer_barriers(r);
+                if (++r == q) { r = 0; it++; if (es || it == p.n_ite) { ph = 1; ok = true; } }
+            } else if (ph == 1) {
+                bool bad = false;
+                if (es) { if (r == 0) __syncthreads(); else bad = vote0(); }
+                else { if (r == q - 1) { if (vote0()) ok = false; } else __syncthreads(); }
+                if (bad) { ok = false; ph = 2; }
+                if (++r == q) { if (ph == 2) __syncthreads(); ph = 3; }
+            } else if (ph == 2) {
+                if (++r == q) { __syncthreads(); ph = 3; }
+            }
+            if (ph == 3) { if (ok || it >= p.n_ite) fin = true; else { ph = 0; r = 0; } }
+        }
+        // outputs: the parked rows go through LDS positions 0 .. NR-1 once the working waves have read the LDS rows
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NR; k++) { const uint32_t b = (uint32_t)k * (uint32_t)W8_ROW; lst(b + a0, R[k][0]); lst(b + a0 + 512u, R[k][1]); lst(b + a2, R[k][2]); }
+        __syncthreads();
+        __syncthreads();                            // the image is reused by the next frame
+        f = s_misc[9];
+    }
+}
+
 // SPA = false: normalised min-sum with the packed per-check state.  SPA = true: sum-product check node, the c->v
 // messages kept per edge (fp32, [layer][slot][360] after the image in the workgroup's global slot).
 template <int DEG, int MODE, bool SPA = false>      // MODE 0: image in LDS, 1: in the workgroup's global slot, 3: static hybrid
@@ -156,6 +255,18 @@ ldpc_wg8_kernel(const LdpcKParams p)
         else if (k == 0) role = simd;
         else role = ((simd >> 1) == s_misc[8]) ? 4 + (simd & 1) : -1;
         role = __builtin_amdgcn_readfirstlane(role);
+        if (MODE == 4 && role < 0) {               // the two waves without checks keep parked rows (w8_park_server): which of the two is this one?
+            int sidx = 0;
+            for (int w = 0; w < wave; w++) {
+                const int s = s_misc[w];
+                int kw = 0;
+                for (int w2 = 0; w2 < w; w2++) kw += s_misc[w2] == s;
+                const int rw = !balanced ? (w < 6 ? w : -1) : kw == 0 ? s : ((s >> 1) == s_misc[8] ? 4 + (s & 1) : -1);
+                sidx += rw < 0;
+            }
+            w8_park_server<DEG>(p, L, s_misc, wave, __builtin_amdgcn_readfirstlane(sidx));
+            return;
+        }
     }
     const int t = role * 64 + lane;
     const bool act = role >= 0 && t < LDPC_Z;
@@ -203,7 +314,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
     auto st_off = [&](int arr, int r) { return st_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u; };
     const int nl_info = p.w8.nl_info, nl = p.w8.nl, ng_info = p.w8.ng_info, ng = p.w8.ng;
     const uint32_t grow0 = 2u * W8_ROW;                      // global image: [junk row][+inf row][group rows ..]
-    constexpr bool FWD = MODE == 3;                    // parity chain forwarded in a register (plan: p_c at slot DEG-2, p_{c-1} at DEG-1, both global)
+    constexpr bool FWD = w8_hybrid(MODE);                    // parity chain forwarded in a register (plan: p_c at slot DEG-2, p_{c-1} at DEG-1, both global)
 #ifdef LDPC_PHASE_PROF
     uint32_t prof[12];
     for (int i = 0; i < 12; i++) prof[i] = 0u;
@@ -409,7 +520,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                                 if (j == DEG - 1 && mask0) a = ljunk;
                                 lst(a, x[j] + nw);
                             } else {
-                                const uint32_t sb = (MODE == 3 || pr) ? base : 0u;
+                                const uint32_t sb = (w8_hybrid(MODE) || pr) ? base : 0u;
                                 const uint32_t vo = (j == DEG - 1 && mask0) ? W8_OOB : wj;
                                 if (FWD && j == DEG - 2 && r + 1 < q) pfw = x[j] + nw;      // p_c: kept for layer r + 1
                                 else if (SPA_ABL & 4) asm volatile("" :: "v"(x[j] + nw), "v"(vo), "s"(sb));
@@ -564,7 +675,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             lst(a, x + nw);
                         } else {
                             // MODE 3: the duplicate edges all live in LDS, a global slot is always primary
-                            const uint32_t sb = (MODE == 3 || pr) ? base : 0u;                // global junk row = row 0
+                            const uint32_t sb = (w8_hybrid(MODE) || pr) ? base : 0u;        // global junk row = row 0
                             const uint32_t vo = (j == DEG - 1 && mask0) ? W8_OOB : w[j];
                             if (FWD && j == DEG - 2) { if (r + 1 < q) pfw = x + nw; else gst(vo, sb, x + nw); }      // p_c: kept for layer r + 1
                             else gst(vo, sb, x + nw);
@@ -630,7 +741,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 // SPA: the workgroup's vote as a ballot per wave + one LDS word out of three in rotation (zeroed two votes ahead), one
                 // barrier per vote; __syncthreads_or keeps the 64-bit thread index alive across the layer loop, which this kernel spills
                 auto vote = [&](int b) -> bool {
-                    if (!SPA) return __syncthreads_or(b) != 0;
+                    if (!SPA && MODE != 4) return __syncthreads_or(b) != 0;
                     const bool any = __ballot(b != 0) != 0ull;
                     lds_int *const w = s_misc + 10;
                     const int k = nvote % 3;
@@ -655,6 +766,17 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #pragma unroll
                         for (int j = 0; j < DEG; j++) x ^= __float_as_uint(Lv[j]);             // NULL slots read +inf
                         bad |= (int)(x >> 31);
+                    }
+                    if (MODE == 4) {
+                        // parked rows: the idle waves move rows for layer r + 1 while this layer is read, so every layer ends at a barrier; under the
+                        // stopping rule layer 0 is voted on BEFORE anything moves (a frame that has not converged nearly always fails there, and
+                        // the schedule then stands where the next iteration needs it), otherwise the idle waves run the schedule to its end
+                        if (p.early_stop) {
+                            if (vote(bad)) { ok = false; if (r > 0) __syncthreads(); break; }
+                            if (r == 0) __syncthreads();
+                        } else if (r == q - 1) { if (vote(bad)) ok = false; }
+                        else __syncthreads();
+                        continue;
                     }
                     if ((p.early_stop || r == q - 1) && vote(bad)) { ok = false; break; }
                 }
@@ -714,6 +836,19 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 for (int k = 0; k < W8_IO; k++) v[k] = act ? gld(t4, grow0 + (uint32_t)(l0 + k < ng_out ? l0 + k : ng_out - 1) * W8_ROW) : 0.f;
 #pragma unroll
                 for (int k = 0; k < W8_IO; k++) if (l0 + k < ng_out) emit((int)rows[nl + l0 + k], v[k]);
+            }
+        }
+        if (MODE == 4) {
+            // the rows parked in the idle waves' registers: handed over through LDS positions 0 .. NR-1 (every LDS row has been read)
+            __syncthreads();
+            __syncthreads();
+            const const_u32 srow = rows + nl + ng + q;
+            for (int l0 = 0; l0 < LDPC_PARK_NR; l0 += W8_IO) {
+                float v[W8_IO];
+#pragma unroll
+                for (int k = 0; k < W8_IO; k++) v[k] = act ? lld((uint32_t)(l0 + k < LDPC_PARK_NR ? l0 + k : LDPC_PARK_NR - 1) * W8_ROW + t4) : 0.f;
+#pragma unroll
+                for (int k = 0; k < W8_IO; k++) if (l0 + k < LDPC_PARK_NR && srow[l0 + k] != 0xFFFFFFFFu) emit((int)srow[l0 + k], v[k]);
             }
         }
         if (first) s_misc[9] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[LDPC_FRAME_CTR], 1u) + gridDim.x) : f + (int)gridDim.x;
@@ -785,7 +920,7 @@ static int wg8_occ(const LdpcPlan &pl)
 }
 
 #define WG8_DISPATCH(FN, ...)                                                                                                              \
-    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3>(__VA_ARGS__) : FN<27, 1>(__VA_ARGS__)) \
+    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3>(__VA_ARGS__) : pl.fast_mode == 4 ? FN<27, 4>(__VA_ARGS__) : FN<27, 1>(__VA_ARGS__)) \
      : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0>(__VA_ARGS__) : FN<13, 1>(__VA_ARGS__))                                           \
                          : (pl.fast_mode == 0 ? FN<11, 0>(__VA_ARGS__) : FN<11, 1>(__VA_ARGS__)))
 
