@@ -29,7 +29,7 @@
 // Tuning / experiment knobs (environment, read when a handle is created):
 //   DVBS2HIP_LDPC_PATH=generic        force the generic kernel
 //   DVBS2HIP_LDPC_WG=12               the two-frames-per-12-wave-workgroup NMS kernel of k_ldpc_fast.hip instead of k_ldpc_wg8.hip
-//   DVBS2HIP_LDPC_FAST_MODE=lds|global|static   posterior image of the fast kernels (default: lds for N = 16200, static hybrid for N = 64800)
+//   DVBS2HIP_LDPC_FAST_MODE=lds|global|static|park   posterior image of the fast kernels (default: lds for N = 16200; for N = 64800 the static hybrid with rows parked in the idle waves' registers (park), static = without them)
 //   DVBS2HIP_LDPC_LOCK_DUPS=0         static hybrid without forcing the duplicate-edge bit-groups into LDS (then the generic kernel runs)
 //   DVBS2HIP_LDPC_C2V=lds|global, DVBS2HIP_LDPC_LDS_GROUPS=n   generic kernel storage policy
 //   DVBS2HIP_LDPC_BLOCKS_PER_CU, DVBS2HIP_LDPC_GRID_MAX, DVBS2HIP_LDS_LIMIT   occupancy / scaling experiments
@@ -298,7 +298,8 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             // upgraded below to the static hybrid where the code allows.  DVBS2HIP_LDPC_FAST_MODE=lds|global|static forces one.
             const char *env_mode = getenv("DVBS2HIP_LDPC_FAST_MODE");
             pl.fast_mode = ((size_t)(pl.n_groups + 1 + xrows) * grp_bytes * 2 <= lds_limit + 1024) ? 0 : 1;
-            if (env_mode && strcmp(env_mode, "static")) pl.fast_mode = (!strcmp(env_mode, "lds") && pl.fast_mode == 0) ? 0 : 1;
+            const bool env_hyb = env_mode && (!strcmp(env_mode, "static") || !strcmp(env_mode, "park"));      // static: hybrid without parked rows; park: the default for the long codes
+            if (env_mode && !env_hyb) pl.fast_mode = (!strcmp(env_mode, "lds") && pl.fast_mode == 0) ? 0 : 1;
             std::vector<uint32_t> gbase(pl.n_groups), glds(pl.n_groups, 0u);
             int n_l = 0, n_g = 0;
             // mode 3 (STATIC hybrid, normal frames): pick the LDS-resident bit-groups so that EVERY layer has
@@ -308,7 +309,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             ParkPlan park;
             {
                 const int NL = 9;
-                const bool want = (env_mode && !strcmp(env_mode, "static")) || (!env_mode && pl.fast_mode == 1);
+                const bool want = env_hyb || (!env_mode && pl.fast_mode == 1);
                 if (want && pl.fast_deg == 27 && !pl.fast_pad) {
                     const int cap = (int)(lds_limit / 2 / grp_bytes) - 1;            // two frames per CU, one junk row each
                     std::vector<std::vector<int>> mult(pl.n_groups, std::vector<int>(q, 0));
@@ -364,7 +365,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     if (c0 == 0) pl.fast_mode = 3;
                     else { std::fill(in_lds.begin(), in_lds.end(), 0); pl.w8_dups_in_lds = false; }
                     // mode 4: rows parked in the idle waves' registers on top of the LDS rows (min-sum kernel; DVBS2HIP_LDPC_FAST_MODE=static keeps mode 3)
-                    if (pl.fast_mode == 3 && pl.w8_dups_in_lds && !spa && !(env_mode && !strcmp(env_mode, "static"))) {
+                    if (pl.fast_mode == 3 && pl.w8_dups_in_lds && !(env_mode && !strcmp(env_mode, "static"))) {
                         std::vector<char> banned(pl.n_groups, 0);
                         for (int g = 0; g < pl.n_groups; g++) banned[g] = banned_g(g);
                         std::string why;

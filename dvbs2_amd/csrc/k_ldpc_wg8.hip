@@ -925,7 +925,7 @@ static int wg8_occ(const LdpcPlan &pl)
                          : (pl.fast_mode == 0 ? FN<11, 0>(__VA_ARGS__) : FN<11, 1>(__VA_ARGS__)))
 
 #define WG8_SPA_DISPATCH(FN, ...)                                                                                                                          \
-    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, true>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3, true>(__VA_ARGS__) : FN<27, 1, true>(__VA_ARGS__)) \
+    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, true>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3, true>(__VA_ARGS__) : pl.fast_mode == 4 ? FN<27, 4, true>(__VA_ARGS__) : FN<27, 1, true>(__VA_ARGS__)) \
      : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0, true>(__VA_ARGS__) : FN<13, 1, true>(__VA_ARGS__))                                                 \
                          : (pl.fast_mode == 0 ? FN<11, 0, true>(__VA_ARGS__) : FN<11, 1, true>(__VA_ARGS__)))
 

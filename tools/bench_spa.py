@@ -18,6 +18,7 @@ for modcod, F in (("QPSK-S_8/9", Fs), ("QPSK-S_3/5", Fs), ("QPSK-N_8/9", Fn)):
         N, K = rx.N_ldpc, rx.K_ldpc
         llr = (2.0 * (1.0 + 0.42 * torch.randn((F, N), device=dev, dtype=torch.float32)) / 0.42 ** 2)
         bits = torch.empty((F, K), dtype=torch.int32, device=dev); cwd = torch.empty(F, dtype=torch.int8, device=dev)
+        torch.cuda.synchronize()          # the decoder runs on the handle's own stream: the LLRs have to be there
         rx.decode_siho_dev(llr.data_ptr(), cwd.data_ptr(), bits.data_ptr(), F); rx.synchronize()
         ts = []
         for _ in range(reps):
