@@ -95,7 +95,7 @@ struct LdpcPlan {             // host-side description, built once per handle
     int fast_deg = 0;             // slots per layer in the unrolled kernel (11, 13 or 27)
     bool fast_pad = false;        // layers padded with NULL slots (irregular code)
     int fast_inf_row = -1;        // byte offset of the +inf row the NULL slots read, or -1
-    int fast_mode = 0;            // posterior image -- 0: in LDS, 1: in the workgroup's global slot, 3: static hybrid (k_ldpc.hip plan), 4: static hybrid + rows parked in the idle waves' registers
+    int fast_mode = 0;            // posterior image -- 0: in LDS, 1: in the workgroup's global slot, 3: static hybrid (k_ldpc.hip plan), 4 / 5: static hybrid + 32 / 39 rows parked in the idle waves' registers
     std::vector<uint32_t> nat_tab, nat_haz;   // k_ldpc_nat.hip: natural-row-order tables
     uint32_t *d_nat_tab = nullptr, *d_nat_haz = nullptr;
     bool fast_wg8 = false;        // one frame per 8-wave workgroup, SIMD-aware roles, two independent workgroups per CU (k_ldpc_wg8.hip)
@@ -112,8 +112,10 @@ constexpr int LDPC_CU_CTR_WORDS = 4096 + 64;   // [0, 4096): arrivals per CU, ke
 constexpr int LDPC_FRAME_CTR = 4096;
 constexpr int LDPC_FAST_STRIDE = 64;   // dwords per layer: 27 entries | prim mask | conflict info | conflict entries 0, 1 | slots with a duplicate edge | 16 conf entries | 16 conf meta
 constexpr int LDPC_FAST_MAXC = 16;
-constexpr int LDPC_PARK_NR = 32;       // mode 4 (k_ldpc_wg8.hip): bit-group rows parked in the registers of a workgroup's two idle waves (3 VGPRs per row and lane)
-constexpr int LDPC_PARK_NL = 14;       // mode 4: LDS slots per layer (the static hybrid without parked rows has 9)
+// modes 4 / 5 (k_ldpc_wg8.hip): bit-group rows parked in the registers of a workgroup's two idle waves (3 VGPRs per row and lane) and LDS slots per
+// layer (the static hybrid without parked rows, mode 3, has 9).  Mode 5 (min-sum kernel only: the sum-product kernel has no registers for it) parks 39.
+__host__ __device__ constexpr int ldpc_park_nr(int mode) { return mode == 5 ? 39 : 32; }
+__host__ __device__ constexpr int ldpc_park_nl(int mode) { return mode == 5 ? 15 : 14; }
 constexpr int LDPC_SPA_MAXC = 6;       // SPA: duplicate edges per layer whose old messages a lane keeps in registers (the DVB-S2 codes have at most 6)
 hipError_t ldpc_nat_launch(const LdpcPlan &pl, const LdpcKParams &kp, float *work, hipStream_t s);
 size_t ldpc_nat_group_words(const LdpcPlan &pl);

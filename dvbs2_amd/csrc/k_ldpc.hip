@@ -49,7 +49,7 @@ static const char *const PLAN_RETRY_GENERIC = "\x01generic";
 // ------------------------------------------------------------------------------------------
 // MODE 4 ("parked rows", k_ldpc_wg8.hip): on-chip bit-groups = LDS rows + rows PARKED in the registers of the workgroup's two
 // idle waves while no layer needs them.  The schedule is static and cyclic over the q layers of an iteration:
-//   * the on-chip set S gives every layer exactly LDPC_PARK_NL of its slots (k_ldpc_wg8.hip knows at compile time which slots
+//   * the on-chip set S gives every layer exactly NL (14 or 15) of its slots (k_ldpc_wg8.hip knows at compile time which slots
 //     are LDS accesses);
 //   * n_pos LDS positions, NR = |S| - n_pos of them each shared by a PAIR of rows (X, Y) with register slot k: while X is in the
 //     position Y sits in the slot, and twice per iteration the idle waves swap them ("during layer s": between the end-of-layer
@@ -61,7 +61,7 @@ static const char *const PLAN_RETRY_GENERIC = "\x01generic";
 struct ParkPlan {
     std::vector<char> in_chip;              // [n_groups]
     std::vector<std::vector<int>> pos;      // [n_groups][q]: LDS position of the row during layer r (-1: not in LDS then)
-    std::vector<uint32_t> srv;              // [q][LDPC_PARK_NR]: LDS position slot k swaps with during layer r (0xFF: none)
+    std::vector<uint32_t> srv;              // [q][NR]: LDS position slot k swaps with during layer r (0xFF: none)
     std::vector<int> lds0, reg0;            // state at the start of layer 0: bit-group at LDS position / in register slot (-1: empty)
     int n_pos = 0, nl0 = 0, n_moves = 0, n_pairs = 0;
 };
@@ -298,7 +298,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             // upgraded below to the static hybrid where the code allows.  DVBS2HIP_LDPC_FAST_MODE=lds|global|static forces one.
             const char *env_mode = getenv("DVBS2HIP_LDPC_FAST_MODE");
             pl.fast_mode = ((size_t)(pl.n_groups + 1 + xrows) * grp_bytes * 2 <= lds_limit + 1024) ? 0 : 1;
-            const bool env_hyb = env_mode && (!strcmp(env_mode, "static") || !strcmp(env_mode, "park"));      // static: hybrid without parked rows; park: the default for the long codes
+            const bool env_hyb = env_mode && (!strcmp(env_mode, "static") || !strcmp(env_mode, "park") || !strcmp(env_mode, "park4"));      // static: hybrid without parked rows; park: the default for the long codes
             if (env_mode && !env_hyb) pl.fast_mode = (!strcmp(env_mode, "lds") && pl.fast_mode == 0) ? 0 : 1;
             std::vector<uint32_t> gbase(pl.n_groups), glds(pl.n_groups, 0u);
             int n_l = 0, n_g = 0;
@@ -364,20 +364,23 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     }
                     if (c0 == 0) pl.fast_mode = 3;
                     else { std::fill(in_lds.begin(), in_lds.end(), 0); pl.w8_dups_in_lds = false; }
-                    // mode 4: rows parked in the idle waves' registers on top of the LDS rows (min-sum kernel; DVBS2HIP_LDPC_FAST_MODE=static keeps mode 3)
+                    // modes 4 / 5: rows parked in the idle waves' registers on top of the LDS rows (DVBS2HIP_LDPC_FAST_MODE=static keeps mode 3, park4 mode 4
+                    // for the min-sum kernel too)
                     if (pl.fast_mode == 3 && pl.w8_dups_in_lds && !(env_mode && !strcmp(env_mode, "static"))) {
                         std::vector<char> banned(pl.n_groups, 0);
                         for (int g = 0; g < pl.n_groups; g++) banned[g] = banned_g(g);
                         std::string why;
-                        if (plan_parked(mult, banned, q, LDPC_PARK_NL, cap, LDPC_PARK_NR, park, why)) {
-                            pl.fast_mode = 4;
-                            for (int g = 0; g < pl.n_groups; g++) in_lds[g] = park.in_chip[g];
-                        } else if (getenv("DVBS2HIP_VERBOSE")) fprintf(stderr, "[dvbs2hip] LDPC plan: parked rows not used (%s)\n", why.c_str());
+                        for (int m = (spa || (env_mode && !strcmp(env_mode, "park4"))) ? 4 : 5; m >= 4 && pl.fast_mode == 3; m--) {
+                            if (plan_parked(mult, banned, q, ldpc_park_nl(m), cap, ldpc_park_nr(m), park, why)) {
+                                pl.fast_mode = m;
+                                for (int g = 0; g < pl.n_groups; g++) in_lds[g] = park.in_chip[g];
+                            } else if (getenv("DVBS2HIP_VERBOSE")) fprintf(stderr, "[dvbs2hip] LDPC plan: mode %d (parked rows) not used (%s)\n", m, why.c_str());
+                        }
                     }
                 }
             }
-            const bool hyb = pl.fast_mode == 3 || pl.fast_mode == 4;       // static hybrid: the first NLH slots of every layer are LDS accesses
-            const int NLH = pl.fast_mode == 4 ? LDPC_PARK_NL : 9;
+            const bool parked = pl.fast_mode == 4 || pl.fast_mode == 5, hyb = pl.fast_mode == 3 || parked;       // static hybrid: the first NLH slots of every layer are LDS accesses
+            const int NLH = parked ? ldpc_park_nl(pl.fast_mode) : 9, NRH = ldpc_park_nr(pl.fast_mode);
             if (hyb) {
                 for (int g = 0; g < pl.n_groups; g++) {
                     if (in_lds[g]) { gbase[g] = (uint32_t)(n_l++ * LDPC_Z); glds[g] = 1u; }       // (mode 4: the LDS position of a row depends on the layer, park.pos)
@@ -390,13 +393,13 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             const uint32_t inf_row_words = (uint32_t)((pl.n_groups + (pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z);
             // k_ldpc_wg8.hip image layout -- LDS: [rows | junk | +inf]; global: [junk | +inf | rows]
             pl.w8_tab.assign((size_t)q * LDPC_FAST_STRIDE, 0u);
-            const int w8_lrows = pl.fast_mode == 0 ? pl.n_groups : pl.fast_mode == 3 ? n_l : pl.fast_mode == 4 ? park.n_pos : 0;
+            const int w8_lrows = pl.fast_mode == 0 ? pl.n_groups : pl.fast_mode == 3 ? n_l : parked ? park.n_pos : 0;
             bool park_bad = false;
             auto pack8 = [&](const Slot &sl, int r) -> uint32_t {
                 if (sl.group < 0) return (uint32_t)((pl.fast_mode == 0 ? (w8_lrows + 1) * LDPC_Z * 4 : LDPC_Z * 4)) << 11;      // the +inf row
                 const bool il = pl.fast_mode == 0 || (hyb && glds[sl.group]);
                 uint32_t base = il ? gbase[sl.group] * 4u : 2u * LDPC_Z * 4u + gbase[sl.group] * 4u;
-                if (il && pl.fast_mode == 4) { const int P = park.pos[sl.group][r]; if (P < 0) park_bad = true; base = (uint32_t)(P < 0 ? 0 : P) * LDPC_Z * 4u; }
+                if (il && parked) { const int P = park.pos[sl.group][r]; if (P < 0) park_bad = true; base = (uint32_t)(P < 0 ? 0 : P) * LDPC_Z * 4u; }
                 return (uint32_t)(sl.t0 * 4) | (base << 11) | (il ? (1u << 29) : 0u);
             };
             for (int r = 0; r < q; r++) {
@@ -448,7 +451,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             {   // image rows in storage order: LDS rows then global rows (bit-groups ascend inside each: info first)
                 std::vector<int> lrow, grow;
                 for (int g = 0; g < pl.n_groups; g++) ((pl.fast_mode == 0 || (hyb && glds[g])) ? lrow : grow).push_back(g);
-                if (pl.fast_mode == 4) {      // LDS rows = the positions that hold a row at the start of an iteration (layer 0), in position order
+                if (parked) {      // LDS rows = the positions that hold a row at the start of an iteration (layer 0), in position order
                     if (park_bad) return "LDPC: internal: parked-row table";
                     lrow.assign(park.lds0.begin(), park.lds0.begin() + park.nl0);
                 }
@@ -463,20 +466,20 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 for (int r = 0; r < q; r++) {
                     const int g = pl.n_info + r;
                     const bool in_lds = pl.fast_mode == 0 || (hyb && glds[g]);
-                    if (in_lds && pl.fast_mode == 4) return "LDPC: internal: parity group among the parked rows";
+                    if (in_lds && parked) return "LDPC: internal: parity group among the parked rows";
                     pl.w8_rows.push_back(in_lds ? (uint32_t)gbase[g] * 4u : 0x80000000u | (uint32_t)((2 * LDPC_Z + (int)gbase[g]) * 4));
                 }
-                if (pl.fast_mode == 4) {      // then the bit-group in register slot k of the idle waves at the start of an iteration (0xFFFFFFFF: empty)
-                    for (int k = 0; k < LDPC_PARK_NR; k++) pl.w8_rows.push_back(park.reg0[k] < 0 ? 0xFFFFFFFFu : (uint32_t)park.reg0[k]);
-                    // and the idle waves' swaps behind the layer tables: [q][LDPC_PARK_NR] x LDS position (0xFF: none)
+                if (parked) {      // then the bit-group in register slot k of the idle waves at the start of an iteration (0xFFFFFFFF: empty)
+                    for (int k = 0; k < NRH; k++) pl.w8_rows.push_back(park.reg0[k] < 0 ? 0xFFFFFFFFu : (uint32_t)park.reg0[k]);
+                    // and the idle waves' swaps behind the layer tables: [q][NR] x LDS position (0xFF: none)
                     pl.w8_tab.insert(pl.w8_tab.end(), park.srv.begin(), park.srv.end());
                 } else
                     for (size_t i = 0; i < lrow.size(); i++) if ((int)gbase[lrow[i]] != (int)i * LDPC_Z) return "LDPC: internal: LDS row order";
                 for (size_t i = 0; i < grow.size(); i++) if ((int)gbase[grow[i]] != (int)i * LDPC_Z) return "LDPC: internal: global row order";
-                const int n_lds_rows = pl.fast_mode == 4 ? park.n_pos : pl.w8_nl;
+                const int n_lds_rows = parked ? park.n_pos : pl.w8_nl;
                 pl.w8_lds_junk = (uint32_t)(n_lds_rows * LDPC_Z * 4);
                 pl.w8_lds_bytes = (n_lds_rows + 1 + (pl.fast_pad && pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z * 4 + 64;
-                pl.w8_park_moves = pl.fast_mode == 4 ? park.n_moves : 0;
+                pl.w8_park_moves = parked ? park.n_moves : 0;
                 pl.w8_st_base = (uint32_t)((2 + pl.w8_ng) * LDPC_Z * 4);
                 pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + 3 * M;
                 if (spa) pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + pl.fast_deg * M;      // SPA: one fp32 message per edge slot, [layer][slot][360]
@@ -489,7 +492,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             }
             // workspace of one workgroup: [posteriors kept in global memory | packed c->v state 3 M words]
             pl.glb_post_words = pl.fast_mode == 1 ? (pl.n_groups + xrows) * LDPC_Z : hyb ? n_g * LDPC_Z : 0;
-            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1 + xrows) * LDPC_Z : pl.fast_mode == 3 ? (n_l + 1) * LDPC_Z : pl.fast_mode == 4 ? (park.n_pos + 1) * LDPC_Z : 0;
+            pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1 + xrows) * LDPC_Z : pl.fast_mode == 3 ? (n_l + 1) * LDPC_Z : parked ? (park.n_pos + 1) * LDPC_Z : 0;
             pl.fast_inf_row = pl.fast_pad ? (int)(inf_row_words * 4u) : -1;
             pl.gwork_words = pl.glb_post_words + (spa ? pl.fast_deg * M : 3 * M);      // SPA: one fp32 message per edge slot
             pl.lds_bytes = (size_t)pl.lds_post_words * 4;

@@ -44,8 +44,9 @@ constexpr int W8_NL = 9;                    // MODE 3: LDS-resident slots per la
 constexpr int W8_ROW = LDPC_Z * 4;          // bytes per bit-group row
 constexpr int W8_IO = 16;                  // independent loads per lane in flight during frame I/O
 constexpr uint32_t W8_OOB = 0x7FFFF000u;    // voffset beyond every workspace: the store is dropped
-__host__ __device__ constexpr bool w8_hybrid(int mode) { return mode == 3 || mode == 4; }      // static hybrid image (4: with rows parked in the idle waves' registers)
-__host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode == 0 || (mode == 3 && j < W8_NL) || (mode == 4 && j < LDPC_PARK_NL); }
+__host__ __device__ constexpr bool w8_parked(int mode) { return mode == 4 || mode == 5; }      // static hybrid with rows parked in the idle waves' registers
+__host__ __device__ constexpr bool w8_hybrid(int mode) { return mode == 3 || w8_parked(mode); }
+__host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode == 0 || (mode == 3 && j < W8_NL) || (w8_parked(mode) && j < ldpc_park_nl(mode)); }
 
 // development knobs of the SPA layer (tools/build_variant.sh): suffix values kept every SPA_BS-th slot; next layer's messages
 // requested under the current layer's stores; cache policy of the message traffic
@@ -123,25 +124,27 @@ __device__ __forceinline__ float w8_boxplus(float a, float b)
     return a == INFINITY ? b : (b == INFINITY ? a : r);
 }
 
-// MODE 4: what the two waves of a workgroup that hold no check do instead of idling -- they keep LDPC_PARK_NR bit-group rows of the frame in
+// MODE 4 / 5: what the two waves of a workgroup that hold no check do instead of idling -- they keep NR = 32 / 39 bit-group rows of the frame in
 // their registers (3 VGPRs per row and lane: lane e of 128 holds elements e, e + 128, e + 256) and swap rows with LDS by the static, cyclic
 // schedule of k_ldpc.hip (plan_parked): slot k and one LDS position are shared by a pair of rows whose layers do not interleave; twice per
 // iteration, during a layer that uses neither, the slot's row goes to the position and the position's row into the slot.  Every register index
 // is a compile-time constant (the loop over the slots is unrolled; the positions come from a table read on the scalar unit).  The waves
 // follow the working waves barrier for barrier; `nvote` and the vote words are shared with them.
-template <int DEG>
+template <int DEG, int NR>
 __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_char *const L, lds_int *const s_misc, const int wave, const int sidx)
 {
-    constexpr int NR = LDPC_PARK_NR;
     const int q = p.q;
     const const_u32 tab = (const_u32)p.w8.tab, srv = tab + q * LDPC_FAST_STRIDE;
     const const_u32 srow = (const_u32)p.w8.rows + p.w8.nl + p.w8.ng + q;        // bit-group in slot k at the start of an iteration
+    // 120 of the 128 lanes hold three elements each: e, e + 120, e + 240 (an exchange must touch every LDS word exactly once)
     const int lane = (int)threadIdx.x & 63, el = sidx * 64 + lane;
-    // lanes 104 .. 127 have no third element: they mirror element 359 (they read and write back the value lane 103 owns)
-    const int e2 = el + 256 < LDPC_Z ? el + 256 : LDPC_Z - 1;
-    const uint32_t a0 = (uint32_t)el * 4u, a2 = (uint32_t)e2 * 4u;
+    const bool on = el < LDPC_Z / 3;
+    const uint32_t a0 = (uint32_t)el * 4u;
+    constexpr uint32_t A1 = LDPC_Z / 3 * 4u, A2 = 2u * A1;
     auto lld = [&](uint32_t a) -> float { return *(lds_float *)(L + a); };
     auto lst = [&](uint32_t a, float v) { *(lds_float *)(L + a) = v; };
+    // one ds_wrxchg_rtn_b32 swaps a register with an LDS word (no temporaries: the rows take 3 NR of the wave's 128 registers)
+    auto lxc = [&](uint32_t a, float v) -> float { return __hip_atomic_exchange((lds_float *)(L + a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     float R[NR][3];
     int nvote = 0;
     auto vote0 = [&]() -> bool {                    // the working waves' vote (ldpc_wg8_kernel), with nothing to report
@@ -154,14 +157,13 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_char *c
     };
     auto moves = [&](int r) {                       // the swaps of layer r: slot k <-> LDS position mv[k] (0xFF: none); same lane, same addresses: read, then write
         const const_u32 mv = srv + r * NR;
+        if (on)
 #pragma unroll
         for (int k = 0; k < NR; k++) {
             const uint32_t e = mv[k];
             if (e != 0xFFu) {
                 const uint32_t b = e * (uint32_t)W8_ROW;
-                const float t0 = lld(b + a0), t1 = lld(b + a0 + 512u), t2 = lld(b + a2);
-                lst(b + a0, R[k][0]); lst(b + a0 + 512u, R[k][1]); lst(b + a2, R[k][2]);
-                R[k][0] = t0; R[k][1] = t1; R[k][2] = t2;
+                R[k][0] = lxc(b + a0, R[k][0]); R[k][1] = lxc(b + a0 + A1, R[k][1]); R[k][2] = lxc(b + a0 + A2, R[k][2]);
             }
         }
     };
@@ -183,11 +185,12 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_char *c
     const bool es = p.early_stop != 0;
     for (int f = blockIdx.x; f < p.n_frames; ) {
         const float *Y = p.llr + (size_t)f * p.N;
+        const int elc = on ? el : 0;                // (the eight lanes without elements load something harmless)
 #pragma unroll
         for (int k = 0; k < NR; k++) {
             const uint32_t g = srow[k];
             const float *Yg = Y + (g == 0xFFFFFFFFu ? 0u : g) * (uint32_t)LDPC_Z;
-            R[k][0] = __builtin_nontemporal_load(&Yg[el]); R[k][1] = __builtin_nontemporal_load(&Yg[el + 128]); R[k][2] = __builtin_nontemporal_load(&Yg[e2]);
+            R[k][0] = __builtin_nontemporal_load(&Yg[elc]); R[k][1] = __builtin_nontemporal_load(&Yg[elc + LDPC_Z / 3]); R[k][2] = __builtin_nontemporal_load(&Yg[elc + 2 * (LDPC_Z / 3)]);
         }
         __syncthreads();                            // the image is in place
         // ph 0: layer r of an iteration; 1: layer r of the syndrome sweep; 2: catching up with the schedule after a sweep that stopped early
@@ -214,7 +217,7 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_char *c
         // outputs: the parked rows go through LDS positions 0 .. NR-1 once the working waves have read the LDS rows
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < NR; k++) { const uint32_t b = (uint32_t)k * (uint32_t)W8_ROW; lst(b + a0, R[k][0]); lst(b + a0 + 512u, R[k][1]); lst(b + a2, R[k][2]); }
+        for (int k = 0; k < NR; k++) if (on) { const uint32_t b = (uint32_t)k * (uint32_t)W8_ROW; lst(b + a0, R[k][0]); lst(b + a0 + A1, R[k][1]); lst(b + a0 + A2, R[k][2]); }
         __syncthreads();
         __syncthreads();                            // the image is reused by the next frame
         f = s_misc[9];
@@ -255,7 +258,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
         else if (k == 0) role = simd;
         else role = ((simd >> 1) == s_misc[8]) ? 4 + (simd & 1) : -1;
         role = __builtin_amdgcn_readfirstlane(role);
-        if (MODE == 4 && role < 0) {               // the two waves without checks keep parked rows (w8_park_server): which of the two is this one?
+        if (w8_parked(MODE) && role < 0) {               // the two waves without checks keep parked rows (w8_park_server): which of the two is this one?
             int sidx = 0;
             for (int w = 0; w < wave; w++) {
                 const int s = s_misc[w];
@@ -264,7 +267,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 const int rw = !balanced ? (w < 6 ? w : -1) : kw == 0 ? s : ((s >> 1) == s_misc[8] ? 4 + (s & 1) : -1);
                 sidx += rw < 0;
             }
-            w8_park_server<DEG>(p, L, s_misc, wave, __builtin_amdgcn_readfirstlane(sidx));
+            w8_park_server<DEG, ldpc_park_nr(MODE)>(p, L, s_misc, wave, __builtin_amdgcn_readfirstlane(sidx));
             return;
         }
     }
@@ -741,7 +744,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 // SPA: the workgroup's vote as a ballot per wave + one LDS word out of three in rotation (zeroed two votes ahead), one
                 // barrier per vote; __syncthreads_or keeps the 64-bit thread index alive across the layer loop, which this kernel spills
                 auto vote = [&](int b) -> bool {
-                    if (!SPA && MODE != 4) return __syncthreads_or(b) != 0;
+                    if (!SPA && !w8_parked(MODE)) return __syncthreads_or(b) != 0;
                     const bool any = __ballot(b != 0) != 0ull;
                     lds_int *const w = s_misc + 10;
                     const int k = nvote % 3;
@@ -767,7 +770,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         for (int j = 0; j < DEG; j++) x ^= __float_as_uint(Lv[j]);             // NULL slots read +inf
                         bad |= (int)(x >> 31);
                     }
-                    if (MODE == 4) {
+                    if (w8_parked(MODE)) {
                         // parked rows: the idle waves move rows for layer r + 1 while this layer is read, so every layer ends at a barrier; under the
                         // stopping rule layer 0 is voted on BEFORE anything moves (a frame that has not converged nearly always fails there, and
                         // the schedule then stands where the next iteration needs it), otherwise the idle waves run the schedule to its end
@@ -838,17 +841,18 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 for (int k = 0; k < W8_IO; k++) if (l0 + k < ng_out) emit((int)rows[nl + l0 + k], v[k]);
             }
         }
-        if (MODE == 4) {
+        if (w8_parked(MODE)) {
+            constexpr int NRP = ldpc_park_nr(MODE);
             // the rows parked in the idle waves' registers: handed over through LDS positions 0 .. NR-1 (every LDS row has been read)
             __syncthreads();
             __syncthreads();
             const const_u32 srow = rows + nl + ng + q;
-            for (int l0 = 0; l0 < LDPC_PARK_NR; l0 += W8_IO) {
+            for (int l0 = 0; l0 < NRP; l0 += W8_IO) {
                 float v[W8_IO];
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) v[k] = act ? lld((uint32_t)(l0 + k < LDPC_PARK_NR ? l0 + k : LDPC_PARK_NR - 1) * W8_ROW + t4) : 0.f;
+                for (int k = 0; k < W8_IO; k++) v[k] = act ? lld((uint32_t)(l0 + k < NRP ? l0 + k : NRP - 1) * W8_ROW + t4) : 0.f;
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) if (l0 + k < LDPC_PARK_NR && srow[l0 + k] != 0xFFFFFFFFu) emit((int)srow[l0 + k], v[k]);
+                for (int k = 0; k < W8_IO; k++) if (l0 + k < NRP && srow[l0 + k] != 0xFFFFFFFFu) emit((int)srow[l0 + k], v[k]);
             }
         }
         if (first) s_misc[9] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[LDPC_FRAME_CTR], 1u) + gridDim.x) : f + (int)gridDim.x;
@@ -920,7 +924,7 @@ static int wg8_occ(const LdpcPlan &pl)
 }
 
 #define WG8_DISPATCH(FN, ...)                                                                                                              \
-    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3>(__VA_ARGS__) : pl.fast_mode == 4 ? FN<27, 4>(__VA_ARGS__) : FN<27, 1>(__VA_ARGS__)) \
+    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3>(__VA_ARGS__) : pl.fast_mode == 4 ? FN<27, 4>(__VA_ARGS__) : pl.fast_mode == 5 ? FN<27, 5>(__VA_ARGS__) : FN<27, 1>(__VA_ARGS__)) \
      : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0>(__VA_ARGS__) : FN<13, 1>(__VA_ARGS__))                                           \
                          : (pl.fast_mode == 0 ? FN<11, 0>(__VA_ARGS__) : FN<11, 1>(__VA_ARGS__)))
 

@@ -292,6 +292,40 @@ def test_ldpc_headline_config_at_size_matches_oracle(O, Rx, n_ite, F, ebn0s):
     assert (CWD[0::2] if len(ebn0s) == 2 else CWD).mean() < 0.5      # 3.0 dB: most frames fail, which is the point
 
 
+@pytest.mark.parametrize("implem", ["NMS", "SPA"])
+@pytest.mark.parametrize("mode,kernel_mode", [("", None), ("park4", 4), ("static", 3), ("global", 1)])
+def test_ldpc_normal_frame_image_modes_agree_with_the_oracle(O, Rx, monkeypatch, mode, kernel_mode, implem):
+    """Where the posteriors of a normal frame live -- static hybrid with 39 / 32 bit-group rows parked in the idle waves' registers (modes 5 / 4, the
+    defaults of the min-sum / sum-product kernel), static hybrid alone (3), the workgroup's global slot (1) -- must not change a bit: 1100 frames
+    (every persistent workgroup decodes a 2nd and 3rd frame; the parked rows' swap schedule runs through iterations, syndrome sweeps that stop
+    early and frames that never converge) at 3.0 / 4.2 dB, fixed iterations and the stopping rule, against the oracle on the last 6 + 6 random frames."""
+    modcod, F = "QPSK-N_8/9", 1100
+    if mode:
+        monkeypatch.setenv("DVBS2HIP_LDPC_FAST_MODE", mode)
+    ch, sent, llr = _big_batch(O, modcod, F, (3.0, 4.2), seed=4242, n_cw=4)
+    rng = np.random.default_rng(8)
+    pick = np.unique(np.concatenate([np.arange(F - 6, F), rng.choice(F - 6, 6, replace=False)]))
+    spa = implem == "SPA"
+    for early in (False, True):
+        n_ite = 3 if spa and not early else 10
+        rx = Rx(modcod, max_frames=F, n_ite=n_ite, alpha=1.0, early_stop=early, implem=implem)
+        want = kernel_mode if kernel_mode is not None else (4 if spa else 5)
+        assert rx.ldpc_kernel_name() == "ldpc_wg8_kernel<27,%d%s>" % (want, ",true" if spa else ""), rx.ldpc_kernel_name()
+        V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+        Vo, posto, cwdo, iteso = ch.ldpc.decode(llr[pick], n_ite=n_ite, alpha=1.0, implem=O.SPA if spa else O.NMS, sched=O.QC, early_stop=early)
+        if spa:
+            assert np.all(np.abs(post[pick] - posto) <= 1e-4 * np.maximum(1.0, np.abs(posto))), float(np.abs(post[pick] - posto).max())
+            assert (V[pick] != Vo).mean() < 1e-4
+        else:
+            assert np.array_equal(post[pick].view(np.uint32), posto.view(np.uint32)), (early, "posterior bit patterns")
+            assert np.array_equal(V[pick], Vo) and np.array_equal(CWD[pick], cwdo) and np.array_equal(ites[pick], iteso)
+        okf = CWD == 1
+        assert np.array_equal(V[okf], sent[okf])
+        if early:
+            assert okf[1::2].mean() > 0.99 and (ites[1::2] < n_ite).mean() > 0.9
+        rx.close()
+
+
 @pytest.mark.parametrize("modcod,F", [("QPSK-N_8/9", 1100), ("QPSK-S_8/9", 2600)])
 def test_ldpc_spa_at_size_matches_oracle(O, Rx, modcod, F):
     """The reference's default decoder (--dec-implem SPA) with more frames than the persistent grid holds: the per-edge message store
