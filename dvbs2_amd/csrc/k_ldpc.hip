@@ -394,7 +394,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             // k_ldpc_wg8.hip image layout -- LDS: [rows | junk | +inf]; global: [junk | +inf | rows]
             pl.w8_tab.assign((size_t)q * LDPC_FAST_STRIDE, 0u);
             const int w8_lrows = pl.fast_mode == 0 ? pl.n_groups : pl.fast_mode == 3 ? n_l : parked ? park.n_pos : 0;
-            bool park_bad = false;
+            bool park_bad = false, kd_ok = true;
             auto pack8 = [&](const Slot &sl, int r) -> uint32_t {
                 if (sl.group < 0) return (uint32_t)((pl.fast_mode == 0 ? (w8_lrows + 1) * LDPC_Z * 4 : LDPC_Z * 4)) << 11;      // the +inf row
                 const bool il = pl.fast_mode == 0 || (hyb && glds[sl.group]);
@@ -419,8 +419,10 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     if (nn < 2 || ord[nn - 2].group != n_rows + r || ord[nn - 1].group != n_rows + (r + q - 1) % q || ord[nn - 2].t0 != 0 || (r > 0 && ord[nn - 1].t0 != 0))
                         return "LDPC: internal: static hybrid needs p_c and p_{c-1} at the last two slots (parity chain forwarding)";
                 } else {
-                    for (const Slot &sl : layers[r]) if (!prev_touch[sl.group]) ord.push_back(sl);
-                    for (const Slot &sl : layers[r]) if (prev_touch[sl.group]) ord.push_back(sl);
+                    // duplicate edges first (the only slots whose stores are redirected: ldpc_w8_kd), never the masked slot (a parity group: no duplicates)
+                    for (const Slot &sl : layers[r]) if (sl.lvl > 0) ord.push_back(sl);
+                    for (const Slot &sl : layers[r]) if (sl.lvl == 0 && !prev_touch[sl.group]) ord.push_back(sl);
+                    for (const Slot &sl : layers[r]) if (sl.lvl == 0 && prev_touch[sl.group]) ord.push_back(sl);
                 }
                 if (!ord.empty() && layers[r].back().mask0 && !ord.back().mask0) return "LDPC: internal: masked slot must stay last";
                 // NULL slots (group -1) go in front of the last real slot, which keeps position fast_deg-1
@@ -442,6 +444,9 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 }
                 // ncf | slot of entry 0 << 8 | level << 13 | slot of entry 1 << 16 | level << 21 ; entries 0 and 1 ; slots with a duplicate edge
                 T8[27] = prim; T8[28] = (uint32_t)nc; T8[31] = dupmask;
+                // contract with k_ldpc_wg8.hip: from slot ldpc_w8_kd(deg) on every slot is a primary edge (no redirected store, no NULL slot)
+                // (the LDS-only image; with the hybrid image the same trick measured 0.7 % SLOWER on the 15 LDS slots of a normal-frame layer and is not used)
+                for (int j = ldpc_w8_kd(pl.fast_deg); j < pl.fast_deg && pl.fast_mode == 0; j++) if (!((prim >> j) & 1u)) kd_ok = false;
                 for (int i = 0; i < 2 && i < nc; i++) {
                     T8[28] |= ((T8[48 + i] & 31u) | ((T8[48 + i] >> 8) << 5)) << (8 + 8 * i);
                     T8[29 + i] = T8[32 + i];
@@ -538,7 +543,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             // one frame per 8-wave workgroup, two independent workgroups per CU (k_ldpc_wg8.hip); a code it cannot take (a static hybrid
             // whose doubly connected bit-groups do not all fit in LDS) goes to the generic table-driven kernel below
             {
-                const bool w8_ok = pl.fast_mode == 0 || pl.fast_mode == 1 || (hyb && pl.w8_dups_in_lds);
+                const bool w8_ok = (pl.fast_mode == 0 || pl.fast_mode == 1 || (hyb && pl.w8_dups_in_lds)) && kd_ok;
                 if (!(w8_ok && (size_t)pl.w8_lds_bytes <= lds_limit + 512) || (spa && maxc > LDPC_SPA_MAXC)) return PLAN_RETRY_GENERIC;
                 pl.fast_wg8 = true; pl.gwork_words = pl.w8_gwork_words;
             }

@@ -183,6 +183,7 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_char *c
         __syncthreads();                            // end of the layer
     };
     const bool es = p.early_stop != 0;
+    // (wave priority 1 / 2 / 3 for these two waves: no difference, 6.00-6.04 ms for every setting, same box)
     for (int f = blockIdx.x; f < p.n_frames; ) {
         const float *Y = p.llr + (size_t)f * p.N;
         const int elc = on ? el : 0;                // (the eight lanes without elements load something harmless)
@@ -268,6 +269,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 sidx += rw < 0;
             }
             w8_park_server<DEG, ldpc_park_nr(MODE)>(p, L, s_misc, wave, __builtin_amdgcn_readfirstlane(sidx));
+#ifdef LDPC_PHASE_PROF
+            if (lane == 0 && p.cu_ctr) for (int i = 0; i < 12; i++) p.cu_ctr[LDPC_CU_CTR_WORDS + ((int)blockIdx.x * 8 + wave) * 12 + i] = 0u;
+#endif
             return;
         }
     }
@@ -594,6 +598,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 }
                 float v[DEG];
                 uint32_t w[DEG];
+                constexpr int KD = MODE == 0 ? ldpc_w8_kd(DEG) : DEG;       // LDS-only image: duplicate edges sit in slots < KD (plan), the others are primary
                 const float c1o = nx1, c2o = nx2;
                 const uint32_t pko = __float_as_uint(nxk);
                 float mn1 = INFINITY, mn2 = INFINITY, cst1 = 0.f, cst2 = 0.f;
@@ -609,7 +614,11 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
                         w[j] = min(d, d + (uint32_t)W8_ROW);
                         if (FWD && j == DEG - 1) { if (r > 0) v[j] = pfw; else v[j] = gld(w[j], base); }      // p_{c-1}: handed over by layer r - 1
-                        else v[j] = w8_slot_lds(MODE, j) ? lld(w[j] + base) : gld(w[j], base);
+                        else if (w8_slot_lds(MODE, j)) {
+                            const uint32_t a = w[j] + base;
+                            v[j] = lld(a);
+                            if (j >= KD) w[j] = a;            // a primary edge by the plan's slot order: pass 2 stores where this came from
+                        } else v[j] = gld(w[j], base);
                     }
                     const int rn = r + 1 < q ? r + 1 : 0;
                     if (it == 0 && r + 1 < q) { nx1 = 0.f; nx2 = 0.f; nxk = 0.f; }       // layer r + 1 has no messages yet in the first iteration
@@ -673,7 +682,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         const bool pr = ((prim >> j) & 1u) != 0u;                             // wave-uniform
                         const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
                         if (w8_slot_lds(MODE, j)) {
-                            uint32_t a = w[j] + (pr ? base : ljunk);
+                            uint32_t a = j >= KD ? w[j] : w[j] + (pr ? base : ljunk);
                             if (j == DEG - 1 && mask0) a = ljunk;
                             lst(a, x + nw);
                         } else {
