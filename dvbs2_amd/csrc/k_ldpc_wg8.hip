@@ -81,6 +81,9 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #define PROF_MARK(i)
 #endif
 
+// LDS word at byte offset a of the workgroup's allocation (see the kernel's note on `smem`)
+__device__ __forceinline__ lds_float *w8_lds(uint32_t a) { return (lds_float *)(size_t)a; }
+
 // (a & m) | b in one VALU operation (the compiler emits v_and + v_or)
 __device__ __forceinline__ float and_or(uint32_t a, uint32_t m_sgpr, float b)
 {
@@ -131,7 +134,7 @@ __device__ __forceinline__ float w8_boxplus(float a, float b)
 // is a compile-time constant (the loop over the slots is unrolled; the positions come from a table read on the scalar unit).  The waves
 // follow the working waves barrier for barrier; `nvote` and the vote words are shared with them.
 template <int DEG, int NR>
-__device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_char *const L, lds_int *const s_misc, const int wave, const int sidx)
+__device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_int *const s_misc, const int wave, const int sidx)
 {
     const int q = p.q;
     const const_u32 tab = (const_u32)p.w8.tab, srv = tab + q * LDPC_FAST_STRIDE;
@@ -141,10 +144,9 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_char *c
     const bool on = el < LDPC_Z / 3;
     const uint32_t a0 = (uint32_t)el * 4u;
     constexpr uint32_t A1 = LDPC_Z / 3 * 4u, A2 = 2u * A1;
-    auto lld = [&](uint32_t a) -> float { return *(lds_float *)(L + a); };
-    auto lst = [&](uint32_t a, float v) { *(lds_float *)(L + a) = v; };
+    auto lst = [&](uint32_t a, float v) { *w8_lds(a) = v; };
     // one ds_wrxchg_rtn_b32 swaps a register with an LDS word (no temporaries: the rows take 3 NR of the wave's 128 registers)
-    auto lxc = [&](uint32_t a, float v) -> float { return __hip_atomic_exchange((lds_float *)(L + a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto lxc = [&](uint32_t a, float v) -> float { return __hip_atomic_exchange(w8_lds(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     float R[NR][3];
     int nvote = 0;
     auto vote0 = [&]() -> bool {                    // the working waves' vote (ldpc_wg8_kernel), with nothing to report
@@ -232,8 +234,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 ldpc_wg8_kernel(const LdpcKParams p)
 {
     extern __shared__ float smem[];
-    lds_char *const L = (lds_char *)(lds_float *)smem;
-    lds_int *const s_misc = (lds_int *)(L + p.w8.lds_bytes - 64);      // [0..7] SIMD of wave w, [8] F
+    // LDS is addressed by plain byte offsets (w8_lds): the kernel has no static LDS, so its dynamic block starts at 0.  Through the symbol every address the
+    // layer loop keeps in a register would carry an "+ smem" that the compiler resolves to an add of 0 only at link time -- one vector instruction per access.
+    if ((uint32_t)(size_t)(lds_float *)smem != 0u) __builtin_trap();
+    lds_int *const s_misc = (lds_int *)w8_lds((uint32_t)p.w8.lds_bytes - 64u);      // [0..7] SIMD of wave w, [8] F
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
     const uint32_t hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);            // HW_REG_HW_ID
     const int simd = (int)((hw >> 4) & 3u);
@@ -268,7 +272,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 const int rw = !balanced ? (w < 6 ? w : -1) : kw == 0 ? s : ((s >> 1) == s_misc[8] ? 4 + (s & 1) : -1);
                 sidx += rw < 0;
             }
-            w8_park_server<DEG, ldpc_park_nr(MODE)>(p, L, s_misc, wave, __builtin_amdgcn_readfirstlane(sidx));
+            w8_park_server<DEG, ldpc_park_nr(MODE)>(p, s_misc, wave, __builtin_amdgcn_readfirstlane(sidx));
 #ifdef LDPC_PHASE_PROF
             if (lane == 0 && p.cu_ctr) for (int i = 0; i < 12; i++) p.cu_ctr[LDPC_CU_CTR_WORDS + ((int)blockIdx.x * 8 + wave) * 12 + i] = 0u;
 #endif
@@ -316,8 +320,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
         const uint32_t g = slot >> 2, k = slot & 3u;
         return g < (uint32_t)MG4 ? mld(tb * 4u, lbase + g * (W8_ROW * 4u) + k * 4u) : mld(tb * (uint32_t)(MR ? MR : 1), lbase + (uint32_t)MG4 * (W8_ROW * 4u) + k * 4u);
     };
-    auto lld = [&](uint32_t a) -> float { return *(lds_float *)(L + a); };
-    auto lst = [&](uint32_t a, float v) { *(lds_float *)(L + a) = v; };
+    auto lld = [&](uint32_t a) -> float { return *w8_lds(a); };
+    auto lst = [&](uint32_t a, float v) { *w8_lds(a) = v; };
     auto st_off = [&](int arr, int r) { return st_base + (uint32_t)(arr * M + r * LDPC_Z) * 4u; };
     const int nl_info = p.w8.nl_info, nl = p.w8.nl, ng_info = p.w8.ng_info, ng = p.w8.ng;
     const uint32_t grow0 = 2u * W8_ROW;                      // global image: [junk row][+inf row][group rows ..]
@@ -750,10 +754,10 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 //      one vote, after the last layer, as before (a vote per layer in that mode too made the bench 0.4 % slower)
                 ok = true;
                 int bad = 0;
-                // SPA: the workgroup's vote as a ballot per wave + one LDS word out of three in rotation (zeroed two votes ahead), one
-                // barrier per vote; __syncthreads_or keeps the 64-bit thread index alive across the layer loop, which this kernel spills
+                // the workgroup's vote as a ballot per wave + one LDS word out of three in rotation (zeroed two votes ahead), one barrier per vote
+                // (__syncthreads_or brings 256 bytes of static LDS: the dynamic block then starts at 0x100 and every LDS address the layer loop keeps in
+                // a register needs that offset added on the vector unit; it also keeps the 64-bit thread index alive across the layer loop)
                 auto vote = [&](int b) -> bool {
-                    if (!SPA && !w8_parked(MODE)) return __syncthreads_or(b) != 0;
                     const bool any = __ballot(b != 0) != 0ull;
                     lds_int *const w = s_misc + 10;
                     const int k = nvote % 3;

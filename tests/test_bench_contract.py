@@ -56,11 +56,11 @@ def test_bench_line_on_the_gpu():
     assert ro["bound"] == "hbm" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
     assert ro["avg_launch_ms"] <= d["ms_per_step"] * 1.02
     assert 0.0 < ro["hbm_true"]["frac"] < 0.1
-    assert ro["binding_resource"] == "fabric" and ro["algorithmic_frac"] == ro["frac"]
+    assert ro["binding_resource"] in ("fabric", "vector-ALU issue") and ro["algorithmic_frac"] == ro["frac"]
     assert d["self_check"]["steps"] == 20 and 0.5 * d["ms_per_step"] < d["self_check"]["ms_per_step"] < 1.5 * d["ms_per_step"]
     if ro["traffic"] is not None:                                          # the committed PMC file matches the running kernel
         b = ro["bounded"]
-        assert ro["bounded_frac"] == b["frac"]
+        assert ro["bounded_frac"] == max(b["frac"], b["valu"]["frac"]) and (ro["binding_resource"] == "fabric") == (b["frac"] >= b["valu"]["frac"])
         assert 0.0 < b["frac"] <= 1.0 and abs(b["achieved"] - ro["traffic"] / (ro["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * b["achieved"]
         assert 0.0 < b["valu"]["frac"] <= 1.0
     else:
