@@ -117,8 +117,9 @@ constexpr int LDPC_FAST_MAXC = 16;
 __host__ __device__ constexpr int ldpc_park_nr(int mode) { return mode == 5 ? 39 : 32; }
 __host__ __device__ constexpr int ldpc_park_nl(int mode) { return mode == 5 ? 15 : 14; }
 // k_ldpc_wg8.hip: duplicate edges (the slots whose stores are redirected to the junk row) sit in the first ldpc_w8_kd(deg) slots of a layer; from
-// there on a slot's store goes where its load came from (one address per LDS slot instead of two).  The padded 13-slot form has NULL slots anywhere.
-__host__ __device__ constexpr int ldpc_w8_kd(int deg) { return deg == 27 ? 6 : deg == 11 ? 3 : deg; }
+// there on a slot's store goes where its load came from (one address per LDS slot instead of two).  The padded 13-slot form (32APSK-S 3/4: checks of degree
+// 9 .. 13) has its NULL slots there too (at most 4 + 2 duplicates).
+__host__ __device__ constexpr int ldpc_w8_kd(int deg) { return deg == 27 ? 6 : deg == 11 ? 3 : deg == 13 ? 6 : deg; }
 constexpr int LDPC_SPA_MAXC = 6;       // SPA: duplicate edges per layer whose old messages a lane keeps in registers (the DVB-S2 codes have at most 6)
 hipError_t ldpc_nat_launch(const LdpcPlan &pl, const LdpcKParams &kp, float *work, hipStream_t s);
 size_t ldpc_nat_group_words(const LdpcPlan &pl);

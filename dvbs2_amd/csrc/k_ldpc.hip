@@ -425,8 +425,13 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     for (const Slot &sl : layers[r]) if (sl.lvl == 0 && prev_touch[sl.group]) ord.push_back(sl);
                 }
                 if (!ord.empty() && layers[r].back().mask0 && !ord.back().mask0) return "LDPC: internal: masked slot must stay last";
-                // NULL slots (group -1) go in front of the last real slot, which keeps position fast_deg-1
-                while ((int)ord.size() < pl.fast_deg) ord.insert(ord.end() - 1, Slot{-1, 0, 0, 0});
+                // NULL slots (group -1): behind the duplicate edges at the front of the layer in the LDS-only image (like those, their stores are redirected:
+                // ldpc_w8_kd), else in front of the last real slot; the last real slot keeps position fast_deg-1 either way
+                {
+                    size_t nd = 0;
+                    while (nd < ord.size() && ord[nd].lvl > 0) nd++;
+                    while ((int)ord.size() < pl.fast_deg) ord.insert(pl.fast_mode == 0 ? ord.begin() + (long)nd : ord.end() - 1, Slot{-1, 0, 0, 0});
+                }
                 // conflict list sorted by level
                 for (int lvl = 1; lvl <= 3; lvl++)
                     for (size_t j = 0; j < ord.size(); j++)
