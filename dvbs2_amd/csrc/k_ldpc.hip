@@ -109,7 +109,7 @@ static bool plan_parked(const std::vector<std::vector<int>> &mult, const std::ve
         if (c0 != 0) { why = "no on-chip set with the same number of slots in every layer"; continue; }
         std::vector<int> S;
         for (int g = 0; g < n_groups; g++) if (inS[g]) S.push_back(g);
-        const int need = (int)S.size() - n_pos;                 // pairs (= register slots) needed
+        const int need = std::max(0, (int)S.size() - n_pos);    // pairs (= register slots) needed
         if (need > NRmax) { why = "on-chip set too large"; continue; }
         // ---- (B) compatible pairs and their swap layers
         struct Edge { int x, y, s1, s2; };                      // x in LDS during (s1, s2), y during (s2, s1)

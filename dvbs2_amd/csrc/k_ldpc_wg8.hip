@@ -450,7 +450,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #pragma unroll
                     for (int i = 0; i < LDPC_SPA_MAXC; i++) od[i] = 0.f;
                     if (act) {
-                        __builtin_amdgcn_s_setprio(3);            // as in the min-sum layer: load issue first, the long arithmetic last
+                        __builtin_amdgcn_s_setprio(3);            // as in the min-sum layer: load issue first, the long arithmetic last ((3, 1) / (2, 1) in and behind pass 2 instead of (2, 0): within 0.4 %)
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
                             const uint32_t base = (E[j] >> 11) & 0x3FFFFu, wj = woff(j);
@@ -610,7 +610,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 if (act) {
                     // ---- pass 1a: every posterior load of the check in flight before any use.  Wave priorities (same-box A/B, tools/ab_kernel.sh):
                     // 3 while the loads are issued, 0 while pass 1b waits for them, 2 in pass 2 (stores, and the way to the barrier) is
-                    // worth 2.5 %; (3, 0, 3) 1.8 %, (3, 1, 2) 1.4 %, load issue alone 1.2 %, the replay stretch on top nothing
+                    // worth 2.5 %; (3, 0, 3) 1.8 %, (3, 1, 2) 1.4 %, load issue alone 1.2 %, the replay stretch on top nothing.  Round 3, LDS-only image (short
+                    // frames): 3 in pass 2 and 1 behind it (replay, end barrier) instead of 2 and 0: QPSK-S 8/9 5.68 -> 5.47 ms, 3/5 8.86 -> 8.75 ms per 16384 frames;
+                    // the hybrid image keeps (3, 0, 2, 0): with (3, 0, 2 | 3, 1) its steady state gains 1.4-2.1 % and the 4096-frame launch of the bench loses 0.3-0.8 %
                     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                     for (int j = 0; j < DEG; j++) {
@@ -668,7 +670,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 if (ncf > 0) __syncthreads();         // every read of the layer precedes its writes
                 PROF_MARK(2);
                 if (act) {
-                    __builtin_amdgcn_s_setprio(2);
+                    __builtin_amdgcn_s_setprio(MODE == 0 ? 3 : 2);
                     // ---- pass 2: new c->v ; posterior = v->c + new c->v.  Duplicate edges (not in `prim`) go to
                     //      the junk row (selected on the scalar unit), the absent edge of lane 0 is dropped.
                     uint32_t idxn = 0u;
@@ -704,7 +706,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         __builtin_amdgcn_raw_buffer_store_b96(sv, rs, t4 * 3u, st_base + (uint32_t)(r * LDPC_Z) * 12u, NMS_AUX_ST);
                     }
                     if (q == 1) { nx1 = cst1; nx2 = cst2; nxk = __uint_as_float(pkn); }
-                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_s_setprio(MODE == 0 ? 1 : 0);
                 }
                 PROF_MARK(3);
                 // ---- duplicate edges of a bit-group inside this layer: ordered delta updates, level by level.  The
