@@ -1,4 +1,2 @@
-cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/ab
-timeout 900 python -m pytest tests/test_ldpc_gpu.py tests/test_golden_gpu.py -m gpu -x -q -k "spa or SPA or image_modes" 2>&1 | tail -2
-python tools/spa_check.py 2>&1 | grep -v amdgpu | tail -14
-AB_ROUNDS=3 AB_CMD='python tools/bench_spa.py 16384 16384 3 2>&1 | grep " SPA"' bash tools/ab_variants.sh 2>&1 | tee gpurun_out/ab/ab.txt
+cd "${GRAFT_REPO_ROOT:-.}"
+for lib in tools/bin/lib_d07.so tools/bin/lib_d17.so; do echo "== $lib"; DVBS2HIP_LIB=$PWD/$lib python tools/spa_dbg.py 2>&1 | grep -v amdgpu | cut -c1-60; done
