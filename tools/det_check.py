@@ -1,16 +1,17 @@
 """Determinism of the LDPC decoders at size (GPU box): the same batch decoded twice, and its first frames decoded alone, must give the same
-hard decisions, CWD and iteration counts.  python tools/det_check.py [frames [sigma]]"""
+hard decisions, CWD and iteration counts.  python tools/det_check.py [frames [sigma [modcod ...]]]   (DET_ITE=n: iterations)"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dvbs2_amd.receiver import Dvbs2Hip
 dev = torch.device("cuda", 0)
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 sigma = float(sys.argv[2]) if len(sys.argv) > 2 else 0.42
+n_ite = int(os.environ.get("DET_ITE", "10"))
 for modcod in sys.argv[3:] or ("QPSK-N_8/9", "QPSK-S_8/9"):
     for implem in ("NMS", "SPA"):
         for es in (False, True):
             torch.manual_seed(7)
-            rx = Dvbs2Hip(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=es, implem=implem)
+            rx = Dvbs2Hip(modcod, max_frames=F, n_ite=n_ite, alpha=1.0, early_stop=es, implem=implem)
             N, K = rx.N_ldpc, rx.K_ldpc
             llr = (2.0 * (1.0 + sigma * torch.randn((F, N), device=dev, dtype=torch.float32)) / sigma ** 2)
             outs = []
