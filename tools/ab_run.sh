@@ -1,2 +1,3 @@
-cd "${GRAFT_REPO_ROOT:-.}"
-python tools/spa_check.py 2>&1 | grep -v amdgpu | head -12 | cut -c1-130
+cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/ab
+timeout 900 python -m pytest tests/test_ldpc_gpu.py tests/test_golden_gpu.py -m gpu -x -q 2>&1 | tail -2
+AB_ROUNDS=3 AB_CMD='python tools/bench_spa.py 0 16384 3 2>&1 | grep " NMS"; python tools/bench_32apsk.py 2>&1 | grep NMS' bash tools/ab_variants.sh 2>&1 | tee gpurun_out/ab/ab.txt
