@@ -65,8 +65,8 @@ struct LdpcKParams {
     int32_t inf_row;           // fast path: byte offset of the +inf row (padded layers) or -1
     uint32_t *cu_ctr;          // 8-wave workgroups: per-CU arrival counter (zeroed before the launch) or null
     struct {                   // k_ldpc_wg8.hip
-        const uint32_t *tab;   // [q][LDPC_FAST_STRIDE]: byte shift | byte offset of the bit-group row << 11 | LDS flag << 29
-        const uint32_t *rows;  // bit-group of LDS row l (nl of them), then of global row l (ng)
+        const uint32_t *tab;   // [q][LDPC_FAST_STRIDE]: byte shift | byte offset of the bit-group row << 11 | LDS flag << 29; modes 4 / 5: then [q][NR] the idle waves' swaps (LDS position or 0xFF)
+        const uint32_t *rows;  // bit-group of LDS row l (nl of them), then of global row l (ng), then where the q parity groups live; modes 4 / 5: then the bit-group in register slot k (NR)
         uint32_t st_base;      // byte offset of the packed c->v state in the workgroup's global slot
         uint32_t lds_junk;     // byte offset of the write-only LDS row (the +inf row of padded codes follows it)
         int32_t lds_bytes, pad;
