@@ -1,3 +1,5 @@
-cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/ab
-B='python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-extras --self-check-steps 0 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d[\"ms_per_step\"],3), d[\"ber\"][\"BE\"])"'
-for i in 1 2 3; do for o in 0 1 2 5 10 6 9; do echo -n "order $o: "; DVBS2HIP_LDPC_HYB_ORDER=$o bash -c "$B"; done; done 2>&1 | tee gpurun_out/ab/order.txt
+cd "${GRAFT_REPO_ROOT:-.}"
+echo "== 1 WG per CU"; DVBS2HIP_LDPC_BLOCKS_PER_CU=1 DET_ITE=2 python tools/det_check.py 4096 0.50 QPSK-S_8/9 2>&1 | grep -v amdgpu | grep SPA | cut -c1-160
+echo "== 2 WG per CU, 512 frames (one frame per WG)"; DET_ITE=2 python tools/det_check.py 512 0.50 QPSK-S_8/9 2>&1 | grep -v amdgpu | grep SPA | cut -c1-160
+echo "== 2 WG per CU, 256 frames"; DET_ITE=2 python tools/det_check.py 256 0.50 QPSK-S_8/9 2>&1 | grep -v amdgpu | grep SPA | cut -c1-160
+echo "== grid max 256 (DVBS2HIP_LDPC_GRID_MAX), 4096 frames"; DVBS2HIP_LDPC_GRID_MAX=256 DET_ITE=2 python tools/det_check.py 4096 0.50 QPSK-S_8/9 2>&1 | grep -v amdgpu | grep SPA | cut -c1-160
