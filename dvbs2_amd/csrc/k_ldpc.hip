@@ -420,7 +420,8 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                         return "LDPC: internal: static hybrid needs p_c and p_{c-1} at the last two slots (parity chain forwarding)";
                 } else {
                     // duplicate edges first (the only slots whose stores are redirected: ldpc_w8_kd), never the masked slot (a parity group: no duplicates)
-                    for (const Slot &sl : layers[r]) if (sl.lvl > 0) ord.push_back(sl);
+                    // in the order of the conflict list (level, then table order): conflict entry i is slot i, which the sum-product layer relies on
+                    for (int lvl = 1; lvl <= 3; lvl++) for (const Slot &sl : layers[r]) if (sl.lvl == lvl) ord.push_back(sl);
                     for (const Slot &sl : layers[r]) if (sl.lvl == 0 && !prev_touch[sl.group]) ord.push_back(sl);
                     for (const Slot &sl : layers[r]) if (sl.lvl == 0 && prev_touch[sl.group]) ord.push_back(sl);
                 }
@@ -457,6 +458,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     T8[29 + i] = T8[32 + i];
                 }
                 if (nc > 0 && (T8[48] >> 8) != 1u) return "LDPC: internal: first conflict entry is not of level 1";
+                if (pl.fast_mode == 0) for (int i = 0; i < nc; i++) if ((T8[48 + i] & 31u) != (uint32_t)i) return "LDPC: internal: conflict entry i is not slot i (LDS-only image)";
             }
             {   // image rows in storage order: LDS rows then global rows (bit-groups ascend inside each: info first)
                 std::vector<int> lrow, grow;

@@ -291,6 +291,11 @@ ldpc_wg8_kernel(const LdpcKParams p)
     const uint32_t ljunk = p.w8.lds_junk;                    // LDS junk row (write-only)
     uint32_t SB = 0x80000000u;
     asm volatile("" : "+s"(SB));                             // the sign mask as an SGPR operand (VOP3 takes no literal)
+    // Offset of a buffer store of MORE THAN 8 BYTES: all of it in the vector register, the scalar offset field zero.  With a scalar offset register the compiler assumes that
+    // the next instruction may overwrite the store's data registers at once (the rule of the first GCN parts); on gfx950 that corrupts the stored data -- found when a variant of
+    // the sum-product layer without branches behind its 16-byte message stores decoded differently from call to call.  With the field zero the compiler's hazard recognizer
+    // puts the wait state in itself (one vector add per store is the price; the opaque copy keeps instruction selection from moving the scalar part back).
+    auto wide_off = [&](uint32_t voff, uint32_t soff) -> uint32_t { uint32_t o = voff + soff; asm volatile("" : "+v"(o)); return o; };
     auto gld = [&](uint32_t voff, uint32_t soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0)); };
     auto gst = [&](uint32_t voff, uint32_t soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, 0); };
     auto mld = [&](uint32_t voff, uint32_t soff) { if (SPA_ABL & 2) return __uint_as_float(voff & 0x3F000000u); return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, SPA_AUX)); };      // SPA messages
@@ -442,6 +447,11 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     // critical path): the full array does not fit the 128-VGPR budget of two workgroups per CU beside x[] and u[]
                     constexpr int BS = DEG > 13 ? SPA_BS : 1, NB = (DEG + BS - 1) / BS;      // (the 11- and 13-slot codes have the registers for every suffix value)
                     float x[DEG], u[DEG], B[NB];                    // v->c ; 2^s2 (1 - tanh(|v->c| / 2)) ; suffix recursion
+                    // LDS-only image (short frames): the plan puts the duplicate edges into the first slots of a layer, conflict entry i = slot i, so what such an edge adds to its
+                    // bit in the replay, new - old message, is ONE subtraction per slot against the old message that came in with the others: no extra loads, no per-slot test
+                    // and six-way match against the conflict list (QPSK-S 8/9: 11.05 -> 9.9 ms per 16384 frames).  (This form first decoded differently from call to call: with
+                    // the branches of the match gone, nothing stood between a 16-byte message store and the next vector write to its data registers -- see wide_off.)
+                    constexpr bool OD_STATIC = MODE == 0;
                     float od[LDPC_SPA_MAXC];                        // old c->v of the duplicate edges, then new - old (what such an edge adds)
                     float mn1 = INFINITY, kap = 1.f, cln = 0.f, key = 0.f;
                     uint32_t sx = 0u;
@@ -465,10 +475,16 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             for (int j = 0; j < DEG; j++) onx[j] = mld(t4, mrow + (uint32_t)j * mpitch);     // old message
 #endif
 #endif
+                            if (!OD_STATIC) {
 #pragma unroll
-                            for (int i = 0; i < LDPC_SPA_MAXC; i++) if (i < ncf) od[i] = SPA_MSG4 ? mone_ld(dup_slot(i), t4, mrow) : mld(t4, mrow + dup_slot(i) * mpitch);
+                                for (int i = 0; i < LDPC_SPA_MAXC; i++) if (i < ncf) od[i] = SPA_MSG4 ? mone_ld(dup_slot(i), t4, mrow) : mld(t4, mrow + dup_slot(i) * mpitch);
+                            }
                         }
                         __builtin_amdgcn_s_setprio(0);
+                        if (OD_STATIC) {
+#pragma unroll
+                            for (int j = 0; j < LDPC_SPA_MAXC && j < DEG; j++) od[j] = onx[j];
+                        }
 #pragma unroll
                         for (int j = 0; j < DEG; j++) x[j] = x[j] - onx[j];      // zeros in the first iteration
                         if (mask0) x[DEG - 1] = INFINITY;
@@ -542,11 +558,11 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             mq[j & 3] = nw;                     // four slots' messages leave as one 16-byte piece (the last group: what is left)
                             if (!(SPA_ABL & 1)) {
                                 if ((j & 3) == 3)
-                                    __builtin_amdgcn_raw_buffer_store_b128(m_u32x4{__float_as_uint(mq[0]), __float_as_uint(mq[1]), __float_as_uint(mq[2]), __float_as_uint(mq[3])}, rs, t4s * 4u,
-                                                                           mrow + (uint32_t)(j >> 2) * (W8_ROW * 4u), SPA_AUX_ST);
+                                    __builtin_amdgcn_raw_buffer_store_b128(m_u32x4{__float_as_uint(mq[0]), __float_as_uint(mq[1]), __float_as_uint(mq[2]), __float_as_uint(mq[3])}, rs,
+                                                                           wide_off(t4s * 4u, mrow + (uint32_t)(j >> 2) * (W8_ROW * 4u)), 0u, SPA_AUX_ST);
                                 else if (j == DEG - 1) {
                                     const uint32_t tbase = mrow + (uint32_t)MG4 * (W8_ROW * 4u);
-                                    if (MR == 3) __builtin_amdgcn_raw_buffer_store_b96(m_u32x3{__float_as_uint(mq[0]), __float_as_uint(mq[1]), __float_as_uint(mq[2])}, rs, t4s * 3u, tbase, SPA_AUX_ST);
+                                    if (MR == 3) __builtin_amdgcn_raw_buffer_store_b96(m_u32x3{__float_as_uint(mq[0]), __float_as_uint(mq[1]), __float_as_uint(mq[2])}, rs, wide_off(t4s * 3u, tbase), 0u, SPA_AUX_ST);
                                     if (MR == 2) __builtin_amdgcn_raw_buffer_store_b64(m_u32x2{__float_as_uint(mq[0]), __float_as_uint(mq[1])}, rs, t4s * 2u, tbase, SPA_AUX_ST);
                                     if (MR == 1) mst(t4s, tbase, mq[0]);
                                 }
@@ -554,7 +570,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #else
                             mst(t4s, mrow + (uint32_t)j * mpitch, nw);
 #endif
-                            if ((dupmask >> j) & 1u) {          // wave-uniform
+                            if (OD_STATIC) { if (j < LDPC_SPA_MAXC) od[j] = nw - od[j]; }
+                            else if ((dupmask >> j) & 1u) {          // wave-uniform
 #pragma unroll
                                 for (int i = 0; i < LDPC_SPA_MAXC; i++) if (i < ncf && dup_slot(i) == (uint32_t)j) od[i] = nw - od[i];
                             }
@@ -704,7 +721,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     {
                         typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
                         u32x3 sv; sv.x = __float_as_uint(cst1); sv.y = __float_as_uint(cst2); sv.z = pkn;
-                        __builtin_amdgcn_raw_buffer_store_b96(sv, rs, t4 * 3u, st_base + (uint32_t)(r * LDPC_Z) * 12u, NMS_AUX_ST);
+                        __builtin_amdgcn_raw_buffer_store_b96(sv, rs, wide_off(t4 * 3u, st_base + (uint32_t)(r * LDPC_Z) * 12u), 0u, NMS_AUX_ST);
                     }
                     if (q == 1) { nx1 = cst1; nx2 = cst2; nxk = __uint_as_float(pkn); }
                     __builtin_amdgcn_s_setprio(MODE == 0 ? 1 : 0);
