@@ -412,7 +412,9 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 for (const Slot &sl : layers[(r + q - 1) % q]) prev_touch[sl.group] = 1;      // (layers[] hold real slots only)
                 std::vector<Slot> ord;
                 if (hyb) {      // static hybrid: the LDS-resident slots first (exactly 9 of them; 14 with parked rows), then the others
-                    for (const Slot &sl : layers[r]) if (in_lds[sl.group]) ord.push_back(sl);
+                    // (sum-product kernel: the duplicate edges first, in the order of the conflict list, so that conflict entry i is slot i as in the LDS-only image)
+                    if (spa) for (int lvl = 1; lvl <= 3; lvl++) for (const Slot &sl : layers[r]) if (in_lds[sl.group] && sl.lvl == lvl) ord.push_back(sl);
+                    for (const Slot &sl : layers[r]) if (in_lds[sl.group] && !(spa && sl.lvl > 0)) ord.push_back(sl);
                     if ((int)ord.size() != NLH) return "LDPC: internal: static hybrid balance broken";
                     for (const Slot &sl : layers[r]) if (!in_lds[sl.group]) ord.push_back(sl);
                     const size_t nn = ord.size();
@@ -458,7 +460,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     T8[29 + i] = T8[32 + i];
                 }
                 if (nc > 0 && (T8[48] >> 8) != 1u) return "LDPC: internal: first conflict entry is not of level 1";
-                if (pl.fast_mode == 0) for (int i = 0; i < nc; i++) if ((T8[48 + i] & 31u) != (uint32_t)i) return "LDPC: internal: conflict entry i is not slot i (LDS-only image)";
+                if (pl.fast_mode == 0 || spa) for (int i = 0; i < nc; i++) if ((T8[48 + i] & 31u) != (uint32_t)i) return "LDPC: internal: conflict entry i is not slot i";
             }
             {   // image rows in storage order: LDS rows then global rows (bit-groups ascend inside each: info first)
                 std::vector<int> lrow, grow;

@@ -447,11 +447,11 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     // critical path): the full array does not fit the 128-VGPR budget of two workgroups per CU beside x[] and u[]
                     constexpr int BS = DEG > 13 ? SPA_BS : 1, NB = (DEG + BS - 1) / BS;      // (the 11- and 13-slot codes have the registers for every suffix value)
                     float x[DEG], u[DEG], B[NB];                    // v->c ; 2^s2 (1 - tanh(|v->c| / 2)) ; suffix recursion
-                    // LDS-only image (short frames): the plan puts the duplicate edges into the first slots of a layer, conflict entry i = slot i, so what such an edge adds to its
+                    // The plan puts the duplicate edges into the first slots of a layer, conflict entry i = slot i, so what such an edge adds to its
                     // bit in the replay, new - old message, is ONE subtraction per slot against the old message that came in with the others: no extra loads, no per-slot test
                     // and six-way match against the conflict list (QPSK-S 8/9: 11.05 -> 9.9 ms per 16384 frames).  (This form first decoded differently from call to call: with
                     // the branches of the match gone, nothing stood between a 16-byte message store and the next vector write to its data registers -- see wide_off.)
-                    constexpr bool OD_STATIC = MODE == 0;
+                    constexpr bool OD_STATIC = true;          // (every image mode: the plan orders the slots of a sum-product plan this way in all of them)
                     float od[LDPC_SPA_MAXC];                        // old c->v of the duplicate edges, then new - old (what such an edge adds)
                     float mn1 = INFINITY, kap = 1.f, cln = 0.f, key = 0.f;
                     uint32_t sx = 0u;
