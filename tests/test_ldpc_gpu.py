@@ -367,8 +367,8 @@ def test_plain_decode_siho_equals_the_posterior_socket_form(O, Rx, modcod, F, ea
 def test_ldpc_decisions_are_reproducible_at_size(Rx, modcod, implem):
     """The same batch decoded twice, and its first frames decoded alone, give the same hard decisions, CWD and iteration counts, bit for bit -- on hard frames (nothing
     converges early, every layer of every iteration runs), with every CU holding two workgroups and every workgroup several frames.  A hazard between two instructions of a
-    layer loop shows up here as a handful of frames that differ from one call to the next (round 3 met one in a variant of the sum-product layer that passed every
-    three-frame parity test: DESIGN section 9); the oracle is not needed for this and the batch is the size of a production call."""
+    layer loop shows up here as a handful of frames that differ from one call to the next (round 3 met one -- a 16-byte store whose data registers the next
+    instruction overwrote -- in a variant of the sum-product layer that passed every three-frame parity test: DESIGN section 6); the oracle is not needed for this and the batch is the size of a production call."""
     import torch
     dev = torch.device("cuda", 0)
     F = 3072
