@@ -25,3 +25,19 @@ def test_no_kernel_spills_vector_registers():
     # private memory only where a kernel calls a non-inlined device function (the delay line's general walk)
     scratch = [(k["name"], k["scratch"]) for k in ks if k["scratch"] > 0]
     assert all("sync_vdelay_batch_kernel" in n for n, _ in scratch), scratch
+
+
+def test_no_wide_buffer_store_takes_a_scalar_offset_register():
+    """with an SGPR in the soffset field the compiler lets the next instruction overwrite the data registers of a 12- or 16-byte buffer store, and on gfx950 the
+    stored data change.  The kernels put the whole offset into the vector register instead (`wide_off`); this reads the disassembly of every translation unit and wants no such store at
+    all -- the stricter condition, so that the next edit of a store cannot bring the form back unseen -- and, as the hazard proper, none followed by a write of its data registers."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no ROCm LLVM tools in this image")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dvbs2_amd import build
+    build.build_lib()
+    import store_hazard
+    rep = store_hazard.report()
+    assert len(rep) >= 10 and rep["k_ldpc_wg8"][0] >= 40, rep        # the layer kernels do store 12 / 16 bytes at a time: the scan sees them
+    assert not [(tu, bad) for tu, (_, _, bad) in rep.items() if bad], rep
+    assert not [(tu, sgpr) for tu, (_, sgpr, _) in rep.items() if sgpr], rep
