@@ -10,6 +10,7 @@
 // (the average per position, the arg max per frame, the delay line), which run frame after frame on
 // device-resident state: no host round trip between the stages.
 #include "dvbs2hip_internal.h"
+#include <cstring>
 #include <type_traits>
 
 namespace dvbs2 {
@@ -461,7 +462,7 @@ constexpr int SFF_MAXP = 64;
 
 // ---- L&R, per frame: tR[f] = (temp_R_l_0, temp_R_l_1) (.cpp:102-130)
 __global__ void __launch_bounds__(256)
-sff_lr_pilot_kernel(const float *__restrict__ X, float2 *__restrict__ tR, int n)
+sff_lr_pilot_kernel(const float *__restrict__ X, float2 *__restrict__ tR, float2 *__restrict__ fr_not_yet, int n)
 {
     __shared__ float2 part[SFF_MAXP * 9];
     const float *x = X + (size_t)blockIdx.x * 2 * n;
@@ -484,6 +485,7 @@ sff_lr_pilot_kernel(const float *__restrict__ X, float2 *__restrict__ tR, int n)
         float t0 = 0.f, t1 = 0.f;
         for (int w = 0; w < P * 9; w++) { t0 += part[w].x; t1 += part[w].y; }             // p-major, m-minor: the reference's order
         tR[blockIdx.x] = make_float2(t0, t1);
+        if (fr_not_yet) fr_not_yet[blockIdx.x] = make_float2(__uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu));      // sff_lr_fused_kernel's SFF_NOT_YET
     }
 }
 
@@ -638,10 +640,126 @@ static void sff_rotate_launch(const float *X, float *Y, const float2 *fr, int n,
                            reinterpret_cast<float2 *>(Y), fr, n, tot);
 }
 
+static hipError_t sff_lr_launch_unfused(const float *X, float *Y, float *R_l, float *tmp, float *FRQ, float *PHS, int n, int F, float alpha, hipStream_t s);
+
+// ---- L&R, recurrence and rotation in ONE launch.  The recurrence over the frames of a call is serial (4096 frames: 50 us in its own kernel, during which the
+// machine idled, then a launch gap, then the rotation); here workgroup 0 runs it while every other workgroup rotates 1024 sample pairs of one frame: it requests
+// its samples, then waits for its frame's estimate.  An estimate is published as ONE 8-byte word per frame (a relaxed agent-scope store; sff_lr_pilot_kernel has
+// left SFF_NOT_YET in every word), so a reader needs no fence -- an agent-scope acquire per workgroup invalidates its XCD's L2 and was measured at ~100 ns per
+// WORKGROUP of the launch, ten times the three kernels -- and no counter is shared by the workgroups.  Workgroup 0 is the first one the dispatcher places; a
+// workgroup that does not see its estimate within about a second traps instead of hanging the queue.  The recurrence itself on two lanes (lane 0 the real, lane 1
+// the imaginary part: two dependent instructions per frame instead of six), its (1 - alpha) t products formed by all lanes before; the values and their order are
+// those of sff_lr_iir_kernel (alpha r + (1 - alpha) t, two roundings).
+constexpr int SFF_RU = 4, SFF_RCH = 256 * SFF_RU;        // 16-byte pairs per lane / per workgroup
+constexpr unsigned long long SFF_NOT_YET = ~0ull;        // (an estimate that is not a number is stored as the canonical NaN: never this pattern)
+template <bool FULL>
+__device__ __forceinline__ void sff_lr_chain1(float *pl, float &r, float alpha, int cnt)
+{
+#pragma unroll 1
+    for (int k0 = 0; k0 < 64; k0 += 16) {
+        if (!FULL && k0 >= cnt) break;
+        float t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = pl[k0 + k];
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (FULL || k0 + k < cnt) { r = alpha * r + t[k]; t[k] = r; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) pl[k0 + k] = t[k];
+    }
+}
+__global__ void __launch_bounds__(256)
+sff_lr_fused_kernel(const vd_f4n *__restrict__ x, vd_f4n *__restrict__ y, const float2 *__restrict__ tR, float *__restrict__ R_l, float2 *fr, float *__restrict__ FRQ,
+                    float *__restrict__ PHS, int F, float alpha, int n, int cpf)
+{
+    __shared__ __attribute__((aligned(16))) float sh[2][2][64];        // [batch parity][component][frame of the batch]
+    __shared__ float2 s_e;
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x >= 128) return;                                 // (waves that have ended do not count at the barriers below)
+        __builtin_amdgcn_s_setprio(3);                                  // the one serial thread of the launch: ahead of the rotating waves on its SIMD
+        const int nb = (F + 63) / 64;
+        if (threadIdx.x < 64) {
+            float r = lane < 2 ? R_l[lane] : 0.f;
+            const float one_m = 1 - alpha;
+            float2 nxt = lane < F ? tR[lane] : make_float2(0.f, 0.f);
+            for (int b = 0; b < nb; b++) {
+                const int f = b * 64 + lane, cnt = F - b * 64 < 64 ? F - b * 64 : 64;
+                sh[b & 1][0][lane] = one_m * nxt.x;
+                sh[b & 1][1][lane] = one_m * nxt.y;
+                if (f + 64 < F) nxt = tR[f + 64];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 2) { if (cnt == 64) sff_lr_chain1<true>(sh[b & 1][lane], r, alpha, cnt); else sff_lr_chain1<false>(sh[b & 1][lane], r, alpha, cnt); }
+                sy_lds_barrier();                                     // batch b is in sh[b & 1]
+            }
+            if (lane < 2) R_l[lane] = r;
+        } else {
+            for (int b = 0; b < nb; b++) {
+                sy_lds_barrier();
+                const int f = b * 64 + lane;
+                if (f < F) {
+                    const float r0 = sh[b & 1][0][lane], r1 = sh[b & 1][1][lane];
+                    float est = atan2f(r1, r0);
+                    est = (float)((double)est / ((18 / 2 + 1) * 3.1415926535897932384626433832795));
+                    const float estpi = (float)((double)est * 3.1415926535897932384626433832795);
+                    const uint32_t w0 = est == est ? __float_as_uint(est) : 0x7FC00000u, w1 = estpi == estpi ? __float_as_uint(estpi) : 0x7FC00000u;
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(fr + f), (unsigned long long)w0 | ((unsigned long long)w1 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (FRQ) FRQ[f] = est;
+                    if (PHS) PHS[f] = 0.f;
+                }
+            }
+        }
+        return;
+    }
+    const int w = (int)blockIdx.x - 1, f = w / cpf, c = w - f * cpf, npf = n / 2;
+    const vd_f4n *xf = x + (size_t)f * npf;
+    vd_f4n *yf = y + (size_t)f * npf;
+    const int p0 = c * SFF_RCH + (int)threadIdx.x;
+    vd_f4n v[SFF_RU];
+#pragma unroll
+    for (int u = 0; u < SFF_RU; u++) { const int q = p0 + u * 256; v[u] = __builtin_nontemporal_load(xf + (q < npf ? q : npf - 1)); }
+    if (threadIdx.x == 0) {
+        unsigned long long e;
+        uint32_t nap = 1, polls = 0;
+        while ((e = __hip_atomic_load(reinterpret_cast<unsigned long long *>(fr + f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == SFF_NOT_YET) {
+            for (uint32_t i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(1);
+            if (nap < 64) nap *= 2;
+            if (++polls > 600000u) __builtin_trap();                    // ~1 s: the recurrence is not running (it cannot happen with in-order dispatch)
+        }
+        s_e = make_float2(__uint_as_float((uint32_t)e), __uint_as_float((uint32_t)(e >> 32)));
+    }
+    __syncthreads();
+    const float2 e = s_e;
+#pragma unroll
+    for (int u = 0; u < SFF_RU; u++) {
+        const int q = p0 + u * 256;
+        if (q < npf) {
+            const float2 a = sff_rotate<0>(make_float2(v[u].x, v[u].y), e, 2 * q), b = sff_rotate<0>(make_float2(v[u].z, v[u].w), e, 2 * q + 1);
+            __builtin_nontemporal_store(vd_f4n{a.x, a.y, b.x, b.y}, yf + q);
+        }
+    }
+}
+
 hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp /* 4 F floats */, float *FRQ, float *PHS, int n, int F, float alpha, hipStream_t s)
 {
+    const char *ev = getenv("DVBS2HIP_LR");                    // read at every call
+    const bool unfused = ev && !strcmp(ev, "unfused");
+    if (!unfused && n % 2 == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0) {
+        float2 *tR = reinterpret_cast<float2 *>(tmp), *fr = tR + F;
+        const int cpf = (n / 2 + SFF_RCH - 1) / SFF_RCH;
+        hipLaunchKernelGGL(sff_lr_pilot_kernel, dim3(F), dim3(256), 0, s, X, tR, fr, n);
+        hipLaunchKernelGGL(sff_lr_fused_kernel, dim3(1 + (unsigned)F * cpf), dim3(256), 0, s, reinterpret_cast<const vd_f4n *>(X), reinterpret_cast<vd_f4n *>(Y), tR, R_l, fr, FRQ, PHS,
+                           F, alpha, n, cpf);
+        return hipGetLastError();
+    }
+    return sff_lr_launch_unfused(X, Y, R_l, tmp, FRQ, PHS, n, F, alpha, s);
+}
+
+static hipError_t sff_lr_launch_unfused(const float *X, float *Y, float *R_l, float *tmp, float *FRQ, float *PHS, int n, int F, float alpha, hipStream_t s)
+{
     float2 *tR = reinterpret_cast<float2 *>(tmp), *fr = tR + F;
-    hipLaunchKernelGGL(sff_lr_pilot_kernel, dim3(F), dim3(256), 0, s, X, tR, n);
+    hipLaunchKernelGGL(sff_lr_pilot_kernel, dim3(F), dim3(256), 0, s, X, tR, (float2 *)nullptr, n);
     hipLaunchKernelGGL(sff_lr_iir_kernel, dim3(1), dim3(128), 0, s, tR, R_l, fr, FRQ, PHS, F, alpha);
     const long long tot = (long long)n * F;
     sff_rotate_launch<0>(X, Y, fr, n, tot, s);

@@ -203,3 +203,34 @@ def test_fine_synchronizers_match_oracle(O, Rx, modcod):
     FRQ, _, _ = rx.sync_lr_synchronize(x[:1])
     assert abs(FRQ[0] - lr.synchronize(x[0])[0]) <= 1e-6
     rx.close()
+
+
+@pytest.mark.parametrize("modcod,F", [("32APSK-S_3/4", 131), ("QPSK-S_8/9", 64), ("QPSK-N_8/9", 3), ("32APSK-S_3/4", 1500)])
+def test_lr_recurrence_and_rotation_in_one_launch_equal_the_three_kernel_path(O, Rx, monkeypatch, modcod, F):
+    """The L&R synchronizer's default form runs the recurrence over the frames in one workgroup of the launch that rotates the frames (k_sync.hip, sff_lr_fused_kernel: the
+    rotating workgroups wait for their frame's estimate); DVBS2HIP_LR=unfused is the recurrence and the rotation as kernels of their own.  Same values in the same order:
+    estimates and rotated frames bit for bit, over two calls (the damped autocorrelation and the launch's counters are carried), batches that are not whole multiples of 64
+    frames, and against the oracle on the first and the last frames."""
+    _, pl, _, _ = make_pl_frames(O, modcod, min(F, 6), 10.0, seed=11)
+    n = pl.shape[1] // 2
+    base = [_rot(O, pl[f], 1e-4 * (f + 1), 0.1 * f) for f in range(pl.shape[0])]
+    rng = np.random.default_rng(5)
+    x = np.stack([base[f % len(base)] for f in range(F)]) + (0.05 * rng.standard_normal((F, 2 * n))).astype(np.float32)
+    out = {}
+    for form in ("fused", "unfused"):
+        if form == "unfused":
+            monkeypatch.setenv("DVBS2HIP_LR", "unfused")
+        else:
+            monkeypatch.delenv("DVBS2HIP_LR", raising=False)
+        rx = Rx(modcod, max_frames=F)
+        rx.sync_lr_set_alpha(0.9)
+        out[form] = [rx.sync_lr_synchronize(x), rx.sync_lr_synchronize(x[::-1].copy()), rx.sync_lr_synchronize(x[:max(1, F // 3)])]
+        rx.close()
+    for a, b in zip(out["fused"], out["unfused"]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    lr = O.SyncLR(n, alpha=0.9)
+    FRQ, _, Y = out["fused"][0]
+    for f in range(F):
+        fo, _, Yo = lr.synchronize(x[f])
+        if f < 3 or f >= F - 3:
+            assert abs(FRQ[f] - fo) <= 1e-6 and np.max(np.abs(Y[f] - Yo)) <= 4e-3
