@@ -1,8 +1,12 @@
 """Row N4 parity on the GPU: frame synchronizer vs the CPU oracle's restatement of
 Synchronizer_frame_DVBS2_fast (correlations within 1e-4 of unit-power signals, the delay exact, the
 aligned output bit-exact since it only copies samples)."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from helpers import make_pl_frames
 
@@ -234,3 +238,12 @@ def test_lr_recurrence_and_rotation_in_one_launch_equal_the_three_kernel_path(O,
         fo, _, Yo = lr.synchronize(x[f])
         if f < 3 or f >= F - 3:
             assert abs(FRQ[f] - fo) <= 1e-6 and np.max(np.abs(Y[f] - Yo)) <= 4e-3
+
+
+def test_lr_one_launch_form_under_another_handles_persistent_kernel():
+    """The rotating workgroups of sff_lr_fused_kernel wait for words that workgroup 0 publishes, which is safe because workgroup 0 is placed first.  Issued while another
+    handle's persistent LDPC launch owns every CU (tools/lr_soak.py), the synchronizer's workgroups are placed a few at a time as LDPC workgroups retire: every call must
+    still end (a workgroup that waits for about a second traps) with the three-kernel path's output."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lr_soak.py"), "25"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "225 calls, 0 bad" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
