@@ -655,15 +655,26 @@ constexpr unsigned long long SFF_NOT_YET = ~0ull;        // (an estimate that is
 template <bool FULL>
 __device__ __forceinline__ void sff_lr_chain1(float *pl, float &r, float alpha, int cnt)
 {
+    if (FULL) {
+        // a whole batch: its 64 values are requested at once (one LDS round trip per batch in front of the 128 dependent instructions instead of one per 16 frames)
+        float t[64];
+#pragma unroll
+        for (int k = 0; k < 64; k++) t[k] = pl[k];
+#pragma unroll
+        for (int k = 0; k < 64; k++) { r = alpha * r + t[k]; t[k] = r; }
+#pragma unroll
+        for (int k = 0; k < 64; k++) pl[k] = t[k];
+        return;
+    }
 #pragma unroll 1
     for (int k0 = 0; k0 < 64; k0 += 16) {
-        if (!FULL && k0 >= cnt) break;
+        if (k0 >= cnt) break;
         float t[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) t[k] = pl[k0 + k];
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            if (FULL || k0 + k < cnt) { r = alpha * r + t[k]; t[k] = r; }
+            if (k0 + k < cnt) { r = alpha * r + t[k]; t[k] = r; }
 #pragma unroll
         for (int k = 0; k < 16; k++) pl[k0 + k] = t[k];
     }
