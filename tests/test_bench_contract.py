@@ -56,7 +56,7 @@ def test_bench_line_on_the_gpu():
     assert ro["bound"] == "hbm" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
     assert ro["avg_launch_ms"] <= d["ms_per_step"] * 1.02
     assert 0.0 < ro["hbm_true"]["frac"] < 0.1
-    assert ro["binding_resource"] in ("fabric", "vector-ALU issue") and ro["algorithmic_frac"] == ro["frac"]
+    assert ro["binding_resource"] in ("fabric", "vector pipes") and ro["algorithmic_frac"] == ro["frac"]
     assert d["self_check"]["steps"] == 20 and 0.5 * d["ms_per_step"] < d["self_check"]["ms_per_step"] < 1.5 * d["ms_per_step"]
     if ro["traffic"] is not None:                                          # the committed PMC file matches the running kernel
         b = ro["bounded"]

@@ -52,7 +52,7 @@ lines = ["# rocprofv3 counters of the non-LDPC kernels (%s) -- `python3 tools/pm
          "reports half of the bytes of a coalesced stream on gfx950, WRITE_SIZE the bytes: calibrated in profiles/r02_ldpc_rocprof.md).",
          "VALU busy = SQ_ACTIVE_INST_VALU / (4 SIMDs x SQ_BUSY_CYCLES summed over the chip's SQs) is shown as the share of wave-cycles instead:",
          "valu/wave-cyc = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES, trans = v_exp / v_log / v_rcp / v_sqrt instructions.", "",
-         "VALU issue = (SQ_INSTS_VALU x 4 + trans x 4 more: transcendentals issue in 8 cycles) / (1024 SIMDs x SQ_BUSY_CYCLES / 32): the share of the chip's vector issue slots.", "",
+         "VALU issue = (SQ_INSTS_VALU x 2 + trans x 6 more: a 32-lane SIMD retires a wave64 instruction in 2 cycles, a transcendental in 8 -- MI355X_MICROARCH.md constants table, tools/probe_dep.hip; priced at 4 / 8 until the end of round 3) / (1024 SIMDs x SQ_BUSY_CYCLES / 32): the share of the chip's vector-pipe cycles.", "",
          "| kernel | grid | launches | avg us | fabric GB | fabric TB/s | VALU inst | trans inst | VALU issue | LDS inst | VMEM rd / wr | valu / wave-cyc | wait / wave-cyc | LDS bank-conflict / LDS active | L2 hit |",
          "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 rows_json = []
@@ -64,7 +64,7 @@ for key in sorted(dur, key=lambda k: -sum(dur[k])):
     def ratio(a, b): return "%.2f" % (a / b) if b else "-"
     hit = c.get("TCC_HIT_sum", 0); miss = c.get("TCC_MISS_sum", 0)
     busy = c.get("SQ_BUSY_CYCLES", 0) / 32.0
-    issue = (c.get("SQ_INSTS_VALU", 0) * 4.0 + c.get("SQ_INSTS_VALU_TRANS_F32", 0) * 4.0) / (1024.0 * busy) if busy else None
+    issue = (c.get("SQ_INSTS_VALU", 0) * 2.0 + c.get("SQ_INSTS_VALU_TRANS_F32", 0) * 6.0) / (1024.0 * busy) if busy else None
     rows_json.append(dict(kernel=key[0], grid=key[1], launches=len(dur[key]), avg_us=us, fabric_bytes=fab, valu_issue=issue, counters=c))
     lines.append("| `%s` | %s | %d | %.1f | %.3f | %.2f | %.3g | %.3g | %s | %.3g | %.3g / %.3g | %s | %s | %s | %s |" % (
         key[0], key[1], len(dur[key]), us, fab / 1e9, fab / (us * 1e-6) / 1e12 if us else 0, c.get("SQ_INSTS_VALU", 0), c.get("SQ_INSTS_VALU_TRANS_F32", 0),

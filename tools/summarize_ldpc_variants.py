@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """gpurun_out/lv_* (tools/profile_ldpc_variants.sh) -> profiles/<tag>_ldpc_variants.md + .json: per LDPC kernel instantiation the launch
 time (rocprofv3 --kernel-trace --stats), the counters per launch (separate --pmc passes) and the BOUNDED figures recomputable from them:
-  vector-ALU issue = (SQ_INSTS_VALU x 4 + SQ_INSTS_VALU_TRANS_F32 x 4 more: transcendentals issue in 8 cycles, MI355X_MICROARCH.md) / (1024 SIMDs x busy cycles)
+  vector-ALU issue = (SQ_INSTS_VALU x 2 + SQ_INSTS_VALU_TRANS_F32 x 6 more: a 32-lane SIMD retires a wave64 instruction in 2 cycles, a transcendental in 8, MI355X_MICROARCH.md
+  constants table and tools/probe_dep.hip; priced at 4 / 8 until the end of round 3) / (1024 SIMDs x busy cycles)
   fabric           = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B / launch time, against 8.6 TB/s (Infinity-Cache gathers) -- FETCH_SIZE x 2 as calibrated
                      for one dword per lane (tools/calibrate_fetch.py, profiles/r02_ldpc_rocprof.md)
   algorithmic      = SURVEY 8(d): 16 B per Tanner edge and iteration + 4 (N + K) per frame, / launch time, against 8 TB/s (an EFFECTIVE rate)."""
@@ -56,8 +57,8 @@ for cfg in sorted(glob.glob(os.path.join(OUT, "lv_*.cfg")), key=lambda s: int(s.
             cyc = pmc["SQ_BUSY_CYCLES"] / 32.0
             tr = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
             r["busy_cycles"] = cyc
-            r["valu_issue_frac"] = (pmc["SQ_INSTS_VALU"] * 4.0 + tr * 4.0) / (1024.0 * cyc)
-            r["trans_share_of_issue"] = tr * 8.0 / (pmc["SQ_INSTS_VALU"] * 4.0 + tr * 4.0)
+            r["valu_issue_frac"] = (pmc["SQ_INSTS_VALU"] * 2.0 + tr * 6.0) / (1024.0 * cyc)
+            r["trans_share_of_issue"] = tr * 8.0 / (pmc["SQ_INSTS_VALU"] * 2.0 + tr * 6.0)
             r["valu_per_edge_ite"] = pmc["SQ_INSTS_VALU"] * 64.0 / (F * 10.0 * E) * (360.0 / 384.0)
         if "TCC_HIT_sum" in pmc:
             r["l2_hit"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])

@@ -36,7 +36,7 @@ for name, c in k.items():
             if isinstance(v, dict):
                 row(kk + " (N4)", name, v["call_ms"], v["GBps_16B_per_sample"])
 bd = r.get("bounded")
-L += ["", "LDPC kernel, what physically bounds it (`roofline.bounded`): fabric traffic %.1f GB per launch = %.2f TB/s = %.2f of the %.1f TB/s Infinity-Cache rate; vector-ALU issue %.2f;"
+L += ["", "LDPC kernel, what physically bounds it (`roofline.bounded`): fabric traffic %.1f GB per launch = %.2f TB/s = %.2f of the %.1f TB/s Infinity-Cache rate; vector pipes %.2f busy (2 cycles per wave64 instruction);"
       % (r["traffic"] / 1e9, bd["achieved"] / 1e3, bd["frac"], bd["peak"] / 1e3, bd["valu"]["frac"]) if bd else "LDPC kernel: no valid PMC traffic file for this kernel source.",
       "bytes that must cross HBM (`roofline.hbm_true`): %.2f GB per launch = %.0f GB/s = %.3f of peak." % (r["hbm_true"]["bytes_per_launch"] / 1e9, r["hbm_true"]["achieved"], r["hbm_true"]["frac"]),
       "Early stop (the reference's default), untimed for `value`: %s frames/s." % ", ".join("%.0f k at %s" % (v / 1e3, kk) for kk, v in b["extra"]["early_stop_fps"].items()),
