@@ -92,6 +92,11 @@ struct dvbs2hip_handle {
     float *d_nat_work = nullptr;       // natural-order LDPC: frame-interleaved image + state, ceil(max_frames / 64) groups
     float *d_lr_R = nullptr;
     float lr_alpha = 0.999f;
+    int lr_timeouts = 0;               // launches whose rotation had to be repeated (dvbs2hip_sync_lr_timeouts)
+    // L&R, recurrence and rotation in one launch (k_sync.hip, sff_lr_fused_kernel): the error word a rotating workgroup sets when it gives up waiting for the
+    // recurrence -- host-mapped memory, so the host reads it at its synchronisation points without a copy
+    uint32_t *lr_err_host = nullptr, *lr_err_dev = nullptr;
+    struct { const float *x = nullptr; float *y = nullptr; int n = 0, F = 0; } lr_last;      // the last device-form call: what dvbs2hip_synchronize re-rotates after a timeout
     float *d_hist_zero = nullptr, *d_hist_junk = nullptr;     // filter2: zero history in, discarded history out
     // monitor reduction over RCCL (one process per GPU): communicator + the 3 x uint64 receive buffer
     void *nccl_comm = nullptr;
@@ -529,6 +534,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     void *sfm_ptrs[] = {h->sfm.xh[0], h->sfm.xh[1], h->sfm.sofh[0], h->sfm.sofh[1], h->sfm.cv, h->sfm.buff2[0], h->sfm.buff2[1], h->sfm.st[0], h->sfm.st[1],
                         h->sfm.yprev[0], h->sfm.yprev[1], h->sfm.keys, h->sfm.metric, h->sfm.frag, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift, h->d_hist_zero, h->d_hist_junk, h->d_red, h->bch.d_prbs_rw};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
+    if (h->lr_err_host) (void)hipHostFree(h->lr_err_host);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -565,6 +571,7 @@ const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
         const LdpcPlan &pl = h->ldpc;
         char buf[96];
         if (!pl.fast) snprintf(buf, sizeof buf, "ldpc_layered_nms_kernel<%d,%s,%s>", pl.ent_stride, pl.hybrid ? "true" : "false", pl.c2v_lds ? "true" : "false");
+        else if (pl.fast_cu1) snprintf(buf, sizeof buf, "ldpc_cu1_kernel<%d>", pl.fast_deg);
         else snprintf(buf, sizeof buf, pl.spa ? "ldpc_wg8_kernel<%d,%d,true>" : "ldpc_wg8_kernel<%d,%d>", pl.fast_deg, pl.fast_mode);
         const_cast<dvbs2hip_t *>(h)->ldpc_name = buf;
     }
@@ -590,11 +597,26 @@ int dvbs2hip_set_ldpc_params(dvbs2hip_t *h, int32_t n_ite, float alpha, int32_t 
 
 void *dvbs2hip_get_stream(dvbs2hip_t *h) { return h ? (void *)h->stream : nullptr; }
 
+// L&R timeout (sff_lr_fused_kernel): every estimate has been published by the time the launch is over, so the rotation alone is run again (the stores
+// the waiting workgroups dropped).  Returns 0 when there was nothing to do or the recovery succeeded.
+static int lr_check_recover(dvbs2hip_t *h, const float *x, float *y, int n, int F)
+{
+    if (!h->lr_err_host || !*(volatile uint32_t *)h->lr_err_host) return 0;
+    *(volatile uint32_t *)h->lr_err_host = 0u;
+    h->lr_timeouts++;
+    void *tmp = nullptr;
+    if (!x || !y || ensure(h, B_SFF_TMP, sizeof(float) * 4 * (size_t)F, &tmp))
+        return fail(h, DVBS2HIP_EHIP, "L&R: a rotating workgroup timed out waiting for the recurrence and the call cannot be repeated (buffers unknown); re-run it with DVBS2HIP_LR=unfused");
+    HIPCHK(h, sff_lr_recover(x, y, (float *)tmp, n, F, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int dvbs2hip_synchronize(dvbs2hip_t *h)
 {
     int r0 = enter(h); if (r0) return r0;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return lr_check_recover(h, h->lr_last.x, h->lr_last.y, h->lr_last.n, h->lr_last.F);      // (device-form L&R calls: their error word is looked at here)
 }
 
 int dvbs2hip_get_sizes(const dvbs2hip_t *h, dvbs2hip_sizes *o)
@@ -1160,6 +1182,11 @@ static int sff_call(dvbs2hip_t *h, bool lr, bool host, const float *X_N1, float 
     const int n = h->pl_frame;
     if (n <= 1530) return fail(h, DVBS2HIP_EUNSUPPORTED, "the PL frame holds no pilot block");
     if (lr && !h->d_lr_R) { HIPCHK(h, hipMalloc((void **)&h->d_lr_R, 2 * sizeof(float))); HIPCHK(h, hipMemsetAsync(h->d_lr_R, 0, 2 * sizeof(float), h->stream)); }
+    if (lr && !h->lr_err_host) {
+        HIPCHK(h, hipHostMalloc((void **)&h->lr_err_host, sizeof(uint32_t), hipHostMallocMapped));
+        *h->lr_err_host = 0u;
+        HIPCHK(h, hipHostGetDevicePointer((void **)&h->lr_err_dev, h->lr_err_host, 0));
+    }
     const size_t nb = sizeof(float) * 2 * (size_t)n * F;
     void *tmp, *din = nullptr, *dout = nullptr, *dfp = nullptr;
     if ((r = ensure(h, B_SFF_TMP, sizeof(float) * 4 * (size_t)F, &tmp))) return r;
@@ -1172,7 +1199,7 @@ static int sff_call(dvbs2hip_t *h, bool lr, bool host, const float *X_N1, float 
     }
     {
         Timer tm(h, DVBS2HIP_K_MISC);
-        if (lr) HIPCHK(h, sff_lr_launch(x, y, h->d_lr_R, (float *)tmp, frq, phs, n, F, h->lr_alpha, h->stream));
+        if (lr) HIPCHK(h, sff_lr_launch(x, y, h->d_lr_R, (float *)tmp, frq, phs, n, F, h->lr_alpha, h->lr_err_dev, h->stream));
         else HIPCHK(h, sff_fp_launch(x, y, (float *)tmp, frq, phs, n, F, h->stream));
     }
     if (host) {
@@ -1180,7 +1207,12 @@ static int sff_call(dvbs2hip_t *h, bool lr, bool host, const float *X_N1, float 
         if (FRQ) HIPCHK(h, hipMemcpyAsync(FRQ, frq, sizeof(float) * (size_t)F, hipMemcpyDeviceToHost, h->stream));
         if (PHS) HIPCHK(h, hipMemcpyAsync(PHS, phs, sizeof(float) * (size_t)F, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
+        if (lr && h->lr_err_host && *(volatile uint32_t *)h->lr_err_host) {      // timeout in the fused L&R launch: rotate again, copy again
+            if ((r = lr_check_recover(h, x, y, n, F))) return r;
+            HIPCHK(h, hipMemcpyAsync(Y_N2, dout, nb, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+    } else if (lr) { h->lr_last.x = x; h->lr_last.y = y; h->lr_last.n = n; h->lr_last.F = F; }
     return 0;
 }
 
@@ -1193,6 +1225,13 @@ int dvbs2hip_sync_lr_set_alpha(dvbs2hip_t *h, float alpha)
 {
     if (!h) return DVBS2HIP_EINVAL;
     h->lr_alpha = alpha;
+    return 0;
+}
+
+int dvbs2hip_sync_lr_timeouts(dvbs2hip_t *h, int32_t *n)
+{
+    if (!h || !n) return DVBS2HIP_EINVAL;
+    *n = h->lr_timeouts;
     return 0;
 }
 

@@ -98,6 +98,8 @@ struct LdpcPlan {             // host-side description, built once per handle
     int fast_mode = 0;            // posterior image -- 0: in LDS, 1: in the workgroup's global slot, 3: static hybrid (k_ldpc.hip plan), 4 / 5: static hybrid + 32 / 39 rows parked in the idle waves' registers
     std::vector<uint32_t> nat_tab, nat_haz;   // k_ldpc_nat.hip: natural-row-order tables
     uint32_t *d_nat_tab = nullptr, *d_nat_haz = nullptr;
+    bool fast_cu1 = false;        // mode 6: one frame per CU, the whole image on chip (k_ldpc_cu1.hip); fast_wg8 is set too (same tables)
+    int cu1_pairs = 0;            // mode 6: pairs of rows that share an LDS position and a register slot of the row-keeping waves
     bool fast_wg8 = false;        // one frame per 8-wave workgroup, SIMD-aware roles, two independent workgroups per CU (k_ldpc_wg8.hip)
     bool w8_dups_in_lds = false;  // static hybrid: every bit-group with two edges in one layer is LDS-resident
     std::vector<uint32_t> w8_tab, w8_rows;
@@ -120,10 +122,20 @@ __host__ __device__ constexpr int ldpc_park_nl(int mode) { return mode == 5 ? 15
 // there on a slot's store goes where its load came from (one address per LDS slot instead of two).  The padded 13-slot form (32APSK-S 3/4: checks of degree
 // 9 .. 13) has its NULL slots there too (at most 4 + 2 duplicates).
 __host__ __device__ constexpr int ldpc_w8_kd(int deg) { return deg == 27 ? 6 : deg == 11 ? 3 : deg == 13 ? 6 : deg; }
+// mode 6 (k_ldpc_cu1.hip): one frame per 16-wave workgroup = per CU.  Two lanes per check: the first half-check's lanes take slots 0 .. LDPC_CU1_HA-1 (the duplicate
+// edges are among them), the second one's the rest (p_c and p_{c-1} last); they exchange {min1 | parity, min2} through 8 bytes per half-check of LDS.  Four
+// row-keeping waves in two groups of two, ldpc_cu1_nrg() rows (3 VGPRs per row and lane) each.
+constexpr int LDPC_CU1_HA = 14;
+constexpr int LDPC_CU1_XCHG_BYTES = 2 * LDPC_Z * 8;
+__host__ __device__ constexpr int ldpc_cu1_nrg() { return 36; }
+#ifndef LDPC_CU1_DEFAULT
+#define LDPC_CU1_DEFAULT 0
+#endif
 constexpr int LDPC_SPA_MAXC = 6;       // SPA: duplicate edges per layer whose old messages a lane keeps in registers (the DVB-S2 codes have at most 6)
 hipError_t ldpc_nat_launch(const LdpcPlan &pl, const LdpcKParams &kp, float *work, hipStream_t s);
 size_t ldpc_nat_group_words(const LdpcPlan &pl);
 hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
+hipError_t ldpc_cu1_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
 int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl);
 
 // builds the layer tables; returns empty string on success, else the error text
@@ -241,7 +253,8 @@ hipError_t sync_corr_metric_launch(const float *x, const float *xh_in, float *xh
                                    const SyncTail &t, int n, int F, float alpha, int vec_width, hipStream_t s);
 hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float *sofh_out, const float *cor_plsc, float *cv, float *corr,
                               const SyncTail &t, int n, int F, float alpha, int vec_width, hipStream_t s);
-hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp, float *FRQ, float *PHS, int n, int F, float alpha, hipStream_t s);
+hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp, float *FRQ, float *PHS, int n, int F, float alpha, uint32_t *err_dev, hipStream_t s);
+hipError_t sff_lr_recover(const float *X, float *Y, float *tmp, int n, int F, hipStream_t s);
 hipError_t sff_fp_launch(const float *X, float *Y, float *tmp, float *FRQ, float *PHS, int n, int F, hipStream_t s);
 hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Yprev_new, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
                               const int32_t *Dtab, int n, int nbuff2, int F, hipStream_t s);

@@ -67,7 +67,7 @@ struct ParkPlan {
 };
 
 static bool plan_parked(const std::vector<std::vector<int>> &mult, const std::vector<char> &banned, int q, int NL, int n_pos, int NRmax,
-                        ParkPlan &out, std::string &why)
+                        ParkPlan &out, std::string &why, const std::vector<char> *nopair = nullptr)
 {
     const int n_groups = (int)mult.size();
     uint32_t rng = 2463534242u;
@@ -117,6 +117,7 @@ static bool plan_parked(const std::vector<std::vector<int>> &mult, const std::ve
         auto used_by = [&](int g, int l) { return mult[g][((l % q) + q) % q] > 0; };
         for (size_t i = 0; i < S.size(); i++) for (size_t j = i + 1; j < S.size(); j++) {
             const int x = S[i], y = S[j];
+            if (nopair && ((*nopair)[x] || (*nopair)[y])) continue;          // rows that own their position for good (mode 6: the parity groups)
             int bs1 = -1, bs2 = -1, bsc = -1;
             for (int s1 = 0; s1 < q; s1++) {
                 if (used_by(x, s1) || used_by(y, s1) || used_by(y, s1 + 1)) continue;          // y leaves during s1: not needed in s1 nor s1 + 1 .. ; x arrives
@@ -140,7 +141,8 @@ static bool plan_parked(const std::vector<std::vector<int>> &mult, const std::ve
             }
             if (bs1 >= 0) edges.push_back({x, y, bs1, bs2});
         }
-        // ---- (C) matching: randomised greedy, low-degree rows first
+        // ---- (C) matching: randomised greedy, low-degree rows first; if that falls short, a MAXIMUM matching (Edmonds' blossom algorithm, started from the greedy
+        //      one: the graph has a few hundred vertices) -- mode 6 needs 72 disjoint pairs among the 160 information rows of the N = 64800 8/9 code and greedy finds 71
         std::vector<int> best_match;
         for (int attempt = 0; attempt < 3000 && (int)best_match.size() < need; attempt++) {
             std::vector<int> deg(n_groups, 0), order(edges.size());
@@ -152,7 +154,54 @@ static bool plan_parked(const std::vector<std::vector<int>> &mult, const std::ve
             std::vector<int> m;
             for (int i : order) if (!taken[edges[i].x] && !taken[edges[i].y]) { taken[edges[i].x] = taken[edges[i].y] = 1; m.push_back(i); }
             if (m.size() > best_match.size()) best_match = m;
+            if (attempt >= 40 && need > 45) break;      // (many pairs wanted: leave the rest to the exact algorithm)
         }
+        if ((int)best_match.size() < need) {
+            const int V = n_groups;
+            std::vector<std::vector<int>> adj(V);
+            std::vector<std::vector<int>> eid(V, std::vector<int>(V, -1));
+            for (size_t i = 0; i < edges.size(); i++) { adj[edges[i].x].push_back(edges[i].y); adj[edges[i].y].push_back(edges[i].x); eid[edges[i].x][edges[i].y] = eid[edges[i].y][edges[i].x] = (int)i; }
+            std::vector<int> mate(V, -1), par(V), base(V), qu;
+            std::vector<char> used(V), blossom(V);
+            for (int i : best_match) { mate[edges[i].x] = edges[i].y; mate[edges[i].y] = edges[i].x; }
+            auto lca = [&](int a, int b) {
+                std::vector<char> seen(V, 0);
+                for (;;) { a = base[a]; seen[a] = 1; if (mate[a] < 0) break; a = par[mate[a]]; }
+                for (;;) { b = base[b]; if (seen[b]) return b; b = par[mate[b]]; }
+            };
+            auto mark_path = [&](int v, int b, int child) {
+                while (base[v] != b) { blossom[base[v]] = blossom[base[mate[v]]] = 1; par[v] = child; child = mate[v]; v = par[mate[v]]; }
+            };
+            auto find_path = [&](int root) -> int {
+                std::fill(used.begin(), used.end(), 0); std::fill(par.begin(), par.end(), -1);
+                for (int i = 0; i < V; i++) base[i] = i;
+                qu.clear(); qu.push_back(root); used[root] = 1;
+                for (size_t qh = 0; qh < qu.size(); qh++) {
+                    const int v = qu[qh];
+                    for (int to : adj[v]) {
+                        if (base[v] == base[to] || mate[v] == to) continue;
+                        if (to == root || (mate[to] >= 0 && par[mate[to]] >= 0)) {
+                            const int cb = lca(v, to);
+                            std::fill(blossom.begin(), blossom.end(), 0);
+                            mark_path(v, cb, to); mark_path(to, cb, v);
+                            for (int i = 0; i < V; i++) if (blossom[base[i]]) { base[i] = cb; if (!used[i]) { used[i] = 1; qu.push_back(i); } }
+                        } else if (par[to] < 0) {
+                            par[to] = v;
+                            if (mate[to] < 0) return to;
+                            used[mate[to]] = 1; qu.push_back(mate[to]);
+                        }
+                    }
+                }
+                return -1;
+            };
+            for (int v = 0; v < V; v++) if (mate[v] < 0 && !adj[v].empty()) {
+                int u = find_path(v);
+                while (u >= 0) { const int pv = par[u], ppv = mate[pv]; mate[u] = pv; mate[pv] = u; u = ppv; }
+            }
+            best_match.clear();
+            for (int v = 0; v < V; v++) if (mate[v] > v) best_match.push_back(eid[v][mate[v]]);
+        }
+        if (getenv("DVBS2HIP_VERBOSE")) fprintf(stderr, "[dvbs2hip] plan_parked: %zu rows on chip, %zu compatible pairs, matching %zu of %d needed\n", S.size(), edges.size(), best_match.size(), need);
         if ((int)best_match.size() < need) { why = "not enough compatible pairs of rows"; continue; }
         best_match.resize((size_t)need);
         // ---- (D) tables: positions 0 .. need-1 are the shared ones (slot k <-> position k), then the rows that own theirs
@@ -307,9 +356,30 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             // accesses.  Greedy fill + randomised local search on sum_r (NL - count_r)^2 (deterministic seed).
             std::vector<char> in_lds(pl.n_groups, 0);
             ParkPlan park;
+            // mode 6 (k_ldpc_cu1.hip): ONE frame per CU, the whole posterior image on chip -- n_pos LDS positions + the rows parked in the registers of the
+            // workgroup's four row-keeping waves (two groups of two waves, ldpc_cu1_nrg() rows each); every slot of every layer is an LDS access.  Parity groups
+            // pair like information groups (the 160 information rows of the N = 64800 8/9 code have a maximum matching of 71 pairs, 72 are needed): a parity row
+            // that starts an iteration in a register slot is loaded by its row-keeping wave (a stride-q gather), the others by the working waves' scatter.
+            const bool env_cu1 = env_mode && !strcmp(env_mode, "cu1");
+            if ((env_cu1 || (!env_mode && LDPC_CU1_DEFAULT)) && pl.fast_mode == 1 && pl.fast_deg == 27 && !pl.fast_pad && !spa) {
+                const int n_pos = ((int)lds_limit - LDPC_CU1_XCHG_BYTES - 128) / (int)grp_bytes - 1;      // [positions | junk row | exchange area | misc]
+                std::vector<std::vector<int>> mult(pl.n_groups, std::vector<int>(q, 0));
+                for (int r = 0; r < q; r++) for (const Slot &sl : layers[r]) mult[sl.group][r]++;
+                std::vector<char> banned(pl.n_groups, 0);
+                std::string why = "more rows than positions and register slots";
+                int maxdup = 0;
+                for (int r = 0; r < q; r++) { int c = 0; for (const Slot &sl : layers[r]) c += sl.lvl > 0; maxdup = std::max(maxdup, c); }
+                const int need = pl.n_groups - n_pos;
+                if (n_pos >= 2 * q && need <= 2 * ldpc_cu1_nrg() && maxdup <= LDPC_CU1_HA - 2 && need > 0 &&
+                    plan_parked(mult, banned, q, pl.fast_deg, n_pos, 2 * ldpc_cu1_nrg(), park, why) && park.n_pairs == need) {
+                    pl.fast_mode = 6;
+                    for (int g = 0; g < pl.n_groups; g++) in_lds[g] = 1;
+                    pl.w8_dups_in_lds = true;
+                } else if (getenv("DVBS2HIP_VERBOSE") || env_cu1) fprintf(stderr, "[dvbs2hip] LDPC plan: mode 6 (one frame per CU) not used (%s)\n", why.c_str());
+            }
             {
                 const int NL = 9;
-                const bool want = env_hyb || (!env_mode && pl.fast_mode == 1);
+                const bool want = pl.fast_mode != 6 && (env_hyb || env_cu1 || (!env_mode && pl.fast_mode == 1));
                 if (want && pl.fast_deg == 27 && !pl.fast_pad) {
                     const int cap = (int)(lds_limit / 2 / grp_bytes) - 1;            // two frames per CU, one junk row each
                     std::vector<std::vector<int>> mult(pl.n_groups, std::vector<int>(q, 0));
@@ -379,8 +449,9 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     }
                 }
             }
-            const bool parked = pl.fast_mode == 4 || pl.fast_mode == 5, hyb = pl.fast_mode == 3 || parked;       // static hybrid: the first NLH slots of every layer are LDS accesses
-            const int NLH = parked ? ldpc_park_nl(pl.fast_mode) : 9, NRH = ldpc_park_nr(pl.fast_mode);
+            const bool cu1 = pl.fast_mode == 6;
+            const bool parked = pl.fast_mode == 4 || pl.fast_mode == 5 || cu1, hyb = pl.fast_mode == 3 || parked;       // static hybrid: the first NLH slots of every layer are LDS accesses
+            const int NLH = cu1 ? pl.fast_deg : parked ? ldpc_park_nl(pl.fast_mode) : 9, NRH = cu1 ? 2 * ldpc_cu1_nrg() : ldpc_park_nr(pl.fast_mode);
             if (hyb) {
                 for (int g = 0; g < pl.n_groups; g++) {
                     if (in_lds[g]) { gbase[g] = (uint32_t)(n_l++ * LDPC_Z); glds[g] = 1u; }       // (mode 4: the LDS position of a row depends on the layer, park.pos)
@@ -411,7 +482,15 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 std::vector<char> prev_touch(pl.n_groups, 0);
                 for (const Slot &sl : layers[(r + q - 1) % q]) prev_touch[sl.group] = 1;      // (layers[] hold real slots only)
                 std::vector<Slot> ord;
-                if (hyb) {      // static hybrid: the LDS-resident slots first (exactly 9 of them; 14 with parked rows), then the others
+                if (cu1) {      // one frame per CU: duplicate edges first (level, then table order; conflict entry i is slot i: all in the first half-check's slots), then the
+                                // other information slots, p_c and p_{c-1} last (parity chain forwarded in a register by the second half-check's lanes)
+                    for (int lvl = 1; lvl <= 3; lvl++) for (const Slot &sl : layers[r]) if (sl.lvl == lvl) ord.push_back(sl);
+                    for (const Slot &sl : layers[r]) if (sl.lvl == 0 && sl.group < n_rows) ord.push_back(sl);
+                    for (const Slot &sl : layers[r]) if (sl.lvl == 0 && sl.group >= n_rows) ord.push_back(sl);
+                    const size_t nn = ord.size();
+                    if ((int)nn != pl.fast_deg || ord[nn - 2].group != n_rows + r || ord[nn - 1].group != n_rows + (r + q - 1) % q || ord[nn - 2].t0 != 0 || (r > 0 && ord[nn - 1].t0 != 0))
+                        return "LDPC: internal: mode 6 needs p_c and p_{c-1} at the last two slots";
+                } else if (hyb) {      // static hybrid: the LDS-resident slots first (exactly 9 of them; 14 with parked rows), then the others
                     // (sum-product kernel: the duplicate edges first, in the order of the conflict list, so that conflict entry i is slot i as in the LDS-only image)
                     if (spa) for (int lvl = 1; lvl <= 3; lvl++) for (const Slot &sl : layers[r]) if (in_lds[sl.group] && sl.lvl == lvl) ord.push_back(sl);
                     for (const Slot &sl : layers[r]) if (in_lds[sl.group] && !(spa && sl.lvl > 0)) ord.push_back(sl);
@@ -460,7 +539,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     T8[29 + i] = T8[32 + i];
                 }
                 if (nc > 0 && (T8[48] >> 8) != 1u) return "LDPC: internal: first conflict entry is not of level 1";
-                if (pl.fast_mode == 0 || spa) for (int i = 0; i < nc; i++) if ((T8[48 + i] & 31u) != (uint32_t)i) return "LDPC: internal: conflict entry i is not slot i";
+                if (pl.fast_mode == 0 || spa || cu1) for (int i = 0; i < nc; i++) if ((T8[48 + i] & 31u) != (uint32_t)i) return "LDPC: internal: conflict entry i is not slot i";
             }
             {   // image rows in storage order: LDS rows then global rows (bit-groups ascend inside each: info first)
                 std::vector<int> lrow, grow;
@@ -470,7 +549,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     lrow.assign(park.lds0.begin(), park.lds0.begin() + park.nl0);
                 }
                 pl.w8_nl = (int)lrow.size(); pl.w8_ng = (int)grow.size();
-                pl.w8_nl_info = (int)std::count_if(lrow.begin(), lrow.end(), [&](int g) { return g < pl.n_info; });
+                pl.w8_nl_info = cu1 ? (int)lrow.size() : (int)std::count_if(lrow.begin(), lrow.end(), [&](int g) { return g < pl.n_info; });      // (mode 6: parity rows may sit among the pairs' positions; the kernel looks at every position)
                 pl.w8_ng_info = (int)std::count_if(grow.begin(), grow.end(), [&](int g) { return g < pl.n_info; });
                 pl.w8_rows.clear();
                 for (int g : lrow) pl.w8_rows.push_back((uint32_t)g);
@@ -480,7 +559,13 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 for (int r = 0; r < q; r++) {
                     const int g = pl.n_info + r;
                     const bool in_lds = pl.fast_mode == 0 || (hyb && glds[g]);
-                    if (in_lds && parked) return "LDPC: internal: parity group among the parked rows";
+                    if (in_lds && parked && !cu1) return "LDPC: internal: parity group among the parked rows";
+                    if (cu1) {      // where the parity group is at the start of an iteration: byte offset of its LDS position, or 0xFFFFFFFF = in a register slot
+                        uint32_t where = 0xFFFFFFFFu;
+                        for (int P = 0; P < park.nl0; P++) if (park.lds0[P] == g) where = (uint32_t)(P * LDPC_Z * 4);
+                        pl.w8_rows.push_back(where);
+                        continue;
+                    }
                     pl.w8_rows.push_back(in_lds ? (uint32_t)gbase[g] * 4u : 0x80000000u | (uint32_t)((2 * LDPC_Z + (int)gbase[g]) * 4));
                 }
                 if (parked) {      // then the bit-group in register slot k of the idle waves at the start of an iteration (0xFFFFFFFF: empty)
@@ -496,8 +581,14 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 pl.w8_park_moves = parked ? park.n_moves : 0;
                 pl.w8_st_base = (uint32_t)((2 + pl.w8_ng) * LDPC_Z * 4);
                 pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + 3 * M;
+                if (cu1) {      // LDS: [positions | junk row | exchange area of the two half-checks | misc]; global: the packed state alone, 16 bytes per check {c1, c2, pk of half A, pk of half B}
+                    pl.w8_lds_bytes = (n_lds_rows + 1) * LDPC_Z * 4 + LDPC_CU1_XCHG_BYTES + 128;
+                    pl.w8_st_base = 0u;
+                    pl.w8_gwork_words = 4 * M;
+                    pl.cu1_pairs = park.n_pairs;
+                }
                 if (spa) pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + pl.fast_deg * M;      // SPA: one fp32 message per edge slot, [layer][slot][360]
-                {   // DVBS2HIP_LDPC_SLOT_ALIGN / _PAD (bytes): where a workgroup's slot starts -- measured without effect, kept for experiments
+                {   // DVBS2HIP_LDPC_SLOT_ALIGN / _PAD (bytes): where a workgroup's slot starts -- measured without effect (docs/negative_results.md), kept for experiments
                     const char *ea = getenv("DVBS2HIP_LDPC_SLOT_ALIGN"), *ep = getenv("DVBS2HIP_LDPC_SLOT_PAD");
                     const size_t al = ea ? (size_t)atoi(ea) / 4 : 1, pad = ep ? (size_t)atoi(ep) / 4 : 0;
                     if (al > 1) pl.w8_gwork_words = (int)(((size_t)pl.w8_gwork_words + al - 1) / al * al);
@@ -507,8 +598,9 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             // workspace of one workgroup: [posteriors kept in global memory | packed c->v state 3 M words]
             pl.glb_post_words = pl.fast_mode == 1 ? (pl.n_groups + xrows) * LDPC_Z : hyb ? n_g * LDPC_Z : 0;
             pl.lds_post_words = pl.fast_mode == 0 ? (pl.n_groups + 1 + xrows) * LDPC_Z : pl.fast_mode == 3 ? (n_l + 1) * LDPC_Z : parked ? (park.n_pos + 1) * LDPC_Z : 0;
+            if (cu1) pl.glb_post_words = 0;
             pl.fast_inf_row = pl.fast_pad ? (int)(inf_row_words * 4u) : -1;
-            pl.gwork_words = pl.glb_post_words + (spa ? pl.fast_deg * M : 3 * M);      // SPA: one fp32 message per edge slot
+            pl.gwork_words = pl.glb_post_words + (spa ? pl.fast_deg * M : cu1 ? 4 * M : 3 * M);      // SPA: one fp32 message per edge slot
             pl.lds_bytes = (size_t)pl.lds_post_words * 4;
             pl.hybrid = hyb; pl.c2v_lds = false; pl.lds_groups = pl.fast_mode == 0 ? pl.n_groups : n_l;
             {   // k_ldpc_nat.hip (natural row order, one lane per frame): per layer the info slots (NULL-padded), then p_c, then p_{c-1}
@@ -554,7 +646,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             {
                 const bool w8_ok = (pl.fast_mode == 0 || pl.fast_mode == 1 || (hyb && pl.w8_dups_in_lds)) && kd_ok;
                 if (!(w8_ok && (size_t)pl.w8_lds_bytes <= lds_limit + 512) || (spa && maxc > LDPC_SPA_MAXC)) return PLAN_RETRY_GENERIC;
-                pl.fast_wg8 = true; pl.gwork_words = pl.w8_gwork_words;
+                pl.fast_wg8 = true; pl.gwork_words = pl.w8_gwork_words; pl.fast_cu1 = cu1;
             }
         }
     }
@@ -843,6 +935,7 @@ static int occ_inst(const LdpcPlan &pl)
 }
 int ldpc_blocks_per_cu(const LdpcPlan &pl)
 {
+    if (pl.fast && pl.fast_cu1) return 1;
     if (pl.fast && pl.fast_wg8) return ldpc_wg8_blocks_per_cu(pl);
     const bool small = pl.ent_stride == 13;
 #define OCC(H, C) (small ? occ_inst<13, H, C>(pl) : occ_inst<LDPC_MAX_SLOTS, H, C>(pl))
@@ -853,6 +946,7 @@ int ldpc_blocks_per_cu(const LdpcPlan &pl)
 
 hipError_t ldpc_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
+    if (pl.fast && pl.fast_cu1) return ldpc_cu1_launch(pl, p, s);
     if (pl.fast && pl.fast_wg8) return ldpc_wg8_launch(pl, p, s);
     p.entries = pl.d_entries; p.layer_deg = pl.d_layer_deg; p.layer_lvl = pl.d_layer_lvl; p.groups = pl.d_groups;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;

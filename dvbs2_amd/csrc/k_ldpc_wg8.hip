@@ -1,7 +1,7 @@
 // a1, production kernel -- layered NMS, one frame per EIGHT-wave workgroup (six waves work), two
 // independent workgroups per CU.  Same schedule and arithmetic as k_ldpc_fast.hip / the oracle
 // (bit-exact), rebuilt around what a per-phase cycle profile of that kernel showed on MI355X
-// (DESIGN.md section 6): 30 % of its time was frame I/O issued as ~180 dependent HBM round trips,
+// (docs/negative_results.md): 30 % of its time was frame I/O issued as ~180 dependent HBM round trips,
 // 12 % the replay of same-layer duplicate edges through global memory, and the layer loop itself
 // a long per-wave instruction stream (~610 VALU + ~250 scalar per layer; one wave issues one instruction
 // every 4.4 cycles whatever its type, tools/probe_valu.hip).
@@ -302,7 +302,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
     auto mst = [&](uint32_t voff, uint32_t soff, float v) { if (SPA_ABL & 1) { asm volatile("" :: "v"(v)); return; } __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, SPA_AUX); };
     // SPA_MSG4: the messages of a layer as [slot / 4][360][4 slots] (the last group holds DEG mod 4 of them): a lane's messages of four consecutive slots are 16
     // consecutive bytes, a wave's access 1 KB -- whole lines written and read by ONE instruction instead of four 256-byte pieces of four rows
-    // (the per-edge message stream, HBM by construction, is what the sum-product kernel is bound by: section 6's ablations).  Same bytes per layer.
+    // (the per-edge message stream, HBM by construction, is what the sum-product kernel is bound by: docs/negative_results.md's ablations).  Same bytes per layer.
     typedef uint32_t m_u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t m_u32x3 __attribute__((ext_vector_type(3)));
     typedef uint32_t m_u32x2 __attribute__((ext_vector_type(2)));
@@ -433,7 +433,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     // magnitude so that the sum seen by the WEAKEST edge is representable; should the weakest edge itself then overflow
                     // (min2 - min1 > 60), the other edges' outputs are min1 to within e^-57.  Per edge: 1 exp + 1 rcp on the way in, 1 rcp + 1 log
                     // on the way out and ~20 full-rate operations, against 2.8 boxplus x (2 exp + 2 log + 12) of the forward / backward form.
-                    constexpr uint32_t mpitch = W8_ROW;      // message rows packed like the image's (a run-time pitch costs two scalar instructions per access; 1536-byte rows -- whole lines -- measured SLOWER)
+                    constexpr uint32_t mpitch = W8_ROW;      // message rows packed like the image's (a run-time pitch costs two scalar instructions per access; 1536-byte rows -- whole lines -- measured SLOWER, docs/negative_results.md)
                     const uint32_t mrow = st_base + (uint32_t)(r * DEG) * mpitch;       // messages of this layer: [slot][360 of mpitch / 4]
                     const uint32_t dupmask = TE[31];
                     // the circulant offsets are formed twice, for the loads and again for the stores (an opaque copy of t4 keeps the compiler

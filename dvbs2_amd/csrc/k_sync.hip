@@ -641,13 +641,23 @@ static void sff_rotate_launch(const float *X, float *Y, const float2 *fr, int n,
 }
 
 static hipError_t sff_lr_launch_unfused(const float *X, float *Y, float *R_l, float *tmp, float *FRQ, float *PHS, int n, int F, float alpha, hipStream_t s);
+// the waiting workgroups' limit in ticks of s_memrealtime (100 MHz): one second; DVBS2HIP_LR_TIMEOUT_US overrides it (tests: 0 makes every waiting workgroup give up at
+// its first unsuccessful poll, which exercises the error word and the recovery)
+static unsigned long long sff_lr_timeout_ticks()
+{
+    const char *ev = getenv("DVBS2HIP_LR_TIMEOUT_US");
+    return ev ? (unsigned long long)atoll(ev) * 100ull : 100000000ull;
+}
 
 // ---- L&R, recurrence and rotation in ONE launch.  The recurrence over the frames of a call is serial (4096 frames: 50 us in its own kernel, during which the
 // machine idled, then a launch gap, then the rotation); here workgroup 0 runs it while every other workgroup rotates 1024 sample pairs of one frame: it requests
 // its samples, then waits for its frame's estimate.  An estimate is published as ONE 8-byte word per frame (a relaxed agent-scope store; sff_lr_pilot_kernel has
 // left SFF_NOT_YET in every word), so a reader needs no fence -- an agent-scope acquire per workgroup invalidates its XCD's L2 and was measured at ~100 ns per
-// WORKGROUP of the launch, ten times the three kernels -- and no counter is shared by the workgroups.  Workgroup 0 is the first one the dispatcher places; a
-// workgroup that does not see its estimate within about a second traps instead of hanging the queue.  The recurrence itself on two lanes (lane 0 the real, lane 1
+// WORKGROUP of the launch, ten times the three kernels -- and no counter is shared by the workgroups.  Workgroup 0 is the first one the dispatcher places (an
+// ASSUMPTION about the dispatcher, not a HIP guarantee: INTEGRATION.md "L&R dispatch order"); a workgroup that does not see its estimate within one second of
+// wall-clock time (s_memrealtime, 100 MHz) sets the handle's error word (host-mapped: the host reads it at its next synchronisation point, no copy), drops its
+// stores and ends -- the queue drains, the context survives, and since workgroup 0 has published every estimate by the time the launch is over the host only has
+// to run the rotation again (sff_lr_recover).  The recurrence itself on two lanes (lane 0 the real, lane 1
 // the imaginary part: two dependent instructions per frame instead of six), its (1 - alpha) t products formed by all lanes before; the values and their order are
 // those of sff_lr_iir_kernel (alpha r + (1 - alpha) t, two roundings).
 constexpr int SFF_RU = 4, SFF_RCH = 256 * SFF_RU;        // 16-byte pairs per lane / per workgroup
@@ -681,10 +691,11 @@ __device__ __forceinline__ void sff_lr_chain1(float *pl, float &r, float alpha, 
 }
 __global__ void __launch_bounds__(256)
 sff_lr_fused_kernel(const vd_f4n *__restrict__ x, vd_f4n *__restrict__ y, const float2 *__restrict__ tR, float *__restrict__ R_l, float2 *fr, float *__restrict__ FRQ,
-                    float *__restrict__ PHS, int F, float alpha, int n, int cpf)
+                    float *__restrict__ PHS, int F, float alpha, int n, int cpf, uint32_t *err, unsigned long long timeout_ticks)
 {
     __shared__ __attribute__((aligned(16))) float sh[2][2][64];        // [batch parity][component][frame of the batch]
     __shared__ float2 s_e;
+    __shared__ int s_drop;
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0) {
         if (threadIdx.x >= 128) return;                                 // (waves that have ended do not count at the barriers below)
@@ -732,15 +743,23 @@ sff_lr_fused_kernel(const vd_f4n *__restrict__ x, vd_f4n *__restrict__ y, const 
     for (int u = 0; u < SFF_RU; u++) { const int q = p0 + u * 256; v[u] = __builtin_nontemporal_load(xf + (q < npf ? q : npf - 1)); }
     if (threadIdx.x == 0) {
         unsigned long long e;
-        uint32_t nap = 1, polls = 0;
+        uint32_t nap = 1;
+        int drop = 0;
+        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         while ((e = __hip_atomic_load(reinterpret_cast<unsigned long long *>(fr + f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == SFF_NOT_YET) {
             for (uint32_t i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(1);
             if (nap < 64) nap *= 2;
-            if (++polls > 600000u) __builtin_trap();                    // ~1 s: the recurrence is not running (it cannot happen with in-order dispatch)
+            if (__builtin_amdgcn_s_memrealtime() - t_start > timeout_ticks) {       // the recurrence is not running (it cannot happen with in-order dispatch): report, do not trap
+                if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                drop = 1;
+                break;
+            }
         }
+        s_drop = drop;
         s_e = make_float2(__uint_as_float((uint32_t)e), __uint_as_float((uint32_t)(e >> 32)));
     }
     __syncthreads();
+    if (s_drop) return;                                                 // nothing of this workgroup's stretch is stored: sff_lr_recover rotates the call again
     const float2 e = s_e;
 #pragma unroll
     for (int u = 0; u < SFF_RU; u++) {
@@ -752,7 +771,15 @@ sff_lr_fused_kernel(const vd_f4n *__restrict__ x, vd_f4n *__restrict__ y, const 
     }
 }
 
-hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp /* 4 F floats */, float *FRQ, float *PHS, int n, int F, float alpha, hipStream_t s)
+// after a launch whose error word was set: every estimate is in `tmp` (workgroup 0 has ended), only rotated samples are missing -- rotate the whole call again
+hipError_t sff_lr_recover(const float *X, float *Y, float *tmp, int n, int F, hipStream_t s)
+{
+    float2 *fr = reinterpret_cast<float2 *>(tmp) + F;
+    sff_rotate_launch<0>(X, Y, fr, n, (long long)n * F, s);
+    return hipGetLastError();
+}
+
+hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp /* 4 F floats */, float *FRQ, float *PHS, int n, int F, float alpha, uint32_t *err_dev, hipStream_t s)
 {
     const char *ev = getenv("DVBS2HIP_LR");                    // read at every call
     const bool unfused = ev && !strcmp(ev, "unfused");
@@ -761,7 +788,7 @@ hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp /* 4 F
         const int cpf = (n / 2 + SFF_RCH - 1) / SFF_RCH;
         hipLaunchKernelGGL(sff_lr_pilot_kernel, dim3(F), dim3(256), 0, s, X, tR, fr, n);
         hipLaunchKernelGGL(sff_lr_fused_kernel, dim3(1 + (unsigned)F * cpf), dim3(256), 0, s, reinterpret_cast<const vd_f4n *>(X), reinterpret_cast<vd_f4n *>(Y), tR, R_l, fr, FRQ, PHS,
-                           F, alpha, n, cpf);
+                           F, alpha, n, cpf, err_dev, sff_lr_timeout_ticks());
         return hipGetLastError();
     }
     return sff_lr_launch_unfused(X, Y, R_l, tmp, FRQ, PHS, n, F, alpha, s);

@@ -62,6 +62,7 @@ ABI = {
     "dvbs2hip_sync_lr_synchronize_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_sync_lr_set_alpha": (C.c_int, [_vp, _f]),
     "dvbs2hip_sync_lr_reset": (C.c_int, [_vp]),
+    "dvbs2hip_sync_lr_timeouts": (C.c_int, [_vp, _vp]),
     "dvbs2hip_sync_freq_phase_synchronize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_sync_freq_phase_synchronize_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_sync_frame_set_params": (C.c_int, [_vp, _f, _f, _i]),

@@ -378,6 +378,12 @@ class Dvbs2Hip:
     def sync_lr_reset(self):
         self._chk(self.L.dvbs2hip_sync_lr_reset(self.h))
 
+    def sync_lr_timeouts(self) -> int:
+        """launches of the fused L&R kernel whose rotation had to be repeated (a waiting workgroup gave up): 0 unless the dispatcher reorders workgroups"""
+        n = C.c_int32()
+        self._chk(self.L.dvbs2hip_sync_lr_timeouts(self.h, C.byref(n)))
+        return n.value
+
     def sync_freq_phase_synchronize(self, X_N1):
         return self._sff(self.L.dvbs2hip_sync_freq_phase_synchronize, X_N1)
 

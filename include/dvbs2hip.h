@@ -359,6 +359,11 @@ int dvbs2hip_sync_lr_synchronize(dvbs2hip_t *h, const float *X_N1, float *FRQ, f
 int dvbs2hip_sync_lr_synchronize_dev(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t n_frames);
 int dvbs2hip_sync_lr_set_alpha(dvbs2hip_t *h, float alpha);
 int dvbs2hip_sync_lr_reset(dvbs2hip_t *h);
+/* L&R runs its serial recurrence and the rotation in ONE launch: the rotating workgroups wait for workgroup 0's estimates, which assumes that the
+ * dispatcher places workgroup 0 first ("L&R dispatch order").  A workgroup that waits longer than one second of wall-clock time
+ * drops its stores and sets an error word; the host-socket form repeats the rotation before it returns, the _dev form when dvbs2hip_synchronize
+ * is called (it returns DVBS2HIP_EHIP only if the repeat itself fails).  This counts the launches that needed the repeat (0 on every box so far). */
+int dvbs2hip_sync_lr_timeouts(dvbs2hip_t *h, int32_t *n_launches_repeated);
 int dvbs2hip_sync_freq_phase_synchronize(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t n_frames);
 int dvbs2hip_sync_freq_phase_synchronize_dev(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t n_frames);
 

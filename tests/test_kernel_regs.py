@@ -28,7 +28,7 @@ def test_no_kernel_spills_vector_registers():
 
 
 def test_no_wide_buffer_store_takes_a_scalar_offset_register():
-    """with an SGPR in the soffset field the compiler lets the next instruction overwrite the data registers of a 12- or 16-byte buffer store, and on gfx950 the
+    """docs/negative_results.md: with an SGPR in the soffset field the compiler lets the next instruction overwrite the data registers of a 12- or 16-byte buffer store, and on gfx950 the
     stored data change.  The kernels put the whole offset into the vector register instead (`wide_off`); this reads the disassembly of every translation unit and wants no such store at
     all -- the stricter condition, so that the next edit of a store cannot bring the form back unseen -- and, as the hazard proper, none followed by a write of its data registers."""
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):

@@ -241,6 +241,9 @@ def test_natural_order_in_the_fused_chain(O, Rx):
     rx.close()
 
 
+DEFAULT_NMS_MODE = 5       # image mode the planner picks for the min-sum decoder on normal frames (6 = one frame per CU, k_ldpc_cu1.hip)
+
+
 def _big_batch(O, modcod, F, ebn0s, seed, n_cw=8):
     """F channel-LLR frames (BPSK-equivalent) of n_cw oracle-encoded codewords, frame f at ebn0s[f % len]"""
     ch = chain(O, modcod)
@@ -293,7 +296,7 @@ def test_ldpc_headline_config_at_size_matches_oracle(O, Rx, n_ite, F, ebn0s):
 
 
 @pytest.mark.parametrize("implem", ["NMS", "SPA"])
-@pytest.mark.parametrize("mode,kernel_mode", [("", None), ("park4", 4), ("static", 3), ("global", 1)])
+@pytest.mark.parametrize("mode,kernel_mode", [("", None), ("cu1", 6), ("park", 5), ("park4", 4), ("static", 3), ("global", 1)])
 def test_ldpc_normal_frame_image_modes_agree_with_the_oracle(O, Rx, monkeypatch, mode, kernel_mode, implem):
     """Where the posteriors of a normal frame live -- static hybrid with 39 / 32 bit-group rows parked in the idle waves' registers (modes 5 / 4, the
     defaults of the min-sum / sum-product kernel), static hybrid alone (3), the workgroup's global slot (1) -- must not change a bit: 1100 frames
@@ -309,8 +312,11 @@ def test_ldpc_normal_frame_image_modes_agree_with_the_oracle(O, Rx, monkeypatch,
     for early in (False, True):
         n_ite = 3 if spa and not early else 10
         rx = Rx(modcod, max_frames=F, n_ite=n_ite, alpha=1.0, early_stop=early, implem=implem)
-        want = kernel_mode if kernel_mode is not None else (4 if spa else 5)
-        assert rx.ldpc_kernel_name() == "ldpc_wg8_kernel<27,%d%s>" % (want, ",true" if spa else ""), rx.ldpc_kernel_name()
+        want = kernel_mode if kernel_mode is not None else (4 if spa else DEFAULT_NMS_MODE)
+        if spa and want >= 5:
+            want = 4                    # (the sum-product kernel has neither the one-frame-per-CU form nor the registers for 39 parked rows)
+        name = "ldpc_cu1_kernel<27>" if want == 6 else "ldpc_wg8_kernel<27,%d%s>" % (want, ",true" if spa else "")
+        assert rx.ldpc_kernel_name() == name, rx.ldpc_kernel_name()
         V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
         Vo, posto, cwdo, iteso = ch.ldpc.decode(llr[pick], n_ite=n_ite, alpha=1.0, implem=O.SPA if spa else O.NMS, sched=O.QC, early_stop=early)
         if spa:
@@ -352,7 +358,7 @@ def test_ldpc_spa_at_size_matches_oracle(O, Rx, modcod, F):
 def test_plain_decode_siho_equals_the_posterior_socket_form(O, Rx, modcod, F, early):
     """decode_siho with the hard-decision socket only against the call that also asks for the posteriors (other output branches of the
     kernel): same V and CWD for converged and unconverged frames, with and without the stopping rule, more frames than the persistent
-    grid.  (Written for an output path that was measured and removed -- DESIGN section 6 -- and kept as a guard of the two socket forms.)"""
+    grid.  (Written for an output path that was measured and removed -- docs/negative_results.md -- and kept as a guard of the two socket forms.)"""
     ch, sent, llr = _big_batch(O, modcod, F, (3.0, 4.3) if "QPSK" in modcod else (2.6, 3.6), seed=31, n_cw=4)
     rx = Rx(modcod, max_frames=F, n_ite=6, early_stop=early)
     V1, C1 = rx.decode_siho(llr)
@@ -368,7 +374,7 @@ def test_ldpc_decisions_are_reproducible_at_size(Rx, modcod, implem):
     """The same batch decoded twice, and its first frames decoded alone, give the same hard decisions, CWD and iteration counts, bit for bit -- on hard frames (nothing
     converges early, every layer of every iteration runs), with every CU holding two workgroups and every workgroup several frames.  A hazard between two instructions of a
     layer loop shows up here as a handful of frames that differ from one call to the next (round 3 met one -- a 16-byte store whose data registers the next
-    instruction overwrote -- in a variant of the sum-product layer that passed every three-frame parity test: DESIGN section 6); the oracle is not needed for this and the batch is the size of a production call."""
+    instruction overwrote -- in a variant of the sum-product layer that passed every three-frame parity test: docs/negative_results.md); the oracle is not needed for this and the batch is the size of a production call."""
     import torch
     dev = torch.device("cuda", 0)
     F = 3072

@@ -240,10 +240,46 @@ def test_lr_recurrence_and_rotation_in_one_launch_equal_the_three_kernel_path(O,
             assert abs(FRQ[f] - fo) <= 1e-6 and np.max(np.abs(Y[f] - Yo)) <= 4e-3
 
 
+@pytest.mark.parametrize("modcod,F", [("32APSK-S_3/4", 700), ("QPSK-N_8/9", 5)])
+def test_lr_waiting_workgroup_that_gives_up_is_reported_and_the_call_repaired(O, Rx, monkeypatch, modcod, F):
+    """a rotating workgroup of sff_lr_fused_kernel that does not see its frame's estimate in time no longer traps (which took the whole context down): it
+    drops its stores and sets the handle's error word; the host form rotates the call again before it returns, the device form when dvbs2hip_synchronize is called.
+    DVBS2HIP_LR_TIMEOUT_US=0 makes every workgroup give up at its first unsuccessful poll: the outputs must still equal the three-kernel path's, bit for bit,
+    dvbs2hip_sync_lr_timeouts must count the repeats, and the handle must keep working with the normal limit afterwards."""
+    import torch
+    _, pl, _, _ = make_pl_frames(O, modcod, min(F, 4), 10.0, seed=12)
+    n = pl.shape[1] // 2
+    rng = np.random.default_rng(6)
+    x = np.stack([_rot(O, pl[f % pl.shape[0]], 2e-4 * (f % 7 + 1), 0.05 * f) for f in range(F)]) + (0.05 * rng.standard_normal((F, 2 * n))).astype(np.float32)
+    monkeypatch.setenv("DVBS2HIP_LR", "unfused")
+    rx = Rx(modcod, max_frames=F); rx.sync_lr_set_alpha(0.9)
+    ref = [rx.sync_lr_synchronize(x), rx.sync_lr_synchronize(x[::-1].copy())]
+    rx.close()
+    monkeypatch.delenv("DVBS2HIP_LR")
+    monkeypatch.setenv("DVBS2HIP_LR_TIMEOUT_US", "0")
+    rx = Rx(modcod, max_frames=F); rx.sync_lr_set_alpha(0.9)
+    got = [rx.sync_lr_synchronize(x)]
+    n_host = rx.sync_lr_timeouts()
+    # device form: nothing is looked at before dvbs2hip_synchronize
+    xd = torch.from_numpy(x[::-1].copy()).cuda(); yd = torch.empty_like(xd); fd = torch.empty(F, dtype=torch.float32, device="cuda"); pd = torch.empty_like(fd)
+    torch.cuda.synchronize()
+    rx._chk(rx.L.dvbs2hip_sync_lr_synchronize_dev(rx.h, xd.data_ptr(), fd.data_ptr(), pd.data_ptr(), yd.data_ptr(), F))
+    rx.synchronize()
+    got.append((fd.cpu().numpy(), pd.cpu().numpy(), yd.cpu().numpy().reshape(F, -1)))
+    n_dev = rx.sync_lr_timeouts()
+    for a, b in zip(got, ref):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2].reshape(F, -1), b[2].reshape(F, -1))
+    assert n_dev >= n_host and (F < 8 or n_dev >= 1)          # (a handful of frames may all be published before the first poll)
+    monkeypatch.delenv("DVBS2HIP_LR_TIMEOUT_US")
+    again = rx.sync_lr_synchronize(x)
+    assert rx.sync_lr_timeouts() == n_dev and again[2].shape == ref[0][2].shape
+    rx.close()
+
+
 def test_lr_one_launch_form_under_another_handles_persistent_kernel():
     """The rotating workgroups of sff_lr_fused_kernel wait for words that workgroup 0 publishes, which is safe because workgroup 0 is placed first.  Issued while another
     handle's persistent LDPC launch owns every CU (tools/lr_soak.py), the synchronizer's workgroups are placed a few at a time as LDPC workgroups retire: every call must
-    still end (a workgroup that waits for about a second traps) with the three-kernel path's output."""
+    still end (a workgroup that waits for a second gives up and the host repeats the rotation: none does) with the three-kernel path's output."""
     import subprocess, sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lr_soak.py"), "25"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "225 calls, 0 bad" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

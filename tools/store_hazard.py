@@ -1,4 +1,4 @@
-"""The store-data hazard of DESIGN section 6, looked for in the code objects: a MUBUF / MTBUF store of more than 8 bytes whose soffset field is an SGPR, followed
+"""The store-data hazard of docs/negative_results.md, looked for in the code objects: a MUBUF / MTBUF store of more than 8 bytes whose soffset field is an SGPR, followed
 with no instruction in between by a vector-ALU instruction that writes one of the store's data registers.  LLVM's hazard recognizer exempts exactly that form
 (GCNHazardRecognizer: the wait state is inserted only when soffset is NOT a register); on gfx950 the stored data were seen to change (tools/det_check.py, round 3).
 CPU-only: python tools/store_hazard.py [-v]   ->   one line per translation unit, the offending pairs listed; exit code 1 if there is any."""
