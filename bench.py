@@ -200,8 +200,10 @@ def main():
                    "achieved": fab, "peak": FABRIC_PEAK_GBPS, "unit": "GB/s", "frac": fab / FABRIC_PEAK_GBPS,
                    "peak_source": "MI355X_MICROARCH.md, Indexed rows: 38 MB table served by the Infinity Cache, 8.6 TB/s chip-wide",
                    "bytes_per_frame": traffic / F, "measured": traffic_meta,
-                   # the second resource: the vector pipes (same PMC passes; a 32-lane SIMD retires a wave64 instruction in 2 cycles: MI355X_MICROARCH.md constants table, tools/probe_dep.hip)
-                   "valu": {"resource": "vector pipes: SQ_INSTS_VALU x 2 cycles (32-lane SIMD, wave64) / (1024 SIMDs x busy cycles)", "frac": traffic_meta.get("valu_occupancy"),
+                   # the second resource: vector issue (same PMC passes).  A SIMD issues a VOP1 / VOP2 / VOPC instruction every ~2.05 cycles and a VOP3-encoded one every ~4.1,
+                   # whatever the number of waves (tools/probe_issue2.hip, profiles/r04_probe_issue.txt); the VOP3 share of the layer loop is read from the code object (tools/kernel_mix.py)
+                   "valu": {"resource": "vector issue: SQ_INSTS_VALU x (2.05 cycles, 4.1 for the VOP3-encoded share of the layer loop) / (1024 SIMDs x busy cycles)", "frac": traffic_meta.get("valu_occupancy"),
+                            "cycles_per_instruction": traffic_meta.get("valu_cycles_per_inst"), "vop3_share": traffic_meta.get("vop3_share"),
                             "wave_issue_slots": traffic_meta.get("wave_issue_occupancy")}}
     io_bytes = (4 * N + 4 * K) * F
     # the resource the kernel runs closest to: the fabric behind L2 or the vector pipes
@@ -214,7 +216,7 @@ def main():
     if bounded and binding == "fabric":
         r_ach, r_peak, r_unit = bounded["achieved"], FABRIC_PEAK_GBPS, "GB/s"
     elif bounded:
-        r_ach, r_peak, r_unit = bounded_frac, 1.0, "fraction of the 1024 SIMDs' cycles (SQ_INSTS_VALU x 2 / busy cycles)"
+        r_ach, r_peak, r_unit = bounded_frac, 1.0, "fraction of the 1024 SIMDs' issue cycles (2.05 per VOP1 / VOP2 / VOPC instruction, 4.1 per VOP3-encoded one)"
     else:
         r_ach, r_peak, r_unit = None, FABRIC_PEAK_GBPS, "GB/s"
 
@@ -467,7 +469,7 @@ def _pmc_traffic(kernel_name, frames, n_ite):
         return None, None
     if d.get("kernel_sha") != kernel_sha() or d.get("frames") != frames or d.get("n_ite") != n_ite or d.get("kernel") not in (None, kernel_name):
         return None, {"stale": True, "file_kernel_sha": d.get("kernel_sha"), "running_kernel_sha": kernel_sha()}
-    return d.get("hbm_bytes_per_launch"), {k: d.get(k) for k in ("kernel_sha", "git_head", "source", "fetch_bytes_raw", "write_bytes_raw", "fetch_correction", "write_correction", "frames", "n_ite", "valu_occupancy", "wave_issue_occupancy", "l2_hit_rate")}
+    return d.get("hbm_bytes_per_launch"), {k: d.get(k) for k in ("kernel_sha", "git_head", "source", "fetch_bytes_raw", "write_bytes_raw", "fetch_correction", "write_correction", "frames", "n_ite", "valu_occupancy", "valu_cycles_per_inst", "vop3_share", "wave_issue_occupancy", "l2_hit_rate")}
 
 
 def _copy_bandwidth(torch, dev):

@@ -125,7 +125,10 @@ __host__ __device__ constexpr int ldpc_w8_kd(int deg) { return deg == 27 ? 6 : d
 // mode 6 (k_ldpc_cu1.hip): one frame per 16-wave workgroup = per CU.  Two lanes per check: the first half-check's lanes take slots 0 .. LDPC_CU1_HA-1 (the duplicate
 // edges are among them), the second one's the rest (p_c and p_{c-1} last); they exchange {min1 | parity, min2} through 8 bytes per half-check of LDS.  Four
 // row-keeping waves in two groups of two, ldpc_cu1_nrg() rows (3 VGPRs per row and lane) each.
-constexpr int LDPC_CU1_HA = 14;
+#ifndef LDPC_CU1_HA_V
+#define LDPC_CU1_HA_V 14
+#endif
+constexpr int LDPC_CU1_HA = LDPC_CU1_HA_V;
 constexpr int LDPC_CU1_XCHG_BYTES = 2 * LDPC_Z * 8;
 __host__ __device__ constexpr int ldpc_cu1_nrg() { return 36; }
 #ifndef LDPC_CU1_DEFAULT

@@ -572,6 +572,19 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     for (int k = 0; k < NRH; k++) pl.w8_rows.push_back(park.reg0[k] < 0 ? 0xFFFFFFFFu : (uint32_t)park.reg0[k]);
                     // and the idle waves' swaps behind the layer tables: [q][NR] x LDS position (0xFF: none)
                     pl.w8_tab.insert(pl.w8_tab.end(), park.srv.begin(), park.srv.end());
+                    if (cu1) {      // k_ldpc_cu1.hip reads the swaps as bit masks: [q][2 groups][lo, hi], bit k = slot k of the group swaps with its position (= its index) during layer r
+                        const int NRG = ldpc_cu1_nrg();
+                        for (int r = 0; r < q; r++) for (int gk = 0; gk < 2; gk++) {
+                            unsigned long long m = 0;
+                            for (int k = 0; k < NRG; k++) {
+                                const uint32_t e = park.srv[(size_t)r * NRH + gk * NRG + k];
+                                if (e == 0xFFu) continue;
+                                if ((int)e != gk * NRG + k) return "LDPC: internal: mode 6 expects pair k at position k";
+                                m |= 1ull << k;
+                            }
+                            pl.w8_tab.push_back((uint32_t)m); pl.w8_tab.push_back((uint32_t)(m >> 32));
+                        }
+                    }
                 } else
                     for (size_t i = 0; i < lrow.size(); i++) if ((int)gbase[lrow[i]] != (int)i * LDPC_Z) return "LDPC: internal: LDS row order";
                 for (size_t i = 0; i < grow.size(); i++) if ((int)gbase[grow[i]] != (int)i * LDPC_Z) return "LDPC: internal: global row order";

@@ -33,6 +33,14 @@ constexpr int C1_IO = 16;                    // independent loads per lane in fl
 constexpr int C1_HA = LDPC_CU1_HA;           // slots of half A
 constexpr int C1_WAVES = 16, C1_THREADS = C1_WAVES * 64;
 
+// development knobs (tools/build_variant_tus.sh): the row-keeping waves swap with ds_wrxchg_rtn (0) or with a read and a write per word (1); they swap right behind the
+// end-of-layer barrier (0) or behind the layer's first barrier (1), when the working waves' loads are out of the way
+#ifndef C1_KEEP_RW
+#define C1_KEEP_RW 0
+#endif
+#ifndef C1_KEEP_LATE
+#define C1_KEEP_LATE 0
+#endif
 #ifdef LDPC_PHASE_PROF
 #define C1_MARK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[i] += (uint32_t)(n_ - pt_); pt_ = n_; } while (0)
 #else
@@ -60,20 +68,30 @@ __device__ __forceinline__ float c1_unpack(float c1, float c2, uint32_t pk, uint
 // barrier and swaps rows with LDS positions by the plan's table (w8_park_server of k_ldpc_wg8.hip, for a workgroup with two such groups and the barrier
 // sequence of this kernel's layer: one barrier always, then the duplicate-edge barriers, then the end barrier)
 template <int NRG>
-__device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const s_misc, const int grp, const int sidx, const int lane, const bool vote_writer)
+__device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const s_misc, const int grp, const int sidx, const int lane, const bool vote_writer
+#ifdef LDPC_PHASE_PROF
+                                           , uint32_t *prof, unsigned long long &pt_
+#endif
+                                           )
 {
     const int q = p.q;
     constexpr int NRT = 2 * NRG;
-    const const_u32 tab = (const_u32)p.w8.tab, srv = tab + q * LDPC_FAST_STRIDE;
+    const const_u32 tab = (const_u32)p.w8.tab;
+    // the swaps of layer r as a 64-bit mask per group (bit k: slot k <-> LDS position grp * NRG + k; the plan gives pair k position k), behind the layer tables
+    // and the [q][NRT] byte table k_ldpc_wg8.hip's modes read
+    const const_u32 swm = tab + q * LDPC_FAST_STRIDE + q * NRT + grp * 2;
     const const_u32 srow = (const_u32)p.w8.rows + p.w8.nl + p.w8.ng + q + grp * NRG;        // bit-group in this group's slot k at the start of an iteration
     const int el = sidx * 64 + lane;
     const bool on = el < LDPC_Z / 3;
-    const uint32_t a0 = (uint32_t)el * 4u;
+    const uint32_t a0 = (uint32_t)el * 4u + (uint32_t)(grp * NRG) * (uint32_t)C1_ROW;       // this lane's first word of the group's first position
     constexpr uint32_t A1 = LDPC_Z / 3 * 4u, A2 = 2u * A1;
     auto lst = [&](uint32_t a, float v) { *c1_lds(a) = v; };
     auto lxc = [&](uint32_t a, float v) -> float { return __hip_atomic_exchange(c1_lds(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     float R[NRG][3];
     int nvote = 0;
+    // The barriers INSIDE a layer are taken without waiting for the exchanges in flight (a plain s_barrier: the working waves do not look at the rows being
+    // swapped before the layer's END barrier, which is a full __syncthreads); a barrier that drained them made the twelve working waves wait for this one.
+    auto bar_nowait = [&]() { __builtin_amdgcn_s_barrier(); };
     auto vote0 = [&]() -> bool {                    // the working waves' vote, with nothing to report
         lds_int *const w = s_misc + 20;
         const int k = nvote % 3;
@@ -82,15 +100,21 @@ __device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const 
         __syncthreads();
         return w[k] != 0;
     };
-    auto moves = [&](int r) {                       // the swaps of layer r: slot k <-> LDS position mv[k] (0xFF: none)
-        const const_u32 mv = srv + r * NRT + grp * NRG;
+    auto moves = [&](int r) {                       // the swaps of layer r: every register index and every LDS offset is a compile-time constant, the test is scalar
+        const uint32_t mlo = swm[r * 4], mhi = swm[r * 4 + 1];
         if (on)
 #pragma unroll
         for (int k = 0; k < NRG; k++) {
-            const uint32_t e = mv[k];
-            if (e != 0xFFu) {
-                const uint32_t b = e * (uint32_t)C1_ROW;
-                R[k][0] = lxc(b + a0, R[k][0]); R[k][1] = lxc(b + a0 + A1, R[k][1]); R[k][2] = lxc(b + a0 + A2, R[k][2]);
+            const bool sw = k < 32 ? ((mlo >> k) & 1u) != 0u : ((mhi >> (k - 32)) & 1u) != 0u;
+            if (sw) {
+                const uint32_t b = a0 + (uint32_t)k * (uint32_t)C1_ROW;
+#if C1_KEEP_RW
+                const float n0 = *c1_lds(b), n1 = *c1_lds(b + A1), n2 = *c1_lds(b + A2);
+                lst(b, R[k][0]); lst(b + A1, R[k][1]); lst(b + A2, R[k][2]);
+                R[k][0] = n0; R[k][1] = n1; R[k][2] = n2;
+#else
+                R[k][0] = lxc(b, R[k][0]); R[k][1] = lxc(b + A1, R[k][1]); R[k][2] = lxc(b + A2, R[k][2]);
+#endif
             }
         }
     };
@@ -98,16 +122,21 @@ __device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const 
         const const_u32 T = tab + r * LDPC_FAST_STRIDE;
         const uint32_t cinfo = T[28];
         const int ncf = (int)(cinfo & 0xFFu);
-        __syncthreads();                            // the halves' partial minima are in the exchange area; every read of the layer precedes its writes
+        bar_nowait();                               // the halves' partial minima are in the exchange area; every read of the layer precedes its writes
+#if C1_KEEP_LATE
+        moves(r);
+#endif
         if (ncf > 0) {
-            __syncthreads();                        // the primary writes are in place
+            bar_nowait();                           // the primary writes are in place
             uint32_t prev_lvl = 1u;
             for (int i = (ncf > 1 && ((cinfo >> 21) & 3u) == 1u) ? 2 : 1; i < ncf; i++) {
                 const uint32_t lvl = T[48 + i] >> 8;
-                if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
+                if (lvl != prev_lvl) { bar_nowait(); prev_lvl = lvl; }
             }
         }
-        __syncthreads();                            // end of the layer
+        C1_MARK(0);
+        __syncthreads();                            // end of the layer: the swapped rows are in place
+        C1_MARK(1);
     };
     const bool es = p.early_stop != 0;
     for (int f = blockIdx.x; f < p.n_frames; ) {
@@ -125,13 +154,14 @@ __device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const 
             R[k][0] = __builtin_nontemporal_load(&Yg[elc]); R[k][1] = __builtin_nontemporal_load(&Yg[elc + LDPC_Z / 3]); R[k][2] = __builtin_nontemporal_load(&Yg[elc + 2 * (LDPC_Z / 3)]);
         }
         __syncthreads();                            // the image is in place
+        C1_MARK(8);
         // ph 0: layer r of an iteration; 1: layer r of the syndrome sweep; 2: catching up with the schedule after a sweep that stopped early
         int ph = 0, r = 0, it = 0;
         bool ok = false, fin = false;
         while (!fin) {
             bool mv = true;
             if (ph == 1 && es && r == 0 && vote0()) { ok = false; mv = false; ph = 3; }       // stopping rule: the vote on layer 0 comes before anything moves
-            if (mv) moves(r);
+            if (mv && !(C1_KEEP_LATE && ph == 0)) moves(r);
             if (ph == 0) {
                 layer_barriers(r);
                 if (++r == q) { r = 0; it++; if (es || it == p.n_ite) { ph = 1; ok = true; } }
@@ -146,13 +176,18 @@ __device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const 
             }
             if (ph == 3) { if (ok || it >= p.n_ite) fin = true; else { ph = 0; r = 0; } }
         }
+        C1_MARK(6);
         // outputs: the parked rows go through LDS positions grp * NRG .. once the working waves have read the LDS rows
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < NRG; k++) if (on) { const uint32_t b = (uint32_t)(grp * NRG + k) * (uint32_t)C1_ROW; lst(b + a0, R[k][0]); lst(b + a0 + A1, R[k][1]); lst(b + a0 + A2, R[k][2]); }
+        for (int k = 0; k < NRG; k++) if (on) { const uint32_t b = a0 + (uint32_t)k * (uint32_t)C1_ROW; lst(b, R[k][0]); lst(b + A1, R[k][1]); lst(b + A2, R[k][2]); }
         __syncthreads();
         __syncthreads();                            // the image is reused by the next frame
         f = s_misc[19];
+        C1_MARK(7);
+#ifdef LDPC_PHASE_PROF
+        prof[9]++;
+#endif
     }
 }
 
@@ -316,6 +351,17 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
                     mn2 = fminf(fminf(mn2, o2), hi);
                     cst1 = mn2 * p.alpha; cst2 = mn1 * p.alpha;
                     pkn = sacc ^ (tot ? ((1u << NS) - 1u) : 0u);                              // sign(new_j) = tot ^ sign(x_j)
+                }
+                // the next layer's table: requested now (the slot entries of this layer are dead: pass 2 stores where pass 1 loaded) so that the scalar loads travel under
+                // pass 2 instead of in front of the end-of-layer barrier
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const const_u32 Tn = tab + (r + 1 < q ? r + 1 : 0) * LDPC_FAST_STRIDE;
+#pragma unroll
+                    for (int j = 0; j < 32; j++) TE[j] = Tn[j];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (act) {
                     // ---- pass 2: new c->v ; posterior = v->c + new c->v.  Duplicate edges (not in `prim`) go to the junk row, the absent edge of lane 0 too
                     uint32_t idxn = 31u;                                                      // 31: the minimum is not among this half's slots
                     float m1s = __uint_as_float(__float_as_uint(cst1) | (tot << 31));         // output magnitudes carrying the total sign
@@ -330,14 +376,11 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
                         idxn = ismin ? (uint32_t)j : idxn;
                         asm("" : "+v"(idxn));
                         uint32_t a = w[j];
-                        if (HALF == 0 && j < ldpc_w8_kd(DEG)) {       // only these slots can hold a duplicate edge (plan): its plain store goes to the junk row
-                            const bool pr = ((prim >> j) & 1u) != 0u;                         // wave-uniform
-                            const uint32_t d = t4 - (E[j] & 0x7FFu);
-                            a = pr ? a : min(d, d + (uint32_t)C1_ROW) + ljunk;
-                        }
                         if (HALF == 1 && j == NS - 1 && mask0) a = ljunk + t4;
                         if (FWD && j == NS - 2 && r + 1 < q) pfw = x + nw;                    // p_c: kept for layer r + 1
-                        else lst(a, x + nw);
+                        else if (HALF == 0 && j < ldpc_w8_kd(DEG)) {      // only these slots can hold a duplicate edge (plan): its plain store is left out (a scalar branch)
+                            if (((prim >> j) & 1u) != 0u) lst(a, x + nw);
+                        } else lst(a, x + nw);
                     }
                     pkn |= idxn << 27;
                     {
@@ -375,11 +418,6 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
                     }
                 }
                 C1_MARK(4);
-                {
-                    const const_u32 Tn = tab + (r + 1 < q ? r + 1 : 0) * LDPC_FAST_STRIDE;
-#pragma unroll
-                    for (int j = 0; j < 32; j++) TE[j] = Tn[j];
-                }
                 __syncthreads();
                 C1_MARK(5);
             }
@@ -521,9 +559,14 @@ ldpc_cu1_kernel(const LdpcKParams p)
     unsigned long long pt_ = prof_t0;
 #endif
     if (role < 0) {
-        cu1_keeper<ldpc_cu1_nrg()>(p, s_misc, keeper >> 1, keeper & 1, lane, keeper == 0);
 #ifdef LDPC_PHASE_PROF
-        if (lane == 0 && p.cu_ctr) for (int i = 0; i < 12; i++) p.cu_ctr[LDPC_CU_CTR_WORDS + ((int)blockIdx.x * C1_WAVES + wave) * 12 + i] = 0u;
+        cu1_keeper<ldpc_cu1_nrg()>(p, s_misc, keeper >> 1, keeper & 1, lane, keeper == 0, prof, pt_);
+        if (lane == 0 && p.cu_ctr) {
+            prof[10] = 1u; prof[11] = (uint32_t)(__builtin_amdgcn_s_memtime() - prof_t0);
+            for (int i = 0; i < 12; i++) p.cu_ctr[LDPC_CU_CTR_WORDS + ((int)blockIdx.x * C1_WAVES + wave) * 12 + i] = prof[i];
+        }
+#else
+        cu1_keeper<ldpc_cu1_nrg()>(p, s_misc, keeper >> 1, keeper & 1, lane, keeper == 0);
 #endif
         return;
     }
@@ -532,7 +575,7 @@ ldpc_cu1_kernel(const LdpcKParams p)
     if (role & 1) cu1_work<DEG, 1>(p, s_misc, role >> 1, lane, wave, false, false, prof, pt_);
     else cu1_work<DEG, 0>(p, s_misc, role >> 1, lane, wave, false, role == 0, prof, pt_);
     if (lane == 0 && p.cu_ctr) {
-        prof[11] = (uint32_t)(__builtin_amdgcn_s_memtime() - prof_t0);
+        prof[10] = 0x100u + (uint32_t)role; prof[11] = (uint32_t)(__builtin_amdgcn_s_memtime() - prof_t0);
         for (int i = 0; i < 12; i++) p.cu_ctr[LDPC_CU_CTR_WORDS + ((int)blockIdx.x * C1_WAVES + wave) * 12 + i] = prof[i];
     }
 #else
@@ -569,8 +612,21 @@ hipError_t ldpc_cu1_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
         (void)hipStreamSynchronize(s);
         std::vector<uint32_t> hbuf((size_t)grid * C1_WAVES * 12);
         (void)hipMemcpy(hbuf.data(), p.cu_ctr + LDPC_CU_CTR_WORDS, hbuf.size() * 4, hipMemcpyDeviceToHost);
-        double acc[12] = {0}; int nw = 0; double fr = 0;
-        for (int w = 0; w < grid * C1_WAVES; w++) { if (!hbuf[(size_t)w * 12 + 11]) continue; nw++; for (int i = 0; i < 12; i++) acc[i] += hbuf[(size_t)w * 12 + i]; fr += hbuf[(size_t)w * 12 + 9]; }
+        double acc[12] = {0}, kacc[12] = {0}, racc[12][12] = {{0}}; int nw = 0, nk = 0, rn[12] = {0}; double fr = 0;
+        for (int w = 0; w < grid * C1_WAVES; w++) {
+            if (!hbuf[(size_t)w * 12 + 11]) continue;
+            if (hbuf[(size_t)w * 12 + 10] == 1u) { nk++; for (int i = 0; i < 12; i++) kacc[i] += hbuf[(size_t)w * 12 + i]; continue; }
+            nw++; for (int i = 0; i < 12; i++) acc[i] += hbuf[(size_t)w * 12 + i]; fr += hbuf[(size_t)w * 12 + 9];
+            const int role = (int)(hbuf[(size_t)w * 12 + 10] & 0xFFu);
+            if (role < 12) { for (int i = 0; i < 12; i++) racc[role][i] += hbuf[(size_t)w * 12 + i]; rn[role]++; }
+        }
+        for (int role = 0; role < 12; role++) if (rn[role]) {
+            const double dn = racc[role][9] * pl.q * p.n_ite;
+            fprintf(stderr, "  role %2d (half %c, checks %3d..): per layer 1a %5.0f 1b %5.0f merge-wait %5.0f pass2 %5.0f replay %5.0f end-wait %5.0f\n", role, role & 1 ? 'B' : 'A', (role >> 1) * 64,
+                    racc[role][0] / dn, racc[role][1] / dn, racc[role][2] / dn, racc[role][3] / dn, racc[role][4] / dn, racc[role][5] / dn);
+        }
+        if (nk) fprintf(stderr, "[ldpc cu1 phase prof] %d row-keeping waves: swaps + inner barriers %.0f, waiting at the end barrier %.0f ticks per layer (of %.0f per wave)\n", nk,
+                        kacc[0] / kacc[9] / (pl.q * p.n_ite), kacc[1] / kacc[9] / (pl.q * p.n_ite), kacc[11] / nk);
         static const char *nm[12] = {"1a issue", "1b", "merge barrier", "pass 2", "replay", "end barrier", "syndrome", "output", "input", "-frames", "-", "TOTAL"};
         fprintf(stderr, "[ldpc cu1 phase prof] %d working waves, %.2f frames per wave, %.0f ticks per frame and layer (q %d, %d iterations)\n", nw, fr / (nw ? nw : 1),
                 (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5]) / (fr > 0 ? fr : 1) / (pl.q * p.n_ite), pl.q, p.n_ite);

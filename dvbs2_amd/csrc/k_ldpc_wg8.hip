@@ -75,6 +75,9 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #define SPA_ABL 0
 #endif
 
+#ifndef W8_IDX_E32        // pass 2's selects in the 32-bit encoding (inline asm): see the note there.  Measured without effect (round 4: 5.94 against 5.95 ms, same box), off
+#define W8_IDX_E32 0
+#endif
 #ifdef LDPC_PHASE_PROF
 #define PROF_MARK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[i] += (uint32_t)(n_ - pt_); pt_ = n_; } while (0)
 #else
@@ -698,11 +701,21 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #pragma unroll
                     for (int j = 0; j < DEG; j++) {
                         const float x = v[j];
+#if W8_IDX_E32
+                        // A SIMD issues a VOP3-encoded instruction every ~4.1 cycles and a VOP2 / VOPC one every ~2.1, whatever the number of waves (tools/probe_issue2.hip):
+                        // the two selects on the comparison are written so that both take the 32-bit encoding (D = vcc ? src1 : src0 with src1 a register: the test is
+                        // "not the minimum", the slot number the inline constant in src0); the compiler's form of the second one is v_cndmask_b32_e64.
+                        float mag;
+                        asm("v_cmp_neq_f32_e64 vcc, |%2|, %3\n\tv_cndmask_b32_e32 %0, %4, %5, vcc\n\tv_cndmask_b32_e32 %1, %6, %1, vcc"
+                            : "=&v"(mag), "+v"(idxn) : "v"(x), "v"(mn1), "v"(m1s), "v"(m2s), "n"(j) : "vcc");
+                        const float nw = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(x) & SB));
+#else
                         const bool ismin = fabsf(x) == mn1;
                         const float mag = ismin ? m1s : m2s;
                         const float nw = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(x) & SB));
                         idxn = ismin ? (uint32_t)j : idxn;
                         asm("" : "+v"(idxn));                     // select now: the comparison mask dies here instead of piling up 27 SGPR pairs
+#endif
                         const bool pr = ((prim >> j) & 1u) != 0u;                             // wave-uniform
                         const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
                         if (w8_slot_lds(MODE, j)) {

@@ -75,7 +75,9 @@ def test_bench_line_on_the_gpu():
     assert set(fw) == {"4.0dB_fixed", "3.0dB_fixed", "4.0dB_stop", "3.0dB_stop"} and all(v["launches"] == 4 and v["frames"] == 4096 for v in fw.values())
     # fixed iterations cost the same whatever the data (no data-dependent branch in the layer loop): the anomaly VERDICT r3 found on 1024 frames / 3 launches
     assert 0.9 < ex["four_way"]["hard_over_easy_fixed"] < 1.1
-    assert fw["3.0dB_stop"]["ms_mean"] > fw["3.0dB_fixed"]["ms_mean"]                            # ten iterations PLUS ten votes cannot be faster than ten iterations
+    # ... and on frames that never converge the stopping rule costs what fixed iterations cost, to a few percent: ten sweeps that stop at their first layer (half a
+    # syndrome pass in all) against the one full pass a fixed-iteration decode ends with ("the 550 k against 695 k of round 3")
+    assert 0.93 < fw["3.0dB_stop"]["ms_mean"] / fw["3.0dB_fixed"]["ms_mean"] < 1.07
     cf = ex["configs"]
     assert set(cf) == {"2", "3", "4"} and cf["2"]["bit_errors"] == 0 and cf["3"]["n_ite"] == 20 and cf["3"]["bit_errors"] == 0
     assert [r["frames"] for r in cf["4"]["per_F"]] == [1, 8, 64, 4096] and all(r["fir_GFLOPs_fp32_equiv"] > 0 for r in cf["4"]["per_F"])

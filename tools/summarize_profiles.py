@@ -70,21 +70,30 @@ if pmc:
     corr_w = known / cal["WRITE_SIZE"] if "WRITE_SIZE" in cal else None
     if "TCC_HIT_sum" in pmc:
         lines.append("L2 hit rate = %.3f" % (pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])))
-    # vector-ALU occupancy: a SIMD is 32 lanes wide and retires a wave64 instruction in 2 cycles (MI355X_MICROARCH.md, constants table: `v_fma_f32` 2 cyc (SIMD-32),
-    # one wave alone 4; tools/probe_dep.hip: two waves on a SIMD each issue a dependent instruction every 4.2 cycles, four every 8.2 = one per 2.05 cycles and SIMD);
-    # rounds 2 and 3 priced it at 4 cycles (a 16-lane SIMD) until the end of round 3 and quoted twice these fractions.  A WAVE issues at most one instruction of any
-    # kind per ~4.2 cycles: the second figure.  SQ_BUSY_CYCLES is summed over the chip's 32 shader engines (8 XCDs x 4): busy cycles of the launch = SQ_BUSY_CYCLES / 32;
-    # 256 CUs x 4 SIMDs.
-    valu_frac = wave_issue = None
+    # vector issue (round 4, tools/probe_issue2.hip / probe_issue3.hip, profiles/r04_probe_issue.txt): a SIMD issues a VOP1 / VOP2 / VOPC instruction every ~2.05 cycles and a
+    # VOP3 / VOP3P-ENCODED one every ~4.1, whatever the number of waves on it (two waves reach the VOP2 rate, the oldest wave alone saturates the VOP3 rate), and a lone
+    # wave issues one instruction of any kind per ~4.3 cycles.  Rounds 2 and 3 priced every vector instruction at 4, then at 2 cycles; the layer loop is 46 % VOP3
+    # (tools/kernel_mix.py reads the share from the code object), i.e. 3.0 cycles per instruction.  SQ_BUSY_CYCLES is summed over the chip's 32 shader engines
+    # (8 XCDs x 4): busy cycles of the launch = SQ_BUSY_CYCLES / 32; 256 CUs x 4 SIMDs.
+    valu_frac = wave_issue = cyc_per_valu = vop3_share = None
     if pmc.get("SQ_INSTS_VALU") and pmc.get("SQ_BUSY_CYCLES"):
         cyc = pmc["SQ_BUSY_CYCLES"] / 32.0
-        valu_frac = pmc["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cyc)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        try:
+            import kernel_mix as KM
+            kname = meta[0].replace("void ", "").split("(")[0].replace("dvbs2::", "")
+            mx = KM.mix("k_ldpc_wg8" if "wg8" in kname else "k_ldpc_cu1" if "cu1" in kname else "k_ldpc", kname)
+            cyc_per_valu, vop3_share = mx[0]["cycles_per_valu"], mx[0]["vop3_share"]
+        except Exception as e:
+            lines.append("(tools/kernel_mix.py failed: %s; every vector instruction priced at 3.0 cycles)" % e)
+        cyc_per_valu = cyc_per_valu or 3.0
+        valu_frac = pmc["SQ_INSTS_VALU"] * cyc_per_valu / (1024.0 * cyc)
         insts = sum(pmc.get(k, 0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
-        wave_issue = insts * 4.2 / (pmc.get("SQ_WAVES", 0) * cyc) if pmc.get("SQ_WAVES") else None
-        lines.append("VALU occupancy = SQ_INSTS_VALU x 2 cycles (32-lane SIMD) / (1024 SIMDs x %.3g busy cycles) = %.2f; SALU: %.3g instructions on 256 scalar units = %.2f of the cycles"
-                     % (cyc, valu_frac, pmc.get("SQ_INSTS_SALU", 0), pmc.get("SQ_INSTS_SALU", 0) / (256.0 * cyc)))
+        wave_issue = insts * 4.3 / (pmc.get("SQ_WAVES", 0) * cyc) if pmc.get("SQ_WAVES") else None
+        lines.append("vector issue = SQ_INSTS_VALU x %.2f SIMD cycles (%.0f %% of the layer loop's vector instructions are VOP3-encoded: 4.1 cycles, the others 2.05) / (1024 SIMDs x %.3g busy cycles) = %.2f; "
+                     "SALU: %.3g instructions on 256 scalar units = %.2f of the cycles" % (cyc_per_valu, 100 * (vop3_share or 0), cyc, valu_frac, pmc.get("SQ_INSTS_SALU", 0), pmc.get("SQ_INSTS_SALU", 0) / (256.0 * cyc)))
         if wave_issue:
-            lines.append("issue slots of a wave = (VALU + SALU + LDS + VMEM instructions) x 4.2 cycles / (%d waves x busy cycles) = %.2f on average over a workgroup's waves"
+            lines.append("issue slots of a wave = (VALU + SALU + LDS + VMEM instructions) x 4.3 cycles / (%d waves x busy cycles) = %.2f on average over a workgroup's waves"
                          % (pmc["SQ_WAVES"], wave_issue))
     cf, cw = (corr_f or 1.0), (corr_w or 1.0)
     lines.append("traffic (calibrated) = %.3f x FETCH + %.3f x WRITE = %.3f GB per launch" % (cf, cw, (cf * fetch_b + cw * write_b) / 1e9))
@@ -100,7 +109,7 @@ if pmc:
                "kernel_sha": _bench.kernel_sha(), "kernel_sources": list(_bench.KERNEL_SOURCES), "git_head": head,
                "kernel": meta[0].replace("void ", "").split("(")[0].replace("dvbs2::", "").replace(", false>", ">").replace(", ", ","),
                "frames": _bench.FRAMES_PER_GPU, "n_ite": _bench.N_ITE,
-               "valu_occupancy": valu_frac, "valu_cycles_per_inst": 2.0, "wave_issue_occupancy": wave_issue, "valu_insts_per_launch": pmc.get("SQ_INSTS_VALU"), "busy_cycles_per_launch": (pmc.get("SQ_BUSY_CYCLES") or 0) / 32.0,
+               "valu_occupancy": valu_frac, "valu_cycles_per_inst": cyc_per_valu, "vop3_share": vop3_share, "wave_issue_occupancy": wave_issue, "valu_insts_per_launch": pmc.get("SQ_INSTS_VALU"), "busy_cycles_per_launch": (pmc.get("SQ_BUSY_CYCLES") or 0) / 32.0,
                "l2_hit_rate": (pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])) if "TCC_HIT_sum" in pmc else None,
                "note": "fabric-side bytes (L2 misses + written-through stores), Infinity-Cache hits included; corrected by the factors "
                        "measured on a known dword-per-lane copy (tools/calibrate_fetch.py)"},
