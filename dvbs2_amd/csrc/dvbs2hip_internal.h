@@ -135,6 +135,8 @@ __host__ __device__ constexpr int ldpc_cu1_nrg() { return 36; }
 #define LDPC_CU1_DEFAULT 0
 #endif
 constexpr int LDPC_SPA_MAXC = 6;       // SPA: duplicate edges per layer whose old messages a lane keeps in registers (the DVB-S2 codes have at most 6)
+constexpr int NAT_AHEAD = 24;           // k_ldpc_nat.hip, lanes-per-frame form: checks whose loads are in flight ahead of the one being computed (8 lanes per frame; 12 with 4 lanes per frame)
+constexpr int NAT_HAZ_WINDOW = NAT_AHEAD + 1;
 hipError_t ldpc_nat_launch(const LdpcPlan &pl, const LdpcKParams &kp, float *work, hipStream_t s);
 size_t ldpc_nat_group_words(const LdpcPlan &pl);
 hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);

@@ -645,13 +645,22 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                         out.push_back(sl.group < pl.n_info ? sl.group * LDPC_Z + e : K + q * e + (sl.group - pl.n_info));
                     }
                 };
+                // second plane (behind the first): check c shares a bit with one of the NAT_HAZ_WINDOW checks before it (cyclically) -- the kernels that request a
+                // check's posteriors several checks ahead (k_ldpc_nat.hip, ldpc_nat_part_kernel: NAT_AHEAD checks) must not do so for these: the checks in between
+                // have not written yet, and the stores of the one or two before them may still be in flight
+                const size_t hw = pl.nat_haz.size();
+                pl.nat_haz.resize(2 * hw, 0u);
                 std::vector<int> a, b;
                 for (int c = 0; c < M; c++) {
-                    vars_of(c, a); vars_of((c + M - 1) % M, b);
+                    vars_of(c, a);
                     const int fwd_bit = c > 0 ? K + c - 1 : -1;
-                    bool hz = false;
-                    for (int x : a) if (x != fwd_bit && std::find(b.begin(), b.end(), x) != b.end()) hz = true;
-                    if (hz) pl.nat_haz[c >> 5] |= 1u << (c & 31);
+                    for (int d = 1; d <= NAT_HAZ_WINDOW; d++) {
+                        vars_of(((c - d) % M + M) % M, b);
+                        bool hz = false;
+                        for (int x : a) if (x != fwd_bit && std::find(b.begin(), b.end(), x) != b.end()) hz = true;
+                        if (hz && d == 1) pl.nat_haz[c >> 5] |= 1u << (c & 31);
+                        if (hz) pl.nat_haz[hw + (c >> 5)] |= 1u << (c & 31);
+                    }
                 }
             }
             // one frame per 8-wave workgroup, two independent workgroups per CU (k_ldpc_wg8.hip); a code it cannot take (a static hybrid

@@ -203,12 +203,288 @@ nat_store_kernel(const NatParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same sweep with a check's edges SPLIT OVER PARTS ADJACENT LANES and G = 64 / PARTS frames per wave -- for batches that do not fill the machine with one
+// lane per frame (the BASELINE batch of 4096 normal frames is 64 waves there: 26 k frames/s, below the host CPU of the same bench line).  Lane (fl, p) = frame fl of the
+// wave's group, part p: it takes slots p SPP .. p SPP + SPP - 1 of the current check (SPP = ceil(DEG / PARTS); slots beyond DEG are NULL), folds them into {min1, min2,
+// parity, its sign bits}, and the PARTS lanes of a frame merge those with DPP exchanges inside their quad / half-row (no LDS, no barrier): the two smallest of the union
+// are min(a1, b1) and min(max(a1, b1), a2, b2) -- the same two fp32 values the one-lane scan finds -- so every message, posterior and state word is bit for bit the
+// one-lane kernel's (and the oracle's ORC_SCHED_NATURAL).  The chain p_c -> p_{c-1} still travels in a register (handed round the frame's lanes by the same exchanges).
+// On top: check c + 1's posteriors and state are REQUESTED BEFORE check c is computed (the sweep is a chain of ~2 us memory round trips otherwise), except where the
+// host's second hazard plane says that check c + 1 shares a bit with check c or c - 1.
+// Image: [bit][G frames] rows of 4 G bytes, same row order as above.
+template <int PARTS> __device__ __forceinline__ float nat_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }     // quad_perm [1,0,3,2]
+template <int PARTS> __device__ __forceinline__ float nat_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }     // quad_perm [2,3,0,1]
+template <int PARTS> __device__ __forceinline__ float nat_mir8(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)); }    // row_half_mirror: lane i <-> 7 - i
+
+// AHEAD = NAT_AHEAD (8 lanes per frame; half of it with 4): the loads of check c + AHEAD go out when check c has been computed -- only for codes whose second hazard plane is empty (no check shares a bit
+// with one of the NAT_HAZ_WINDOW before it: every DVB-S2 code of this library); the loop body is then free of branches and unrolled AHEAD times over a ring of AHEAD requests in registers.  AHEAD = 1: any code -- check c + 1 is requested behind a drain of check c's stores.
+template <int DEG, int PARTS, int AHEAD>
+__global__ void __launch_bounds__(64)
+ldpc_nat_part_kernel(const NatParams p)
+{
+    constexpr int G = 64 / PARTS, SPP = (DEG + PARTS - 1) / PARTS, DEGP = SPP * PARTS;
+    constexpr uint32_t RB = G * 4;                 // bytes per row
+    extern __shared__ uint32_t s_tab[];            // [q][DEGP][2]: per slot {byte offset of element 0 of its bit run | NULL: the +inf row ; t0 | byte stride between elements << 16}
+    const int g = blockIdx.x, lane = threadIdx.x, part = lane % PARTS, fl = lane / PARTS, f = g * G + fl;
+    float *W = p.work + (size_t)g * p.grp_words;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(W, 0, p.grp_words * 4, 0x00020000);
+    const uint32_t vo = (uint32_t)fl * 4u;
+    const int q = p.q, M = p.M;
+    const uint32_t inf_row = (uint32_t)p.N * RB, junk_row = inf_row + RB, st0 = junk_row + RB;
+    uint32_t SB = 0x80000000u;
+    asm volatile("" : "+s"(SB));
+    for (int i = lane; i < q * DEGP; i += 64) {
+        const int r = i / DEGP, j = i - r * DEGP;
+        const uint32_t e = j < DEG ? p.tab[(size_t)(r * DEG + j) * 2] : (1u << 17), A = j < DEG ? p.tab[(size_t)(r * DEG + j) * 2 + 1] : 0u;
+        const bool null = ((e >> 17) & 1u) != 0u;
+        const uint32_t stride = null ? 0u : (((e >> 16) & 1u) ? (uint32_t)q : 1u) * RB;
+        s_tab[2 * i] = null ? inf_row : A * RB;
+        s_tab[2 * i + 1] = (null ? 0u : (e & 0xFFFFu)) | (stride << 16) | (null ? 0x80000000u : 0u);      // (stride < 2^15: q * RB <= 135 * 256)
+    }
+    __syncthreads();
+    auto gldv = [&](uint32_t voff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0)); };
+    auto gstv = [&](uint32_t voff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, 0, 0); };
+    const int js0 = part * SPP;                    // this lane's first slot
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+    const uint32_t tab_lane = (uint32_t)js0 * 8u;  // byte offset of this lane's first slot inside a layer's table row
+    // byte offset (row + frame) of local slot k of check (r, t): base + ((t - t0) mod 360) x stride + 4 fl
+    auto addr_of = [&](int r, int t, int k, bool &real) -> uint32_t {
+        const u32x2 e = *(lds_u32x2 *)(size_t)((uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)s_tab + (uint32_t)(r * DEGP) * 8u + tab_lane + (uint32_t)k * 8u);
+        int elem = t - (int)(e.y & 0xFFFFu);
+        elem += (elem >> 31) & LDPC_Z;
+        real = (int)e.y >= 0;
+        return e.x + __umul24((uint32_t)elem, (e.y >> 16) & 0x7FFFu) + vo;
+    };
+    auto merge_min = [&](float &m1, float &m2, float o1, float o2) { const float hi = fmaxf(m1, o1); m1 = fminf(m1, o1); m2 = fminf(fminf(m2, o2), hi); };
+
+    bool live = f < p.F, ok = false;
+    int it = 0, my_ite = 0;
+    struct Req { uint32_t a[SPP]; float v[SPP]; float c1, c2, pk; };
+    auto request = [&](Req &R, int c, int r, int t) {       // the loads of check c = (r, t): posteriors of this lane's slots (not the forwarded one), the check's packed state
+#pragma unroll
+        for (int k = 0; k < SPP; k++) {
+            bool real;
+            const uint32_t a = addr_of(r, t, k, real);
+            const bool fwd_slot = js0 + k == DEG - 1;                      // p_{c-1}: comes from check c - 1 in a register, its row is only stored to
+            R.a[k] = (real && !(fwd_slot && c == 0)) ? a : junk_row + vo;  // where pass 2 stores (NULL slots and the absent p_{c-1} of check 0: the junk row)
+            R.v[k] = gldv(fwd_slot ? inf_row + vo : a);                    // (a NULL slot's `a` is the +inf row already)
+        }
+        const uint32_t srow = st0 + (uint32_t)c * 3u * RB + vo;
+        R.c1 = gldv(srow); R.c2 = gldv(srow + RB); R.pk = gldv(srow + 2 * RB);
+    };
+    while (it < p.n_ite) {
+        float fwd = INFINITY;                     // posterior of p_{c-1} as check c-1 left it (every lane of the frame holds it)
+        __builtin_amdgcn_s_waitcnt(0);
+        Req ring[AHEAD];
+        int rq = 0, tq = 0, cq = 0;               // the request stream: the next check to ask for (AHEAD checks in front of the one being computed)
+        auto request_next = [&](Req &R) {
+            request(R, cq, rq, tq);
+            if (cq + 1 < M) { cq++; if (++rq == q) { rq = 0; tq++; } }      // beyond the last check: the last one again (harmless; every check issues the same instructions)
+        };
+#pragma unroll
+        for (int u = 0; u < AHEAD; u++) request_next(ring[u]);
+        int r = 0, t = 0;
+        const bool st_lane = part == 0;
+        for (int c0 = 0; c0 < M; c0 += AHEAD) {
+#pragma unroll
+            for (int u = 0; u < AHEAD; u++) {
+                const int c = c0 + u;
+                Req &R = ring[u];
+                // (The compiler drains the vector memory queue once per trip of the unrolled loop -- at its head it cannot bound what is in flight -- and needs no wait for the
+                // other AHEAD - 1 checks of the trip, whose loads went out a whole trip earlier: the memory round trip is paid once per AHEAD checks.)
+                // ---- this lane's slots of check c
+                float v[SPP];
+                const float c1o = R.c1, c2o = R.c2;
+                const uint32_t pko = __float_as_uint(R.pk), idxo = pko >> 27;
+                float mn1 = INFINITY, mn2 = INFINITY;
+                uint32_t sacc = 0u;
+#pragma unroll
+                for (int k = 0; k < SPP; k++) {
+                    const uint32_t js = (uint32_t)(js0 + k);
+                    float val = R.v[k];
+                    if (js0 + k == DEG - 1) val = c == 0 ? INFINITY : fwd;
+                    const float mag = (idxo == js) ? c1o : c2o;
+                    const float old = nat_and_or(pko << (((32u - DEG) + js) & 31u), SB, mag);
+                    float x = val - old;
+                    if (js0 + k >= DEG) x = INFINITY;                          // NULL slot of the padding
+                    v[k] = x;
+                    const float a = fabsf(x);
+                    mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);
+                    mn1 = fminf(mn1, a);
+                    sacc = __builtin_amdgcn_alignbit(sacc, __float_as_uint(x), 31);
+                }
+                // ---- merge over the PARTS lanes of the frame: minima, parity, the sign word
+                uint32_t sw = sacc << (uint32_t)(DEGP - js0 - SPP);             // this part's sign bits where slot js has bit DEGP - 1 - js
+                merge_min(mn1, mn2, nat_xor1<PARTS>(mn1), nat_xor1<PARTS>(mn2));
+                sw |= __float_as_uint(nat_xor1<PARTS>(__uint_as_float(sw)));
+                merge_min(mn1, mn2, nat_xor2<PARTS>(mn1), nat_xor2<PARTS>(mn2));
+                sw |= __float_as_uint(nat_xor2<PARTS>(__uint_as_float(sw)));
+                if (PARTS == 8) {
+                    merge_min(mn1, mn2, nat_mir8<PARTS>(mn1), nat_mir8<PARTS>(mn2));
+                    sw |= __float_as_uint(nat_mir8<PARTS>(__uint_as_float(sw)));
+                }
+                sw >>= (uint32_t)(DEGP - DEG);                                  // slot js at bit DEG - 1 - js, as the one-lane kernel packs it (the padding's zero bits fall off)
+                const float cst1 = mn2 * p.alpha, cst2 = mn1 * p.alpha;
+                const uint32_t tot = (uint32_t)(__popc(sw) & 1);
+                uint32_t pkn = sw ^ (tot ? ((1u << DEG) - 1u) : 0u);
+                int idxn = 0;                                                    // the LAST slot that holds the minimum (the one-lane scan's rule); none in this part: 0, as there
+                float m1s = __uint_as_float(__float_as_uint(cst1) | (tot << 31)), m2s = __uint_as_float(__float_as_uint(cst2) | (tot << 31));
+                asm volatile("" : "+v"(m1s), "+v"(m2s));
+#pragma unroll
+                for (int k = 0; k < SPP; k++) {
+                    const float x = v[k];
+                    const bool ismin = fabsf(x) == mn1;
+                    const float mag = ismin ? m1s : m2s;
+                    const float nw = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(x) & SB));
+                    idxn = ismin ? js0 + k : idxn;
+                    v[k] = x + nw;
+                }
+                {
+                    int o = __builtin_amdgcn_update_dpp(0, idxn, 0xB1, 0xF, 0xF, true); idxn = idxn > o ? idxn : o;
+                    o = __builtin_amdgcn_update_dpp(0, idxn, 0x4E, 0xF, 0xF, true); idxn = idxn > o ? idxn : o;
+                    if (PARTS == 8) { o = __builtin_amdgcn_update_dpp(0, idxn, 0x141, 0xF, 0xF, true); idxn = idxn > o ? idxn : o; }
+                }
+                pkn |= (uint32_t)idxn << 27;
+                // stores: always issued (a frame that has converged, or lies beyond the batch, writes the junk row), the state by the frame's first lane
+#pragma unroll
+                for (int k = 0; k < SPP; k++) gstv(live ? R.a[k] : junk_row + vo, v[k]);
+                {
+                    const uint32_t srow = (live && st_lane) ? st0 + (uint32_t)c * 3u * RB + vo : junk_row + vo;
+                    const uint32_t sr1 = (live && st_lane) ? RB : 0u;
+                    gstv(srow, cst1); gstv(srow + sr1, cst2); gstv(srow + 2 * sr1, __uint_as_float(pkn));
+                }
+                {   // p_c's new posterior is the next check's p_{c-1}: handed to every lane of the frame (whichever part holds slot DEG-1 picks it up) as an OR over the parts
+                    uint32_t fb = 0u;
+#pragma unroll
+                    for (int k = 0; k < SPP; k++) if (js0 + k == DEG - 2) fb = __float_as_uint(v[k]);
+                    fb |= __float_as_uint(nat_xor1<PARTS>(__uint_as_float(fb)));
+                    fb |= __float_as_uint(nat_xor2<PARTS>(__uint_as_float(fb)));
+                    if (PARTS == 8) fb |= __float_as_uint(nat_mir8<PARTS>(__uint_as_float(fb)));
+                    fwd = __uint_as_float(fb);
+                }
+                // the slot is free: check c + AHEAD goes out now (beyond the last check: check M - 1 again, harmless, so that every check issues the same instructions)
+                if (AHEAD == 1) __builtin_amdgcn_s_waitcnt(0);                  // any code: the stores first
+                request_next(R);
+                if (++r == q) { r = 0; t++; }
+            }
+        }
+        it++;
+        if (live) my_ite = it;
+        if (p.early_stop || it == p.n_ite) {
+            // ---- syndrome of the hard decisions, every check of the frame (the parity of a check is the XOR over its parts: combined per check, before the OR over the checks)
+            __builtin_amdgcn_s_waitcnt(0);
+            uint32_t bad = 0u;
+            int r2 = 0, t2 = 0;
+            for (int c = 0; c < M; c++) {
+                uint32_t x = 0u;
+#pragma unroll
+                for (int k = 0; k < SPP; k++) {
+                    bool real;
+                    const uint32_t a = addr_of(r2, t2, k, real);
+                    const float Lv = gldv((js0 + k == DEG - 1 && c == 0) ? inf_row + vo : a);       // (+inf: sign bit 0)
+                    x ^= __float_as_uint(Lv);
+                }
+                x ^= __float_as_uint(nat_xor1<PARTS>(__uint_as_float(x)));
+                x ^= __float_as_uint(nat_xor2<PARTS>(__uint_as_float(x)));
+                if (PARTS == 8) x ^= __float_as_uint(nat_mir8<PARTS>(__uint_as_float(x)));
+                bad |= x >> 31;
+                if (++r2 == q) { r2 = 0; t2++; }
+            }
+            if (live) { ok = bad == 0u; if (ok) live = false; }
+            if (!__any(live)) break;
+        }
+    }
+    if (f < p.F && part == 0) {
+        if (p.cwd) p.cwd[f] = ok ? 1 : 0;
+        if (p.ites) p.ites[f] = my_ite;
+    }
+}
+
+// ---- llr [F][N] <-> rows of G frames (G = 64 / PARTS), the general forms of nat_load_kernel / nat_store_kernel
+__global__ void __launch_bounds__(256)
+nat_load_g_kernel(const NatParams p, int G)
+{
+    __shared__ float tile[64][65];
+    const int g = blockIdx.y, n0 = blockIdx.x * 64;
+    float *W = p.work + (size_t)g * p.grp_words;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int l = ty; l < G; l += 4) {
+        const int f = g * G + l, n = n0 + tx;
+        tile[l][tx] = (f < p.F && n < p.N) ? __builtin_nontemporal_load(&p.llr[(size_t)f * p.N + n]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * G; i += 256) {
+        const int k = i / G, l = i - k * G, n = n0 + k;
+        if (n < p.N) W[(size_t)n * G + l] = tile[l][k];
+    }
+    const size_t st0 = (size_t)(p.N + 2) * G, st_words = (size_t)3 * p.M * G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < st_words; i += (size_t)gridDim.x * 256) W[st0 + i] = 0.f;
+    if (blockIdx.x == 0 && (int)threadIdx.x < G) { W[(size_t)p.N * G + threadIdx.x] = INFINITY; W[(size_t)(p.N + 1) * G + threadIdx.x] = 0.f; }
+}
+
+__global__ void __launch_bounds__(256)
+nat_store_g_kernel(const NatParams p, int G)
+{
+    __shared__ float tile[64][65];                  // tile[bit][frame]
+    const int g = blockIdx.y, n0 = blockIdx.x * 64;
+    const float *W = p.work + (size_t)g * p.grp_words;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * G; i += 256) {
+        const int k = i / G, l = i - k * G, n = n0 + k;
+        tile[k][l] = n < p.N ? W[(size_t)n * G + l] : 0.f;
+    }
+    __syncthreads();
+    for (int l = ty; l < G; l += 4) {
+        const int f = g * G + l, n = n0 + tx;
+        if (f >= p.F || n >= p.N) continue;
+        const float Lv = tile[tx][l];
+        if (p.post) p.post[(size_t)f * p.N + n] = Lv;
+        if (p.bits && n < p.K) __builtin_nontemporal_store((int32_t)(Lv < 0.f ? 1 : 0), &p.bits[(size_t)f * p.K + n]);
+    }
+    if (p.packed && n0 < p.K && (int)threadIdx.x < 2 * G) {
+        const int l = threadIdx.x >> 1, h = threadIdx.x & 1, f = g * G + l;
+        if (f < p.F) {
+            uint32_t word = 0u;
+            for (int b = 0; b < 32; b++) { const int n = n0 + 32 * h + b; if (n < p.K && tile[32 * h + b][l] < 0.f) word |= 1u << b; }
+            const int n_words = (p.K + 31) / 32, wd = (n0 >> 5) + h;
+            if (wd < n_words) p.packed[(size_t)f * n_words + wd] = word;
+        }
+    }
+}
+
+template <int DEG, int PARTS>
+static hipError_t nat_part_launch(const LdpcPlan &pl, NatParams p, hipStream_t s)
+{
+    bool clean = true;      // the second hazard plane is empty: loads may run NAT_AHEAD checks ahead
+    for (size_t i = pl.nat_haz.size() / 2; i < pl.nat_haz.size(); i++) clean &= pl.nat_haz[i] == 0u;
+    constexpr int G = 64 / PARTS, SPP = (DEG + PARTS - 1) / PARTS;
+    p.grp_words = (uint32_t)((size_t)(pl.N + 2 + 3 * pl.M) * G);
+    const int groups = (p.F + G - 1) / G, tiles = (pl.N + 63) / 64;
+    hipLaunchKernelGGL(nat_load_g_kernel, dim3(tiles, groups), dim3(256), 0, s, p, G);
+    constexpr int AH = PARTS == 8 ? NAT_AHEAD : NAT_AHEAD / 2;
+    if (clean && pl.M % AH == 0) hipLaunchKernelGGL((ldpc_nat_part_kernel<DEG, PARTS, AH>), dim3(groups), dim3(64), (size_t)pl.q * SPP * PARTS * 8, s, p);
+    else hipLaunchKernelGGL((ldpc_nat_part_kernel<DEG, PARTS, 1>), dim3(groups), dim3(64), (size_t)pl.q * SPP * PARTS * 8, s, p);
+    hipLaunchKernelGGL(nat_store_g_kernel, dim3(tiles, groups), dim3(256), 0, s, p, G);
+    return hipGetLastError();
+}
+
 hipError_t ldpc_nat_launch(const LdpcPlan &pl, const LdpcKParams &kp, float *work, hipStream_t s)
 {
     NatParams p;
     p.llr = kp.llr; p.work = work; p.tab = pl.d_nat_tab; p.haz = pl.d_nat_haz;
     p.bits = kp.bits; p.packed = kp.packed; p.cwd = kp.cwd; p.post = kp.post; p.ites = kp.ites;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.F = kp.n_frames; p.n_ite = kp.n_ite; p.early_stop = kp.early_stop; p.alpha = kp.alpha;
+    // Lanes per frame by the size of the batch: one (64 frames per wave) when that alone gives every SIMD a wave, else 4 or 8 lanes per frame (16 / 8 frames per wave:
+    // a check's edges split over adjacent lanes, the next check's loads requested early).  DVBS2HIP_NAT_PARTS = 1 | 4 | 8 overrides.
+    int parts = kp.n_frames >= 32768 ? 1 : kp.n_frames > 6144 ? 4 : 8;
+    if (const char *ev = getenv("DVBS2HIP_NAT_PARTS")) { const int v = atoi(ev); if (v == 1 || v == 4 || v == 8) parts = v; }
+    if (parts > 1) {
+        if (pl.fast_deg == 27) return parts == 4 ? nat_part_launch<27, 4>(pl, p, s) : nat_part_launch<27, 8>(pl, p, s);
+        if (pl.fast_deg == 13) return parts == 4 ? nat_part_launch<13, 4>(pl, p, s) : nat_part_launch<13, 8>(pl, p, s);
+        return parts == 4 ? nat_part_launch<11, 4>(pl, p, s) : nat_part_launch<11, 8>(pl, p, s);
+    }
     p.grp_words = (uint32_t)ldpc_nat_group_words(pl);
     const int groups = (kp.n_frames + 63) / 64, tiles = (pl.N + 63) / 64;
     hipLaunchKernelGGL(nat_load_kernel, dim3(tiles, groups), dim3(256), 0, s, p);

@@ -202,11 +202,14 @@ NAT_CASES = [("QPSK-S_8/9", 4.4, 5), ("QPSK-S_8/9", 3.2, 70), ("QPSK-S_3/5", 1.2
 
 @pytest.mark.parametrize("modcod,ebn0,F", NAT_CASES)
 @pytest.mark.parametrize("early", [False, True])
-def test_ldpc_natural_order_matches_oracle(O, Rx, modcod, ebn0, F, early):
-    """dvbs2hip_set_ldpc_schedule(NATURAL): the reference's sweep order (checks in row order, one lane per frame)
-    against the oracle's ORC_SCHED_NATURAL -- hard decisions, iteration counts and posteriors bit for bit; more
-    than 64 frames = more than one wave, a ragged last group."""
+@pytest.mark.parametrize("parts", [1, 4, 8])
+def test_ldpc_natural_order_matches_oracle(O, Rx, monkeypatch, modcod, ebn0, F, early, parts):
+    """dvbs2hip_set_ldpc_schedule(NATURAL): the reference's sweep order (checks in row order) against the oracle's ORC_SCHED_NATURAL -- hard decisions, iteration
+    counts and posteriors bit for bit -- in its three forms: one lane per frame (64 frames per wave, what large batches get) and a check's edges split over 4 / 8
+    adjacent lanes (16 / 8 frames per wave: the merged minima, the sign word and the forwarded parity posterior come from exchanges inside the wave); more frames
+    than one wave holds, a ragged last group."""
     from dvbs2_amd import lib_binding as B
+    monkeypatch.setenv("DVBS2HIP_NAT_PARTS", str(parts))
     ch = chain(O, modcod)
     _, llr, cw = make_llrs(O, modcod, F, ebn0, seed=21)
     rx = Rx(modcod, max_frames=F, n_ite=8, alpha=0.875, early_stop=early)

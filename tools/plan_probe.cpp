@@ -25,6 +25,12 @@ int main(int argc, char **argv)
         std::printf("hybrid: %d LDS slots per layer %s | parked rows %d, row moves per iteration %d, swaps in the table %d\n", NL, ok ? "ok" : "BROKEN", pl.fast_mode >= 4 ? ldpc_park_nr(pl.fast_mode) : 0,
                     pl.w8_park_moves, swaps);
     }
+    if (!pl.nat_haz.empty()) {      // natural-order kernels: how many checks the hazard planes flag (plane 0: shares a bit with the check before it; plane 1: with one of the NAT_HAZ_WINDOW before it)
+        const size_t hw = pl.nat_haz.size() / 2;
+        int n0 = 0, n1 = 0;
+        for (size_t i = 0; i < hw; i++) { n0 += __builtin_popcount(pl.nat_haz[i]); n1 += __builtin_popcount(pl.nat_haz[hw + i]); }
+        std::printf("natural order: %d of %d checks share a bit with the check before them, %d with one of the %d before them\n", n0, pl.M, n1, NAT_HAZ_WINDOW);
+    }
     if (pl.fast_cu1) {
         // mode 6 (k_ldpc_cu1.hip): replay one cycle of the tables as the kernel reads them -- where every slot's row is said to be (LDS position in THAT layer) against
         // a simulation of the row-keeping waves' swaps from the start state (w8_rows: rows at the positions, then the parity groups' positions, then the slots' rows)
