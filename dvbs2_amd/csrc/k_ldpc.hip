@@ -572,6 +572,19 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     for (int k = 0; k < NRH; k++) pl.w8_rows.push_back(park.reg0[k] < 0 ? 0xFFFFFFFFu : (uint32_t)park.reg0[k]);
                     // and the idle waves' swaps behind the layer tables: [q][NR] x LDS position (0xFF: none)
                     pl.w8_tab.insert(pl.w8_tab.end(), park.srv.begin(), park.srv.end());
+                    if (!cu1) {     // modes 4 / 5 (round 4): the same swaps as ONE 64-bit mask per layer ([q][lo, hi]; bit k = slot k swaps with LDS position k during layer r) -- the
+                                    // row-keeping waves test a bit per slot instead of loading and comparing a table entry per slot (39 dependent scalar loads per layer)
+                        for (int r = 0; r < q; r++) {
+                            unsigned long long m = 0;
+                            for (int k = 0; k < NRH; k++) {
+                                const uint32_t e = park.srv[(size_t)r * NRH + k];
+                                if (e == 0xFFu) continue;
+                                if ((int)e != k) return "LDPC: internal: parked rows: pair k is expected at position k";
+                                m |= 1ull << k;
+                            }
+                            pl.w8_tab.push_back((uint32_t)m); pl.w8_tab.push_back((uint32_t)(m >> 32));
+                        }
+                    }
                     if (cu1) {      // k_ldpc_cu1.hip reads the swaps as bit masks: [q][2 groups][lo, hi], bit k = slot k of the group swaps with its position (= its index) during layer r
                         const int NRG = ldpc_cu1_nrg();
                         for (int r = 0; r < q; r++) for (int gk = 0; gk < 2; gk++) {

@@ -75,6 +75,9 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #define SPA_ABL 0
 #endif
 
+#ifndef W8_KEEP_NOWAIT    // the row-keeping waves take a layer's inner barriers without draining their exchanges
+#define W8_KEEP_NOWAIT 1
+#endif
 #ifndef W8_IDX_E32        // pass 2's selects in the 32-bit encoding (inline asm): see the note there.  Measured without effect (round 4: 5.94 against 5.95 ms, same box), off
 #define W8_IDX_E32 0
 #endif
@@ -160,29 +163,38 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_int *co
         __syncthreads();
         return w[k] != 0;
     };
-    auto moves = [&](int r) {                       // the swaps of layer r: slot k <-> LDS position mv[k] (0xFF: none); same lane, same addresses: read, then write
-        const const_u32 mv = srv + r * NR;
+    // (round 4) the swaps of layer r come as a 64-bit mask (bit k: slot k <-> LDS position k; the plan gives pair k position k) behind the [q][NR] byte table: a scalar bit
+    // test per slot, every register index and LDS offset a compile-time constant.  The per-slot table entries of round 3 were 39 dependent scalar loads per layer
+    // (~3000 cycles of a layer's ~6800), which put these two waves last at the layer's first barrier.
+    const const_u32 swm = srv + q * NR;
+    auto moves = [&](int r) {
+        const uint32_t mlo = swm[2 * r], mhi = swm[2 * r + 1];
         if (on)
 #pragma unroll
         for (int k = 0; k < NR; k++) {
-            const uint32_t e = mv[k];
-            if (e != 0xFFu) {
-                const uint32_t b = e * (uint32_t)W8_ROW;
+            const bool sw = k < 32 ? ((mlo >> k) & 1u) != 0u : ((mhi >> (k - 32)) & 1u) != 0u;
+            if (sw) {
+                const uint32_t b = (uint32_t)k * (uint32_t)W8_ROW;
                 R[k][0] = lxc(b + a0, R[k][0]); R[k][1] = lxc(b + a0 + A1, R[k][1]); R[k][2] = lxc(b + a0 + A2, R[k][2]);
             }
         }
     };
+#if W8_KEEP_NOWAIT
+    auto bar_inner = [&]() { __builtin_amdgcn_s_barrier(); };      // inside a layer: no wait for the exchanges in flight (nobody looks at the rows being swapped before the layer's end barrier)
+#else
+    auto bar_inner = [&]() { __syncthreads(); };
+#endif
     auto layer_barriers = [&](int r) {              // the barriers of one min-sum layer, as the working waves take them
         const const_u32 T = tab + r * LDPC_FAST_STRIDE;
         const uint32_t cinfo = T[28];
         const int ncf = (int)(cinfo & 0xFFu);
         if (ncf > 0) {
-            __syncthreads();                        // every read of the layer precedes its writes
-            __syncthreads();                        // the primary writes are in place
+            bar_inner();                            // every read of the layer precedes its writes
+            bar_inner();                            // the primary writes are in place
             uint32_t prev_lvl = 1u;
             for (int i = (ncf > 1 && ((cinfo >> 21) & 3u) == 1u) ? 2 : 1; i < ncf; i++) {
                 const uint32_t lvl = T[48 + i] >> 8;
-                if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
+                if (lvl != prev_lvl) { bar_inner(); prev_lvl = lvl; }
             }
         }
         __syncthreads();                            // end of the layer

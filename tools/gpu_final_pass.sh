@@ -7,7 +7,7 @@
 #      afterwards: cp gpurun_out/bench.json profiles/<tag>_bench.json; cp gpurun_out/*_1rank.log profiles/; python tools/make_design_tables.py <tag> --write
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/final
 case "${1:-A}" in
-A) bash tools/gpu_round.sh bench kernels prof > gpurun_out/final/round_a.log 2>&1; tail -3 gpurun_out/final/round_a.log
+A) bash tools/gpu_round.sh bench kernels prof profk > gpurun_out/final/round_a.log 2>&1; tail -3 gpurun_out/final/round_a.log
    bash tools/profile_ldpc_variants.sh > gpurun_out/final/profile_lv.log 2>&1; tail -3 gpurun_out/final/profile_lv.log
    python tools/bench_spa.py 4096 8192 3 2>&1 | grep -v amdgpu > gpurun_out/final/bench_spa_4096.txt; python tools/bench_spa.py 16384 32768 3 2>&1 | grep -v amdgpu > gpurun_out/final/bench_spa_steady.txt
    cat gpurun_out/final/bench_spa_4096.txt gpurun_out/final/bench_spa_steady.txt

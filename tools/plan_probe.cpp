@@ -21,7 +21,7 @@ int main(int argc, char **argv)
         bool ok = true;
         for (int r = 0; r < pl.q; r++) for (int j = 0; j < pl.fast_deg; j++) ok &= (((pl.w8_tab[(size_t)r * LDPC_FAST_STRIDE + j] >> 29) & 1u) != 0u) == (j < NL);
         int swaps = 0;
-        if (pl.fast_mode >= 4) for (size_t i = (size_t)pl.q * LDPC_FAST_STRIDE; i < pl.w8_tab.size(); i++) swaps += pl.w8_tab[i] != 0xFFu;
+        if (pl.fast_mode >= 4) for (size_t i = (size_t)pl.q * LDPC_FAST_STRIDE; i < (size_t)pl.q * LDPC_FAST_STRIDE + (size_t)pl.q * ldpc_park_nr(pl.fast_mode); i++) swaps += pl.w8_tab[i] != 0xFFu;
         std::printf("hybrid: %d LDS slots per layer %s | parked rows %d, row moves per iteration %d, swaps in the table %d\n", NL, ok ? "ok" : "BROKEN", pl.fast_mode >= 4 ? ldpc_park_nr(pl.fast_mode) : 0,
                     pl.w8_park_moves, swaps);
     }

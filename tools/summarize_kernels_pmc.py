@@ -52,7 +52,7 @@ lines = ["# rocprofv3 counters of the non-LDPC kernels (%s) -- `python3 tools/pm
          "reports half of the bytes of a coalesced stream on gfx950, WRITE_SIZE the bytes: calibrated in profiles/r02_ldpc_rocprof.md).",
          "VALU busy = SQ_ACTIVE_INST_VALU / (4 SIMDs x SQ_BUSY_CYCLES summed over the chip's SQs) is shown as the share of wave-cycles instead:",
          "valu/wave-cyc = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES, trans = v_exp / v_log / v_rcp / v_sqrt instructions.", "",
-         "VALU issue = (SQ_INSTS_VALU x 2 + trans x 6 more: a 32-lane SIMD retires a wave64 instruction in 2 cycles, a transcendental in 8 -- MI355X_MICROARCH.md constants table, tools/probe_dep.hip; priced at 4 / 8 until the end of round 3) / (1024 SIMDs x SQ_BUSY_CYCLES / 32): the share of the chip's vector-pipe cycles.", "",
+         "VALU issue = (non-transcendental SQ_INSTS_VALU x the price of the kernel's static instruction mix + trans x 8.06) / (1024 SIMDs x SQ_BUSY_CYCLES / 32).  Prices (round 4, profiles/r04_probe_issue.txt, tools/kernel_mix.py): a SIMD issues a plain VOP1 / VOP2 / VOPC instruction every 2.07 cycles, a VOP3 / VOP3P-encoded one every 4.2, one that reads an SGPR every 4.25, one with a literal every 2.6, v_exp / v_log / v_rcp every 8.06 -- whatever the number of waves (round 3 priced everything at 2, round 2 at 4).", "",
          "| kernel | grid | launches | avg us | fabric GB | fabric TB/s | VALU inst | trans inst | VALU issue | LDS inst | VMEM rd / wr | valu / wave-cyc | wait / wave-cyc | LDS bank-conflict / LDS active | L2 hit |",
          "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 rows_json = []
@@ -64,8 +64,10 @@ for key in sorted(dur, key=lambda k: -sum(dur[k])):
     def ratio(a, b): return "%.2f" % (a / b) if b else "-"
     hit = c.get("TCC_HIT_sum", 0); miss = c.get("TCC_MISS_sum", 0)
     busy = c.get("SQ_BUSY_CYCLES", 0) / 32.0
-    issue = (c.get("SQ_INSTS_VALU", 0) * 2.0 + c.get("SQ_INSTS_VALU_TRANS_F32", 0) * 6.0) / (1024.0 * busy) if busy else None
-    rows_json.append(dict(kernel=key[0], grid=key[1], launches=len(dur[key]), avg_us=us, fabric_bytes=fab, valu_issue=issue, counters=c))
+    cpi, how = KM.price_kernel(key[0])
+    tr = c.get("SQ_INSTS_VALU_TRANS_F32", 0)
+    issue = ((c.get("SQ_INSTS_VALU", 0) - tr) * (cpi or 3.0) + tr * 8.06) / (1024.0 * busy) if busy else None
+    rows_json.append(dict(kernel=key[0], grid=key[1], launches=len(dur[key]), avg_us=us, fabric_bytes=fab, valu_issue=issue, cycles_per_valu=cpi, valu_mix=how, counters=c))
     lines.append("| `%s` | %s | %d | %.1f | %.3f | %.2f | %.3g | %.3g | %s | %.3g | %.3g / %.3g | %s | %s | %s | %s |" % (
         key[0], key[1], len(dur[key]), us, fab / 1e9, fab / (us * 1e-6) / 1e12 if us else 0, c.get("SQ_INSTS_VALU", 0), c.get("SQ_INSTS_VALU_TRANS_F32", 0),
         ("%.2f" % issue) if issue is not None else "-", c.get("SQ_INSTS_LDS", 0), c.get("SQ_INSTS_VMEM_RD", 0), c.get("SQ_INSTS_VMEM_WR", 0), ratio(c.get("SQ_ACTIVE_INST_VALU", 0), wc), ratio(c.get("SQ_WAIT_ANY", 0), wc),
