@@ -414,8 +414,9 @@ static bool front_reg_try(const FrontKParams &p, hipStream_t s)
     if (pair_ok && small) hipLaunchKernelGGL((front_reg2_kernel<4>), g, b, 0, s, p);
     else if (pair_ok && big) hipLaunchKernelGGL((front_reg2_kernel<16>), g, b, 0, s, p);
     // one symbol per lane and access: short frames (8 symbols per lane) and the 8PSK normal frame (21600 symbols: 22 per lane = 44 registers
-    // of frame, which leaves the demapper its own; the 32-per-lane forms of round 2 spilled frame symbols and are gone -- a QPSK normal frame
-    // that cannot take the pair kernel, i.e. unaligned sockets or a non-separable mapping, goes to the two-sweep kernel)
+    // of frame, which leaves the demapper its own; round 2's 32-per-lane 8PSK form spilled frame symbols and is gone).  A separable QPSK normal frame that
+    // cannot take the pair kernel (unaligned sockets) still runs the 32-per-lane QPSK form below (no spills since the estimator's finish lost its powf / log10f);
+    // a non-separable mapping goes to the two-sweep kernel
     else if (p.bps == 2 && p.sep && small) hipLaunchKernelGGL((front_reg_kernel<2, 8, true>), g, b, 0, s, p);
     else if (p.bps == 2 && p.sep && big) hipLaunchKernelGGL((front_reg_kernel<2, 32, true>), g, b, 0, s, p);
     else if (p.bps == 2 && small) hipLaunchKernelGGL((front_reg_kernel<2, 8, false>), g, b, 0, s, p);

@@ -21,15 +21,14 @@
 // kernels, and (2) the GENERIC table-driven kernel (per-slot flags, hybrid LDS/global image), which is
 // the fallback for codes the fast kernels reject -- check degree above 27 or more than 16 duplicate
 // edges per layer -- and the subject of `DVBS2HIP_LDPC_PATH=generic` experiments.  Every DVB-S2 code
-// shipped here runs on k_ldpc_wg8.hip (NMS / MS) or k_ldpc_fast.hip (SPA).
+// shipped here runs on k_ldpc_wg8.hip (NMS / MS / SPA; mode 6 of the min-sum decoder: k_ldpc_cu1.hip).
 //
 // Schedule and arithmetic are restated in oracle/dvbs2_oracle.c (ORC_SCHED_QC) and the two
 // must agree bit for bit: tests/test_ldpc_gpu.py.
 //
 // Tuning / experiment knobs (environment, read when a handle is created):
 //   DVBS2HIP_LDPC_PATH=generic        force the generic kernel
-//   DVBS2HIP_LDPC_WG=12               the two-frames-per-12-wave-workgroup NMS kernel of k_ldpc_fast.hip instead of k_ldpc_wg8.hip
-//   DVBS2HIP_LDPC_FAST_MODE=lds|global|static|park   posterior image of the fast kernels (default: lds for N = 16200; for N = 64800 the static hybrid with rows parked in the idle waves' registers (park), static = without them)
+//   DVBS2HIP_LDPC_FAST_MODE=lds|global|static|park|park4|cu1   posterior image of the fast kernels (default: lds for N = 16200; for N = 64800 the static hybrid with rows parked in the idle waves' registers (park), static = without them)
 //   DVBS2HIP_LDPC_LOCK_DUPS=0         static hybrid without forcing the duplicate-edge bit-groups into LDS (then the generic kernel runs)
 //   DVBS2HIP_LDPC_C2V=lds|global, DVBS2HIP_LDPC_LDS_GROUPS=n   generic kernel storage policy
 //   DVBS2HIP_LDPC_BLOCKS_PER_CU, DVBS2HIP_LDPC_GRID_MAX, DVBS2HIP_LDS_LIMIT   occupancy / scaling experiments
@@ -70,6 +69,8 @@ static bool plan_parked(const std::vector<std::vector<int>> &mult, const std::ve
                         ParkPlan &out, std::string &why, const std::vector<char> *nopair = nullptr)
 {
     const int n_groups = (int)mult.size();
+    // the row-keeping waves hand their NRmax rows back through LDS positions 0 .. NRmax-1 at the end of a frame (w8_park_server, cu1_keeper): there have to be that many
+    if (n_pos < NRmax) { why = "fewer LDS positions than parked rows (DVBS2HIP_LDS_LIMIT too small for this mode)"; return false; }
     uint32_t rng = 2463534242u;
     auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return rng >> 4; };
     std::vector<int> touches(n_groups, 0);

@@ -1,6 +1,6 @@
 // a1, production kernel -- layered NMS, one frame per EIGHT-wave workgroup (six waves work), two
-// independent workgroups per CU.  Same schedule and arithmetic as k_ldpc_fast.hip / the oracle
-// (bit-exact), rebuilt around what a per-phase cycle profile of that kernel showed on MI355X
+// independent workgroups per CU.  Same schedule and arithmetic as the oracle's ORC_SCHED_QC
+// (bit-exact), built around what a per-phase cycle profile of its round-1 predecessor showed on MI355X
 // (docs/negative_results.md): 30 % of its time was frame I/O issued as ~180 dependent HBM round trips,
 // 12 % the replay of same-layer duplicate edges through global memory, and the layer loop itself
 // a long per-wave instruction stream (~610 VALU + ~250 scalar per layer; one wave issues one instruction
@@ -75,6 +75,9 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #define SPA_ABL 0
 #endif
 
+#ifndef W8_FAST_OUT       // output loops of their own for the bits socket alone and for the fused chain (buffer descriptors per frame, scalar descrambling)
+#define W8_FAST_OUT 1
+#endif
 #ifndef W8_KEEP_NOWAIT    // the row-keeping waves take a layer's inner barriers without draining their exchanges
 #define W8_KEEP_NOWAIT 1
 #endif
@@ -883,36 +886,72 @@ ldpc_wg8_kernel(const LdpcKParams p)
             }
         };
         const int nl_out = p.post ? nl : nl_info, ng_out = p.post ? ng : ng_info;
-        if (role >= 0) {
-            for (int l0 = 0; l0 < nl_out; l0 += W8_IO) {
-                float v[W8_IO];
+        // (round 4) The two output forms every production call uses get loops of their own: `emit` tests four wave-uniform pointers per row and forms 64-bit
+        // addresses per lane (the frame index of the min-sum kernel lives in a vector register), ~110 instructions per row and wave -- the output phase was 7 % of
+        // the launch, as long as 17 layers.  Here the frame's output block is a buffer descriptor made once per frame on the scalar unit (the row offset goes into the
+        // instruction's scalar offset, a lane beyond the block is dropped by the range check: no compare, no address arithmetic on the vector unit) and the chain's
+        // descrambling is ONE scalar XOR of the wave's ballot with the 64 PRBS bits of its stretch of the row.
+        const int fu = __builtin_amdgcn_readfirstlane(f);
+        const bool out_plain = p.bits && !p.post && !p.info_out && !p.packed, out_chain = p.info_out && p.packed && !p.bits && !p.post;
+        const uint32_t vo_out = act ? (uint32_t)to * 4u : W8_OOB;      // (the lanes past the 360th check store nowhere)
+        const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(out_plain ? (void *)(p.bits + (size_t)fu * p.K) : (void *)gwork, 0, out_plain ? p.K * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_info = __builtin_amdgcn_make_buffer_rsrc(out_chain ? (void *)(p.info_out + (size_t)fu * p.K_info) : (void *)gwork, 0, out_chain ? p.K_info * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_pack = __builtin_amdgcn_make_buffer_rsrc(out_chain ? (void *)(p.packed + (size_t)fu * n_words) : (void *)gwork, 0, out_chain ? n_words * 4 : 0, 0x00020000);
+        const int nb_w = role * 64 + 64 <= LDPC_Z ? 8 : (LDPC_Z - role * 64) / 8;      // whole bytes of a row this wave's ballot holds
+        const uint32_t pk_vo = (role >= 0 && lo < nb_w) ? (uint32_t)(role * 8 + lo) : W8_OOB, pk_sh = (uint32_t)(lo & 3) * 8u;
+        const bool pk_hi = lo >= 4;
+        auto emit_plain = [&](int g, float Lv) {       // bits socket alone (dvbs2hip_ldpc_decode_siho*, the bench line)
+            __builtin_amdgcn_raw_buffer_store_b32(Lv < 0.f ? 1u : 0u, rs_bits, vo_out, (uint32_t)g * (uint32_t)W8_ROW, 2);
+        };
+        auto emit_chain = [&](int g, float Lv) {       // fused chain: packed hard decisions for the BCH stage + descrambled information bits as int32 (rows of information groups only)
+            const unsigned long long m = __ballot(Lv < 0.f);                      // (inactive lanes hold 0.f)
+            const const_u32 pq = prbs_c + 2 * (g * 6 + role);
+            const unsigned long long d = m ^ ((unsigned long long)pq[0] | ((unsigned long long)pq[1] << 32));
+            uint32_t bit;
+            asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(bit) : "s"(d));             // this lane's bit of the descrambled word (the 64-bit mask is the select's condition)
+            // (the whole offset in the vector register: the range check that drops the bits behind K_info then sees all of it)
+            __builtin_amdgcn_raw_buffer_store_b32(bit, rs_info, vo_out + (uint32_t)g * (uint32_t)W8_ROW, 0u, 2);
+            const uint32_t half = pk_hi ? (uint32_t)(m >> 32) : (uint32_t)m;
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(half >> pk_sh), rs_pack, pk_vo, (uint32_t)g * (uint32_t)(LDPC_Z / 8), 0);
+        };
+        auto run_out = [&](auto &&em) {
+            if (role >= 0) {
+                for (int l0 = 0; l0 < nl_out; l0 += W8_IO) {
+                    float v[W8_IO];
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) v[k] = act ? lld((uint32_t)(l0 + k < nl_out ? l0 + k : nl_out - 1) * W8_ROW + t4) : 0.f;
+                    for (int k = 0; k < W8_IO; k++) v[k] = act ? lld((uint32_t)(l0 + k < nl_out ? l0 + k : nl_out - 1) * W8_ROW + t4) : 0.f;
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) if (l0 + k < nl_out) emit((int)rows[l0 + k], v[k]);
+                    for (int k = 0; k < W8_IO; k++) if (l0 + k < nl_out) em((int)rows[l0 + k], v[k]);
+                }
+                for (int l0 = 0; l0 < ng_out; l0 += W8_IO) {
+                    float v[W8_IO];
+#pragma unroll
+                    for (int k = 0; k < W8_IO; k++) v[k] = act ? gld(t4, grow0 + (uint32_t)(l0 + k < ng_out ? l0 + k : ng_out - 1) * W8_ROW) : 0.f;
+#pragma unroll
+                    for (int k = 0; k < W8_IO; k++) if (l0 + k < ng_out) em((int)rows[nl + l0 + k], v[k]);
+                }
             }
-            for (int l0 = 0; l0 < ng_out; l0 += W8_IO) {
-                float v[W8_IO];
+            if (w8_parked(MODE)) {
+                constexpr int NRP = ldpc_park_nr(MODE);
+                // the rows parked in the idle waves' registers: handed over through LDS positions 0 .. NR-1 (every LDS row has been read)
+                __syncthreads();
+                __syncthreads();
+                const const_u32 srow = rows + nl + ng + q;
+                for (int l0 = 0; l0 < NRP; l0 += W8_IO) {
+                    float v[W8_IO];
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) v[k] = act ? gld(t4, grow0 + (uint32_t)(l0 + k < ng_out ? l0 + k : ng_out - 1) * W8_ROW) : 0.f;
+                    for (int k = 0; k < W8_IO; k++) v[k] = act ? lld((uint32_t)(l0 + k < NRP ? l0 + k : NRP - 1) * W8_ROW + t4) : 0.f;
 #pragma unroll
-                for (int k = 0; k < W8_IO; k++) if (l0 + k < ng_out) emit((int)rows[nl + l0 + k], v[k]);
+                    for (int k = 0; k < W8_IO; k++) if (l0 + k < NRP && srow[l0 + k] != 0xFFFFFFFFu) em((int)srow[l0 + k], v[k]);
+                }
             }
-        }
-        if (w8_parked(MODE)) {
-            constexpr int NRP = ldpc_park_nr(MODE);
-            // the rows parked in the idle waves' registers: handed over through LDS positions 0 .. NR-1 (every LDS row has been read)
-            __syncthreads();
-            __syncthreads();
-            const const_u32 srow = rows + nl + ng + q;
-            for (int l0 = 0; l0 < NRP; l0 += W8_IO) {
-                float v[W8_IO];
-#pragma unroll
-                for (int k = 0; k < W8_IO; k++) v[k] = act ? lld((uint32_t)(l0 + k < NRP ? l0 + k : NRP - 1) * W8_ROW + t4) : 0.f;
-#pragma unroll
-                for (int k = 0; k < W8_IO; k++) if (l0 + k < NRP && srow[l0 + k] != 0xFFFFFFFFu) emit((int)srow[l0 + k], v[k]);
-            }
-        }
+        };
+#if W8_FAST_OUT
+        if (out_plain) run_out(emit_plain);
+        else if (out_chain) run_out(emit_chain);
+        else
+#endif
+            run_out(emit);
         if (first) s_misc[9] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[LDPC_FRAME_CTR], 1u) + gridDim.x) : f + (int)gridDim.x;
         __syncthreads();     // the posterior image is reused by the next frame of this workgroup
         f = SPA ? __builtin_amdgcn_readfirstlane(s_misc[9]) : s_misc[9];      // (uniform: the frame's base addresses stay on the scalar unit)

@@ -303,8 +303,8 @@ static void inter_ws_free(inter_ws *w) { free(w->L); free(w->msg); free(w->v2c);
 
 /* one vector = the ORC_W frames of a block (GCC vector extensions: one zmm register with AVX-512, two ymm with AVX2); the running
  * minima and the sign word stay in registers across a check's edges */
-typedef float vf32 __attribute__((vector_size(4 * ORC_W), aligned(64)));
-typedef int32_t vi32 __attribute__((vector_size(4 * ORC_W), aligned(64)));
+typedef float vf32 __attribute__((vector_size(4 * ORC_W), aligned(4 * ORC_W)));       /* (aligned to its own size: the arrays are indexed at 4 ORC_W-byte strides, 32 bytes in the portable AVX2 build) */
+typedef int32_t vi32 __attribute__((vector_size(4 * ORC_W), aligned(4 * ORC_W)));
 #define v_sel(m, a, b) ((vf32)(((vi32)(a) & (m)) | ((vi32)(b) & ~(m))))      /* m ? a : b, lane by lane (a macro: a 64-byte vector argument would go through memory in an AVX2 build) */
 
 static __attribute__((noinline)) void decode_inter_block(const orc_ldpc *c, const float *llr, int nf, int n_ite, float alpha, int32_t *bits, inter_ws *ws)
