@@ -4,6 +4,8 @@ path (other than the LDPC decoder) and per workload size -- launches of one kern
 duration, calibrated fabric bytes (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; MI355X_MICROARCH.md HBM section), instruction
 counts and the busy / wait shares that say what bounds it."""
 import collections, csv, glob, hashlib, json, os, sys
+sys_path_fix = __import__('sys').path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+import kernel_mix as KM
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 OUT = os.path.join(ROOT, "gpurun_out")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"

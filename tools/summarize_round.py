@@ -15,7 +15,7 @@ L = ["# Round summary (%s, one MI355X; sources: `profiles/%s_bench.json`, `resul
      "| kernel (row) | workload | time | algorithmic GB/s | frac of 8 TB/s | of the measured copy rate |", "|---|---|---|---|---|---|"]
 def row(name, wl, ms, gbs):
     L.append("| %s | %s | %.3f ms | %.0f | %.2f | %.2f |" % (name, wl, ms, gbs, gbs / 8000.0, gbs / copy if copy else 0))
-row("`%s` (a1, headline)" % r["kernel"], "4096 frames N=64800 8/9, 10 iterations, `bench.py`", r["avg_launch_ms"], r["achieved"])
+row("`%s` (a1, headline)" % r["kernel"], "4096 frames N=64800 8/9, 10 iterations, `bench.py`", r["avg_launch_ms"], r.get("algorithmic_GBps", r["achieved"]))
 for name, c in k.items():
     if isinstance(c, dict) and "kernels" in c:
         for kk, v in c["kernels"].items():
@@ -36,7 +36,7 @@ for name, c in k.items():
             if isinstance(v, dict):
                 row(kk + " (N4)", name, v["call_ms"], v["GBps_16B_per_sample"])
 bd = r.get("bounded")
-L += ["", "LDPC kernel, what physically bounds it (`roofline.bounded`): fabric traffic %.1f GB per launch = %.2f TB/s = %.2f of the %.1f TB/s Infinity-Cache rate; vector pipes %.2f busy (2 cycles per wave64 instruction);"
+L += ["", "LDPC kernel, what physically bounds it (`roofline.bounded`): fabric traffic %.1f GB per launch = %.2f TB/s = %.2f of the %.1f TB/s Infinity-Cache rate; vector issue port %.2f busy (instruction prices of profiles/r04_probe_issue.txt);"
       % (r["traffic"] / 1e9, bd["achieved"] / 1e3, bd["frac"], bd["peak"] / 1e3, bd["valu"]["frac"]) if bd else "LDPC kernel: no valid PMC traffic file for this kernel source.",
       "bytes that must cross HBM (`roofline.hbm_true`): %.2f GB per launch = %.0f GB/s = %.3f of peak." % (r["hbm_true"]["bytes_per_launch"] / 1e9, r["hbm_true"]["achieved"], r["hbm_true"]["frac"]),
       "Early stop (the reference's default), untimed for `value`: %s frames/s." % ", ".join("%.0f k at %s" % (v / 1e3, kk) for kk, v in b["extra"]["early_stop_fps"].items()),
