@@ -41,3 +41,20 @@ def test_no_wide_buffer_store_takes_a_scalar_offset_register():
     assert len(rep) >= 10 and rep["k_ldpc_wg8"][0] >= 40, rep        # the layer kernels do store 12 / 16 bytes at a time: the scan sees them
     assert not [(tu, bad) for tu, (_, _, bad) in rep.items() if bad], rep
     assert not [(tu, sgpr) for tu, (_, sgpr, _) in rep.items() if sgpr], rep
+
+
+def test_layer_loop_instruction_mix_is_read_from_the_code_object():
+    """tools/kernel_mix.py prices a kernel's vector instructions by encoding (profiles/r04_probe_issue.txt: 2.07 SIMD cycles plain VOP1 / VOP2 / VOPC, 4.2 VOP3 / VOP3P encoding, 4.25
+    with an SGPR operand, 2.6 with a literal, 8.06 transcendental); bench.py's roofline.bounded.valu and the profile summaries multiply SQ_INSTS_VALU by that price.  The min-sum
+    layer loop is made of the expensive kind: nearly half of it VOP3-encoded, 3.2 .. 3.5 cycles per instruction; no transcendental in it."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_mix as KM
+    from dvbs2_amd import build
+    build.build_lib()
+    cpi, how = KM.price_kernel("ldpc_wg8_kernel<27,5>")
+    assert how["scope"] == "layer loop" and how["mix"]["trans"] == 0 and 3.1 < cpi < 3.6, (cpi, how)
+    n = sum(how["mix"].values())
+    assert 500 < n < 800 and 0.40 < how["mix"]["vop3"] / n < 0.55
+    cpi_spa, how_spa = KM.price_kernel("ldpc_wg8_kernel<27,0,true>")
+    assert how_spa["mix"]["trans"] >= 100 and cpi_spa < cpi + 0.5

@@ -45,3 +45,27 @@ def test_normal_frame_plan(probe, spa, mode, want, lds_slots, parked, glob_rows)
 
 def test_short_frame_plan_is_all_lds(probe):
     assert "mode 0 wg8 1" in probe("QPSK-S_8/9").splitlines()[0]
+
+
+def test_mode6_one_frame_per_cu_plan(probe):
+    """Mode 6 (k_ldpc_cu1.hip, DVBS2HIP_LDPC_FAST_MODE=cu1): every bit-group row of the N = 64800 8/9 code on chip -- 108 LDS positions + 72 pairs of rows that share a position and
+    a register slot of the row-keeping waves (a MAXIMUM matching: greedy finds 71 of the 72 pairs among the information rows, so parity rows pair too).  tools/plan_probe.cpp
+    replays one cycle of the tables the way the kernel reads them: every slot of every layer is an LDS access whose base is the position that holds its row in THAT layer, the
+    duplicate edges are the first slots (conflict entry i = slot i), p_c / p_{c-1} the last two, no swap touches a row the current layer uses, the cycle closes, and the
+    start-of-frame placement of the parity groups (position or register slot) is consistent."""
+    out = probe("QPSK-N_8/9", False, "cu1")
+    head = out.splitlines()[0]
+    assert "plan: ''" in head and "mode 6 wg8 1 dups_in_lds 1" in head and "LDS rows 108 (info 108) global rows 0" in head, head
+    cu1 = [l for l in out.splitlines() if l.startswith("cu1:")][0]
+    assert cu1 == "cu1: positions 108 pairs 72 swaps per iteration 144 max duplicate edges per layer 3 tables ok", cu1
+    # the sum-product decoder has no such mode: the request falls back to the parked-row hybrid
+    assert "mode 4 wg8 1" in probe("QPSK-N_8/9", True, "cu1").splitlines()[0]
+
+
+def test_natural_order_hazard_planes_are_empty_for_the_dvbs2_codes(probe):
+    """k_ldpc_nat.hip requests a check's posteriors NAT_AHEAD (24) checks before it is computed, which is legal only if no check shares a bit with one of the 25 before
+    it (cyclically, the forwarded parity bit aside): the host's second hazard plane.  It is empty for every code of the library (a code for which it is not gets the
+    one-check-ahead kernel behind a drain)."""
+    for modcod in ("QPSK-N_8/9", "QPSK-S_8/9", "QPSK-S_3/5", "32APSK-S_3/4"):
+        line = [l for l in probe(modcod).splitlines() if l.startswith("natural order:")][0]
+        assert " 0 of " in line and ", 0 with one of the 25 before them" in line, line
