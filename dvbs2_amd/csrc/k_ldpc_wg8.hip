@@ -75,6 +75,9 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #define SPA_ABL 0
 #endif
 
+#ifndef W8_DELTA_REG      // LDS-only image: new - old of the duplicate-edge slots kept from the passes instead of rebuilt behind the barrier
+#define W8_DELTA_REG 1
+#endif
 #ifndef W8_FAST_OUT       // output loops of their own for the bits socket alone and for the fused chain (buffer descriptors per frame, scalar descrambling)
 #define W8_FAST_OUT 1
 #endif
@@ -639,6 +642,14 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 float v[DEG];
                 uint32_t w[DEG];
                 constexpr int KD = MODE == 0 ? ldpc_w8_kd(DEG) : DEG;       // LDS-only image: duplicate edges sit in slots < KD (plan), the others are primary
+                // (round 4) LDS-only image: conflict entry i is slot i < KDD (plan), so what a duplicate edge adds in the replay, new - old message, is kept from the passes
+                // (one subtraction per slot) instead of being rebuilt from the packed states behind the barrier (two unpacks = 8 vector instructions per entry on the
+                // critical path between the layer's last two barriers: the replay was 18 % of a short-frame launch).  The hybrid images have no registers for it.
+                constexpr bool DREG = W8_DELTA_REG && MODE == 0;
+                constexpr int KDD = ldpc_w8_kd(DEG);
+                float dold[KDD];
+#pragma unroll
+                for (int j = 0; j < KDD; j++) dold[j] = 0.f;
                 const float c1o = nx1, c2o = nx2;
                 const uint32_t pko = __float_as_uint(nxk);
                 float mn1 = INFINITY, mn2 = INFINITY, cst1 = 0.f, cst2 = 0.f;
@@ -690,6 +701,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     for (int j = 0; j < DEG; j++) {
                         const float mag = (idxo == (uint32_t)j) ? c1o : c2o;
                         const float old = and_or(pko << ((32u - DEG) + j), SB, mag);          // sign bit of slot j | magnitude (>= 0)
+                        if (DREG && j < KDD) dold[j] = old;
                         float x = v[j] - old;
                         if (j == DEG - 1 && mask0) x = INFINITY;
                         v[j] = x;
@@ -731,6 +743,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         idxn = ismin ? (uint32_t)j : idxn;
                         asm("" : "+v"(idxn));                     // select now: the comparison mask dies here instead of piling up 27 SGPR pairs
 #endif
+                        if (DREG && j < KDD) dold[j] = nw - dold[j];
                         const bool pr = ((prim >> j) & 1u) != 0u;                             // wave-uniform
                         const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
                         if (w8_slot_lds(MODE, j)) {
@@ -762,17 +775,33 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     auto delta_of = [&](uint32_t j) { return w8_unpack<DEG>(cst1, cst2, pkn, j, SB) - w8_unpack<DEG>(c1o, c2o, pko, j, SB); };
                     const uint32_t j0 = (cinfo >> 8) & 31u, j1 = (cinfo >> 16) & 31u, lvl1 = (cinfo >> 21) & 3u;
                     const bool two = ncf > 1 && lvl1 == 1u;         // entry 1 commutes with entry 0 (another bit-group)
+                    // (round 4, LDS-only image) addresses and deltas of the first two entries are ready BEFORE the barrier: behind it only load, add, store remain
+                    // (the hybrid images keep round 3's order -- everything behind the barrier: hoisting it measured 1 % SLOWER there, 5.72 against 5.67 ms)
+                    uint32_t o0 = 0, b0 = 0, o1 = 0, b1 = 0;
+                    float d0 = 0.f, d1 = 0.f;
+                    if (DREG) { o0 = addr_of(ce0); b0 = (ce0 >> 11) & 0x3FFFFu; o1 = addr_of(ce1); b1 = (ce1 >> 11) & 0x3FFFFu; d0 = dold[0]; d1 = dold[KDD > 1 ? 1 : 0]; }
                     __syncthreads();                                // the primary writes of the layer are in place
                     if (act) {
-                        const uint32_t o0 = addr_of(ce0), b0 = (ce0 >> 11) & 0x3FFFFu, o1 = addr_of(ce1), b1 = (ce1 >> 11) & 0x3FFFFu;
+                        if (!DREG) { o0 = addr_of(ce0); b0 = (ce0 >> 11) & 0x3FFFFu; o1 = addr_of(ce1); b1 = (ce1 >> 11) & 0x3FFFFu; d0 = delta_of(j0); d1 = delta_of(j1); }
                         float L0, L1 = 0.f;
                         if (MODE != 1) { L0 = lld(o0 + b0); if (two) L1 = lld(o1 + b1); }
                         else { L0 = gld(o0, b0); if (two) L1 = gld(o1, b1); }
-                        const float n0 = L0 + delta_of(j0), n1 = L1 + delta_of(j1);
+                        const float n0 = L0 + d0, n1 = L1 + d1;
                         if (MODE != 1) { lst(o0 + b0, n0); if (two) lst(o1 + b1, n1); }
                         else { gst(o0, b0, n0); if (two) gst(o1, b1, n1); }
                     }
                     uint32_t prev_lvl = 1u;
+                    if (DREG) {
+#pragma unroll
+                        for (int i = 1; i < KDD; i++) {
+                            if (i < (two ? 2 : 1)) continue;
+                            if (i >= ncf) break;
+                            const uint32_t e = T[32 + i], lvl = T[48 + i] >> 8;
+                            const uint32_t off = addr_of(e), base = (e >> 11) & 0x3FFFFu;
+                            if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
+                            if (act) { const float Lv = lld(off + base); lst(off + base, Lv + dold[i]); }
+                        }
+                    } else
                     for (int i = two ? 2 : 1; i < ncf; i++) {
                         const uint32_t e = T[32 + i], meta = T[48 + i];
                         const uint32_t j = meta & 31u, lvl = meta >> 8;
