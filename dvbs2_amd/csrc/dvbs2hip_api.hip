@@ -349,6 +349,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         CREATE_FAIL(DVBS2HIP_EHIP, h->err);
     if (lp.fast_wg8) {
         if (upload(h, &lp.d_w8_tab, lp.w8_tab.data(), lp.w8_tab.size()) || upload(h, &lp.d_w8_rows, lp.w8_rows.data(), lp.w8_rows.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+        if (!lp.w8_atab.empty() && upload(h, &lp.d_w8_atab, lp.w8_atab.data(), lp.w8_atab.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
         CREATE_HIP(hipMalloc((void **)&lp.d_cu_ctr, (LDPC_CU_CTR_WORDS + LDPC_PROF_WORDS) * sizeof(uint32_t)));
         CREATE_HIP(hipMemset(lp.d_cu_ctr, 0, LDPC_CU_CTR_WORDS * sizeof(uint32_t)));
     }
@@ -535,7 +536,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
                         h->sfm.yprev[0], h->sfm.yprev[1], h->sfm.keys, h->sfm.metric, h->sfm.frag, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift, h->d_hist_zero, h->d_hist_junk, h->d_red, h->bch.d_prbs_rw};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     if (h->lr_err_host) (void)hipHostFree(h->lr_err_host);
-    void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
+    void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_atab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);

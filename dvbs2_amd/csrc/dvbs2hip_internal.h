@@ -66,6 +66,7 @@ struct LdpcKParams {
     uint32_t *cu_ctr;          // 8-wave workgroups: per-CU arrival counter (zeroed before the launch) or null
     struct {                   // k_ldpc_wg8.hip
         const uint32_t *tab;   // [q][LDPC_FAST_STRIDE]: byte shift | byte offset of the bit-group row << 11 | LDS flag << 29; modes 4 / 5: then [q][NR] the idle waves' swaps (LDS position or 0xFF)
+        const uint32_t *atab;  // per-lane address table (LdpcPlan::w8_atab) or null
         const uint32_t *rows;  // bit-group of LDS row l (nl of them), then of global row l (ng), then where the q parity groups live; modes 4 / 5: then the bit-group in register slot k (NR)
         uint32_t st_base;      // byte offset of the packed c->v state in the workgroup's global slot
         uint32_t lds_junk;     // byte offset of the write-only LDS row (the +inf row of padded codes follows it)
@@ -104,6 +105,10 @@ struct LdpcPlan {             // host-side description, built once per handle
     bool w8_dups_in_lds = false;  // static hybrid: every bit-group with two edges in one layer is LDS-resident
     std::vector<uint32_t> w8_tab, w8_rows;
     uint32_t *d_w8_tab = nullptr, *d_w8_rows = nullptr;
+    // (round 4) per-lane address table of the min-sum layer: [q][ceil(deg / 4)][LDPC_AT_LANES][4] dwords -- for slot j of layer r and check t the LDS byte address of the
+    // posterior (LDS slot) or its rotated byte offset inside the row (global slot): what the layer loop formed with 3-4 vector instructions per slot and iteration
+    std::vector<uint32_t> w8_atab;
+    uint32_t *d_w8_atab = nullptr;
     uint32_t w8_st_base = 0, w8_lds_junk = 0;
     int w8_lds_bytes = 0, w8_gwork_words = 0, w8_nl_info = 0, w8_nl = 0, w8_ng_info = 0, w8_ng = 0;
     int w8_park_moves = 0;        // mode 4: row moves between LDS and the idle waves' registers per iteration
@@ -112,6 +117,7 @@ struct LdpcPlan {             // host-side description, built once per handle
 constexpr int LDPC_PROF_WORDS = 1024 * 64;   // development aid (LDPC_PHASE_PROF builds): per-wave phase timers
 constexpr int LDPC_CU_CTR_WORDS = 4096 + 64;   // [0, 4096): arrivals per CU, key = XCC_ID << 8 | SE_ID << 5 | SH_ID << 4 | CU_ID; [4096]: frames handed out (work queue)
 constexpr int LDPC_FRAME_CTR = 4096;
+constexpr int LDPC_AT_LANES = 384;      // lanes per row of the address table (6 waves; lanes 360 .. 383 hold the junk row / an offset that is dropped)
 constexpr int LDPC_FAST_STRIDE = 64;   // dwords per layer: 27 entries | prim mask | conflict info | conflict entries 0, 1 | slots with a duplicate edge | 16 conf entries | 16 conf meta
 constexpr int LDPC_FAST_MAXC = 16;
 // modes 4 / 5 (k_ldpc_wg8.hip): bit-group rows parked in the registers of a workgroup's two idle waves (3 VGPRs per row and lane) and LDS slots per

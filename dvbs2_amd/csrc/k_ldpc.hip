@@ -542,6 +542,24 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 if (nc > 0 && (T8[48] >> 8) != 1u) return "LDPC: internal: first conflict entry is not of level 1";
                 if (pl.fast_mode == 0 || spa || cu1) for (int i = 0; i < nc; i++) if ((T8[48 + i] & 31u) != (uint32_t)i) return "LDPC: internal: conflict entry i is not slot i";
             }
+            if (!spa && pl.fast_mode == 0) {      // per-lane address table of the min-sum layer, LDS-only image (k_ldpc_wg8.hip, W8_ATAB)
+                const int NW4 = (pl.fast_deg + 3) / 4;
+                pl.w8_atab.assign((size_t)q * NW4 * LDPC_AT_LANES * 4, 0u);
+                for (int r = 0; r < q; r++) {
+                    const uint32_t *T8 = &pl.w8_tab[(size_t)r * LDPC_FAST_STRIDE];
+                    for (int j = 0; j < 4 * NW4; j++)
+                        for (int t = 0; t < LDPC_AT_LANES; t++) {
+                            uint32_t v = 0x7FFFF000u;                                        // lanes past the 360th check / padding slots: an offset every buffer access drops
+                            if (j < pl.fast_deg) {
+                                const uint32_t e = T8[j], shift = e & 0x7FFu, base = (e >> 11) & 0x3FFFFu;
+                                const bool il = pl.fast_mode == 0 || (hyb && j < NLH);            // (what the kernel takes for an LDS slot: w8_slot_lds; a NULL slot's entry carries no flag)
+                                if (t < LDPC_Z) { const uint32_t d = ((uint32_t)t * 4u + (uint32_t)LDPC_Z * 4u - shift) % ((uint32_t)LDPC_Z * 4u); v = il ? d + base : d; }
+                                else if (il) v = base;                                      // an LDS slot of an idle lane: any address inside the allocation (never accessed: `act`)
+                            }
+                            pl.w8_atab[(((size_t)r * NW4 + j / 4) * LDPC_AT_LANES + t) * 4 + (j & 3)] = v;
+                        }
+                }
+            }
             {   // image rows in storage order: LDS rows then global rows (bit-groups ascend inside each: info first)
                 std::vector<int> lrow, grow;
                 for (int g = 0; g < pl.n_groups; g++) ((pl.fast_mode == 0 || (hyb && glds[g])) ? lrow : grow).push_back(g);

@@ -587,7 +587,7 @@ ldpc_cu1_kernel(const LdpcKParams p)
 hipError_t ldpc_cu1_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
     p.cu_ctr = pl.d_cu_ctr;
-    p.w8.tab = pl.d_w8_tab; p.w8.rows = pl.d_w8_rows;
+    p.w8.tab = pl.d_w8_tab; p.w8.rows = pl.d_w8_rows; p.w8.atab = nullptr;
     p.w8.st_base = pl.w8_st_base; p.w8.lds_junk = pl.w8_lds_junk; p.w8.lds_bytes = pl.w8_lds_bytes; p.w8.pad = 0;
     p.w8.nl_info = pl.w8_nl_info; p.w8.nl = pl.w8_nl; p.w8.ng_info = pl.w8_ng_info; p.w8.ng = pl.w8_ng;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;

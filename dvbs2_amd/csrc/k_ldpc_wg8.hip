@@ -75,6 +75,9 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #define SPA_ABL 0
 #endif
 
+#ifndef W8_ATAB           // min-sum layer: the slots' addresses come from a per-lane table (L2-resident, requested behind the previous layer's last store) instead of the vector ALU
+#define W8_ATAB 1
+#endif
 #ifndef W8_DELTA_REG      // LDS-only image: new - old of the duplicate-edge slots kept from the passes instead of rebuilt behind the barrier
 #define W8_DELTA_REG 1
 #endif
@@ -350,6 +353,10 @@ ldpc_wg8_kernel(const LdpcKParams p)
     auto lst = [&](uint32_t a, float v) { *w8_lds(a) = v; };
     const int nl_info = p.w8.nl_info, nl = p.w8.nl, ng_info = p.w8.ng_info, ng = p.w8.ng;
     const uint32_t grow0 = 2u * W8_ROW;                      // global image: [junk row][+inf row][group rows ..]
+    // (LDS-only image only: on the hybrid image of the normal frames the table's loads queue behind the global rows' and the kernel is 19 % SLOWER, 6.73 against 5.65 ms)
+    constexpr bool ATAB = W8_ATAB && !SPA && MODE == 0;
+    const __amdgpu_buffer_rsrc_t rs_at = __builtin_amdgcn_make_buffer_rsrc((void *)(ATAB ? p.w8.atab : (const uint32_t *)p.w8.tab), 0, ATAB ? p.q * ((DEG + 3) / 4) * (LDPC_AT_LANES * 16) : 0, 0x00020000);
+    const uint32_t at_vo = (uint32_t)(role >= 0 ? t : 0) * 16u;
     constexpr bool FWD = w8_hybrid(MODE);                    // parity chain forwarded in a register (plan: p_c at slot DEG-2, p_{c-1} at DEG-1, both global)
 #ifdef LDPC_PHASE_PROF
     uint32_t prof[12];
@@ -433,6 +440,20 @@ ldpc_wg8_kernel(const LdpcKParams p)
         uint32_t TE[32];
 #pragma unroll
         for (int j = 0; j < 32; j++) TE[j] = tab[j];
+        // (round 4) the slots' addresses of the NEXT layer, 16 bytes (four slots) per load from the per-lane table
+        constexpr int NW4 = (DEG + 3) / 4;
+        uint32_t w[4 * NW4];                        // (loop-carried: the addresses of the current layer until its stores have been issued, then the next layer's)
+        auto at_request = [&](int rl) {
+            typedef uint32_t at_u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int g4 = 0; g4 < NW4; g4++) {
+                const at_u32x4 q4 = __builtin_amdgcn_raw_buffer_load_b128(rs_at, at_vo, (uint32_t)((rl * NW4 + g4) * (LDPC_AT_LANES * 16)), 0);
+                w[4 * g4] = q4.x; w[4 * g4 + 1] = q4.y; w[4 * g4 + 2] = q4.z; w[4 * g4 + 3] = q4.w;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < 4 * NW4; j++) w[j] = 0u;
+        if (ATAB && role >= 0) at_request(0);
         while (it < p.n_ite) {
             for (int r = 0; r < q; r++) {
                 const const_u32 T = tab + r * LDPC_FAST_STRIDE;
@@ -640,7 +661,6 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     continue;
                 }
                 float v[DEG];
-                uint32_t w[DEG];
                 constexpr int KD = MODE == 0 ? ldpc_w8_kd(DEG) : DEG;       // LDS-only image: duplicate edges sit in slots < KD (plan), the others are primary
                 // (round 4) LDS-only image: conflict entry i is slot i < KDD (plan), so what a duplicate edge adds in the replay, new - old message, is kept from the passes
                 // (one subtraction per slot) instead of being rebuilt from the packed states behind the barrier (two unpacks = 8 vector instructions per entry on the
@@ -663,8 +683,16 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                     for (int j = 0; j < DEG; j++) {
-                        const uint32_t d = t4 - (E[j] & 0x7FFu);
                         const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
+                        if (ATAB) {
+                            // (round 4) the address comes from the per-lane table (requested behind the previous layer's last store): an LDS slot's entry is the whole
+                            // LDS address, a global slot's the rotated offset inside its row -- no vector instruction per slot (they were 21 % of the layer's vector issue
+                            // cycles: three instructions per slot, two of them at the 4.25-cycle price of an SGPR operand, four for an LDS slot, every iteration again)
+                            if (FWD && j == DEG - 1) { if (r > 0) v[j] = pfw; else v[j] = gld(w[j], base); }
+                            else v[j] = w8_slot_lds(MODE, j) ? lld(w[j]) : gld(w[j], base);
+                            continue;
+                        }
+                        const uint32_t d = t4 - (E[j] & 0x7FFu);
                         w[j] = min(d, d + (uint32_t)W8_ROW);
                         if (FWD && j == DEG - 1) { if (r > 0) v[j] = pfw; else v[j] = gld(w[j], base); }      // p_{c-1}: handed over by layer r - 1
                         else if (w8_slot_lds(MODE, j)) {
@@ -746,7 +774,12 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         if (DREG && j < KDD) dold[j] = nw - dold[j];
                         const bool pr = ((prim >> j) & 1u) != 0u;                             // wave-uniform
                         const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
-                        if (w8_slot_lds(MODE, j)) {
+                        if (w8_slot_lds(MODE, j) && ATAB) {
+                            // the table's address is where the value came from; a duplicate edge's plain store (redirected to the junk row without the table) is left out
+                            uint32_t a = w[j];
+                            if (j == DEG - 1 && mask0) a = ljunk;
+                            if (j >= KD || pr) lst(a, x + nw);
+                        } else if (w8_slot_lds(MODE, j)) {
                             uint32_t a = j >= KD ? w[j] : w[j] + (pr ? base : ljunk);
                             if (j == DEG - 1 && mask0) a = ljunk;
                             lst(a, x + nw);
@@ -766,6 +799,11 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     }
                     if (q == 1) { nx1 = cst1; nx2 = cst2; nxk = __uint_as_float(pkn); }
                     __builtin_amdgcn_s_setprio(MODE == 0 ? 1 : 0);
+                }
+                if (ATAB && role >= 0) {      // the next layer's addresses: requested now (this layer's stores have read theirs), they travel under the replay and the end barrier
+                    __builtin_amdgcn_sched_barrier(0);
+                    at_request(r + 1 < q ? r + 1 : 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 PROF_MARK(3);
                 // ---- duplicate edges of a bit-group inside this layer: ordered delta updates, level by level.  The
@@ -1064,7 +1102,7 @@ int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl) { return pl.spa ? WG8_SPA_DISPATC
 hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
     p.cu_ctr = pl.d_cu_ctr;
-    p.w8.tab = pl.d_w8_tab; p.w8.rows = pl.d_w8_rows;
+    p.w8.tab = pl.d_w8_tab; p.w8.rows = pl.d_w8_rows; p.w8.atab = pl.d_w8_atab;
     p.w8.st_base = pl.w8_st_base; p.w8.lds_junk = pl.w8_lds_junk; p.w8.lds_bytes = pl.w8_lds_bytes; p.w8.pad = pl.fast_pad ? 1 : 0;
     p.w8.nl_info = pl.w8_nl_info; p.w8.nl = pl.w8_nl; p.w8.ng_info = pl.w8_ng_info; p.w8.ng = pl.w8_ng;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
