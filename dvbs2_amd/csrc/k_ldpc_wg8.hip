@@ -78,6 +78,10 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #ifndef W8_ATAB           // min-sum layer: the slots' addresses come from a per-lane table (L2-resident, requested behind the previous layer's last store) instead of the vector ALU
 #define W8_ATAB 1
 #endif
+#ifndef W8_ATAB_HYB       // the table for the LDS slots of the hybrid images too: measured and left off (docs/negative_results.md: 2 % slower with the request in front of the global stores, 19 % behind them --
+                          // the table's loads share the fabric the image's global rows already keep 0.64 busy)
+#define W8_ATAB_HYB 0
+#endif
 #ifndef W8_DELTA_REG      // LDS-only image: new - old of the duplicate-edge slots kept from the passes instead of rebuilt behind the barrier
 #define W8_DELTA_REG 1
 #endif
@@ -354,7 +358,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
     const int nl_info = p.w8.nl_info, nl = p.w8.nl, ng_info = p.w8.ng_info, ng = p.w8.ng;
     const uint32_t grow0 = 2u * W8_ROW;                      // global image: [junk row][+inf row][group rows ..]
     // (LDS-only image only: on the hybrid image of the normal frames the table's loads queue behind the global rows' and the kernel is 19 % SLOWER, 6.73 against 5.65 ms)
-    constexpr bool ATAB = W8_ATAB && !SPA && MODE == 0;
+    constexpr bool ATAB = W8_ATAB && !SPA && (MODE == 0 || (W8_ATAB_HYB && w8_hybrid(MODE)));
     const __amdgpu_buffer_rsrc_t rs_at = __builtin_amdgcn_make_buffer_rsrc((void *)(ATAB ? p.w8.atab : (const uint32_t *)p.w8.tab), 0, ATAB ? p.q * ((DEG + 3) / 4) * (LDPC_AT_LANES * 16) : 0, 0x00020000);
     const uint32_t at_vo = (uint32_t)(role >= 0 ? t : 0) * 16u;
     constexpr bool FWD = w8_hybrid(MODE);                    // parity chain forwarded in a register (plan: p_c at slot DEG-2, p_{c-1} at DEG-1, both global)
@@ -443,12 +447,19 @@ ldpc_wg8_kernel(const LdpcKParams p)
         // (round 4) the slots' addresses of the NEXT layer, 16 bytes (four slots) per load from the per-lane table
         constexpr int NW4 = (DEG + 3) / 4;
         uint32_t w[4 * NW4];                        // (loop-carried: the addresses of the current layer until its stores have been issued, then the next layer's)
+        constexpr int AT_NS = MODE == 0 ? DEG : (MODE == 3 ? W8_NL : w8_parked(MODE) ? ldpc_park_nl(MODE) : 0);      // slots whose address the table supplies (hybrid: the LDS slots, the first ones)
         auto at_request = [&](int rl) {
             typedef uint32_t at_u32x4 __attribute__((ext_vector_type(4)));
+            typedef uint32_t at_u32x3 __attribute__((ext_vector_type(3)));
+            typedef uint32_t at_u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int g4 = 0; g4 < NW4; g4++) {
-                const at_u32x4 q4 = __builtin_amdgcn_raw_buffer_load_b128(rs_at, at_vo, (uint32_t)((rl * NW4 + g4) * (LDPC_AT_LANES * 16)), 0);
-                w[4 * g4] = q4.x; w[4 * g4 + 1] = q4.y; w[4 * g4 + 2] = q4.z; w[4 * g4 + 3] = q4.w;
+            for (int g4 = 0; g4 < (AT_NS + 3) / 4; g4++) {
+                const uint32_t so = (uint32_t)((rl * NW4 + g4) * (LDPC_AT_LANES * 16));
+                const int left = AT_NS - 4 * g4;          // (the last piece loads only what the table supplies: the registers behind it hold global slots' offsets)
+                if (left >= 4 || MODE == 0) { const at_u32x4 q4 = __builtin_amdgcn_raw_buffer_load_b128(rs_at, at_vo, so, 0); w[4 * g4] = q4.x; w[4 * g4 + 1] = q4.y; w[4 * g4 + 2] = q4.z; w[4 * g4 + 3] = q4.w; }
+                else if (left == 3) { const at_u32x3 q3 = __builtin_amdgcn_raw_buffer_load_b96(rs_at, at_vo, so, 0); w[4 * g4] = q3.x; w[4 * g4 + 1] = q3.y; w[4 * g4 + 2] = q3.z; }
+                else if (left == 2) { const at_u32x2 q2 = __builtin_amdgcn_raw_buffer_load_b64(rs_at, at_vo, so, 0); w[4 * g4] = q2.x; w[4 * g4 + 1] = q2.y; }
+                else w[4 * g4] = __builtin_amdgcn_raw_buffer_load_b32(rs_at, at_vo, so, 0);
             }
         };
 #pragma unroll
@@ -684,7 +695,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #pragma unroll
                     for (int j = 0; j < DEG; j++) {
                         const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
-                        if (ATAB) {
+                        if (ATAB && (MODE == 0 || w8_slot_lds(MODE, j))) {
                             // (round 4) the address comes from the per-lane table (requested behind the previous layer's last store): an LDS slot's entry is the whole
                             // LDS address, a global slot's the rotated offset inside its row -- no vector instruction per slot (they were 21 % of the layer's vector issue
                             // cycles: three instructions per slot, two of them at the 4.25-cycle price of an SGPR operand, four for an LDS slot, every iteration again)
@@ -774,11 +785,18 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         if (DREG && j < KDD) dold[j] = nw - dold[j];
                         const bool pr = ((prim >> j) & 1u) != 0u;                             // wave-uniform
                         const uint32_t base = (E[j] >> 11) & 0x3FFFFu;
-                        if (w8_slot_lds(MODE, j) && ATAB) {
+                        if (w8_slot_lds(MODE, j) && ATAB) {      // (hybrid images: every LDS slot is covered by the table's pieces)
                             // the table's address is where the value came from; a duplicate edge's plain store (redirected to the junk row without the table) is left out
                             uint32_t a = w[j];
                             if (j == DEG - 1 && mask0) a = ljunk;
-                            if (j >= KD || pr) lst(a, x + nw);
+                            if ((MODE == 0 && j >= KD) || pr) lst(a, x + nw);
+                            if (MODE != 0 && j == AT_NS - 1 && role >= 0) {
+                                // hybrid image: the next layer's LDS addresses are requested HERE, behind the last LDS slot's store and in front of the global slots' stores --
+                                // their registers are free, and the wait for them does not have to sit out the stores' acknowledgements (vmcnt counts in order)
+                                __builtin_amdgcn_sched_barrier(0);
+                                at_request(r + 1 < q ? r + 1 : 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         } else if (w8_slot_lds(MODE, j)) {
                             uint32_t a = j >= KD ? w[j] : w[j] + (pr ? base : ljunk);
                             if (j == DEG - 1 && mask0) a = ljunk;
@@ -800,7 +818,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     if (q == 1) { nx1 = cst1; nx2 = cst2; nxk = __uint_as_float(pkn); }
                     __builtin_amdgcn_s_setprio(MODE == 0 ? 1 : 0);
                 }
-                if (ATAB && role >= 0) {      // the next layer's addresses: requested now (this layer's stores have read theirs), they travel under the replay and the end barrier
+                if (ATAB && MODE == 0 && role >= 0) {      // the next layer's addresses: requested now (this layer's stores have read theirs), they travel under the replay and the end barrier
                     __builtin_amdgcn_sched_barrier(0);
                     at_request(r + 1 < q ? r + 1 : 0);
                     __builtin_amdgcn_sched_barrier(0);
