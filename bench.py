@@ -200,9 +200,10 @@ def main():
                    "achieved": fab, "peak": FABRIC_PEAK_GBPS, "unit": "GB/s", "frac": fab / FABRIC_PEAK_GBPS,
                    "peak_source": "MI355X_MICROARCH.md, Indexed rows: 38 MB table served by the Infinity Cache, 8.6 TB/s chip-wide",
                    "bytes_per_frame": traffic / F, "measured": traffic_meta,
-                   # the second resource: vector issue (same PMC passes).  A SIMD issues a plain VOP1 / VOP2 / VOPC instruction every ~2.07 cycles and a VOP3-encoded or SGPR-reading one every ~4.2,
-                   # whatever the number of waves (tools/probe_issue2.hip, profiles/r04_probe_issue.txt); the VOP3 share of the layer loop is read from the code object (tools/kernel_mix.py)
-                   "valu": {"resource": "vector issue: SQ_INSTS_VALU x the price of the layer loop's static instruction mix (tools/kernel_mix.py: 2.07 / 4.2 / 4.25 / 2.6 SIMD cycles per plain / VOP3-encoded / SGPR-reading / literal instruction) / (1024 SIMDs x busy cycles)", "frac": traffic_meta.get("valu_occupancy"),
+                   # the second resource: vector issue (same PMC passes).  A SIMD issues an instruction of the simple two-operand class every ~2.07 cycles and anything else every ~4.2,
+                   # whatever the number of waves (tools/probe_issue2.hip .. probe_issue4.hip, profiles/r04_probe_issue.txt); the layer loop's mix is read from the code object (tools/kernel_mix.py).
+                   # An UPPER estimate of the port's load: the probes run one class on every wave of the SIMD; the ablations (profiles/r04_ldpc_phases.md) show the kernel co-limited by this and the fabric's latency
+                   "valu": {"resource": "vector issue: SQ_INSTS_VALU x the price of the layer loop's static instruction mix (tools/kernel_mix.py: 2.07 SIMD cycles per instruction of the simple two-operand class (v_mov / v_and / v_or / v_xor / v_add / v_sub / v_mul with register or inline operands), 2.6 the same with a literal, 4.2-4.25 for everything else (VOP3 / VOP3P / SDWA / DPP encodings, SGPR or vcc operands, VOPC, v_min / v_max / shifts / conversions / v_fmac)) / (1024 SIMDs x busy cycles)", "frac": traffic_meta.get("valu_occupancy"),
                             "cycles_per_instruction": traffic_meta.get("valu_cycles_per_inst"), "vop3_share": traffic_meta.get("vop3_share"),
                             "wave_issue_slots": traffic_meta.get("wave_issue_occupancy")}}
     io_bytes = (4 * N + 4 * K) * F
@@ -216,7 +217,7 @@ def main():
     if bounded and binding == "fabric":
         r_ach, r_peak, r_unit = bounded["achieved"], FABRIC_PEAK_GBPS, "GB/s"
     elif bounded:
-        r_ach, r_peak, r_unit = bounded_frac, 1.0, "fraction of the 1024 SIMDs' vector issue cycles (2.07 per plain VOP1 / VOP2 / VOPC instruction, 4.2 VOP3-encoded, 4.25 SGPR-reading, 2.6 with a literal: profiles/r04_probe_issue.txt)"
+        r_ach, r_peak, r_unit = bounded_frac, 1.0, "fraction of the 1024 SIMDs' vector issue cycles (2.07 SIMD cycles per instruction of the simple two-operand class (v_mov / v_and / v_or / v_xor / v_add / v_sub / v_mul with register or inline operands), 2.6 the same with a literal, 4.2-4.25 for everything else (VOP3 / VOP3P / SDWA / DPP encodings, SGPR or vcc operands, VOPC, v_min / v_max / shifts / conversions / v_fmac): profiles/r04_probe_issue.txt)"
     else:
         r_ach, r_peak, r_unit = None, FABRIC_PEAK_GBPS, "GB/s"
 

@@ -78,6 +78,18 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #ifndef W8_ATAB           // min-sum layer: the slots' addresses come from a per-lane table (L2-resident, requested behind the previous layer's last store) instead of the vector ALU
 #define W8_ATAB 1
 #endif
+#ifndef W8_ABL             // development only (wrong results): what the min-sum layer is sensitive to.  1: pass 2's global stores dropped; 2: pass 1a's global loads replaced by a
+#define W8_ABL 0           // register move; 4: pass 1b without the min / sign tracking (3 of 8.5 instructions per slot); 8: pass 2 without the compare and the two selects (3 of 5); 16 / 32: the fused chain's output phase without the packed bytes / the information bits
+#endif
+#ifndef W8_P2_GFIRST       // pass 2 on the hybrid images: the global slots first, the LDS slots behind them -- a wave sits out its stores' acknowledgements (s_waitcnt vmcnt(0)) in front of
+#define W8_P2_GFIRST 1     // the layer's barrier; issued first they come back under the LDS slots' work (the ablation: no global store in pass 2 is worth 11 % of the launch)
+#endif
+#ifndef W8_ABS_FOLD       // min-sum layer, pass 1b: min1 = v_min_f32(min1, |x|) with the modifier in the instruction; `fminf(m, fabsf(x))` costs a v_max_f32 |x|, |x| in front of it (IEEE
+#define W8_ABS_FOLD 1     // mode: the compiler quiets a signalling NaN first), one instruction of 17 per slot at the 4.25-cycle price (tools/probe_issue4.hip)
+#endif
+#ifndef W8_SIGN_ADD       // pass 1b: the old message's sign bit moves up by p += p (v_add_u32: 2.1 SIMD cycles) instead of a shift per slot (v_lshlrev_b32: 4.25)
+#define W8_SIGN_ADD 1
+#endif
 #ifndef W8_ATAB_HYB       // the table for the LDS slots of the hybrid images too: measured and left off (docs/negative_results.md: 2 % slower with the request in front of the global stores, 19 % behind them --
                           // the table's loads share the fabric the image's global rows already keep 0.64 busy)
 #define W8_ATAB_HYB 0
@@ -326,6 +338,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
     auto wide_off = [&](uint32_t voff, uint32_t soff) -> uint32_t { uint32_t o = voff + soff; asm volatile("" : "+v"(o)); return o; };
     auto gld = [&](uint32_t voff, uint32_t soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0)); };
     auto gst = [&](uint32_t voff, uint32_t soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, 0); };
+    auto gld1 = [&](uint32_t voff, uint32_t soff) { if (W8_ABL & 2) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(voff | 0x3F000000u)); return r; } return gld(voff, soff); };
+    auto gst2 = [&](uint32_t voff, uint32_t soff, float v) { if (W8_ABL & 1) { asm volatile("" :: "v"(v), "v"(voff), "s"(soff)); return; } gst(voff, soff, v); };
     auto mld = [&](uint32_t voff, uint32_t soff) { if (SPA_ABL & 2) return __uint_as_float(voff & 0x3F000000u); return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, SPA_AUX)); };      // SPA messages
     auto mst = [&](uint32_t voff, uint32_t soff, float v) { if (SPA_ABL & 1) { asm volatile("" :: "v"(v)); return; } __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, SPA_AUX); };
     // SPA_MSG4: the messages of a layer as [slot / 4][360][4 slots] (the last group holds DEG mod 4 of them): a lane's messages of four consecutive slots are 16
@@ -672,6 +686,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     continue;
                 }
                 float v[DEG];
+                // (LDS-only image only -- same-box A/B: short frames 4.51 -> 4.44 ms per 16384, the hybrid image of the normal frames 5.77 -> 5.85 per 4096 with them)
+                constexpr bool ABSF = W8_ABS_FOLD && MODE == 0, SGNA = W8_SIGN_ADD && MODE == 0;
                 constexpr int KD = MODE == 0 ? ldpc_w8_kd(DEG) : DEG;       // LDS-only image: duplicate edges sit in slots < KD (plan), the others are primary
                 // (round 4) LDS-only image: conflict entry i is slot i < KDD (plan), so what a duplicate edge adds in the replay, new - old message, is kept from the passes
                 // (one subtraction per slot) instead of being rebuilt from the packed states behind the barrier (two unpacks = 8 vector instructions per entry on the
@@ -699,18 +715,18 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             // (round 4) the address comes from the per-lane table (requested behind the previous layer's last store): an LDS slot's entry is the whole
                             // LDS address, a global slot's the rotated offset inside its row -- no vector instruction per slot (they were 21 % of the layer's vector issue
                             // cycles: three instructions per slot, two of them at the 4.25-cycle price of an SGPR operand, four for an LDS slot, every iteration again)
-                            if (FWD && j == DEG - 1) { if (r > 0) v[j] = pfw; else v[j] = gld(w[j], base); }
-                            else v[j] = w8_slot_lds(MODE, j) ? lld(w[j]) : gld(w[j], base);
+                            if (FWD && j == DEG - 1) { if (r > 0) v[j] = pfw; else v[j] = gld1(w[j], base); }
+                            else v[j] = w8_slot_lds(MODE, j) ? lld(w[j]) : gld1(w[j], base);
                             continue;
                         }
                         const uint32_t d = t4 - (E[j] & 0x7FFu);
                         w[j] = min(d, d + (uint32_t)W8_ROW);
-                        if (FWD && j == DEG - 1) { if (r > 0) v[j] = pfw; else v[j] = gld(w[j], base); }      // p_{c-1}: handed over by layer r - 1
+                        if (FWD && j == DEG - 1) { if (r > 0) v[j] = pfw; else v[j] = gld1(w[j], base); }      // p_{c-1}: handed over by layer r - 1
                         else if (w8_slot_lds(MODE, j)) {
                             const uint32_t a = w[j] + base;
                             v[j] = lld(a);
                             if (j >= KD) w[j] = a;            // a primary edge by the plan's slot order: pass 2 stores where this came from
-                        } else v[j] = gld(w[j], base);
+                        } else v[j] = gld1(w[j], base);
                     }
                     const int rn = r + 1 < q ? r + 1 : 0;
                     if (it == 0 && r + 1 < q) { nx1 = 0.f; nx2 = 0.f; nxk = 0.f; }       // layer r + 1 has no messages yet in the first iteration
@@ -732,22 +748,26 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             v[j] = x;
                             const float a = fabsf(x);
                             mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);
-                            mn1 = fminf(mn1, a);
+                            if (ABSF) asm("v_min_f32_e64 %0, %0, |%1|" : "+v"(mn1) : "v"(x)); else mn1 = fminf(mn1, a);
                             sacc = __builtin_amdgcn_alignbit(sacc, __float_as_uint(x), 31);
                         }
-                    } else
+                    } else {
+                    uint32_t psh = pko << (32u - DEG);      // (W8_SIGN_ADD) sign bit of slot j in bit 31 at slot j
 #pragma unroll
                     for (int j = 0; j < DEG; j++) {
                         const float mag = (idxo == (uint32_t)j) ? c1o : c2o;
-                        const float old = and_or(pko << ((32u - DEG) + j), SB, mag);          // sign bit of slot j | magnitude (>= 0)
+                        const float old = and_or(SGNA ? psh : pko << ((32u - DEG) + j), SB, mag);          // sign bit of slot j | magnitude (>= 0)
+                        if (SGNA && j + 1 < DEG) asm("v_add_u32_e32 %0, %0, %0" : "+v"(psh));      // (written out: the compiler turns p + p back into a shift)
                         if (DREG && j < KDD) dold[j] = old;
                         float x = v[j] - old;
                         if (j == DEG - 1 && mask0) x = INFINITY;
                         v[j] = x;
                         const float a = fabsf(x);
+                        if (W8_ABL & 4) { if (j == 0) { mn1 = a; mn2 = a + 1.f; sacc = __float_as_uint(x); } continue; }
                         mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);
-                        mn1 = fminf(mn1, a);
+                        if (ABSF) asm("v_min_f32_e64 %0, %0, |%1|" : "+v"(mn1) : "v"(x)); else mn1 = fminf(mn1, a);
                         sacc = __builtin_amdgcn_alignbit(sacc, __float_as_uint(x), 31);      // shift the sign bit in
+                    }
                     }
                     cst1 = mn2 * p.alpha; cst2 = mn1 * p.alpha;
                     tot = (uint32_t)(__popc(sacc) & 1);                                       // parity of all signs
@@ -764,8 +784,10 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     float m1s = __uint_as_float(__float_as_uint(cst1) | (tot << 31));        // output magnitudes carrying the total sign
                     float m2s = __uint_as_float(__float_as_uint(cst2) | (tot << 31));
                     asm volatile("" : "+v"(m1s), "+v"(m2s));      // keep the sign folded in: one select + one bit-op per edge
+                    constexpr int P2_ROT = (W8_P2_GFIRST && w8_hybrid(MODE) && !ATAB) ? (MODE == 3 ? W8_NL : ldpc_park_nl(MODE)) : 0;      // first slot of pass 2 (the first global one)
 #pragma unroll
-                    for (int j = 0; j < DEG; j++) {
+                    for (int jj = 0; jj < DEG; jj++) {
+                        const int j = jj + P2_ROT < DEG ? jj + P2_ROT : jj + P2_ROT - DEG;
                         const float x = v[j];
 #if W8_IDX_E32
                         // A SIMD issues a VOP3-encoded instruction every ~4.1 cycles and a VOP2 / VOPC one every ~2.1, whatever the number of waves (tools/probe_issue2.hip):
@@ -776,7 +798,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             : "=&v"(mag), "+v"(idxn) : "v"(x), "v"(mn1), "v"(m1s), "v"(m2s), "n"(j) : "vcc");
                         const float nw = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(x) & SB));
 #else
-                        const bool ismin = fabsf(x) == mn1;
+                        const bool ismin = (W8_ABL & 8) ? j == 3 : fabsf(x) == mn1;
                         const float mag = ismin ? m1s : m2s;
                         const float nw = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(x) & SB));
                         idxn = ismin ? (uint32_t)j : idxn;
@@ -805,8 +827,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             // MODE 3: the duplicate edges all live in LDS, a global slot is always primary
                             const uint32_t sb = (w8_hybrid(MODE) || pr) ? base : 0u;        // global junk row = row 0
                             const uint32_t vo = (j == DEG - 1 && mask0) ? W8_OOB : w[j];
-                            if (FWD && j == DEG - 2) { if (r + 1 < q) pfw = x + nw; else gst(vo, sb, x + nw); }      // p_c: kept for layer r + 1
-                            else gst(vo, sb, x + nw);
+                            if (FWD && j == DEG - 2) { if (r + 1 < q) pfw = x + nw; else gst2(vo, sb, x + nw); }      // p_c: kept for layer r + 1
+                            else gst2(vo, sb, x + nw);
                         }
                     }
                     pkn |= idxn << 27;
@@ -850,8 +872,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     if (DREG) {
 #pragma unroll
                         for (int i = 1; i < KDD; i++) {
-                            if (i < (two ? 2 : 1)) continue;
-                            if (i >= ncf) break;
+                            if (i < (two ? 2 : 1) || i >= ncf) continue;      // (no `break`: the loop has to unroll completely, dold[] lives in registers)
                             const uint32_t e = T[32 + i], lvl = T[48 + i] >> 8;
                             const uint32_t off = addr_of(e), base = (e >> 11) & 0x3FFFFu;
                             if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
@@ -995,9 +1016,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
             uint32_t bit;
             asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(bit) : "s"(d));             // this lane's bit of the descrambled word (the 64-bit mask is the select's condition)
             // (the whole offset in the vector register: the range check that drops the bits behind K_info then sees all of it)
-            __builtin_amdgcn_raw_buffer_store_b32(bit, rs_info, vo_out + (uint32_t)g * (uint32_t)W8_ROW, 0u, 2);
+            if (!(W8_ABL & 32)) __builtin_amdgcn_raw_buffer_store_b32(bit, rs_info, vo_out + (uint32_t)g * (uint32_t)W8_ROW, 0u, 2);
             const uint32_t half = pk_hi ? (uint32_t)(m >> 32) : (uint32_t)m;
-            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(half >> pk_sh), rs_pack, pk_vo, (uint32_t)g * (uint32_t)(LDPC_Z / 8), 0);
+            if (!(W8_ABL & 16)) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(half >> pk_sh), rs_pack, pk_vo, (uint32_t)g * (uint32_t)(LDPC_Z / 8), 0);
         };
         auto run_out = [&](auto &&em) {
             if (role >= 0) {

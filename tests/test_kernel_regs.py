@@ -24,7 +24,17 @@ def test_no_kernel_spills_vector_registers():
     assert not bad, bad
     # private memory only where a kernel calls a non-inlined device function (the delay line's general walk)
     scratch = [(k["name"], k["scratch"]) for k in ks if k["scratch"] > 0]
-    assert all("sync_vdelay_batch_kernel" in n for n, _ in scratch), scratch
+    # ... and a 20-byte slot the backend reserves in the LDS-only min-sum kernels since their layer loop carries the address table's 28 registers (W8_ATAB; gone with -DW8_ATAB=0):
+    # no instruction of the kernels touches it -- checked here in the disassembly -- so it is a frame-size entry, not a spill
+    dead = [n for n, b in scratch if "ldpc_wg8_kernel<" in n and ", 0, false>" in n and b <= 32]
+    assert all("sync_vdelay_batch_kernel" in n or n in dead for n, _ in scratch), scratch
+    if dead:
+        import subprocess
+        import kernel_mix as KM
+        for name, ins in KM.functions(KM.disassemble("k_ldpc_wg8")).items():
+            dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout
+            if any(d in dem for d in dead):
+                assert not [i for i in ins if i[1].startswith("scratch_") or "flat_scratch" in i[4]], dem
 
 
 def test_no_wide_buffer_store_takes_a_scalar_offset_register():
@@ -44,17 +54,18 @@ def test_no_wide_buffer_store_takes_a_scalar_offset_register():
 
 
 def test_layer_loop_instruction_mix_is_read_from_the_code_object():
-    """tools/kernel_mix.py prices a kernel's vector instructions by encoding (profiles/r04_probe_issue.txt: 2.07 SIMD cycles plain VOP1 / VOP2 / VOPC, 4.2 VOP3 / VOP3P encoding, 4.25
-    with an SGPR operand, 2.6 with a literal, 8.06 transcendental); bench.py's roofline.bounded.valu and the profile summaries multiply SQ_INSTS_VALU by that price.  The min-sum
-    layer loop is made of the expensive kind: nearly half of it VOP3-encoded, 3.2 .. 3.5 cycles per instruction; no transcendental in it."""
+    """tools/kernel_mix.py prices a kernel's vector instructions by class (profiles/r04_probe_issue.txt: 2.07 SIMD cycles for the simple two-operand class -- v_mov / v_and / v_or / v_xor /
+    v_add / v_sub / v_mul with register or inline operands --, 2.6 the same with a literal, 4.2-4.25 everything else: VOP3 / VOP3P / SDWA / DPP encodings, SGPR or vcc operands, VOPC, v_min /
+    v_max / shifts / conversions / v_fmac; 8.06 transcendental); bench.py's roofline.bounded.valu and the profile summaries multiply SQ_INSTS_VALU by that price.  The min-sum layer loop
+    is made of the expensive kind: nearly half of it VOP3-encoded, under a tenth of it in the simple class, 3.8 .. 4.1 cycles per instruction; no transcendental in it."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_mix as KM
     from dvbs2_amd import build
     build.build_lib()
     cpi, how = KM.price_kernel("ldpc_wg8_kernel<27,5>")
-    assert how["scope"] == "layer loop" and how["mix"]["trans"] == 0 and 3.1 < cpi < 3.6, (cpi, how)
+    assert how["scope"] == "layer loop" and how["mix"]["trans"] == 0 and 3.8 < cpi < 4.1, (cpi, how)
     n = sum(how["mix"].values())
-    assert 500 < n < 800 and 0.40 < how["mix"]["vop3"] / n < 0.55
+    assert 500 < n < 800 and 0.40 < how["mix"]["vop3"] / n < 0.55 and how["mix"]["plain"] / n < 0.12
     cpi_spa, how_spa = KM.price_kernel("ldpc_wg8_kernel<27,0,true>")
     assert how_spa["mix"]["trans"] >= 100 and cpi_spa < cpi + 0.5

@@ -6,10 +6,14 @@ usage: python tools/kernel_mix.py [translation unit] [substring of the demangled
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
-# SIMD cycles per instruction with four waves on the SIMD (profiles/r04_probe_issue.txt): plain VOP1 / VOP2 / VOPC 2.07; VOP3 / VOP3P encoding (v_fma_f32, v_med3_f32,
-# v_pk_add_f32, a VOP2 opcode with |abs| ...) 4.2; a VOP1 / VOP2 / VOPC instruction that reads an SGPR 4.25; one with a 32-bit literal 2.6; v_exp / v_log / v_rcp ... 8.06
-CYC = {"plain": 2.07, "vop3": 4.2, "sgpr": 4.25, "literal": 2.6, "trans": 8.06}
+# SIMD cycles per instruction with four waves on the SIMD (profiles/r04_probe_issue.txt, probe_issue2 / 3 / 4): only the SIMPLE two-operand class -- v_mov_b32, v_and / v_or / v_xor_b32,
+# v_add / v_sub / v_mul_f32, v_add_u32 with register or inline-constant operands -- issues every 2.07 cycles (two waves at full speed side by side); the same with a 32-bit literal 2.6;
+# EVERYTHING ELSE 4.2-4.25, the waves of the SIMD one after the other: the VOP3 / VOP3P encoding (v_fma_f32, v_med3_f32, v_pk_add_f32, a VOP2 opcode with |abs| ...), SDWA and DPP,
+# an SGPR operand, VOPC (v_cmp_*_e32 writes vcc) and the vcc readers (v_cndmask_b32_e32, v_addc_co_u32), and -- probe_issue4, measured after the first pricing of this round -- plain
+# VOP1 / VOP2 opcodes outside the simple class: v_min / v_max (f32 and u32), v_lshlrev_b32, v_cvt_*, v_mul_u32_u24, v_fmac_f32.  v_exp / v_log / v_rcp ... 8.06.
+CYC = {"plain": 2.07, "slow": 4.25, "vop3": 4.2, "sgpr": 4.25, "literal": 2.6, "trans": 8.06}
 CYC_VOP2, CYC_VOP3 = CYC["plain"], CYC["vop3"]
+FAST = ("v_mov_b32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_add_u32", "v_sub_u32", "v_subrev_u32")
 TRANS = ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32", "v_exp_legacy_f32", "v_log_legacy_f32")
 
 
@@ -36,7 +40,7 @@ def functions(txt):
 
 
 def classify(op, w0, operands="", two_words=False):
-    """other | trans | vop3 | sgpr | literal | plain"""
+    """other | trans | vop3 | sgpr | slow | literal | plain"""
     if not op.startswith("v_"):
         return "other"
     base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
@@ -47,6 +51,8 @@ def classify(op, w0, operands="", two_words=False):
     srcs = operands.split(",")[1:] if not base.startswith("v_cmp") else operands.split(",")      # (VOPC e32 writes vcc implicitly: every listed operand is a source)
     if any(re.search(r"(^|[^a-z])s\d+|s\[\d+:\d+\]|ttmp|m0", x) for x in srcs):
         return "sgpr"
+    if base not in FAST or op.endswith(("_sdwa", "_dpp")):
+        return "slow"
     if two_words and (w0 & 0x1FF) == 0xFF:
         return "literal"
     return "plain"
@@ -77,7 +83,7 @@ def mix(tu, pat, marker="v_med3_f32"):
             continue
         loop = layer_loop(ins, marker)
         sel = [i for i in ins if loop and loop[0] <= i[0] <= loop[1]] if loop else ins
-        c = {k: 0 for k in ("plain", "vop3", "sgpr", "literal", "trans", "other")}
+        c = {k: 0 for k in list(CYC) + ["other"]}
         for a, op, w, t, opnds, w2 in sel:
             c[classify(op, w, opnds, w2)] += 1
         nv = sum(c[k] for k in CYC)

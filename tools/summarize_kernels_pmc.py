@@ -54,7 +54,7 @@ lines = ["# rocprofv3 counters of the non-LDPC kernels (%s) -- `python3 tools/pm
          "reports half of the bytes of a coalesced stream on gfx950, WRITE_SIZE the bytes: calibrated in profiles/r02_ldpc_rocprof.md).",
          "VALU busy = SQ_ACTIVE_INST_VALU / (4 SIMDs x SQ_BUSY_CYCLES summed over the chip's SQs) is shown as the share of wave-cycles instead:",
          "valu/wave-cyc = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES, trans = v_exp / v_log / v_rcp / v_sqrt instructions.", "",
-         "VALU issue = (non-transcendental SQ_INSTS_VALU x the price of the kernel's static instruction mix + trans x 8.06) / (1024 SIMDs x SQ_BUSY_CYCLES / 32).  Prices (round 4, profiles/r04_probe_issue.txt, tools/kernel_mix.py): a SIMD issues a plain VOP1 / VOP2 / VOPC instruction every 2.07 cycles, a VOP3 / VOP3P-encoded one every 4.2, one that reads an SGPR every 4.25, one with a literal every 2.6, v_exp / v_log / v_rcp every 8.06 -- whatever the number of waves (round 3 priced everything at 2, round 2 at 4).", "",
+         "VALU issue = (non-transcendental SQ_INSTS_VALU x the price of the kernel's static instruction mix + trans x 8.06) / (1024 SIMDs x SQ_BUSY_CYCLES / 32).  Prices (round 4, profiles/r04_probe_issue.txt, tools/kernel_mix.py): 2.07 SIMD cycles per instruction of the simple two-operand class (v_mov / v_and / v_or / v_xor / v_add / v_sub / v_mul with register or inline operands), 2.6 the same with a literal, 4.2-4.25 for everything else (VOP3 / VOP3P / SDWA / DPP encodings, SGPR or vcc operands, VOPC, v_min / v_max / shifts / conversions / v_fmac), v_exp / v_log / v_rcp 8.06 -- whatever the number of waves (round 3 priced everything at 2, round 2 at 4; the first pricing of round 4 had VOPC, v_cndmask_b32_e32, v_min / v_max and the shifts in the 2.07 class: probe_issue4 put them at 4.25).", "",
          "| kernel | grid | launches | avg us | fabric GB | fabric TB/s | VALU inst | trans inst | VALU issue | LDS inst | VMEM rd / wr | valu / wave-cyc | wait / wave-cyc | LDS bank-conflict / LDS active | L2 hit |",
          "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 rows_json = []

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gpurun_out/lv_* (tools/profile_ldpc_variants.sh) -> profiles/<tag>_ldpc_variants.md + .json: per LDPC kernel instantiation the launch
 time (rocprofv3 --kernel-trace --stats), the counters per launch (separate --pmc passes) and the BOUNDED figures recomputable from them:
-  vector-ALU issue = (non-transcendental SQ_INSTS_VALU x the price of the layer loop's static mix -- 2.07 / 4.2 / 4.25 / 2.6 cycles per plain / VOP3-encoded / SGPR-reading / literal instruction, tools/kernel_mix.py -- + SQ_INSTS_VALU_TRANS_F32 x 8.06; profiles/r04_probe_issue.txt
+  vector-ALU issue = (non-transcendental SQ_INSTS_VALU x the price of the layer loop's static mix -- 2.07 cycles for the simple two-operand class, 2.6 with a literal, 4.2-4.25 everything else, tools/kernel_mix.py -- + SQ_INSTS_VALU_TRANS_F32 x 8.06; profiles/r04_probe_issue.txt
   constants table and tools/probe_dep.hip; priced at 4 / 8 until the end of round 3) / (1024 SIMDs x busy cycles)
   fabric           = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B / launch time, against 8.6 TB/s (Infinity-Cache gathers) -- FETCH_SIZE x 2 as calibrated
                      for one dword per lane (tools/calibrate_fetch.py, profiles/r02_ldpc_rocprof.md)
@@ -61,9 +61,9 @@ for cfg in sorted(glob.glob(os.path.join(OUT, "lv_*.cfg")), key=lambda s: int(s.
             tr = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
             r["busy_cycles"] = cyc
             # prices of round 4 (profiles/r04_probe_issue.txt, tools/kernel_mix.py): the non-transcendental instructions at the static mix of the kernel's layer loop
-            # (2.07 plain VOP1 / VOP2 / VOPC, 4.2 VOP3 / VOP3P encoding, 4.25 with an SGPR operand, 2.6 with a literal), the transcendentals at 8.06 cycles
+            # (2.07 the simple two-operand class, 2.6 with a literal, 4.2-4.25 everything else), the transcendentals at 8.06 cycles
             cpi, how = KM.price_kernel(r["kernel"])
-            cpi = cpi or 3.35
+            cpi = cpi or 3.97
             r["cycles_per_valu"] = cpi; r["valu_mix"] = how
             r["valu_issue_frac"] = ((pmc["SQ_INSTS_VALU"] - tr) * cpi + tr * 8.06) / (1024.0 * cyc)
             r["trans_share_of_issue"] = tr * 8.06 / ((pmc["SQ_INSTS_VALU"] - tr) * cpi + tr * 8.06)

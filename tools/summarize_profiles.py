@@ -73,7 +73,8 @@ if pmc:
     # vector issue (round 4, tools/probe_issue2.hip / probe_issue3.hip, profiles/r04_probe_issue.txt): a SIMD issues a VOP1 / VOP2 / VOPC instruction every ~2.05 cycles and a
     # VOP3 / VOP3P-ENCODED one every ~4.1, whatever the number of waves on it (two waves reach the VOP2 rate, the oldest wave alone saturates the VOP3 rate), and a lone
     # wave issues one instruction of any kind per ~4.3 cycles.  Rounds 2 and 3 priced every vector instruction at 4, then at 2 cycles; the layer loop is 46 % VOP3
-    # (tools/kernel_mix.py reads the share from the code object), i.e. 3.0 cycles per instruction.  SQ_BUSY_CYCLES is summed over the chip's 32 shader engines
+    # and under a tenth of it in the simple 2.07-cycle class (tools/kernel_mix.py reads the mix from the code object: probe_issue4 moved VOPC, v_cndmask_b32_e32, v_min / v_max and the
+    # shifts to the 4.25 class), i.e. ~3.97 cycles per instruction.  SQ_BUSY_CYCLES is summed over the chip's 32 shader engines
     # (8 XCDs x 4): busy cycles of the launch = SQ_BUSY_CYCLES / 32; 256 CUs x 4 SIMDs.
     valu_frac = wave_issue = cyc_per_valu = vop3_share = None
     if pmc.get("SQ_INSTS_VALU") and pmc.get("SQ_BUSY_CYCLES"):
@@ -85,12 +86,12 @@ if pmc:
             mx = KM.mix("k_ldpc_wg8" if "wg8" in kname else "k_ldpc_cu1" if "cu1" in kname else "k_ldpc", kname)
             cyc_per_valu, vop3_share = mx[0]["cycles_per_valu"], mx[0]["vop3_share"]
         except Exception as e:
-            lines.append("(tools/kernel_mix.py failed: %s; every vector instruction priced at 3.0 cycles)" % e)
-        cyc_per_valu = cyc_per_valu or 3.0
+            lines.append("(tools/kernel_mix.py failed: %s; every vector instruction priced at 3.97 cycles)" % e)
+        cyc_per_valu = cyc_per_valu or 3.97
         valu_frac = pmc["SQ_INSTS_VALU"] * cyc_per_valu / (1024.0 * cyc)
         insts = sum(pmc.get(k, 0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
         wave_issue = insts * 4.3 / (pmc.get("SQ_WAVES", 0) * cyc) if pmc.get("SQ_WAVES") else None
-        lines.append("vector issue = SQ_INSTS_VALU x %.2f SIMD cycles (static mix of the layer loop, tools/kernel_mix.py: %.0f %% VOP3-encoded at 4.2 cycles, SGPR-reading 4.25, literal 2.6, plain 2.07) / (1024 SIMDs x %.3g busy cycles) = %.2f; "
+        lines.append("vector issue = SQ_INSTS_VALU x %.2f SIMD cycles (static mix of the layer loop, tools/kernel_mix.py: %.0f %% VOP3-encoded; 2.07 cycles for the simple two-operand class, 2.6 with a literal, 4.2-4.25 everything else) / (1024 SIMDs x %.3g busy cycles) = %.2f; "
                      "SALU: %.3g instructions on 256 scalar units = %.2f of the cycles" % (cyc_per_valu, 100 * (vop3_share or 0), cyc, valu_frac, pmc.get("SQ_INSTS_SALU", 0), pmc.get("SQ_INSTS_SALU", 0) / (256.0 * cyc)))
         if wave_issue:
             lines.append("issue slots of a wave = (VALU + SALU + LDS + VMEM instructions) x 4.3 cycles / (%d waves x busy cycles) = %.2f on average over a workgroup's waves"
