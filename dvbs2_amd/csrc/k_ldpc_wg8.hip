@@ -81,6 +81,9 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #ifndef W8_ABL             // development only (wrong results): what the min-sum layer is sensitive to.  1: pass 2's global stores dropped; 2: pass 1a's global loads replaced by a
 #define W8_ABL 0           // register move; 4: pass 1b without the min / sign tracking (3 of 8.5 instructions per slot); 8: pass 2 without the compare and the two selects (3 of 5); 16 / 32: the fused chain's output phase without the packed bytes / the information bits
 #endif
+#ifndef W8_EARLY_B1        // LDS-only image: the layer's "every read precedes the writes" barrier (duplicate edges) sits right behind pass 1a -- the loads are back within ~100 cycles of the layer's
+#define W8_EARLY_B1 1      // start, when the waves have just left the end barrier together -- instead of behind pass 1b, 3000 contended cycles later (QPSK-S 8/9 +2 %, 32APSK-S 3/4 +1.3 %, 3/5 -0.5 %)
+#endif
 #ifndef W8_P2_GFIRST       // pass 2 on the hybrid images: the global slots first, the LDS slots behind them -- a wave sits out its stores' acknowledgements (s_waitcnt vmcnt(0)) in front of
 #define W8_P2_GFIRST 1     // the layer's barrier; issued first they come back under the LDS slots' work (the ablation: no global store in pass 2 is worth 11 % of the launch)
 #endif
@@ -687,6 +690,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 }
                 float v[DEG];
                 // (LDS-only image only -- same-box A/B: short frames 4.51 -> 4.44 ms per 16384, the hybrid image of the normal frames 5.77 -> 5.85 per 4096 with them)
+                // (LDS-only image only.  On the hybrid images -- global slots' loads first, LDS slots' behind them, barrier once the LDS data are back -- it is 2.5-5.7 % SLOWER, same-box
+                // A/B 5.94-6.04 against 5.62-5.70 ms: a barrier at the layer's start keeps the waves in phase, and in-phase waves want the issue port at the same moment)
+                constexpr bool EARLY_B1 = W8_EARLY_B1 && MODE == 0;
                 constexpr bool ABSF = W8_ABS_FOLD && MODE == 0, SGNA = W8_SIGN_ADD && MODE == 0;
                 constexpr int KD = MODE == 0 ? ldpc_w8_kd(DEG) : DEG;       // LDS-only image: duplicate edges sit in slots < KD (plan), the others are primary
                 // (round 4) LDS-only image: conflict entry i is slot i < KDD (plan), so what a duplicate edge adds in the replay, new - old message, is kept from the passes
@@ -701,6 +707,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 const uint32_t pko = __float_as_uint(nxk);
                 float mn1 = INFINITY, mn2 = INFINITY, cst1 = 0.f, cst2 = 0.f;
                 uint32_t sacc = 0u, tot = 0u, pkn = 0u;
+                if (EARLY_B1 && ncf > 0 && role < 0) asm volatile("s_barrier" ::: "memory");      // (the waves without checks of the modes without parked rows)
                 if (act) {
                     // ---- pass 1a: every posterior load of the check in flight before any use.  Wave priorities (same-box A/B, tools/ab_kernel.sh):
                     // 3 while the loads are issued, 0 while pass 1b waits for them, 2 in pass 2 (stores, and the way to the barrier) is
@@ -736,6 +743,10 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         nx1 = __uint_as_float(sv.x); nx2 = __uint_as_float(sv.y); nxk = __uint_as_float(sv.z);
                     }
                     __builtin_amdgcn_s_setprio(0);
+                    // every read of a row with duplicate edges precedes the layer's writes: those rows are LDS rows, so "the LDS loads of every wave are back" is enough; the global
+                    // rows' loads stay in flight across the barrier (no vmcnt wait: __syncthreads would drain them).  Inside the block of the active lanes (a working wave always has
+                    // some): closing the block here would split pass 1a / 1b into two scheduling regions, which alone costs 3-4 % (same-box A/B)
+                    if (EARLY_B1 && ncf > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     PROF_MARK(0);
                     // ---- pass 1b: v->c = posterior - old c->v ; running min1 / min2 / signs
                     const uint32_t idxo = pko >> 27;
@@ -774,7 +785,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     pkn = sacc ^ (tot ? ((1u << DEG) - 1u) : 0u);                             // sign(new_j) = tot ^ sign(x_j)
                 }
                 PROF_MARK(1);
-                if (ncf > 0) __syncthreads();         // every read of the layer precedes its writes
+                if (!EARLY_B1 && ncf > 0) __syncthreads();         // every read of the layer precedes its writes
                 PROF_MARK(2);
                 if (act) {
                     __builtin_amdgcn_s_setprio(MODE == 0 ? 3 : 2);
