@@ -13,7 +13,7 @@ int main(int argc, char **argv)
     dvbs2hip_cfg cfg;
     if (dvbs2hip_cfg_from_modcod(argc > 1 ? argv[1] : "QPSK-N_8/9", &cfg)) { std::printf("unknown modcod\n"); return 1; }
     LdpcPlan pl;
-    const std::string e = ldpc_build_plan(pl, cfg.N_ldpc, cfg.K_ldpc, cfg.ldpc_n_rows, cfg.ldpc_row_ptr, cfg.ldpc_addr, -1, argc > 3 ? atoi(argv[3]) : 160 * 1024, argc > 2 && argv[2][0] == 'v');
+    const std::string e = ldpc_build_plan(pl, cfg.N_ldpc, cfg.K_ldpc, cfg.ldpc_n_rows, cfg.ldpc_row_ptr, cfg.ldpc_addr, -1, argc > 3 ? atoi(argv[3]) : 160 * 1024, argc > 2 && argv[2][0] == 's');
     std::printf("plan: '%s' fast %d deg %d mode %d wg8 %d dups_in_lds %d | LDS rows %d (info %d) global rows %d (info %d) | lds bytes %d gwork words %d\n", e.c_str(), pl.fast,
                 pl.fast_deg, pl.fast_mode, pl.fast_wg8, pl.w8_dups_in_lds, pl.w8_nl, pl.w8_nl_info, pl.w8_ng, pl.w8_ng_info, pl.w8_lds_bytes, pl.w8_gwork_words);
     if (pl.fast_wg8 && (pl.fast_mode == 3 || pl.fast_mode == 4 || pl.fast_mode == 5)) {
