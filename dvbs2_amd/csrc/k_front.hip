@@ -34,12 +34,11 @@ __device__ __forceinline__ int pl_index(int k, int n_pilots)
 // multiply by conj(exp(j pi/2 R)) (Scrambler_PL.hxx:66-76 with scr_flag = false)
 __device__ __forceinline__ float2 pl_derotate(float2 x, int R)
 {
-    switch (R & 3) {
-        case 0: return x;
-        case 1: return make_float2(x.y, -x.x);
-        case 2: return make_float2(-x.x, -x.y);
-        default: return make_float2(-x.y, x.x);
-    }
+    // R = 0: (x, y)   1: (y, -x)   2: (-x, -y)   3: (-y, x) -- branch-free (a switch becomes four exec-masked paths per wave, every wave holds all four values):
+    // odd R swaps the parts, bit 1 of R negates the first output, bit 1 of R + 1 the second
+    const bool sw = (R & 1) != 0;
+    const float a = sw ? x.y : x.x, b = sw ? x.x : x.y;
+    return make_float2(__uint_as_float(__float_as_uint(a) ^ (((uint32_t)R << 30) & 0x80000000u)), __uint_as_float(__float_as_uint(b) ^ (((uint32_t)(R + 1) << 30) & 0x80000000u)));
 }
 
 // position of interleaved LLR i = k*bps + b in the natural (code) order
@@ -69,13 +68,34 @@ __device__ __forceinline__ int deitl_index(int k, int b, int bps, int cols, int 
 // relative precision unless the whole subset lies 2^-220 below the maximum (|LLR| beyond ~150: sum < 2^-100); such a
 // symbol takes the per-subset form, every term relative to its own subset's maximum.
 // |LLR error| vs the pairwise form stays below 1e-4 * max(1, |LLR|) (tests/test_front_gpu.py).
+#ifndef FRONT_TAB_SCALAR   // 1: the general demapper takes the frame's constellation table from scalar registers (demap_symbols_s), 0: from LDS (demap_symbols)
+#define FRONT_TAB_SCALAR 1
+#endif
+#ifndef FRONT_BUF_ST
+#define FRONT_BUF_ST 1
+#endif
+#ifndef FRONT_REG_TS       // the register-resident 8PSK kernels: scalar-side table and buffer stores as in front_kernel
+#define FRONT_REG_TS 1
+#endif
+#ifndef FRONT_TAB_VGPR
+#define FRONT_TAB_VGPR 0
+#endif
+#ifndef FRONT_PK           // demap_symbols_s: two points per v_pk_fma_f32 / v_pk_add_f32
+#define FRONT_PK 1
+#endif
+#ifndef FRONT_U_APSK
+#define FRONT_U_APSK 1
+#endif
+#ifndef FRONT_ANALYTIC_REF
+#define FRONT_ANALYTIC_REF 1
+#endif
 constexpr float FRONT_LOG2E = 1.44269504088896341f, FRONT_LN2 = 0.693147180559945309f;
 
 // per-frame table of the constellation, thread s < 2^bps:  tab[s] = c log2(e) (2 re, 2 im, -|s|^2, 0)
 __device__ __forceinline__ float4 demap_table_entry(const float *cstl, int s, float inv2s2)
 {
     const float k = inv2s2 * FRONT_LOG2E, sr = cstl[2 * s], si = cstl[2 * s + 1];
-    return make_float4(2.0f * k * sr, 2.0f * k * si, -k * (sr * sr + si * si), 0.f);
+    return make_float4(2.0f * k * sr, 2.0f * k * si, -k * (sr * sr + si * si), k);      // .w: the scale itself (FRONT_ANALYTIC_REF)
 }
 
 template <int BPS>
@@ -107,12 +127,24 @@ __device__ __forceinline__ void demap_symbols(const float2 (&y)[U], const float4
     float u[U][P], mx[U];
 #pragma unroll
     for (int i = 0; i < U; i++) mx[i] = -INFINITY;
+#if FRONT_ANALYTIC_REF
+    // (round 4) the reference exponent without a running maximum over the points: u_s = k (|y|^2 - |y - s|^2) <= k |y|^2, so k |y|^2 bounds every term from above
+    // (v_max_f32 per point and symbol is a 4.25-cycle instruction: 32 of them were ~10 % of the 32APSK demapper's issue cycles).  The largest term is then
+    // 2^(120 - k d_min^2) instead of 2^120 (d_min: distance to the nearest point, k d_min^2 a few units at the noise levels the decoder works at), the sums keep their
+    // relative precision and the per-subset form below takes over a little earlier (|LLR| beyond ~130 instead of ~150).
+    const float kq = tab[0].w;
+#pragma unroll
+    for (int i = 0; i < U; i++) mx[i] = kq * fmaf(y[i].x, y[i].x, y[i].y * y[i].y);
+#endif
 #pragma unroll
     for (int s = 0; s < P; s++) {
         if ((s & 7) == 0) asm volatile("" ::: "memory");          // at most 8 table rows in flight (registers)
         const float4 t = tab[s];
 #pragma unroll
-        for (int i = 0; i < U; i++) { u[i][s] = fmaf(y[i].x, t.x, fmaf(y[i].y, t.y, t.z)); mx[i] = fmaxf(mx[i], u[i][s]); }
+        for (int i = 0; i < U; i++) {
+            u[i][s] = fmaf(y[i].x, t.x, fmaf(y[i].y, t.y, t.z));
+            if (!FRONT_ANALYTIC_REF) mx[i] = fmaxf(mx[i], u[i][s]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < U; i++) {
@@ -134,6 +166,67 @@ __device__ __forceinline__ void demap_symbols(const float2 (&y)[U], const float4
             for (int j = 0; j < n / 2; j++) u[i][j] = u[i][2 * j] + u[i][2 * j + 1];
         }
         // wave-uniform test first: a real branch around the rare path (a per-lane condition alone is flattened into predicated code)
+        if (__builtin_amdgcn_ballot_w64(lo < 0x1p-100f) != 0ull) { if (lo < 0x1p-100f) demap_symbol_far<BPS>(y[i].x, y[i].y, tab, out[i]); }
+    }
+}
+
+// (round 4) The frame's table on the SCALAR side.  demap_symbols reads the constellation table with one 16-byte LDS broadcast per point and symbol: 32 x 1 KB per
+// wave and 32APSK symbol is 0.67 of the LDS pipe's rate at the kernel's speed -- as busy as the vector issue port, so trimming either alone moved nothing (analytic
+// reference: -1 %; packed FMAs in round 2: 0).  The table is wave-uniform and constant over the frame: A_s, B_s live in SGPRs (v_readlane once per frame), D_s replicated in
+// vector registers (an SGPR operand would make the add a 4.25-cycle instruction), and the inner loop has no LDS access at all:
+//     2^(u_s - ref) = exp2( yr A_s + (yi B_s + (120 - k |y|^2)) + D_s ),   pairs of points in the halves of v_pk_fma_f32 / v_pk_add_f32.
+typedef float front_v2 __attribute__((ext_vector_type(2)));
+template <int BPS>
+struct DemapTabS { float A[1 << BPS], B[1 << BPS], D[1 << BPS], k; };
+template <int BPS>
+__device__ __forceinline__ void demap_tab_scalar(DemapTabS<BPS> &T, const float4 *tab)
+{
+    constexpr int P = 1 << BPS;
+    const float4 t = tab[threadIdx.x & (P - 1)];
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.x), s)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.y), s));
+        const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.z), s));
+        // replicated in vector registers, opaquely: left to itself the compiler keeps the lane-0 copy and re-reads all 2 P values with v_readlane in every iteration of
+        // the symbol loop (102 + 48 moves per 32APSK symbol), the operands of the packed instructions being register pairs
+        if (FRONT_TAB_VGPR) { asm volatile("v_mov_b32 %0, %1" : "=v"(T.A[s]) : "s"(a)); asm volatile("v_mov_b32 %0, %1" : "=v"(T.B[s]) : "s"(b)); }
+        else { T.A[s] = a; T.B[s] = b; }
+        asm volatile("v_mov_b32 %0, %1" : "=v"(T.D[s]) : "s"(d));
+    }
+    T.k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.w), 0));
+}
+template <int BPS, int U>
+__device__ __forceinline__ void demap_symbols_s(const float2 (&y)[U], const DemapTabS<BPS> &T, const float4 *tab, float (&out)[U][BPS])
+{
+    constexpr int P = 1 << BPS;
+    float u[U][P];
+#pragma unroll
+    for (int i = 0; i < U; i++) {
+        const float c0 = fmaf(-T.k, fmaf(y[i].x, y[i].x, y[i].y * y[i].y), 120.0f);
+#if FRONT_PK
+        const front_v2 yr = {y[i].x, y[i].x}, yi = {y[i].y, y[i].y}, cc = {c0, c0};
+#pragma unroll
+        for (int s = 0; s < P; s += 2) {
+            const front_v2 a = {T.A[s], T.A[s + 1]}, b = {T.B[s], T.B[s + 1]}, d = {T.D[s], T.D[s + 1]};
+            const front_v2 e = __builtin_elementwise_fma(yr, a, __builtin_elementwise_fma(yi, b, cc)) + d;
+            u[i][s] = __builtin_amdgcn_exp2f(e.x); u[i][s + 1] = __builtin_amdgcn_exp2f(e.y);
+        }
+#else
+#pragma unroll
+        for (int s = 0; s < P; s++) u[i][s] = __builtin_amdgcn_exp2f(fmaf(y[i].x, T.A[s], fmaf(y[i].y, T.B[s], c0)) + T.D[s]);
+#endif
+        float lo = 1.0f;
+#pragma unroll
+        for (int b = 0; b < BPS; b++) {
+            const int n = P >> b;                      // partial sums left at this level: index bit 0 is bit b of the point
+            float s0 = u[i][0], s1 = u[i][1];
+#pragma unroll
+            for (int j = 1; j < n / 2; j++) { s0 += u[i][2 * j]; s1 += u[i][2 * j + 1]; }
+            out[i][b] = FRONT_LN2 * (__builtin_amdgcn_logf(s0) - __builtin_amdgcn_logf(s1));
+            lo = fminf(lo, fminf(s0, s1));
+#pragma unroll
+            for (int j = 0; j < n / 2; j++) u[i][j] = u[i][2 * j] + u[i][2 * j + 1];
+        }
         if (__builtin_amdgcn_ballot_w64(lo < 0x1p-100f) != 0ull) { if (lo < 0x1p-100f) demap_symbol_far<BPS>(y[i].x, y[i].y, tab, out[i]); }
     }
 }
@@ -183,7 +276,7 @@ template <int BPS, bool FROM_PL, bool DEITL>
 __global__ void __launch_bounds__(FRONT_THREADS)
 front_kernel(const FrontKParams p)
 {
-    constexpr int U = BPS <= 3 ? 4 : 1;          // symbols a lane demaps per read of the constellation table
+    constexpr int U = BPS <= 3 ? 4 : FRONT_U_APSK;          // symbols a lane demaps per read of the constellation table
     __shared__ float4 tab[1 << BPS];
     __shared__ float red[FRONT_THREADS / 64];
     __shared__ float s_sigma;
@@ -214,9 +307,19 @@ front_kernel(const FrontKParams p)
     const float inv2s2 = 1.0f / (2.0f * sigma * sigma);
     if (tid < (1 << BPS)) tab[tid] = demap_table_entry(p.cstl, tid, inv2s2);
     __syncthreads();
+    constexpr bool TS = FRONT_TAB_SCALAR && BPS >= 3;
+    DemapTabS<TS ? BPS : 0> T;
+    if constexpr (TS) demap_tab_scalar<BPS>(T, tab);
     float *llr = p.llr + (size_t)f * n_sym * BPS;
     const int n_rows = (n_sym * BPS) / (p.itl_cols > 1 ? p.itl_cols : 1);
     const bool sep = BPS == 2 && p.sep != 0;
+    const bool st_fast = !DEITL || p.itl_cols <= 1 || p.itl_cols == BPS;
+    const bool st_rows = DEITL && p.itl_cols == BPS;
+    const uint32_t kstride = st_rows ? 4u : 4u * BPS;
+    uint32_t boff[BPS];
+#pragma unroll
+    for (int b = 0; b < BPS; b++) boff[b] = st_rows ? (uint32_t)((p.itl_order == DVBS2HIP_ITL_TOP_LEFT ? b : BPS - 1 - b) * n_rows) * 4u : 4u * b;
+    const __amdgpu_buffer_rsrc_t rllr = __builtin_amdgcn_make_buffer_rsrc(llr, 0, n_sym * BPS * 4, 0x00020000);
     // the symbols of iteration i + 1 are requested before those of iteration i are demapped (the arithmetic of one
     // iteration is about as long as an HBM round trip, and a lane has nothing else to overlap it with)
     float2 yn[U];
@@ -242,11 +345,19 @@ front_kernel(const FrontKParams p)
         if (sep) {
 #pragma unroll
             for (int i = 0; i < U; i++) demap_sep2(y[i], inv2s2, p, out[i]);
-        } else demap_symbols<BPS, U>(y, tab, out);
+        } else if constexpr (TS) demap_symbols_s<BPS, U>(y, T, tab, out);
+        else demap_symbols<BPS, U>(y, tab, out);
 #pragma unroll
         for (int i = 0; i < U; i++) {
             const int k = k0 + i * FRONT_THREADS;
             if (k >= n_sym) continue;
+            if (FRONT_BUF_ST && st_fast) {
+                // LLR b of symbol k sits at  k * kstride + boff[b]  (no interleaver: k bps + b; as many columns as bits: column (b or cols - 1 - b), row k): one vector offset
+                // per symbol, the bit's part in the instruction's scalar offset -- the generic index below costs three wave-uniform branches and a 64-bit address per LLR
+#pragma unroll
+                for (int b = 0; b < BPS; b++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[i][b]), rllr, (uint32_t)k * kstride, boff[b], 0);
+                continue;
+            }
 #pragma unroll
             for (int b = 0; b < BPS; b++) {
                 const int dst = DEITL ? deitl_index(k, b, BPS, p.itl_cols, p.itl_order, n_rows) : k * BPS + b;
@@ -309,9 +420,18 @@ front_reg_kernel(const FrontKParams p)
         if (tid < (1 << BPS)) tab[tid] = demap_table_entry(p.cstl, tid, inv2s2);
         __syncthreads();
     }
+    constexpr bool TS = FRONT_TAB_SCALAR && FRONT_REG_TS && BPS >= 3 && !SEP;
+    DemapTabS<TS ? BPS : 0> T;
+    if constexpr (TS) demap_tab_scalar<BPS>(T, tab);
     float *llr = p.llr + (size_t)f * n_sym * BPS;
     const int n_rows = (n_sym * BPS) / (p.itl_cols > 1 ? p.itl_cols : 1);
     const bool pairs = BPS == 2 && p.itl_cols <= 1;
+    const bool st_fast = FRONT_REG_TS && !pairs && (p.itl_cols <= 1 || p.itl_cols == BPS), st_rows = p.itl_cols == BPS;
+    const uint32_t kstride = st_rows ? 4u : 4u * BPS;
+    uint32_t boff[BPS];
+#pragma unroll
+    for (int b = 0; b < BPS; b++) boff[b] = st_rows ? (uint32_t)((p.itl_order == DVBS2HIP_ITL_TOP_LEFT ? b : BPS - 1 - b) * n_rows) * 4u : 4u * b;
+    const __amdgpu_buffer_rsrc_t rllr = __builtin_amdgcn_make_buffer_rsrc(llr, 0, n_sym * BPS * 4, 0x00020000);
     constexpr bool sep = SEP;
     constexpr int U = 1;                           // the frame itself fills the registers
     static_assert(SPT % U == 0, "symbols per lane come in groups of U");
@@ -330,12 +450,16 @@ front_reg_kernel(const FrontKParams p)
         if constexpr (sep) {
 #pragma clang loop unroll(full)
             for (int i = 0; i < U; i++) demap_sep2(yy[i], inv2s2, p, out[i]);
-        } else demap_symbols<BPS, U>(yy, tab, out);
+        } else if constexpr (TS) demap_symbols_s<BPS, U>(yy, T, tab, out);
+        else demap_symbols<BPS, U>(yy, tab, out);
 #pragma clang loop unroll(full)
         for (int i = 0; i < U; i++) {
             const int k = tid + (i0 + i) * WIDE;
             if (k >= n_sym) continue;
-            if (pairs) { front_f2 v; v.x = out[i][0]; v.y = out[i][BPS - 1]; __builtin_nontemporal_store(v, reinterpret_cast<front_f2 *>(llr) + k); }
+            if (st_fast) {
+#pragma clang loop unroll(full)
+                for (int b = 0; b < BPS; b++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[i][b]), rllr, (uint32_t)k * kstride, boff[b], 0);
+            } else if (pairs) { front_f2 v; v.x = out[i][0]; v.y = out[i][BPS - 1]; __builtin_nontemporal_store(v, reinterpret_cast<front_f2 *>(llr) + k); }
             else {
 #pragma clang loop unroll(full)
                 for (int b = 0; b < BPS; b++) llr[deitl_index(k, b, BPS, p.itl_cols, p.itl_order, n_rows)] = out[i][b];
@@ -422,6 +546,8 @@ static bool front_reg_try(const FrontKParams &p, hipStream_t s)
     else if (p.bps == 2 && small) hipLaunchKernelGGL((front_reg_kernel<2, 8, false>), g, b, 0, s, p);
     else if (p.bps == 3 && small) hipLaunchKernelGGL((front_reg_kernel<3, 8, false>), g, b, 0, s, p);
     else if (p.bps == 3 && mid) hipLaunchKernelGGL((front_reg_kernel<3, 22, false>), g, b, 0, s, p);
+    // (round 4: the APSK frames in registers as well -- front_reg_kernel<4, 4>, <4, 16>, <5, 4> -- measured 0.398 against 0.398 ms (16APSK-N), 0.098 against 0.093 (16APSK-S),
+    // 0.136 against 0.121 (32APSK-S): with sigma given they read the frame once either way, and the two-sweep kernel overlaps eight workgroups per CU)
     else return false;
     return true;
 }
