@@ -398,9 +398,12 @@ def _fir_config(Dvbs2Hip, torch, B, local_rank, rank):
         once(); once(); rx.synchronize()
         reps = 20 if F <= 64 else 5
         lat = []
-        rx.timing_enable(True); rx.timing_reset()
-        for _ in range(reps):
+        for _ in range(reps):           # (the library's per-kernel timers stay off here: two hipEvents per kernel would be part of the latency)
             t = time.perf_counter(); once(); rx.synchronize(); lat.append(time.perf_counter() - t)
+        rx.timing_enable(True); rx.timing_reset()
+        for _ in range(5):
+            once()
+        rx.synchronize()
         fir_ms, fir_n = rx.timing_get(B.K_FIR)
         rx.timing_enable(False)
         fir_ms /= max(fir_n, 1)

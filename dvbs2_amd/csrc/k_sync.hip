@@ -215,10 +215,16 @@ __device__ __forceinline__ void sy_wave_umax4(uint32_t &a, uint32_t &b, uint32_t
 // Every workgroup leaves its key of every frame in keys[frame][workgroup] (plain stores: agent-scope atomics on one word per frame from 521
 // workgroups were what this kernel waited for); sync_finalize_kernel takes their maximum.  A frame without a value above 0 gets key 0.
 constexpr int SYM_UF = 24;
+#ifndef SYNC_ARGMAX10      // 1: the ten-wave form of the average / arg max stage (loaders, chain, arg-max waves), 0: the four-wave form of round 3
+#define SYNC_ARGMAX10 1
+#endif
+#ifndef SYNC_UF96_MAX_WG
+#define SYNC_UF96_MAX_WG 256
+#endif
 __device__ __forceinline__ void sy_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __global__ void __launch_bounds__(256)
-sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr, unsigned long long *__restrict__ keys, int n, int F, float alpha, int end_vec)
+sync_metric_argmax4_kernel(float *__restrict__ cv, const float *__restrict__ corr, unsigned long long *__restrict__ keys, int n, int F, float alpha, int end_vec)
 {
     __shared__ uint32_t ring[2][SYM_UF][64];
     // which of the four waves runs the chain rotates with the workgroup, so that the chain waves of the two or three workgroups a CU holds do
@@ -293,6 +299,201 @@ sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr
         }
     }
 }
+
+// ---- (round 4) the same stage with the chain wave's instruction stream cut to what only it can do, and many more frames between two barriers.
+// The four-wave form above spends ~56 cycles per frame on the chain wave -- not on its two dependent operations (alpha c, then the add; 4.3 cycles each) but on everything
+// else that wave issues per frame at a lone wave's one instruction per ~4.5 cycles (the load and its address, (1 - alpha) m, the LDS store), and on what a barrier costs per
+// 24 frames (LDS round trips and the barrier itself: ~500 cycles, measured with one role at a time): 96 us for the 4096 frames of a 32APSK-S call, more than the correlators
+// and the delay line together.  Here a workgroup is 1 + UF / 8 waves for 64 positions and a tick (the stretch between two barriers) is UF frames:
+//   * UF / 16 LOADER waves, sixteen frames of every chunk each, their loads in flight for two ticks (two register sets), scale by (1 - alpha) and leave the chunk in
+//     LDS as [lane][frame];
+//   * ONE CHAIN wave reads four frames per ds_read_b128 (24 frames ahead of the arithmetic), does the two dependent operations per frame and writes four averages per
+//     ds_write_b128 out of registers that nothing overwrites before the queue has taken them -- 2.5 instructions per frame;
+//   * UF / 16 ARG-MAX waves take the previous chunk: lane (frame, part) scans 16 of the 64 positions of its frame out of LDS (strictly greater: the first maximum, as
+//     the reference's scan), the four parts of a frame merge their 64-bit keys inside their quad (two DPP exchanges) -- ~7 instructions per frame instead of the ~29 of
+//     the wave-wide DPP ladders.
+// Same operations in the same order per position: al * c, om * m, their sum, each rounded once.  Used when the call has few positions (one workgroup per CU at
+// most: 100 KB of LDS); long frames, where the stage is bound by its 4 bytes per sample anyway, keep the four-wave form.
+#ifndef SYM_ABL            // timing-only ablations (wrong results): 1 no loads, 2 no arg max, 4 no chain arithmetic
+#define SYM_ABL 0
+#endif
+#ifdef SYM_PROF
+#define SYB() do { const unsigned long long t_a = __builtin_amdgcn_s_memtime(); busy += t_a - t_last; sy_lds_barrier(); t_last = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SYB() sy_lds_barrier()
+#endif
+template <int UF>
+__global__ void __launch_bounds__(64 * (1 + UF / 8))
+sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr, unsigned long long *__restrict__ keys, int n, int F, float alpha, int end_vec)
+{
+    constexpr int ST = UF + 4;           // LDS row of a lane: UF frames + 4 words (16-byte pieces of the 64 lanes on all banks: ST / 4 is odd)
+    constexpr int NL = UF / 16;
+    static_assert(UF == 96 && ((ST / 4) & 1) == 1, "role placement below is written for 13 waves");
+    __shared__ __attribute__((aligned(16))) float pm[2][64][ST];          // (1 - alpha) m of a chunk, [lane][frame]
+    // the averaged metric of a chunk, [lane][frame] with 16 words of padding behind every 16 rows: the arg-max waves' four parts of a frame (rows 16 part + j) then
+    // fall on different banks (without it all four hit one bank: their conflicted reads kept the LDS queue busy while the chain wave waited for its own)
+    constexpr int RG = 16 * ST + 16;
+    __shared__ __attribute__((aligned(16))) uint32_t ring[2][4 * RG];
+    // (roles in wave order: chain, loaders, arg-max waves.  Placing the roles by SIMD -- the chain wave with three loaders, the arg-max waves on the other three SIMDs -- measured
+    // 57 against 52.5 us; three more waves that leave at once, so that the chain wave has its SIMD to itself: 55.1 against 54.8; the other roles asleep for the first 256 /
+    // 512 / 768 cycles of a tick, so that the chain wave's LDS reads go first: 47.2 / 47.8 / 49.9 against 45.9)
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const int i = blockIdx.x * 64 + lane;
+    const bool act = i < n;
+    const int il = act ? i : n - 1;
+    const int nq = (F + UF - 1) / UF;
+#ifdef SYM_PROF
+    unsigned long long busy = 0ull, t_last = __builtin_amdgcn_s_memtime(), t_rd = 0ull, t_ar = 0ull;
+    const unsigned long long t_begin = t_last;
+#endif
+    typedef float sy_f4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t sy_u4 __attribute__((ext_vector_type(4)));
+    if (wv == 0) {
+        // ---- chain
+        __builtin_amdgcn_s_setprio(3);
+        float c = act ? cv[il] : 0.f;
+        const float al = il < end_vec ? alpha : 0.f;          // positions past the last full vector are not averaged (:284-285): 0 c + 1 m = m exactly
+        SYB();                                                // chunk 0 is in pm[0]
+        for (int t = 0; t <= nq; t++) {
+            if (t < nq && !(SYM_ABL & 4)) {
+                const sy_f4 *src = reinterpret_cast<const sy_f4 *>(&pm[t & 1][lane][0]);
+                sy_u4 *dst = reinterpret_cast<sy_u4 *>(&ring[t & 1][(lane >> 4) * RG + (lane & 15) * ST]);
+                const int cnt = F - t * UF;
+                if (cnt >= UF) {
+                    // 16-byte groups of the chunk, read AH groups ahead of the arithmetic and in this order exactly (sched_barrier): left to the scheduler a group's read
+                    // sinks to just in front of its use and every group waits a whole LDS round trip (28 cycles per frame); all G reads up front need a count the 4-bit
+                    // lgkmcnt cannot hold, so the first multiply waits for the LAST read (measured: 1230 of a tick's 2490 cycles).  The averages leave in two batches, each
+                    // behind the arithmetic of its half: a ds_write_b128 whose data registers a later multiply overwrites holds the vector unit until the LDS queue has
+                    // taken them, and the scheduler puts every write right in front of the instruction that reuses its registers.
+                    constexpr int G = UF / 4, AH = 10;
+                    sy_f4 in[G];
+                    sy_u4 r[G];
+#pragma unroll
+                    for (int g = 0; g < AH; g++) in[g] = src[g];
+                    __builtin_amdgcn_sched_barrier(0);
+#ifdef SYM_PROF
+                    const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+                    t_rd += tq0 - t_last;
+#endif
+#pragma unroll
+                    for (int g = 0; g < G; g++) {
+                        c = al * c + in[g].x; r[g].x = __float_as_uint(c);
+                        c = al * c + in[g].y; r[g].y = __float_as_uint(c);
+                        c = al * c + in[g].z; r[g].z = __float_as_uint(c);
+                        c = al * c + in[g].w; r[g].w = __float_as_uint(c);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (g + AH < G) in[g + AH] = src[g + AH];
+                        if (g == G / 2 - 1) {
+#pragma unroll
+                            for (int k = 0; k < G / 2; k++) dst[k] = r[k];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int k = G / 2; k < G; k++) dst[k] = r[k];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < G; g++) asm volatile("" :: "v"(r[g]));
+#ifdef SYM_PROF
+                    t_ar += __builtin_amdgcn_s_memtime() - tq0;
+#endif
+                } else {                                      // the partial last chunk: the chain stops at the call's last frame
+                    for (int g = 0; 4 * g < cnt; g++) {
+                        const sy_f4 cur = src[g];
+                        sy_u4 r;
+                        c = al * c + cur.x; r.x = __float_as_uint(c);
+                        if (4 * g + 1 < cnt) c = al * c + cur.y;
+                        r.y = __float_as_uint(c);
+                        if (4 * g + 2 < cnt) c = al * c + cur.z;
+                        r.z = __float_as_uint(c);
+                        if (4 * g + 3 < cnt) c = al * c + cur.w;
+                        r.w = __float_as_uint(c);
+                        dst[g] = r;
+                    }
+                }
+            }
+            SYB();
+        }
+        if (act) cv[i] = c;
+    } else if (wv <= NL) {
+        // ---- loaders: frames 16 L .. 16 L + 15 of every chunk; the loads of chunk t + 3 leave in tick t and are taken up in tick t + 2
+        const int L = wv - 1;
+        const float om = !act ? 0.f : il < end_vec ? 1.0f - alpha : 1.f;      // (lanes past the last position carry 0)
+        const size_t stride = (size_t)n;
+        float ma[16], mb[16];
+        auto issue = [&](float (&m)[16], int chunk) {
+            const int f0 = chunk * UF + 16 * L;
+            const float *p = corr + (size_t)f0 * stride + il;
+            if (SYM_ABL & 1) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) m[k] = (float)(f0 + k);
+            } else if (f0 + 16 <= F) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) m[k] = __builtin_nontemporal_load(p + (size_t)k * stride);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) m[k] = f0 + k < F ? __builtin_nontemporal_load(p + (size_t)k * stride) : 0.f;      // (wave-uniform test)
+            }
+        };
+        auto stage = [&](const float (&m)[16], int chunk) {
+            sy_f4 *dst = reinterpret_cast<sy_f4 *>(&pm[chunk & 1][lane][16 * L]);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                sy_f4 a;
+                a.x = om * m[4 * g]; a.y = om * m[4 * g + 1]; a.z = om * m[4 * g + 2]; a.w = om * m[4 * g + 3];
+                dst[g] = a;
+            }
+        };
+        // chunk c travels in set c & 1
+        issue(ma, 0);
+        if (nq > 1) issue(mb, 1);
+        stage(ma, 0);
+        if (nq > 2) issue(ma, 2);
+        SYB();
+        for (int t = 0; t <= nq; t += 2) {
+            if (t + 1 < nq) { stage(mb, t + 1); if (t + 3 < nq) issue(mb, t + 3); }
+            SYB();
+            if (t + 1 > nq) break;
+            if (t + 2 < nq) { stage(ma, t + 2); if (t + 4 < nq) issue(ma, t + 4); }
+            SYB();
+        }
+    } else {
+        // ---- arg max of the chunk the chain wave finished one barrier ago: sixteen frames per wave, lane = (frame, part of the 64 positions)
+        const int R = wv - 1 - NL, part = lane & 3;
+        const int fr = 16 * R + (lane >> 2);
+        const unsigned nwg = gridDim.x;
+        SYB();
+        for (int t = 0; t <= nq; t++) {
+            if (t >= 1 && !(SYM_ABL & 2)) {
+                const int q = t - 1;
+                const int cnt = F - q * UF < UF ? F - q * UF : UF;
+                if (16 * R < cnt) {
+                    const uint32_t *src = &ring[q & 1][part * RG + fr];
+                    uint32_t best = 0u, bi = 0u, v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) v[j] = src[j * ST];
+                    __builtin_amdgcn_sched_barrier(0);      // all sixteen reads in flight before the first compare (left alone, the scheduler waits for them pair by pair)
+#pragma unroll
+                    for (int j = 0; j < 16; j++) { const bool g = v[j] > best; best = g ? v[j] : best; bi = g ? (uint32_t)j : bi; }
+                    uint32_t hi = best, lo = best != 0u ? 0xffffffffu - (uint32_t)(blockIdx.x * 64 + 16 * part + (int)bi) : 0u;
+#pragma unroll
+                    for (int st = 0; st < 2; st++) {
+                        const uint32_t ohi = st == 0 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xf, 0xf, false) : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xf, 0xf, false);
+                        const uint32_t olo = st == 0 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xf, 0xf, false) : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xf, 0xf, false);
+                        const bool tk = ohi > hi || (ohi == hi && olo > lo);
+                        hi = tk ? ohi : hi; lo = tk ? olo : lo;
+                    }
+                    if (part == 0 && fr < cnt) keys[(size_t)(q * UF + fr) * nwg + blockIdx.x] = ((unsigned long long)hi << 32) | lo;
+                }
+            }
+            SYB();
+        }
+    }
+#ifdef SYM_PROF
+    if (blockIdx.x == 1 && lane == 0) printf("wv %d wave %d busy %llu total %llu ticks %d rd %llu ar %llu\n", wv, (int)(threadIdx.x >> 6), busy, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin), nq, t_rd, t_ar);
+#endif
+}
+#undef SYB
 
 // per frame (one wave each): the maximum of the workgroups' keys -> delay (:296), TRI = get_metric() (Synchronizer_frame.hxx:181),
 // FLG = get_packet_flag() (.hpp:60); the delay line's table D[f] = 2 ((n - delay[f]) % n) (set_delay((cplx_in_sz - delay) % cplx_in_sz), :298);
@@ -831,7 +1032,10 @@ hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, c
 static void sync_average_argmax(float *cv, float *corr, int n, int F, float alpha, int vec_width, const SyncTail &t, hipStream_t s)
 {
     const int end_vec = (n / vec_width) * vec_width, nwg = (n + 63) / 64;
-    hipLaunchKernelGGL(sync_metric_argmax_kernel, dim3(nwg), dim3(256), 0, s, cv, corr, t.keys, n, F, alpha, end_vec);
+    // few positions (short frames): the thirteen-wave form, one workgroup per CU at most; long frames: round 3's four-wave form (the stage is bound by its 4 bytes per
+    // sample there: QPSK-N 1024 frames 42-45 us in the four-wave form, 65 us in this one)
+    if (SYNC_ARGMAX10 && nwg <= SYNC_UF96_MAX_WG) hipLaunchKernelGGL(sync_metric_argmax_kernel<96>, dim3(nwg), dim3(64 * 13), 0, s, cv, corr, t.keys, n, F, alpha, end_vec);
+    else hipLaunchKernelGGL(sync_metric_argmax4_kernel, dim3(nwg), dim3(256), 0, s, cv, corr, t.keys, n, F, alpha, end_vec);
     hipLaunchKernelGGL(sync_finalize_kernel, dim3(F), dim3(64), 0, s, t.keys, nwg, t.delay, t.metric, t.flag, t.trigger, t.Dtab, t.last_metric, n, 25, 64, F);
 }
 
