@@ -1034,7 +1034,8 @@ static void sync_average_argmax(float *cv, float *corr, int n, int F, float alph
     const int end_vec = (n / vec_width) * vec_width, nwg = (n + 63) / 64;
     // few positions (short frames): the thirteen-wave form, one workgroup per CU at most; long frames: round 3's four-wave form (the stage is bound by its 4 bytes per
     // sample there: QPSK-N 1024 frames 42-45 us in the four-wave form, 65 us in this one)
-    if (SYNC_ARGMAX10 && nwg <= SYNC_UF96_MAX_WG) hipLaunchKernelGGL(sync_metric_argmax_kernel<96>, dim3(nwg), dim3(64 * 13), 0, s, cv, corr, t.keys, n, F, alpha, end_vec);
+    static const bool four = getenv("DVBS2HIP_SYNC_ARGMAX4") != nullptr;      // development: round 3's kernel for every frame length
+    if (SYNC_ARGMAX10 && !four && nwg <= SYNC_UF96_MAX_WG) hipLaunchKernelGGL(sync_metric_argmax_kernel<96>, dim3(nwg), dim3(64 * 13), 0, s, cv, corr, t.keys, n, F, alpha, end_vec);
     else hipLaunchKernelGGL(sync_metric_argmax4_kernel, dim3(nwg), dim3(256), 0, s, cv, corr, t.keys, n, F, alpha, end_vec);
     hipLaunchKernelGGL(sync_finalize_kernel, dim3(F), dim3(64), 0, s, t.keys, nwg, t.delay, t.metric, t.flag, t.trigger, t.Dtab, t.last_metric, n, 25, 64, F);
 }

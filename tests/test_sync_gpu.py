@@ -125,6 +125,40 @@ def test_frame_synchronizer_at_size_locks_and_realigns_the_stream(O, Rx):
     rx.close(); rx2.close()
 
 
+def test_average_and_arg_max_over_many_short_frames(O, Rx):
+    """The thirteen-wave form of the average over frames / arg max (k_sync.hip, sync_metric_argmax_kernel<96>: short frames, 96 frames between two barriers) on a call of
+    2 whole chunks + a partial one, then calls of 96, 1 and 132 frames (a whole chunk exactly, less than one, one + a partial one): delays and aligned frames equal to the
+    oracle's frame by frame, the metric within the correlators' tolerance, and every socket bit for bit what round 3's four-wave kernel gives (a child process with
+    DVBS2HIP_SYNC_ARGMAX4 set: the knob is read once per process)."""
+    import subprocess, sys, tempfile
+    modcod, F, off = "32APSK-S_3/4", 229, 1501
+    _, pl, _, _ = make_pl_frames(O, modcod, 7, 9.0, seed=31)
+    n = pl.shape[1] // 2
+    stream = np.concatenate([np.zeros(2 * off, np.float32), np.tile(pl.reshape(-1), F // 7 + 2)])[:F * 2 * n].reshape(F, 2 * n)
+    sf = O.SyncFrame(n, alpha=0.9, trigger=30.0, vec_width=8)
+    rx = Rx(modcod, max_frames=F)
+    d, flg, tri, Y = rx.sync_frame_synchronize(stream, with_flags=True)
+    for f in range(F):
+        do, Yo = sf.synchronize(stream[f])
+        assert d[f] == do and np.array_equal(Y[f], Yo), f
+        assert abs(tri[f] - sf.metric) <= TOL * max(1.0, sf.metric) and bool(flg[f]) == sf.packet_flag, f
+    assert d[-1] == off
+    rx2 = Rx(modcod, max_frames=F)
+    parts = [rx2.sync_frame_synchronize(stream[a:b], with_flags=True) for a, b in ((0, 96), (96, 97), (97, F))]
+    assert np.array_equal(np.concatenate([q[0] for q in parts]), d) and np.array_equal(np.concatenate([q[3] for q in parts]), Y)
+    assert np.array_equal(np.concatenate([q[2] for q in parts]).view(np.uint32), tri.view(np.uint32))
+    rx.close(); rx2.close()
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "x.npy"), stream)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); from dvbs2_amd.receiver import Dvbs2Hip; x = np.load(%r); rx = Dvbs2Hip(%r, max_frames=%d); "
+                "d, flg, tri, Y = rx.sync_frame_synchronize(x, with_flags=True); np.savez(%r, d=d, flg=flg, tri=tri, Y=Y)"
+                % (ROOT, os.path.join(td, "x.npy"), modcod, F, os.path.join(td, "o.npz")))
+        subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, DVBS2HIP_SYNC_ARGMAX4="1"))
+        o = np.load(os.path.join(td, "o.npz"))
+        assert np.array_equal(o["d"], d) and np.array_equal(o["flg"], flg) and np.array_equal(o["Y"], Y)
+        assert np.array_equal(o["tri"].view(np.uint32), tri.view(np.uint32))
+
+
 def test_two_task_form_and_correlations(O, Rx):
     modcod = "8PSK-S_3/5"
     F = 5
