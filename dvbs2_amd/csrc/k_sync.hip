@@ -314,6 +314,9 @@ sync_metric_argmax4_kernel(float *__restrict__ cv, const float *__restrict__ cor
 //     the wave-wide DPP ladders.
 // Same operations in the same order per position: al * c, om * m, their sum, each rounded once.  Used when the call has few positions (one workgroup per CU at
 // most: 100 KB of LDS); long frames, where the stage is bound by its 4 bytes per sample anyway, keep the four-wave form.
+#ifndef SYM_NC             // chain waves per workgroup (1, 2 or 4: 64 / NC positions each; measured 47.8 / 49.8 / 52.1 us -- an LDS piece does not get cheaper with fewer active lanes)
+#define SYM_NC 1
+#endif
 #ifndef SYM_ABL            // timing-only ablations (wrong results): 1 no loads, 2 no arg max, 4 no chain arithmetic
 #define SYM_ABL 0
 #endif
@@ -323,11 +326,11 @@ sync_metric_argmax4_kernel(float *__restrict__ cv, const float *__restrict__ cor
 #define SYB() sy_lds_barrier()
 #endif
 template <int UF>
-__global__ void __launch_bounds__(64 * (1 + UF / 8))
+__global__ void __launch_bounds__(64 * (SYM_NC + UF / 8))
 sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr, unsigned long long *__restrict__ keys, int n, int F, float alpha, int end_vec)
 {
     constexpr int ST = UF + 4;           // LDS row of a lane: UF frames + 4 words (16-byte pieces of the 64 lanes on all banks: ST / 4 is odd)
-    constexpr int NL = UF / 16;
+    constexpr int NL = UF / 16, NC = SYM_NC;
     static_assert(UF == 96 && ((ST / 4) & 1) == 1, "role placement below is written for 13 waves");
     __shared__ __attribute__((aligned(16))) float pm[2][64][ST];          // (1 - alpha) m of a chunk, [lane][frame]
     // the averaged metric of a chunk, [lane][frame] with 16 words of padding behind every 16 rows: the arg-max waves' four parts of a frame (rows 16 part + j) then
@@ -348,24 +351,27 @@ sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr
 #endif
     typedef float sy_f4 __attribute__((ext_vector_type(4)));
     typedef uint32_t sy_u4 __attribute__((ext_vector_type(4)));
-    if (wv == 0) {
-        // ---- chain
+    if (wv < NC) {
+        // ---- chain (NC = 1: one wave; the split over NC waves of 64 / NC positions each is kept as a knob, it measured slower)
         __builtin_amdgcn_s_setprio(3);
-        float c = act ? cv[il] : 0.f;
-        const float al = il < end_vec ? alpha : 0.f;          // positions past the last full vector are not averaged (:284-285): 0 c + 1 m = m exactly
+        const int pc = (64 / NC) * wv + (lane & (64 / NC - 1)), ic = blockIdx.x * 64 + pc;
+        const bool mine = lane < 64 / NC, actc = ic < n;
+        const int ilc = actc ? ic : n - 1;
+        float c = mine && actc ? cv[ilc] : 0.f;
+        const float al = ilc < end_vec ? alpha : 0.f;         // positions past the last full vector are not averaged (:284-285): 0 c + 1 m = m exactly
         SYB();                                                // chunk 0 is in pm[0]
         for (int t = 0; t <= nq; t++) {
-            if (t < nq && !(SYM_ABL & 4)) {
-                const sy_f4 *src = reinterpret_cast<const sy_f4 *>(&pm[t & 1][lane][0]);
-                sy_u4 *dst = reinterpret_cast<sy_u4 *>(&ring[t & 1][(lane >> 4) * RG + (lane & 15) * ST]);
+            if (t < nq && !(SYM_ABL & 4) && mine) {
+                const sy_f4 *src = reinterpret_cast<const sy_f4 *>(&pm[t & 1][pc][0]);
+                sy_u4 *dst = reinterpret_cast<sy_u4 *>(&ring[t & 1][(pc >> 4) * RG + (pc & 15) * ST]);
                 const int cnt = F - t * UF;
                 if (cnt >= UF) {
-                    // 16-byte groups of the chunk, read AH groups ahead of the arithmetic and in this order exactly (sched_barrier): left to the scheduler a group's read
-                    // sinks to just in front of its use and every group waits a whole LDS round trip (28 cycles per frame); all G reads up front need a count the 4-bit
-                    // lgkmcnt cannot hold, so the first multiply waits for the LAST read (measured: 1230 of a tick's 2490 cycles).  The averages leave in two batches, each
-                    // behind the arithmetic of its half: a ds_write_b128 whose data registers a later multiply overwrites holds the vector unit until the LDS queue has
-                    // taken them, and the scheduler puts every write right in front of the instruction that reuses its registers.
-                    constexpr int G = UF / 4, AH = 10;
+                    // The chain wave's tick is its LDS traffic, not its arithmetic (tools/probe_lds128.hip: a lone wave's ds_read_b128 of 64 x 16 bytes takes ~20 cycles,
+                    // a ds_write_b128 ~34; 24 + 24 of them = 1280 cycles against 825 for the 192 dependent operations), so the two run side by side: half of the chunk's
+                    // reads first, then group after group { arithmetic in place, its write, the read twelve groups ahead }, in this order exactly (sched_barrier: left to
+                    // the scheduler a read sinks to just in front of its use and a write to just in front of the instruction that reuses its registers -- and a
+                    // ds_write_b128 whose data registers are overwritten holds the vector unit, so every group keeps registers of its own until the tick is over).
+                    constexpr int G = UF / 4, AH = G / 2;
                     sy_f4 in[G];
                     sy_u4 r[G];
 #pragma unroll
@@ -382,16 +388,10 @@ sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr
                         c = al * c + in[g].z; r[g].z = __float_as_uint(c);
                         c = al * c + in[g].w; r[g].w = __float_as_uint(c);
                         __builtin_amdgcn_sched_barrier(0);
+                        dst[g] = r[g];
                         if (g + AH < G) in[g + AH] = src[g + AH];
-                        if (g == G / 2 - 1) {
-#pragma unroll
-                            for (int k = 0; k < G / 2; k++) dst[k] = r[k];
-                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#pragma unroll
-                    for (int k = G / 2; k < G; k++) dst[k] = r[k];
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int g = 0; g < G; g++) asm volatile("" :: "v"(r[g]));
 #ifdef SYM_PROF
@@ -414,10 +414,10 @@ sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr
             }
             SYB();
         }
-        if (act) cv[i] = c;
-    } else if (wv <= NL) {
+        if (mine && actc) cv[ic] = c;
+    } else if (wv < NC + NL) {
         // ---- loaders: frames 16 L .. 16 L + 15 of every chunk; the loads of chunk t + 3 leave in tick t and are taken up in tick t + 2
-        const int L = wv - 1;
+        const int L = wv - NC;
         const float om = !act ? 0.f : il < end_vec ? 1.0f - alpha : 1.f;      // (lanes past the last position carry 0)
         const size_t stride = (size_t)n;
         float ma[16], mb[16];
@@ -459,7 +459,7 @@ sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr
         }
     } else {
         // ---- arg max of the chunk the chain wave finished one barrier ago: sixteen frames per wave, lane = (frame, part of the 64 positions)
-        const int R = wv - 1 - NL, part = lane & 3;
+        const int R = wv - NC - NL, part = lane & 3;
         const int fr = 16 * R + (lane >> 2);
         const unsigned nwg = gridDim.x;
         SYB();
@@ -1035,7 +1035,7 @@ static void sync_average_argmax(float *cv, float *corr, int n, int F, float alph
     // few positions (short frames): the thirteen-wave form, one workgroup per CU at most; long frames: round 3's four-wave form (the stage is bound by its 4 bytes per
     // sample there: QPSK-N 1024 frames 42-45 us in the four-wave form, 65 us in this one)
     static const bool four = getenv("DVBS2HIP_SYNC_ARGMAX4") != nullptr;      // development: round 3's kernel for every frame length
-    if (SYNC_ARGMAX10 && !four && nwg <= SYNC_UF96_MAX_WG) hipLaunchKernelGGL(sync_metric_argmax_kernel<96>, dim3(nwg), dim3(64 * 13), 0, s, cv, corr, t.keys, n, F, alpha, end_vec);
+    if (SYNC_ARGMAX10 && !four && nwg <= SYNC_UF96_MAX_WG) hipLaunchKernelGGL(sync_metric_argmax_kernel<96>, dim3(nwg), dim3(64 * (SYM_NC + 12)), 0, s, cv, corr, t.keys, n, F, alpha, end_vec);
     else hipLaunchKernelGGL(sync_metric_argmax4_kernel, dim3(nwg), dim3(256), 0, s, cv, corr, t.keys, n, F, alpha, end_vec);
     hipLaunchKernelGGL(sync_finalize_kernel, dim3(F), dim3(64), 0, s, t.keys, nwg, t.delay, t.metric, t.flag, t.trigger, t.Dtab, t.last_metric, n, 25, 64, F);
 }
