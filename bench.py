@@ -400,6 +400,13 @@ def _fir_config(Dvbs2Hip, torch, B, local_rank, rank):
         lat = []
         for _ in range(reps):           # (the library's per-kernel timers stay off here: two hipEvents per kernel would be part of the latency)
             t = time.perf_counter(); once(); rx.synchronize(); lat.append(time.perf_counter() - t)
+        # the same sequence 50 times without a synchronize in between: what a pipeline that keeps the device busy pays per call (the one-call latency above is measured
+        # on an otherwise idle device, whose clocks the power management has lowered: a lone 32APSK-S frame's ten iterations take ~0.4 ms there, ~0.1 ms in a stream of calls)
+        t = time.perf_counter()
+        for _ in range(50 if F <= 64 else 5):
+            once()
+        rx.synchronize()
+        b2b = (time.perf_counter() - t) / (50 if F <= 64 else 5)
         rx.timing_enable(True); rx.timing_reset()
         for _ in range(5):
             once()
@@ -410,7 +417,7 @@ def _fir_config(Dvbs2Hip, torch, B, local_rank, rank):
         lat.sort()
         n_cplx = n * osf * F
         ok = int((got[: max(F - 1, 1)] == sent[: max(F - 1, 1)]).all(dim=1).sum().item())      # (the stream's last frame lacks its 40 tail symbols)
-        rows.append({"frames": F, "latency_ms_median": 1e3 * lat[len(lat) // 2], "latency_ms_min": 1e3 * lat[0], "latency_us_per_frame": 1e6 * lat[len(lat) // 2] / F,
+        rows.append({"frames": F, "latency_ms_median": 1e3 * lat[len(lat) // 2], "latency_ms_min": 1e3 * lat[0], "latency_us_per_frame": 1e6 * lat[len(lat) // 2] / F, "back_to_back_ms_per_call": 1e3 * b2b,
                      "frames_per_s": F / lat[len(lat) // 2], "fir_kernel_us": 1e3 * fir_ms, "fir_GFLOPs_fp32_equiv": 324.0 * n_cplx / (fir_ms * 1e-3) / 1e9 if fir_ms else None,
                      "fir_GBps": 16.0 * n_cplx / (fir_ms * 1e-3) / 1e9 if fir_ms else None, "frames_decoded_exactly": ok, "frames_checked": max(F - 1, 1)})
         rx.close()
