@@ -67,6 +67,10 @@ def test_bench_line_on_the_gpu():
         assert 0.0 < b["valu"]["frac"] <= 1.0
     else:
         assert ro["bounded"] is None and ro["bounded_frac"] is None and ro["frac"] is None
+    # the fabric bytes are re-measured in the run itself (rocprofv3 --pmc child runs of bench.py) and agree with the committed, sha-stamped passes
+    lp = ro["live_pmc"]
+    assert lp and "error" not in lp, lp
+    assert lp["launches_counted"] >= 3 and ro["traffic"] == lp["hbm_bytes_per_launch"] and 0.9 < lp["live_over_committed"] < 1.1, lp
     ex = d["extra"]
     assert set(ex["early_stop_fps"]) == {"4.0 dB", "3.0 dB"} and ex["early_stop_fps"]["4.0 dB"] > d["fec_frames_per_s"]       # converging frames stop early
     hb = ex["hard_batch_fixed_10_ite"]
