@@ -569,7 +569,7 @@ const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
     if (!h) return "";
     if (h->ldpc_sched == DVBS2HIP_SCHED_NATURAL) {      // one lane per frame from 32768 frames on, a check's edges over 4 / 8 lanes below (k_ldpc_nat.hip: ldpc_nat_launch)
         const std::string d = std::to_string(h->ldpc.fast_deg);
-        const_cast<dvbs2hip_t *>(h)->ldpc_name = "ldpc_nat_kernel<" + d + "> / ldpc_nat_part_kernel<" + d + ",4|8> by batch size";
+        const_cast<dvbs2hip_t *>(h)->ldpc_name = "ldpc_nat_kernel<" + d + "> / ldpc_nat_part_kernel<" + d + ",4|8> / ldpc_nat_ck_kernel<" + d + ",8|4> by batch size";
         return h->ldpc_name.c_str();
     }
     {

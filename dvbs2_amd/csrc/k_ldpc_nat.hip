@@ -402,6 +402,193 @@ ldpc_nat_part_kernel(const NatParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------
+// Round 4, second form for small batches: EIGHT CONSECUTIVE CHECKS of a frame in eight adjacent lanes (lane = 8 x frame-of-the-wave + k, check c0 + k), eight frames per wave --
+// the same [bit][8 frames] image as the 8-lanes-per-check kernel above.  A check has 27 edges of which ONE, the parity bit it shares with the check before it, makes the
+// sweep serial; the other 26 belong to this check alone among its 25 predecessors (the host's second hazard plane is empty for every code of the library).  So:
+//   A. every lane forms v -> c = L - old for its own check's 26 other edges and their two smallest magnitudes, parity and sign word -- 8 checks x 8 frames at once, no exchange;
+//   B. the chain runs as a scan over the eight lanes of a frame: in step s every lane takes the posterior of p_{c-1} from its left neighbour (DPP row_shr:1; lane k = 0 from the
+//      previous group's last lane), folds that edge in and forms p_c's new posterior; after step s lanes 0 .. s hold their final values (a lane whose input was final repeats
+//      the same result), so eight unconditional steps of ~16 instructions leave every lane right -- no select, no LDS, no barrier;
+//   C. every lane forms the new messages and posteriors of its check and stores them.
+// Per frame and check the wave issues ~11 instructions instead of the ~26 of the form above (no merge rounds, no padding slots, every lane busy), and the loads of a group of
+// eight checks go out NAT_CK_AHEAD groups ahead (the last check of the group in flight is 8 NAT_CK_AHEAD + 7 <= NAT_HAZ_WINDOW checks in front of the first one not yet written).
+// Same fp32 operations per edge, the same two minima (the two smallest of a set do not depend on the order they are found in), the index of the LAST slot that holds the
+// minimum: bit for bit the one-lane kernel and the oracle's ORC_SCHED_NATURAL.
+constexpr int NAT_CK_AHEAD = 2;
+#ifndef NAT_CK_TRIP
+#define NAT_CK_TRIP 6
+#endif
+static_assert(NAT_CK_TRIP % NAT_CK_AHEAD == 0, "the ring has to be back at its start when a trip ends");
+static_assert(8 * NAT_CK_AHEAD + 7 <= NAT_HAZ_WINDOW, "the requests run further ahead than the host's hazard plane covers");
+// WV waves per workgroup share an image whose rows hold the posteriors of 64 / CK x WV frames (a 128-byte line for CK = 8, WV = 4): every wave takes its own 64 / CK frames
+// through the same checks at about the same time, so a line is fetched over the fabric once and found in the CU's L1 / the XCD's L2 by the other waves -- with rows of 32
+// bytes (one wave's eight frames) the form was bound by the 128 bytes the fabric moves per row touched (1.8 TB/s of its own bytes at every batch size).
+template <int DEG, int CK, int WV>
+__global__ void __launch_bounds__(64 * WV)
+ldpc_nat_ck_kernel(const NatParams p)
+{
+    constexpr int GW = 64 / CK, G = GW * WV, AH = NAT_CK_AHEAD;      // frames per wave, frames per workgroup = per image row
+    static_assert(CK == 8 || CK == 4, "checks side by side");
+    constexpr uint32_t RB = G * 4;                 // bytes per row
+    extern __shared__ uint32_t s_tab[];            // [q][DEG][2]: per slot {byte offset of element 0 of its bit run | NULL: the +inf row ; t0 | byte stride between elements << 16 | NULL << 31}
+    const int g = blockIdx.x, lane = threadIdx.x & 63, k = lane & (CK - 1), fl = lane / CK + GW * (int)(threadIdx.x >> 6), f = g * G + fl;
+    float *W = p.work + (size_t)g * p.grp_words;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(W, 0, p.grp_words * 4, 0x00020000);
+    const uint32_t vo = (uint32_t)fl * 4u;
+    const int q = p.q, M = p.M;
+    const uint32_t inf_row = (uint32_t)p.N * RB, junk_row = inf_row + RB, st0 = junk_row + RB;
+    uint32_t SB = 0x80000000u;
+    asm volatile("" : "+s"(SB));
+    for (int i = threadIdx.x; i < q * DEG; i += 64 * WV) {
+        const uint32_t e = p.tab[(size_t)i * 2], A = p.tab[(size_t)i * 2 + 1];
+        const bool null = ((e >> 17) & 1u) != 0u;
+        const uint32_t stride = null ? 0u : (((e >> 16) & 1u) ? (uint32_t)q : 1u) * RB;
+        s_tab[2 * i] = null ? inf_row : A * RB;
+        s_tab[2 * i + 1] = (null ? 0u : (e & 0xFFFFu)) | (stride << 16) | (null ? 0x80000000u : 0u);      // (stride < 2^15: q * RB <= 135 * 128)
+    }
+    __syncthreads();
+    auto gldv = [&](uint32_t voff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0)); };
+    auto gstv = [&](uint32_t voff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, 0, 0); };
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+    const uint32_t tab_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)s_tab;
+    auto addr_of = [&](int r, int t, int j, bool &real) -> uint32_t {
+        const u32x2 e = *(lds_u32x2 *)(size_t)(tab_base + (uint32_t)(r * DEG + j) * 8u);
+        int elem = t - (int)(e.y & 0xFFFFu);
+        elem += (elem >> 31) & LDPC_Z;
+        real = (int)e.y >= 0;
+        return e.x + __umul24((uint32_t)elem, (e.y >> 16) & 0x7FFFu) + vo;
+    };
+    const int dr = CK % q, dt = CK / q;            // (r, t) of check c + 8 from those of check c
+    bool live = f < p.F, ok = false;
+    int it = 0, my_ite = 0;
+    struct Req { uint32_t a[DEG]; float v[DEG - 1]; float c1, c2, pk; };
+    auto request = [&](Req &R, int c, int r, int t) {       // this lane's check c = (r, t): the posteriors of its slots but the forwarded one, its packed state, and where pass C stores
+#pragma unroll
+        for (int j = 0; j < DEG; j++) {
+            bool real;
+            const uint32_t a = addr_of(r, t, j, real);
+            R.a[j] = (real && !(j == DEG - 1 && c == 0)) ? a : junk_row + vo;      // (NULL slots and the absent p_{c-1} of check 0: the junk row)
+            if (j < DEG - 1) R.v[j] = gldv(a);                                     // (a NULL slot's `a` is the +inf row already)
+        }
+        const uint32_t srow = st0 + (uint32_t)c * 3u * RB + vo;
+        R.c1 = gldv(srow); R.c2 = gldv(srow + RB); R.pk = gldv(srow + 2 * RB);
+    };
+    const int ngrp = M / CK;
+    while (it < p.n_ite) {
+        float carry = INFINITY;                   // posterior of p_{c0 - 1} as the previous group's last check left it (check 0: absent, +inf)
+        __builtin_amdgcn_s_waitcnt(0);
+        Req ring[AH];
+        int cq = k, rq = k % q, tq = k / q;        // the request stream of this lane: its check of the next group to ask for
+        auto request_next = [&](Req &R) {
+            request(R, cq, rq, tq);
+            if (cq + CK < M) { cq += CK; rq += dr; tq += dt; if (rq >= q) { rq -= q; tq++; } }      // beyond the last group: the last one again (harmless)
+        };
+#pragma unroll
+        for (int u = 0; u < AH; u++) request_next(ring[u]);
+        // (the compiler drains the vector memory queue at the head of the loop -- it cannot bound what is in flight there: a whole memory round trip per trip -- so a trip is
+        // NAT_CK_TRIP groups long, the ring of AH requests going round inside it)
+        for (int g0 = 0; g0 < ngrp; g0 += NAT_CK_TRIP) {
+            if (WV > 1) __builtin_amdgcn_s_barrier();      // the waves of a workgroup stay within a trip of each other: a line one of them has fetched is still near when the others ask
+#pragma unroll
+            for (int u = 0; u < NAT_CK_TRIP; u++) {
+                if (g0 + u >= ngrp) break;
+                const int c = (g0 + u) * CK + k;
+                Req &R = ring[u % AH];
+                // ---- A. the 26 edges that are this check's own
+                float v[DEG];
+                const float c1o = R.c1, c2o = R.c2;
+                const uint32_t pko = __float_as_uint(R.pk), idxo = pko >> 27;
+                float pm1 = INFINITY, pm2 = INFINITY;
+                uint32_t psacc = 0u;
+#pragma unroll
+                for (int j = 0; j < DEG - 1; j++) {
+                    const float mag = (idxo == (uint32_t)j) ? c1o : c2o;
+                    const float old = nat_and_or(pko << ((32u - DEG) + j), SB, mag);
+                    const float x = R.v[j] - old;
+                    v[j] = x;
+                    const float a = fabsf(x);
+                    pm2 = __builtin_amdgcn_fmed3f(pm1, pm2, a);
+                    pm1 = fminf(pm1, a);
+                    psacc = __builtin_amdgcn_alignbit(psacc, __float_as_uint(x), 31);
+                }
+                const float oldp = nat_and_or(pko << ((32u - DEG) + (DEG - 1)), SB, (idxo == (uint32_t)(DEG - 1)) ? c1o : c2o);
+                const float xc = v[DEG - 2];      // p_c's edge
+                // ---- B. the chain over the eight checks of the group
+                float lout = 0.f, xl = 0.f, mn1 = 0.f, m1s = 0.f, m2s = 0.f, cst1 = 0.f, cst2 = 0.f;
+                uint32_t sacc = 0u, tot = 0u;
+#pragma unroll
+                for (int s8 = 0; s8 < CK; s8++) {
+                    const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lout), 0x111, 0xF, 0xF, false));      // row_shr:1
+                    const float lp = k == 0 ? carry : left;
+                    xl = lp - oldp;
+                    const float a = fabsf(xl);
+                    const float mn2 = __builtin_amdgcn_fmed3f(pm1, pm2, a);
+                    mn1 = fminf(pm1, a);
+                    sacc = __builtin_amdgcn_alignbit(psacc, __float_as_uint(xl), 31);
+                    cst1 = mn2 * p.alpha; cst2 = mn1 * p.alpha;
+                    tot = (uint32_t)(__popc(sacc) & 1);
+                    m1s = __uint_as_float(__float_as_uint(cst1) | (tot << 31)); m2s = __uint_as_float(__float_as_uint(cst2) | (tot << 31));
+                    const float mag = (fabsf(xc) == mn1) ? m1s : m2s;
+                    lout = xc + __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(xc) & SB));
+                }
+                // the next group's first lane continues from this group's last one
+                carry = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane & ~(CK - 1)) | (CK - 1)) * 4, __builtin_bit_cast(int, lout)));
+                // ---- C. new messages and posteriors of this lane's check
+                v[DEG - 1] = xl;
+                uint32_t pkn = sacc ^ (tot ? ((1u << DEG) - 1u) : 0u), idxn = 0u;
+                asm volatile("" : "+v"(m1s), "+v"(m2s));
+#pragma unroll
+                for (int j = 0; j < DEG; j++) {
+                    const float x = v[j];
+                    const bool ismin = fabsf(x) == mn1;
+                    const float mag = ismin ? m1s : m2s;
+                    const float nw = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(x) & SB));
+                    idxn = ismin ? (uint32_t)j : idxn;
+                    gstv(live ? R.a[j] : junk_row + vo, x + nw);      // (slot DEG-2, p_c, leaves before the next lane's slot DEG-1 of the same row: the later check's value stays)
+                }
+                pkn |= idxn << 27;
+                {
+                    const uint32_t srow = live ? st0 + (uint32_t)c * 3u * RB + vo : junk_row + vo;
+                    const uint32_t sr1 = live ? RB : 0u;
+                    gstv(srow, cst1); gstv(srow + sr1, cst2); gstv(srow + 2 * sr1, __uint_as_float(pkn));
+                }
+                request_next(R);
+            }
+        }
+        it++;
+        if (live) my_ite = it;
+        if (p.early_stop || it == p.n_ite) {
+            // ---- syndrome of the hard decisions: lane k takes checks k, k + 8, ..; the frame's eight lanes OR their findings
+            __builtin_amdgcn_s_waitcnt(0);
+            uint32_t bad = 0u;
+            int r2 = k % q, t2 = k / q;
+            for (int c = k; c < M; c += CK) {
+                uint32_t x = 0u;
+#pragma unroll
+                for (int j = 0; j < DEG; j++) {
+                    bool real;
+                    const uint32_t a = addr_of(r2, t2, j, real);
+                    x ^= __float_as_uint(gldv((j == DEG - 1 && c == 0) ? inf_row + vo : a));       // (+inf: sign bit 0)
+                }
+                bad |= x >> 31;
+                r2 += dr; t2 += dt; if (r2 >= q) { r2 -= q; t2++; }
+            }
+            bad |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bad, 0xB1, 0xF, 0xF, true);
+            bad |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bad, 0x4E, 0xF, 0xF, true);
+            if (CK == 8) bad |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bad, 0x141, 0xF, 0xF, true);
+            if (live) { ok = bad == 0u; if (ok) live = false; }
+            if (WV > 1) { if (!__syncthreads_or(live ? 1 : 0)) break; }      // (the waves of a workgroup leave together: they meet at the barriers above)
+            else if (!__any(live)) break;
+        }
+    }
+    if (f < p.F && k == 0) {
+        if (p.cwd) p.cwd[f] = ok ? 1 : 0;
+        if (p.ites) p.ites[f] = my_ite;
+    }
+}
+
 // ---- llr [F][N] <-> rows of G frames (G = 64 / PARTS), the general forms of nat_load_kernel / nat_store_kernel
 __global__ void __launch_bounds__(256)
 nat_load_g_kernel(const NatParams p, int G)
@@ -454,6 +641,18 @@ nat_store_g_kernel(const NatParams p, int G)
     }
 }
 
+template <int DEG, int CK, int WV>
+static hipError_t nat_ck_launch(const LdpcPlan &pl, NatParams p, hipStream_t s)
+{
+    constexpr int G = 64 / CK * WV;
+    p.grp_words = (uint32_t)((size_t)(pl.N + 2 + 3 * pl.M) * G);
+    const int groups = (p.F + G - 1) / G, tiles = (pl.N + 63) / 64;
+    hipLaunchKernelGGL(nat_load_g_kernel, dim3(tiles, groups), dim3(256), 0, s, p, G);
+    hipLaunchKernelGGL((ldpc_nat_ck_kernel<DEG, CK, WV>), dim3(groups), dim3(64 * WV), (size_t)pl.q * DEG * 8, s, p);
+    hipLaunchKernelGGL(nat_store_g_kernel, dim3(tiles, groups), dim3(256), 0, s, p, G);
+    return hipGetLastError();
+}
+
 template <int DEG, int PARTS>
 static hipError_t nat_part_launch(const LdpcPlan &pl, NatParams p, hipStream_t s)
 {
@@ -476,10 +675,24 @@ hipError_t ldpc_nat_launch(const LdpcPlan &pl, const LdpcKParams &kp, float *wor
     p.llr = kp.llr; p.work = work; p.tab = pl.d_nat_tab; p.haz = pl.d_nat_haz;
     p.bits = kp.bits; p.packed = kp.packed; p.cwd = kp.cwd; p.post = kp.post; p.ites = kp.ites;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.F = kp.n_frames; p.n_ite = kp.n_ite; p.early_stop = kp.early_stop; p.alpha = kp.alpha;
-    // Lanes per frame by the size of the batch: one (64 frames per wave) when that alone gives every SIMD a wave, else 4 or 8 lanes per frame (16 / 8 frames per wave:
-    // a check's edges split over adjacent lanes, the next check's loads requested early).  DVBS2HIP_NAT_PARTS = 1 | 4 | 8 overrides.
-    int parts = kp.n_frames >= 32768 ? 1 : kp.n_frames > 6144 ? 4 : 8;
-    if (const char *ev = getenv("DVBS2HIP_NAT_PARTS")) { const int v = atoi(ev); if (v == 1 || v == 4 || v == 8) parts = v; }
+    // Form by the size of the batch.  Codes whose second hazard plane is empty and whose check count divides by eight (every DVB-S2 code of the library) run CONSECUTIVE CHECKS
+    // side by side (ldpc_nat_ck_kernel): 8 checks x 8 frames per wave, four waves per 32-frame workgroup, up to 6144 frames (the BASELINE batch: 78 -> 110 k normal frames/s),
+    // 4 checks x 16 frames, two waves per workgroup, beyond (16384+ normal frames: 245 k frames/s; one lane per frame reached 171 k at 32768).  Any other code: one lane per
+    // frame when that alone gives every SIMD a wave, else a check's edges over 4 or 8 lanes.  DVBS2HIP_NAT_PARTS = 1 | 4 | 8 (those forms), 88 | 44 (the two above) overrides.
+    bool clean = pl.M % 8 == 0;
+    for (size_t i = pl.nat_haz.size() / 2; i < pl.nat_haz.size(); i++) clean &= pl.nat_haz[i] == 0u;
+    int parts = clean ? (kp.n_frames > 6144 ? 44 : 88) : kp.n_frames >= 32768 ? 1 : kp.n_frames > 6144 ? 4 : 8;
+    if (const char *ev = getenv("DVBS2HIP_NAT_PARTS")) { const int v = atoi(ev); if (v == 1 || v == 4 || v == 8 || ((v == 88 || v == 44) && clean)) parts = v; }
+    if (parts == 88) {
+        if (pl.fast_deg == 27) return nat_ck_launch<27, 8, 4>(pl, p, s);
+        if (pl.fast_deg == 13) return nat_ck_launch<13, 8, 4>(pl, p, s);
+        return nat_ck_launch<11, 8, 4>(pl, p, s);
+    }
+    if (parts == 44) {
+        if (pl.fast_deg == 27) return nat_ck_launch<27, 4, 2>(pl, p, s);
+        if (pl.fast_deg == 13) return nat_ck_launch<13, 4, 2>(pl, p, s);
+        return nat_ck_launch<11, 4, 2>(pl, p, s);
+    }
     if (parts > 1) {
         if (pl.fast_deg == 27) return parts == 4 ? nat_part_launch<27, 4>(pl, p, s) : nat_part_launch<27, 8>(pl, p, s);
         if (pl.fast_deg == 13) return parts == 4 ? nat_part_launch<13, 4>(pl, p, s) : nat_part_launch<13, 8>(pl, p, s);
