@@ -396,23 +396,27 @@ def _fir_config(Dvbs2Hip, torch, B, local_rank, rank):
     dev = torch.device("cuda", local_rank)
     rows = []
     for F in (1, 8, 64, 4096):
-        rx = Dvbs2Hip(modcod, max_frames=F, n_ite=n_ite, alpha=1.0, early_stop=False, device=local_rank)
+        # the stream holds ONE FRAME MORE than the call decodes: the batch is one stream whose last frame lacks its 40 tail symbols behind the matched filter's group delays, and a
+        # frame that cannot decode sends the BCH stage through Berlekamp-Massey and the Chien search (~0.2 ms for that one frame: round 4's first latency figures, 0.43 ms at F = 1,
+        # were those of a call whose only frame was that one)
+        Fg = F + 1
+        rx = Dvbs2Hip(modcod, max_frames=Fg, n_ite=n_ite, alpha=1.0, early_stop=False, device=local_rank)
         n = rx.pl_frame
         sig_sym = float(P.esn0_to_sigma(P.ebn0_to_esn0(ebn0, mc.code_rate, mc.bps)))
-        zero = torch.zeros((F,), dtype=torch.float32, device=dev)
-        sig_smp = torch.full((F,), sig_sym * 2.0 ** 0.5, dtype=torch.float32, device=dev)     # matched filter of gain 1: per-sample noise at osf 2
-        sig_c = torch.full((F,), sig_sym, dtype=torch.float32, device=dev)
-        sent = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev); got = torch.empty_like(sent)
-        pl = torch.empty((F, 2 * n), dtype=torch.float32, device=dev)
-        up = torch.empty((F, 2 * n * osf), dtype=torch.float32, device=dev); noisy = torch.empty_like(up); mf = torch.empty_like(up)
-        sym = torch.empty((F, 2 * n), dtype=torch.float32, device=dev)
-        rx.tx_bb_dev(None, 777 + rank, zero.data_ptr(), sent.data_ptr(), pl.data_ptr(), F)
-        rx.shape_filter_dev(pl.data_ptr(), up.data_ptr(), n, F)
-        rx.add_noise_dev(sig_smp.data_ptr(), up.data_ptr(), noisy.data_ptr(), 5, 2 * n * osf, F)
+        zero = torch.zeros((Fg,), dtype=torch.float32, device=dev)
+        sig_smp = torch.full((Fg,), sig_sym * 2.0 ** 0.5, dtype=torch.float32, device=dev)     # matched filter of gain 1: per-sample noise at osf 2
+        sig_c = torch.full((Fg,), sig_sym, dtype=torch.float32, device=dev)
+        sent = torch.empty((Fg, rx.K_bch), dtype=torch.int32, device=dev); got = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev)
+        pl = torch.empty((Fg, 2 * n), dtype=torch.float32, device=dev)
+        up = torch.empty((Fg, 2 * n * osf), dtype=torch.float32, device=dev); noisy = torch.empty_like(up); mf = torch.empty_like(up)
+        sym = torch.empty((Fg, 2 * n), dtype=torch.float32, device=dev)
+        rx.tx_bb_dev(None, 777 + rank, zero.data_ptr(), sent.data_ptr(), pl.data_ptr(), Fg)
+        rx.shape_filter_dev(pl.data_ptr(), up.data_ptr(), n, Fg)
+        rx.add_noise_dev(sig_smp.data_ptr(), up.data_ptr(), noisy.data_ptr(), 5, 2 * n * osf, Fg)
         def once():
             rx.filter_reset()
-            rx.filter_dev(noisy.data_ptr(), mf.data_ptr(), n * osf, F)
-            rx.extract_dev(mf.data_ptr(), sym.data_ptr(), n, osf, 80, F)      # two group delays of 40 samples; the batch is one stream (its last 40 symbols read as zero)
+            rx.filter_dev(noisy.data_ptr(), mf.data_ptr(), n * osf, Fg)
+            rx.extract_dev(mf.data_ptr(), sym.data_ptr(), n, osf, 80, Fg)     # two group delays of 40 samples; the stream's last frame (its last 40 symbols read as zero) is not decoded
             rx.rx_bb_dev(sym.data_ptr(), sig_c.data_ptr(), got.data_ptr(), None, None, F)
         sym.zero_()
         once(); once(); rx.synchronize()
@@ -420,8 +424,8 @@ def _fir_config(Dvbs2Hip, torch, B, local_rank, rank):
         lat = []
         for _ in range(reps):           # (the library's per-kernel timers stay off here: two hipEvents per kernel would be part of the latency)
             t = time.perf_counter(); once(); rx.synchronize(); lat.append(time.perf_counter() - t)
-        # the same sequence 50 times without a synchronize in between: what a pipeline that keeps the device busy pays per call (the one-call latency above is measured
-        # on an otherwise idle device, whose clocks the power management has lowered: a lone 32APSK-S frame's ten iterations take ~0.4 ms there, ~0.1 ms in a stream of calls)
+        # the same sequence 50 times without a synchronize in between: what a pipeline that keeps the device busy pays per call (at F <= 64 the call is one workgroup's ten
+        # iterations over one frame, ~0.17 ms for this code, plus the launches around it: the calls do not overlap, so this is close to the latency above)
         t = time.perf_counter()
         for _ in range(50 if F <= 64 else 5):
             once()
@@ -435,11 +439,11 @@ def _fir_config(Dvbs2Hip, torch, B, local_rank, rank):
         rx.timing_enable(False)
         fir_ms /= max(fir_n, 1)
         lat.sort()
-        n_cplx = n * osf * F
-        ok = int((got[: max(F - 1, 1)] == sent[: max(F - 1, 1)]).all(dim=1).sum().item())      # (the stream's last frame lacks its 40 tail symbols)
+        n_cplx = n * osf * Fg
+        ok = int((got == sent[:F]).all(dim=1).sum().item())
         rows.append({"frames": F, "latency_ms_median": 1e3 * lat[len(lat) // 2], "latency_ms_min": 1e3 * lat[0], "latency_us_per_frame": 1e6 * lat[len(lat) // 2] / F, "back_to_back_ms_per_call": 1e3 * b2b,
                      "frames_per_s": F / lat[len(lat) // 2], "fir_kernel_us": 1e3 * fir_ms, "fir_GFLOPs_fp32_equiv": 324.0 * n_cplx / (fir_ms * 1e-3) / 1e9 if fir_ms else None,
-                     "fir_GBps": 16.0 * n_cplx / (fir_ms * 1e-3) / 1e9 if fir_ms else None, "frames_decoded_exactly": ok, "frames_checked": max(F - 1, 1)})
+                     "fir_GBps": 16.0 * n_cplx / (fir_ms * 1e-3) / 1e9 if fir_ms else None, "frames_decoded_exactly": ok, "frames_checked": F, "frames_filtered": Fg})
         rx.close()
         del pl, up, noisy, mf, sym, sent, got
     big = rows[-1]

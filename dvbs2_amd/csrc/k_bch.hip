@@ -80,6 +80,19 @@ std::string bch_build_plan(BchPlan &pl, int m, const int32_t *prim, int t, int N
             T[256 + u] = (uint16_t)lo; T[512 + u] = (uint16_t)hi;
         }
     }
+    // ---- Chien search tables (behind the syndrome tables): thread d of the kernel visits field positions d, d + 256, d + 512, ..; from one to the next the term
+    // sigma_i alpha^(i (n - d)) is multiplied by the constant c_i = alpha^(-256 i), and a multiplication by a constant is two byte look-ups:
+    // c_i v = LO_i[v & 255] ^ HI_i[v >> 8].  [i][0 .. 256) = LO_i, [i][256 .. 512) = HI_i, i = 0 .. t.
+    const size_t c0 = pl.syn_tab.size();
+    pl.syn_tab.resize(c0 + (size_t)512 * (t + 1), 0);
+    for (int i = 0; i <= t; i++) {
+        const int e = (n - (int)(((long long)256 * i) % n)) % n;       // log c_i
+        for (int b = 0; b < 256; b++) {
+            pl.syn_tab[c0 + (size_t)512 * i + b] = b ? pl.exp_[(pl.log_[b] + e) % n] : 0;
+            const int hb = b << 8;
+            pl.syn_tab[c0 + (size_t)512 * i + 256 + b] = (b && hb <= n) ? pl.exp_[(pl.log_[hb] + e) % n] : 0;
+        }
+    }
     return "";
 }
 
@@ -129,6 +142,8 @@ bch_decode_kernel(const BchKParams p)
     __shared__ int Cs[2 * BCH_TMAX + 4], Bs[2 * BCH_TMAX + 4], Ts[2 * BCH_TMAX + 4];
     __shared__ int s_L, s_status, s_nroots, s_any;
     __shared__ int roots[BCH_TMAX + 4];
+    __shared__ uint16_t ctab[(BCH_TMAX + 1) * 512];      // Chien step tables, staged by the first frame of this workgroup that needs them
+    bool ctab_ready = false;
     const int tid = threadIdx.x, lane = tid & 63;
     const int N = p.N, K = p.K, t = p.t, m = p.m;
     const uint32_t n = (uint32_t)p.n;
@@ -204,52 +219,70 @@ bch_decode_kernel(const BchKParams p)
         __syncthreads();
 
         if (s_any) {
-            // ---- 3. Berlekamp-Massey (serial, <= 2t steps; same recurrence as the oracle)
-            if (tid == 0) {
+            // ---- 3. Berlekamp-Massey (<= 2t steps; same recurrence as the oracle).  (round 4) By the first WAVE instead of the first lane: lane i holds C[i] and B[i]; a step's
+            // discrepancy is one product per lane (three table look-ups, all lanes' in flight together) and an XOR over the wave, its update one product per lane with B taken
+            // from lane i - m.  On one lane the look-ups of a step -- global memory, each behind the one before -- made a frame that does not decode cost 0.19 ms (t = 12) / 0.36 ms
+            // (t = 8, GF(2^16)), and ONE such frame in a batch is what the launch then takes; the field operations and their order per coefficient are unchanged.
+            if (tid < 64) {
                 const uint16_t *ex = p.exp_, *lg = p.log_;
-                for (int i = 0; i < 2 * BCH_TMAX + 4; i++) { Cs[i] = 0; Bs[i] = 0; }
-                Cs[0] = 1; Bs[0] = 1;
+                constexpr int lim = 2 * BCH_TMAX + 4;
+                int Ci = lane == 0 ? 1 : 0, Bi = lane == 0 ? 1 : 0;          // (lanes >= lim stay 0)
                 int L = 0, mm = 1, bb = 1;
-                const int lim = 2 * BCH_TMAX + 4;
                 for (int k = 0; k < 2 * t; k++) {
-                    int d = (int)S[k + 1];
-                    for (int i = 1; i <= L; i++) {
-                        const int c = Cs[i], s = (int)S[k + 1 - i];
-                        if (c && s) d ^= ex[lg[c] + lg[s]];
-                    }
+                    int term = 0;
+                    if (lane >= 1 && lane <= L && Ci) { const int sv = (int)S[k + 1 - lane]; if (sv) term = ex[lg[Ci] + lg[sv]]; }
+                    for (int o = 32; o > 0; o >>= 1) term ^= __shfl_xor(term, o);
+                    const int d = (int)S[k + 1] ^ term;
                     if (d == 0) { mm++; continue; }
                     const int lcoef = (int)lg[d] + (int)n - (int)lg[bb];       // log(d / b)
+                    const int Bsrc = __shfl(Bi, lane - mm);                   // B[i - m] (lanes below m: no term)
+                    int upd = 0;
+                    if (lane >= mm && lane < lim && Bsrc) upd = ex[mod_n((uint32_t)(lcoef + lg[Bsrc]), m, n)];
                     if (2 * L <= k) {
-                        for (int i = 0; i < lim; i++) Ts[i] = Cs[i];
-                        for (int i = 0; i + mm < lim; i++) if (Bs[i]) Cs[i + mm] ^= ex[mod_n((uint32_t)(lcoef + lg[Bs[i]]), m, n)];
+                        const int Told = Ci;
+                        Ci ^= upd;
                         L = k + 1 - L;
-                        for (int i = 0; i < lim; i++) Bs[i] = Ts[i];
+                        Bi = Told;
                         bb = d; mm = 1;
                     } else {
-                        for (int i = 0; i + mm < lim; i++) if (Bs[i]) Cs[i + mm] ^= ex[mod_n((uint32_t)(lcoef + lg[Bs[i]]), m, n)];
+                        Ci ^= upd;
                         mm++;
                     }
                 }
-                s_L = L;
-                if (L > t) s_status = 1;
+                if (lane < lim) Cs[lane] = Ci;
+                if (lane == 0) { s_L = L; if (L > t) s_status = 1; }
             }
             __syncthreads();
             const int L = s_L;
             if (!s_status) {
-                // ---- 4. Chien search over the whole field: sigma(alpha^-d) == 0 <=> error at degree d
-                uint32_t lc[BCH_TMAX + 1];
-#pragma unroll
-                for (int i = 0; i <= BCH_TMAX; i++) lc[i] = (i <= L && Cs[i]) ? (uint32_t)p.log_[Cs[i]] : 0xFFFFFFFFu;
-                for (uint32_t d = tid; d < n; d += BCH_THREADS) {
-                    uint32_t v = 0u;
-                    const uint32_t nd = n - d;        // 1..n
+                // ---- 4. Chien search over the whole field: sigma(alpha^-d) == 0 <=> error at degree d.  (round 4) A thread's positions d, d + 256, .. differ by a constant
+                // factor per term, so one exp look-up per term STARTS the thread and every further position is two LDS byte look-ups per term (bch_build_plan's c_i tables)
+                // instead of a multiply-modulo and a global look-up: the search over GF(2^16) was 0.3 ms of a frame that does not decode.
+                if (!ctab_ready) {
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.syn_tab + 256 + 768 * t);
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(ctab);
+                    for (int i = tid; i < (t + 1) * 256; i += BCH_THREADS) dst[i] = src[i];
+                    ctab_ready = true;
+                    __syncthreads();
+                }
+                uint32_t term[BCH_TMAX + 1];
+                {
+                    const uint32_t nd = n - (uint32_t)tid;        // tid < 256 <= n
 #pragma unroll
                     for (int i = 0; i <= BCH_TMAX; i++)
-                        if (lc[i] != 0xFFFFFFFFu) v ^= p.exp_[lc[i] + mod_n((uint32_t)i * nd, m, n)];
+                        term[i] = (i <= L && Cs[i]) ? (uint32_t)p.exp_[(uint32_t)p.log_[Cs[i]] + mod_n((uint32_t)i * nd, m, n)] : 0u;
+                }
+                for (uint32_t d = tid; d < n; d += BCH_THREADS) {
+                    uint32_t v = 0u;
+#pragma unroll
+                    for (int i = 0; i <= BCH_TMAX; i++) v ^= term[i];
                     if (v == 0u) {
                         const int slot = atomicAdd(&s_nroots, 1);
                         if (slot < BCH_TMAX + 4) roots[slot] = (int)d;
                     }
+#pragma unroll
+                    for (int i = 1; i <= BCH_TMAX; i++)
+                        if (i <= t) term[i] = (uint32_t)ctab[512 * i + (term[i] & 0xFFu)] ^ (uint32_t)ctab[512 * i + 256 + (term[i] >> 8)];
                 }
                 __syncthreads();
                 if (s_nroots == L) {

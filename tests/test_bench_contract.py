@@ -85,7 +85,7 @@ def test_bench_line_on_the_gpu():
     cf = ex["configs"]
     assert set(cf) == {"2", "3", "4"} and cf["2"]["bit_errors"] == 0 and cf["3"]["n_ite"] == 20 and cf["3"]["bit_errors"] == 0
     assert [r["frames"] for r in cf["4"]["per_F"]] == [1, 8, 64, 4096] and all(r["fir_GFLOPs_fp32_equiv"] > 0 for r in cf["4"]["per_F"])
-    assert cf["4"]["per_F"][-1]["frames_decoded_exactly"] == 4095
+    assert all(r["frames_decoded_exactly"] == r["frames"] for r in cf["4"]["per_F"])          # (the stream is one frame longer than the call: every decoded frame is whole)
     assert ex["natural_order_fps"] > 0 and ex["host_socket_form"]["fec_frames_per_s"] > 0
 
 
