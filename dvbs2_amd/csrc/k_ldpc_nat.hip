@@ -415,9 +415,12 @@ ldpc_nat_part_kernel(const NatParams p)
 // eight checks go out NAT_CK_AHEAD groups ahead (the last check of the group in flight is 8 NAT_CK_AHEAD + 7 <= NAT_HAZ_WINDOW checks in front of the first one not yet written).
 // Same fp32 operations per edge, the same two minima (the two smallest of a set do not depend on the order they are found in), the index of the LAST slot that holds the
 // minimum: bit for bit the one-lane kernel and the oracle's ORC_SCHED_NATURAL.
-constexpr int NAT_CK_AHEAD = 2;
+#ifndef NAT_CK_AHEAD_N
+#define NAT_CK_AHEAD_N 2
+#endif
+constexpr int NAT_CK_AHEAD = NAT_CK_AHEAD_N;
 #ifndef NAT_CK_TRIP
-#define NAT_CK_TRIP 6
+#define NAT_CK_TRIP 12
 #endif
 static_assert(NAT_CK_TRIP % NAT_CK_AHEAD == 0, "the ring has to be back at its start when a trip ends");
 static_assert(8 * NAT_CK_AHEAD + 7 <= NAT_HAZ_WINDOW, "the requests run further ahead than the host's hazard plane covers");
@@ -488,7 +491,7 @@ ldpc_nat_ck_kernel(const NatParams p)
 #pragma unroll
         for (int u = 0; u < AH; u++) request_next(ring[u]);
         // (the compiler drains the vector memory queue at the head of the loop -- it cannot bound what is in flight there: a whole memory round trip per trip -- so a trip is
-        // NAT_CK_TRIP groups long, the ring of AH requests going round inside it)
+        // NAT_CK_TRIP groups long, the ring of AH requests going round inside it; 12 against 6: 8192 normal frames 41.7 -> 37.2 ms, 4096 frames 37.7 -> 36.8)
         for (int g0 = 0; g0 < ngrp; g0 += NAT_CK_TRIP) {
             if (WV > 1) __builtin_amdgcn_s_barrier();      // the waves of a workgroup stay within a trip of each other: a line one of them has fetched is still near when the others ask
 #pragma unroll
@@ -676,12 +679,13 @@ hipError_t ldpc_nat_launch(const LdpcPlan &pl, const LdpcKParams &kp, float *wor
     p.bits = kp.bits; p.packed = kp.packed; p.cwd = kp.cwd; p.post = kp.post; p.ites = kp.ites;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.F = kp.n_frames; p.n_ite = kp.n_ite; p.early_stop = kp.early_stop; p.alpha = kp.alpha;
     // Form by the size of the batch.  Codes whose second hazard plane is empty and whose check count divides by eight (every DVB-S2 code of the library) run CONSECUTIVE CHECKS
-    // side by side (ldpc_nat_ck_kernel): 8 checks x 8 frames per wave, four waves per 32-frame workgroup, up to 6144 frames (the BASELINE batch: 78 -> 110 k normal frames/s),
-    // 4 checks x 16 frames, two waves per workgroup, beyond (16384+ normal frames: 245 k frames/s; one lane per frame reached 171 k at 32768).  Any other code: one lane per
+    // side by side (ldpc_nat_ck_kernel): 8 checks x 8 frames per wave, four waves per 32-frame workgroup, below 3072 frames (1024 normal frames: 32 against 35 ms),
+    // 4 checks x 16 frames, two waves per workgroup, from there on (the BASELINE batch of 4096: 78 -> 111-115 k normal frames/s; 16384+ frames: 245-253 k; one lane per frame
+    // reached 171 k at 32768).  Any other code: one lane per
     // frame when that alone gives every SIMD a wave, else a check's edges over 4 or 8 lanes.  DVBS2HIP_NAT_PARTS = 1 | 4 | 8 (those forms), 88 | 44 (the two above) overrides.
     bool clean = pl.M % 8 == 0;
     for (size_t i = pl.nat_haz.size() / 2; i < pl.nat_haz.size(); i++) clean &= pl.nat_haz[i] == 0u;
-    int parts = clean ? (kp.n_frames > 6144 ? 44 : 88) : kp.n_frames >= 32768 ? 1 : kp.n_frames > 6144 ? 4 : 8;
+    int parts = clean ? (kp.n_frames >= 3072 ? 44 : 88) : kp.n_frames >= 32768 ? 1 : kp.n_frames > 6144 ? 4 : 8;
     if (const char *ev = getenv("DVBS2HIP_NAT_PARTS")) { const int v = atoi(ev); if (v == 1 || v == 4 || v == 8 || ((v == 88 || v == 44) && clean)) parts = v; }
     if (parts == 88) {
         if (pl.fast_deg == 27) return nat_ck_launch<27, 8, 4>(pl, p, s);
