@@ -115,9 +115,11 @@ def test_monitor_check_errors2_sockets(O, Rx):
     rx.close()
 
 
-def test_sigma_per_frame_and_high_snr_signs(O, Rx):
-    """CP socket holds one sigma per frame; at high SNR the LLR sign is the hard decision."""
-    modcod = "16APSK-S_8/9"
+@pytest.mark.parametrize("modcod", ["16APSK-S_8/9", "32APSK-S_3/4", "8PSK-S_8/9", "8PSK-N_8/9"])
+def test_sigma_per_frame_and_high_snr_signs(O, Rx, modcod):
+    """CP socket holds one sigma per frame; at high SNR the LLR sign is the hard decision.  With sigma = 0.05 the LLRs run into the hundreds: the general demapper's reference
+    exponent k |y|^2 (round 4: no running maximum over the points) and its per-subset form for symbols whose weaker subset underflows are both on the path, for every
+    constellation that takes the general demapper."""
     ch = chain(O, modcod)
     mc = ch.mc
     F = 3
