@@ -307,8 +307,9 @@ sync_metric_argmax4_kernel(float *__restrict__ cv, const float *__restrict__ cor
 // and the delay line together.  Here a workgroup is 1 + UF / 8 waves for 64 positions and a tick (the stretch between two barriers) is UF frames:
 //   * UF / 16 LOADER waves, sixteen frames of every chunk each, their loads in flight for two ticks (two register sets), scale by (1 - alpha) and leave the chunk in
 //     LDS as [lane][frame];
-//   * ONE CHAIN wave reads four frames per ds_read_b128 (24 frames ahead of the arithmetic), does the two dependent operations per frame and writes four averages per
-//     ds_write_b128 out of registers that nothing overwrites before the queue has taken them -- 2.5 instructions per frame;
+//   * ONE CHAIN wave reads four frames per ds_read_b128 (half a chunk ahead of the arithmetic), does the two dependent operations per frame in place and writes four
+//     averages per ds_write_b128 out of registers that nothing overwrites before the tick is over -- 2.5 instructions per frame; its tick is its own LDS traffic
+//     (~1280 cycles for the 24 + 24 pieces of a chunk) plus its arithmetic (~825): tools/probe_lds128.hip, profiles/r04_probe_lds128.txt;
 //   * UF / 16 ARG-MAX waves take the previous chunk: lane (frame, part) scans 16 of the 64 positions of its frame out of LDS (strictly greater: the first maximum, as
 //     the reference's scan), the four parts of a frame merge their 64-bit keys inside their quad (two DPP exchanges) -- ~7 instructions per frame instead of the ~29 of
 //     the wave-wide DPP ladders.
