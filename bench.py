@@ -525,7 +525,7 @@ def _live_pmc(frames):
             d = os.path.join(td, ctrs[0])
             cmd = [exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--", "python3", os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--frames", str(frames),
                                            "--no-cpu-baseline", "--no-extras", "--self-check-steps", "0", "--no-live-pmc"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=90)
             files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
             if r.returncode != 0 or not files:
                 err = "rocprofv3 --pmc %s: rc %d, %d csv file(s): %s" % (" ".join(ctrs), r.returncode, len(files), r.stderr.decode(errors="replace")[-300:])
