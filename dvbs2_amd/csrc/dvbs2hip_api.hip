@@ -61,6 +61,8 @@ struct dvbs2hip_handle {
     float *d_plh = nullptr;
     int enc_stride = 0;
     unsigned long long *d_bch_tab = nullptr, *d_bch_shift = nullptr;
+    uint32_t *d_syn_pos = nullptr, *d_prbs_s = nullptr;     // (round 5) the LDPC kernel's BCH verification in the fused chain: row records + reduction table (LdpcKParams::syn_tab), PRBS words by (storage row, wave)
+    int syn_words = 0, syn_rows = 0;
     std::map<int, DevBuf> bufs;        // lazily grown staging / intermediate buffers
     // frame synchronizer (N4): device-resident state of Synchronizer_frame_DVBS2_fast
     struct {
@@ -95,8 +97,12 @@ struct dvbs2hip_handle {
     int lr_timeouts = 0;               // launches whose rotation had to be repeated (dvbs2hip_sync_lr_timeouts)
     // L&R, recurrence and rotation in one launch (k_sync.hip, sff_lr_fused_kernel): the error word a rotating workgroup sets when it gives up waiting for the
     // recurrence -- host-mapped memory, so the host reads it at its synchronisation points without a copy
-    uint32_t *lr_err_host = nullptr, *lr_err_dev = nullptr;
-    struct { const float *x = nullptr; float *y = nullptr; int n = 0, F = 0; } lr_last;      // the last device-form call: what dvbs2hip_synchronize re-rotates after a timeout
+    // (round 5) every outstanding L&R call has its OWN error word and its OWN estimate buffer (LR_SLOTS in rotation): a later L&R or pilot-phase call
+    // neither consumes an earlier call's error word nor overwrites the estimates its repair needs
+    static constexpr int LR_SLOTS = 4;
+    uint32_t *lr_err_host = nullptr, *lr_err_dev = nullptr;          // [LR_SLOTS]
+    struct { const float *x = nullptr; float *y = nullptr; int n = 0, F = 0; bool pending = false; } lr_slot[LR_SLOTS];      // device-form calls not yet looked at: what dvbs2hip_synchronize re-rotates after a timeout
+    int lr_next = 0;
     float *d_hist_zero = nullptr, *d_hist_junk = nullptr;     // filter2: zero history in, discarded history out
     // monitor reduction over RCCL (one process per GPU): communicator + the 3 x uint64 receive buffer
     void *nccl_comm = nullptr;
@@ -125,7 +131,7 @@ int fail(dvbs2hip_t *h, int code, const std::string &msg)
     } while (0)
 
 enum BufId { B_IN = 0, B_OUT, B_AUX0, B_AUX1, B_AUX2, B_AUX3, B_LLR, B_PACKED, B_EST, B_CWD0, B_CWD1, B_INFO, B_SIG, B_TXBCH, B_TXLDPC,
-             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY, B_SFM_DTAB, B_SFF_TMP, B_SFF_OUT, B_FLT2, B_MON_BE, B_MON_OUT };
+             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY, B_SFM_DTAB, B_SFF_TMP, B_SFF_OUT, B_FLT2, B_MON_BE, B_MON_OUT, B_BCHFLAG, B_LR_TMP0, B_LR_TMP1, B_LR_TMP2, B_LR_TMP3 };
 
 int ensure(dvbs2hip_t *h, int id, size_t bytes, void **out)
 {
@@ -433,6 +439,56 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
                 }
                 if (upload(h, &h->d_bch_shift, sh.data(), sh.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
             }
+            // (round 5) tables of the BCH verification inside the LDPC kernel's output phase (k_ldpc_wg8.hip, `syn_tab`): position i = 360 g + t of the BCH word is the
+            // coefficient of x^(N_bch - 1 - i) = x^(360 (G - 1 - g)) x^(359 - t) (k_bch.hip).  One 32-byte record per row in the kernel's STORAGE order (LDS rows, global
+            // rows, register slots) {1440 g, last-row flag, A_g = x^(360 (G - 1 - g)) mod g(x)}, then [LDPC_SYN_RED][nsw]: x^k mod g(x) for the once-per-frame reduction;
+            // 4 (deg g <= 128) or 6 little-endian 32-bit words; and the BB descrambler's bits by (storage row, wave)
+            if (h->ldpc.fast_wg8 && !h->ldpc.fast_cu1) {
+                const LdpcPlan &lp = h->ldpc;
+                const int G = cfg->K_ldpc / 360, nsw = r <= 128 ? 4 : 6;
+                const bool parked = lp.fast_mode == 4 || lp.fast_mode == 5;
+                const int nrp = parked ? ldpc_park_nr(lp.fast_mode) : 0, q_ = lp.q;
+                std::vector<int> order;                       // bit-group of every emitted row (-1: empty register slot)
+                for (int l = 0; l < lp.w8_nl_info; l++) order.push_back((int)lp.w8_rows[l]);
+                for (int l = 0; l < lp.w8_ng_info; l++) order.push_back((int)lp.w8_rows[lp.w8_nl + l]);
+                for (int k = 0; k < nrp; k++) { const uint32_t g = lp.w8_rows[lp.w8_nl + lp.w8_ng + q_ + k]; order.push_back(g == 0xFFFFFFFFu ? -1 : (int)g); }
+                {   // every information row exactly once
+                    std::vector<int> seen(G, 0);
+                    for (int g : order) if (g >= 0) { if (g >= G || seen[g]++) CREATE_FAIL(DVBS2HIP_EINVAL, "internal: LDPC plan emits an information row twice or a parity row"); }
+                    for (int g = 0; g < G; g++) if (!seen[g]) CREATE_FAIL(DVBS2HIP_EINVAL, "internal: LDPC plan does not emit every information row");
+                }
+                const int rows = (int)order.size();
+                std::vector<uint32_t> ag((size_t)G * 6, 0u), sp((size_t)rows * 8 + (size_t)LDPC_SYN_RED * nsw, 0u);
+                const int nmax = std::max(360 * (G - 1), LDPC_SYN_RED - 1);
+                unsigned long long v[3] = {1ull, 0ull, 0ull};                       // x^n mod g, n = 0, 1, ..
+                for (int n = 0; n <= nmax; n++) {
+                    auto put = [&](uint32_t *d) {
+                        d[0] = (uint32_t)v[0]; d[1] = (uint32_t)(v[0] >> 32); d[2] = (uint32_t)v[1]; d[3] = (uint32_t)(v[1] >> 32);
+                        if (nsw == 6) { d[4] = (uint32_t)v[2]; d[5] = (uint32_t)(v[2] >> 32); }
+                    };
+                    if (n % 360 == 0 && n / 360 < G) put(&ag[(size_t)(G - 1 - n / 360) * 6]);
+                    if (n < LDPC_SYN_RED) put(&sp[(size_t)rows * 8 + (size_t)n * nsw]);
+                    const int top = r - 1;
+                    const bool fb = (v[top / 64] >> (top % 64)) & 1ull;
+                    v[2] = (v[2] << 1) | (v[1] >> 63); v[1] = (v[1] << 1) | (v[0] >> 63); v[0] <<= 1;
+                    for (int w = 0; w < 3; w++) { const int lo = 64 * w; if (r <= lo) v[w] = 0; else if (r < lo + 64) v[w] &= (1ull << (r - lo)) - 1ull; }
+                    if (fb) { v[0] ^= gl[0]; v[1] ^= gl[1]; v[2] ^= gl[2]; }
+                }
+                std::vector<uint32_t> ps((size_t)rows * 6 * 2, 0u);
+                for (int k = 0; k < rows; k++) {
+                    uint32_t *d = &sp[(size_t)k * 8];
+                    const int g = order[k];
+                    if (g < 0) { d[0] = 0x7FFFF000u; continue; }
+                    d[0] = (uint32_t)g * 1440u; d[1] = g == G - 1 ? 1u : 0u;
+                    for (int i = 0; i < 6; i++) d[2 + i] = ag[(size_t)g * 6 + i];
+                    for (int e = 0; e < 360; e++) {
+                        const int i = g * 360 + e;
+                        if (i < cfg->K_bch && ((prbs[i >> 5] >> (i & 31)) & 1u)) { const int w = e >> 6, l = e & 63; ps[(size_t)(k * 6 + w) * 2 + (l >> 5)] |= 1u << (l & 31); }
+                    }
+                }
+                if (upload(h, &h->d_syn_pos, sp.data(), sp.size()) || upload(h, &h->d_prbs_s, ps.data(), ps.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
+                h->syn_words = nsw; h->syn_rows = rows;
+            }
         }
         // PLHEADER = 26 SOF + 64 PLS symbols, pi/2-BPSK (Framer.hxx:97-196)
         static const int G[7][32] = {
@@ -537,7 +593,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     if (h->lr_err_host) (void)hipHostFree(h->lr_err_host);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_atab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
-                    h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
+                    h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_syn_pos, h->d_prbs_s, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -603,25 +659,43 @@ int dvbs2hip_set_ldpc_params(dvbs2hip_t *h, int32_t n_ite, float alpha, int32_t 
 void *dvbs2hip_get_stream(dvbs2hip_t *h) { return h ? (void *)h->stream : nullptr; }
 
 // L&R timeout (sff_lr_fused_kernel): every estimate has been published by the time the launch is over, so the rotation alone is run again (the stores
-// the waiting workgroups dropped).  Returns 0 when there was nothing to do or the recovery succeeded.
-static int lr_check_recover(dvbs2hip_t *h, const float *x, float *y, int n, int F)
+// the waiting workgroups dropped) -- with the estimates of THAT launch (the slot's own buffer).  The caller has synchronized the stream.  Returns 0 when there was
+// nothing to do or the recovery succeeded.
+static int lr_check_recover(dvbs2hip_t *h, int slot)
 {
-    if (!h->lr_err_host || !*(volatile uint32_t *)h->lr_err_host) return 0;
-    *(volatile uint32_t *)h->lr_err_host = 0u;
+    auto &ls = h->lr_slot[slot];
+    ls.pending = false;
+    if (!h->lr_err_host || !((volatile uint32_t *)h->lr_err_host)[slot]) return 0;
+    ((volatile uint32_t *)h->lr_err_host)[slot] = 0u;
     h->lr_timeouts++;
-    void *tmp = nullptr;
-    if (!x || !y || ensure(h, B_SFF_TMP, sizeof(float) * 4 * (size_t)F, &tmp))
+    auto it = h->bufs.find(B_LR_TMP0 + slot);
+    if (!ls.x || !ls.y || it == h->bufs.end() || !it->second.p || it->second.bytes < sizeof(float) * 4 * (size_t)ls.F)
         return fail(h, DVBS2HIP_EHIP, "L&R: a rotating workgroup timed out waiting for the recurrence and the call cannot be repeated (buffers unknown); re-run it with DVBS2HIP_LR=unfused");
-    HIPCHK(h, sff_lr_recover(x, y, (float *)tmp, n, F, h->stream));
+    HIPCHK(h, sff_lr_recover(ls.x, ls.y, (float *)it->second.p, ls.n, ls.F, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return 0;
+}
+
+// every device-form L&R call that has not been looked at yet, oldest first (the stream is synchronized here)
+static int lr_check_all(dvbs2hip_t *h)
+{
+    bool any = false;
+    for (int i = 0; i < dvbs2hip_handle::LR_SLOTS; i++) any |= h->lr_slot[i].pending;
+    if (!any) return 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int r = 0;
+    for (int i = 0; i < dvbs2hip_handle::LR_SLOTS; i++) {
+        const int s = (h->lr_next + i) % dvbs2hip_handle::LR_SLOTS;          // lr_next is the oldest slot
+        if (h->lr_slot[s].pending) { const int ri = lr_check_recover(h, s); if (ri && !r) r = ri; }
+    }
+    return r;
 }
 
 int dvbs2hip_synchronize(dvbs2hip_t *h)
 {
     int r0 = enter(h); if (r0) return r0;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return lr_check_recover(h, h->lr_last.x, h->lr_last.y, h->lr_last.n, h->lr_last.F);      // (device-form L&R calls: their error word is looked at here)
+    return lr_check_all(h);      // (device-form L&R calls: their error words are looked at here)
 }
 
 int dvbs2hip_get_sizes(const dvbs2hip_t *h, dvbs2hip_sizes *o)
@@ -636,12 +710,18 @@ int dvbs2hip_get_sizes(const dvbs2hip_t *h, dvbs2hip_sizes *o)
 // the LDPC kernel can write the chain's output socket itself (descrambled info bits of a frame the BCH stage leaves alone)
 static bool ldpc_writes_info(const dvbs2hip_t *h) { return h->ldpc.fast_wg8 && h->ldpc_sched == DVBS2HIP_SCHED_QC && !getenv("DVBS2HIP_CHAIN_UNFUSED"); }
 
-static int ldpc_dev(dvbs2hip_t *h, const float *Y, int8_t *CWD, int32_t *V, uint32_t *packed, float *post, int32_t *ites, int F, int32_t *info_out = nullptr)
+// (round 5) ... and check the BCH remainder of what it outputs: the BCH stage then decodes the flagged frames only (DVBS2HIP_CHAIN_SYN=0: round 4's form, the BCH stage
+// forms the syndromes of every frame from the packed hard decisions)
+static bool ldpc_verifies_bch(const dvbs2hip_t *h) { const char *e = getenv("DVBS2HIP_CHAIN_SYN"); return ldpc_writes_info(h) && h->d_syn_pos && !h->ldpc.fast_cu1 && !(e && e[0] == '0'); }
+
+static int ldpc_dev(dvbs2hip_t *h, const float *Y, int8_t *CWD, int32_t *V, uint32_t *packed, float *post, int32_t *ites, int F, int32_t *info_out = nullptr,
+                    uint8_t *bch_flag = nullptr, int8_t *cwd_bch = nullptr)
 {
     LdpcKParams p;
     memset(&p, 0, sizeof p);
     p.llr = Y; p.bits = V; p.packed = packed; p.cwd = CWD; p.post = post; p.ites = ites; p.gwork = h->d_gwork;
     p.info_out = info_out; p.info_prbs = h->bch.d_prbs_rw; p.K_info = h->K_bch;
+    if (info_out && bch_flag) { p.syn_tab = h->d_syn_pos; p.info_prbs_s = h->d_prbs_s; p.syn_words = h->syn_words; p.syn_rows = h->syn_rows; p.bch_flag = bch_flag; p.cwd_bch = cwd_bch; }
     p.n_frames = F; p.n_ite = h->n_ite; p.early_stop = h->early_stop; p.alpha = h->alpha;
     if (h->ldpc_sched == DVBS2HIP_SCHED_NATURAL) {
         LdpcPlan &pl = h->ldpc;
@@ -702,11 +782,11 @@ int dvbs2hip_ldpc_decode_siho(dvbs2hip_t *h, const float *Y_N, int8_t *CWD, int3
 }
 
 // ------------------------------------------------------------------ a2
-static int bch_dev(dvbs2hip_t *h, const int32_t *Y, const uint32_t *packed, int8_t *CWD, int32_t *V, bool descramble, int F, bool patch_only = false)
+static int bch_dev(dvbs2hip_t *h, const int32_t *Y, const uint32_t *packed, int8_t *CWD, int32_t *V, bool descramble, int F, bool patch_only = false, const uint8_t *flag = nullptr)
 {
     BchKParams p;
     memset(&p, 0, sizeof p);
-    p.in_bits = Y; p.in_packed = packed; p.out_bits = V; p.cwd = CWD; p.n_frames = F; p.patch_only = patch_only ? 1 : 0;
+    p.in_bits = Y; p.in_packed = packed; p.out_bits = V; p.cwd = CWD; p.n_frames = F; p.patch_only = patch_only ? 1 : 0; p.flag = flag;
     p.prbs = descramble ? h->bch.d_prbs : nullptr;
     Timer tm(h, DVBS2HIP_K_BCH);
     HIPCHK(h, bch_launch(h->bch, p, h->stream));
@@ -1188,36 +1268,46 @@ static int sff_call(dvbs2hip_t *h, bool lr, bool host, const float *X_N1, float 
     if (n <= 1530) return fail(h, DVBS2HIP_EUNSUPPORTED, "the PL frame holds no pilot block");
     if (lr && !h->d_lr_R) { HIPCHK(h, hipMalloc((void **)&h->d_lr_R, 2 * sizeof(float))); HIPCHK(h, hipMemsetAsync(h->d_lr_R, 0, 2 * sizeof(float), h->stream)); }
     if (lr && !h->lr_err_host) {
-        HIPCHK(h, hipHostMalloc((void **)&h->lr_err_host, sizeof(uint32_t), hipHostMallocMapped));
-        *h->lr_err_host = 0u;
+        HIPCHK(h, hipHostMalloc((void **)&h->lr_err_host, dvbs2hip_handle::LR_SLOTS * sizeof(uint32_t), hipHostMallocMapped));
+        for (int i = 0; i < dvbs2hip_handle::LR_SLOTS; i++) h->lr_err_host[i] = 0u;
         HIPCHK(h, hipHostGetDevicePointer((void **)&h->lr_err_dev, h->lr_err_host, 0));
     }
     const size_t nb = sizeof(float) * 2 * (size_t)n * F;
     void *tmp, *din = nullptr, *dout = nullptr, *dfp = nullptr;
-    if ((r = ensure(h, B_SFF_TMP, sizeof(float) * 4 * (size_t)F, &tmp))) return r;
+    // the estimates: the pilot-phase synchronizer's buffer is its own; an L&R call takes the next of LR_SLOTS slots (estimates + error word).  A slot whose last
+    // device-form call has not been looked at yet (LR_SLOTS such calls without a dvbs2hip_synchronize between them) is looked at first -- one stream synchronization,
+    // and only then -- so that its repair never meets estimates of another launch
+    const int slot = lr ? h->lr_next : 0;
+    if (lr) {
+        if (h->lr_slot[slot].pending) { HIPCHK(h, hipStreamSynchronize(h->stream)); if ((r = lr_check_recover(h, slot))) return r; }
+        h->lr_next = (slot + 1) % dvbs2hip_handle::LR_SLOTS;
+    }
+    if ((r = ensure(h, lr ? B_LR_TMP0 + slot : B_SFF_TMP, sizeof(float) * 4 * (size_t)F, &tmp))) return r;
     const float *x = X_N1;
     float *y = Y_N2, *frq = FRQ, *phs = PHS;
     if (host) {
+        if ((r = lr_check_all(h))) return r;          // (the host form reuses B_IN / B_OUT: nothing of an earlier device-form call is left pending behind it)
         if ((r = ensure(h, B_IN, nb, &din)) || (r = ensure(h, B_OUT, nb, &dout)) || (r = ensure(h, B_SFF_OUT, sizeof(float) * 2 * (size_t)F, &dfp))) return r;
         HIPCHK(h, hipMemcpyAsync(din, X_N1, nb, hipMemcpyHostToDevice, h->stream));
         x = (const float *)din; y = (float *)dout; frq = (float *)dfp; phs = frq + F;
     }
     {
         Timer tm(h, DVBS2HIP_K_MISC);
-        if (lr) HIPCHK(h, sff_lr_launch(x, y, h->d_lr_R, (float *)tmp, frq, phs, n, F, h->lr_alpha, h->lr_err_dev, h->stream));
+        if (lr) HIPCHK(h, sff_lr_launch(x, y, h->d_lr_R, (float *)tmp, frq, phs, n, F, h->lr_alpha, h->lr_err_dev + slot, h->stream));
         else HIPCHK(h, sff_fp_launch(x, y, (float *)tmp, frq, phs, n, F, h->stream));
     }
+    if (lr) { auto &ls = h->lr_slot[slot]; ls.x = x; ls.y = y; ls.n = n; ls.F = F; ls.pending = !host; }
     if (host) {
         HIPCHK(h, hipMemcpyAsync(Y_N2, dout, nb, hipMemcpyDeviceToHost, h->stream));
         if (FRQ) HIPCHK(h, hipMemcpyAsync(FRQ, frq, sizeof(float) * (size_t)F, hipMemcpyDeviceToHost, h->stream));
         if (PHS) HIPCHK(h, hipMemcpyAsync(PHS, phs, sizeof(float) * (size_t)F, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (lr && h->lr_err_host && *(volatile uint32_t *)h->lr_err_host) {      // timeout in the fused L&R launch: rotate again, copy again
-            if ((r = lr_check_recover(h, x, y, n, F))) return r;
+        if (lr && h->lr_err_host && ((volatile uint32_t *)h->lr_err_host)[slot]) {      // timeout in the fused L&R launch: rotate again, copy again
+            if ((r = lr_check_recover(h, slot))) return r;
             HIPCHK(h, hipMemcpyAsync(Y_N2, dout, nb, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
         }
-    } else if (lr) { h->lr_last.x = x; h->lr_last.y = y; h->lr_last.n = n; h->lr_last.F = F; }
+    }
     return 0;
 }
 
@@ -1595,8 +1685,12 @@ int dvbs2hip_rx_bb_dev(dvbs2hip_t *h, const float *pl, const float *sigma, int32
     // frame it does not correct: nearly all of them behind a converged LDPC decoder); the BCH stage then only checks the syndromes of the
     // packed hard decisions and flips the bits it corrects -- its 4 K_bch output bytes per frame were 90 % of its time
     const bool fused_out = ldpc_writes_info(h);
-    if ((r = ldpc_dev(h, (const float *)dllr, cwd_l, nullptr, (uint32_t *)dpk, nullptr, nullptr, F, fused_out ? info : nullptr))) return r;
-    return bch_dev(h, nullptr, (const uint32_t *)dpk, cwd_b, info, true, F, fused_out);
+    // (round 5) ... and forms the frame's BCH remainder r(x) mod g(x) from the hard decisions it outputs: a frame whose remainder is zero is finished (information bits and
+    // both CWD flags written by the LDPC kernel); the BCH stage rebuilds and decodes the flagged frames only
+    void *dflag = nullptr;
+    if (fused_out && ldpc_verifies_bch(h) && (r = ensure(h, B_BCHFLAG, (size_t)F, &dflag))) return r;
+    if ((r = ldpc_dev(h, (const float *)dllr, cwd_l, nullptr, (uint32_t *)dpk, nullptr, nullptr, F, fused_out ? info : nullptr, (uint8_t *)dflag, cwd_b))) return r;
+    return bch_dev(h, nullptr, (const uint32_t *)dpk, cwd_b, info, true, F, fused_out, (const uint8_t *)dflag);
 }
 
 int dvbs2hip_rx_bb(dvbs2hip_t *h, const float *pl, const float *sigma, int32_t *info, int8_t *cwd_l, int8_t *cwd_b, int32_t F)

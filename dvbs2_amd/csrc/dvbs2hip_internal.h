@@ -50,6 +50,17 @@ struct LdpcKParams {
     int32_t *info_out;       // [F][K_info]       (may be null)
     const uint32_t *info_prbs;  // PRBS by (row g, wave w): 64-bit word [g * 6 + w], bit l = PRBS bit 360 g + 64 w + l (zero from K_info on); wave-uniform scalars
     int32_t K_info;
+    // (round 5) fused chain, BCH verification inside the LDPC kernel: a frame is a BCH codeword iff r(x) mod g(x) = 0.  Bit t of information row g is the coefficient
+    // of x^(360 (G - 1 - g)) x^(359 - t): each lane XORs the row's factor A_g into its accumulator for every set hard decision it outputs, the wave applies the lanes'
+    // factors once per frame (k_ldpc_wg8.hip, fold_syn).  The BCH stage then runs only over the flagged frames.
+    const uint32_t *syn_tab;    // [syn_rows][8]: per row in STORAGE order (the order k_ldpc_wg8.hip emits the rows in: LDS rows, global rows, register slots) {byte offset 1440 g of the row in the int32
+                                // socket (0x7FFFF000: an empty register slot), 1 = the last information row, A_g[0 .. 5] = x^(360 (n_info - 1 - g)) mod g(x)}, then [LDPC_SYN_RED][syn_words]: x^k mod g(x),
+                                // little-endian 32-bit words; or null (no verification)
+    const uint32_t *info_prbs_s;   // the PRBS words of info_prbs by (storage row, wave)
+    int32_t syn_words;          // 4 (deg g <= 128) or 6 (<= 192)
+    int32_t syn_rows;           // rows the kernel emits (information rows + empty register slots)
+    uint8_t *bch_flag;          // [F]: 1 = remainder not zero (the BCH stage decodes this frame), 0 = codeword
+    int8_t *cwd_bch;            // [F] or null: the BCH stage's CWD flag, written (1) for a frame whose remainder is zero
     float *gwork;            // [grid][gwork_words] per-workgroup global workspace
     const LdpcEntry *entries;  // [q][deg_max_padded]
     const int32_t *layer_deg;  // [q]
@@ -122,12 +133,12 @@ constexpr int LDPC_FAST_STRIDE = 64;   // dwords per layer: 27 entries | prim ma
 constexpr int LDPC_FAST_MAXC = 16;
 // modes 4 / 5 (k_ldpc_wg8.hip): bit-group rows parked in the registers of a workgroup's two idle waves (3 VGPRs per row and lane) and LDS slots per
 // layer (the static hybrid without parked rows, mode 3, has 9).  Mode 5 (min-sum kernel only: the sum-product kernel has no registers for it) parks 39.
-__host__ __device__ constexpr int ldpc_park_nr(int mode) { return mode == 5 ? 39 : 32; }
-__host__ __device__ constexpr int ldpc_park_nl(int mode) { return mode == 5 ? 15 : 14; }
+__host__ __device__ __forceinline__ constexpr int ldpc_park_nr(int mode) { return mode == 5 ? 39 : 32; }
+__host__ __device__ __forceinline__ constexpr int ldpc_park_nl(int mode) { return mode == 5 ? 15 : 14; }
 // k_ldpc_wg8.hip: duplicate edges (the slots whose stores are redirected to the junk row) sit in the first ldpc_w8_kd(deg) slots of a layer; from
 // there on a slot's store goes where its load came from (one address per LDS slot instead of two).  The padded 13-slot form (32APSK-S 3/4: checks of degree
 // 9 .. 13) has its NULL slots there too (at most 4 + 2 duplicates).
-__host__ __device__ constexpr int ldpc_w8_kd(int deg) { return deg == 27 ? 6 : deg == 11 ? 3 : deg == 13 ? 6 : deg; }
+__host__ __device__ __forceinline__ constexpr int ldpc_w8_kd(int deg) { return deg == 27 ? 6 : deg == 11 ? 3 : deg == 13 ? 6 : deg; }
 // mode 6 (k_ldpc_cu1.hip): one frame per 16-wave workgroup = per CU.  Two lanes per check: the first half-check's lanes take slots 0 .. LDPC_CU1_HA-1 (the duplicate
 // edges are among them), the second one's the rest (p_c and p_{c-1} last); they exchange {min1 | parity, min2} through 8 bytes per half-check of LDS.  Four
 // row-keeping waves in two groups of two, ldpc_cu1_nrg() rows (3 VGPRs per row and lane) each.
@@ -136,10 +147,12 @@ __host__ __device__ constexpr int ldpc_w8_kd(int deg) { return deg == 27 ? 6 : d
 #endif
 constexpr int LDPC_CU1_HA = LDPC_CU1_HA_V;
 constexpr int LDPC_CU1_XCHG_BYTES = 2 * LDPC_Z * 8;
-__host__ __device__ constexpr int ldpc_cu1_nrg() { return 36; }
+__host__ __device__ __forceinline__ constexpr int ldpc_cu1_nrg() { return 36; }
 #ifndef LDPC_CU1_DEFAULT
 #define LDPC_CU1_DEFAULT 0
 #endif
+constexpr int LDPC_W8_MISC_BYTES = 96;  // k_ldpc_wg8.hip: words behind the image -- [0..7] SIMD of wave w, [8] first / second workgroup of the CU, [9] next frame, [10..12] vote words, [16..21] BCH remainder of the frame
+constexpr int LDPC_SYN_RED = 640;       // entries x^k mod g(x), k = 0 .. 639, of the BCH verification's reduction table (k <= 64 * 5 + 32 * 8 + 63)
 constexpr int LDPC_SPA_MAXC = 6;       // SPA: duplicate edges per layer whose old messages a lane keeps in registers (the DVB-S2 codes have at most 6)
 constexpr int NAT_AHEAD = 24;           // k_ldpc_nat.hip, lanes-per-frame form: checks whose loads are in flight ahead of the one being computed (8 lanes per frame; 12 with 4 lanes per frame)
 constexpr int NAT_HAZ_WINDOW = NAT_AHEAD + 1;
@@ -171,6 +184,9 @@ struct BchPlan {
 struct BchKParams {
     const int32_t *in_bits;     // [F][N] or null
     const uint32_t *in_packed;  // [F][ceil(N/32)] or null
+    // (round 5) fused chain behind an LDPC kernel that has verified the frames itself: only frames with flag[f] != 0 are decoded; their first K bits are
+    // out_bits (descrambled by the producer: re-scrambled here with `prbs`), the N - K parity bits come from in_packed
+    const uint8_t *flag;        // [F] or null (every frame is decoded)
     int32_t *out_bits;          // [F][K]
     int8_t *cwd;                // [F] or null
     const uint16_t *exp_, *log_, *syn_tab;

@@ -149,16 +149,37 @@ bch_decode_kernel(const BchKParams p)
     const uint32_t n = (uint32_t)p.n;
     const int nw = (N + 31) / 32;
     uint16_t *stab = reinterpret_cast<uint16_t *>(words + nw);
-    {   // the tables, two entries per load (the entry count 256 + 768 t is even, both sides are 4-byte aligned)
+    bool stab_ready = false;
+    auto stage_tables = [&]() {   // the tables, two entries per load (the entry count 256 + 768 t is even, both sides are 4-byte aligned)
         const uint32_t *src = reinterpret_cast<const uint32_t *>(p.syn_tab);
         uint32_t *dst = reinterpret_cast<uint32_t *>(stab);
         for (int i = tid; i < (256 + 768 * t) / 2; i += BCH_THREADS) dst[i] = src[i];
-    }
-    __syncthreads();
+        stab_ready = true;
+    };
+    if (!p.flag) { stage_tables(); __syncthreads(); }
 
     for (int f = blockIdx.x; f < p.n_frames; f += gridDim.x) {
+        if (p.flag) {
+            // (round 5) behind an LDPC kernel that has checked r(x) mod g(x) itself (k_ldpc_wg8.hip, `syn_tab`): a frame that is a codeword is left alone -- its
+            // information bits and its CWD flag are in place -- and a workgroup that meets no flagged frame does not even stage the tables
+            if (!p.flag[f]) continue;                 // (uniform over the workgroup)
+            if (!stab_ready) stage_tables();          // (the barrier behind the bit image covers it)
+        }
         // ---- 1. bit image
-        if (p.in_packed) {
+        if (p.flag) {
+            // the first K bits: the producer's descrambled information bits, scrambled again; the N - K parity bits: the packed bytes of the frame's last row
+            const int32_t *src = p.out_bits + (size_t)f * K;
+            const uint32_t *pk = p.in_packed + (size_t)f * nw;
+            for (int base = 0; base < nw * 32; base += BCH_THREADS) {
+                const int i = base + tid;
+                int bit = 0;
+                if (i < K) { bit = src[i] & 1; if (p.prbs) bit ^= (int)((p.prbs[i >> 5] >> (i & 31)) & 1u); }
+                else if (i < N) bit = (int)((pk[i >> 5] >> (i & 31)) & 1u);
+                const unsigned long long mask = __ballot(bit);
+                if (lane == 0 && (i >> 5) < nw) words[i >> 5] = (uint32_t)mask;
+                if (lane == 32 && (i >> 5) < nw) words[i >> 5] = (uint32_t)(mask >> 32);
+            }
+        } else if (p.in_packed) {
             const uint32_t *src = p.in_packed + (size_t)f * nw;
             for (int w = tid; w < nw; w += BCH_THREADS) words[w] = src[w];
         } else {

@@ -622,7 +622,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 for (size_t i = 0; i < grow.size(); i++) if ((int)gbase[grow[i]] != (int)i * LDPC_Z) return "LDPC: internal: global row order";
                 const int n_lds_rows = parked ? park.n_pos : pl.w8_nl;
                 pl.w8_lds_junk = (uint32_t)(n_lds_rows * LDPC_Z * 4);
-                pl.w8_lds_bytes = (n_lds_rows + 1 + (pl.fast_pad && pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z * 4 + 64;
+                pl.w8_lds_bytes = (n_lds_rows + 1 + (pl.fast_pad && pl.fast_mode == 0 ? 1 : 0)) * LDPC_Z * 4 + LDPC_W8_MISC_BYTES;
                 pl.w8_park_moves = parked ? park.n_moves : 0;
                 pl.w8_st_base = (uint32_t)((2 + pl.w8_ng) * LDPC_Z * 4);
                 pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + 3 * M;

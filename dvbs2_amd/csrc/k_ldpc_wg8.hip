@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+#include <type_traits>
 
 namespace dvbs2 {
 
@@ -44,9 +45,10 @@ constexpr int W8_NL = 9;                    // MODE 3: LDS-resident slots per la
 constexpr int W8_ROW = LDPC_Z * 4;          // bytes per bit-group row
 constexpr int W8_IO = 16;                  // independent loads per lane in flight during frame I/O
 constexpr uint32_t W8_OOB = 0x7FFFF000u;    // voffset beyond every workspace: the store is dropped
-__host__ __device__ constexpr bool w8_parked(int mode) { return mode == 4 || mode == 5; }      // static hybrid with rows parked in the idle waves' registers
-__host__ __device__ constexpr bool w8_hybrid(int mode) { return mode == 3 || w8_parked(mode); }
-__host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode == 0 || (mode == 3 && j < W8_NL) || (w8_parked(mode) && j < ldpc_park_nl(mode)); }
+__host__ __device__ __forceinline__ constexpr bool w8_parked(int mode) { return mode == 4 || mode == 5; }      // static hybrid with rows parked in the idle waves' registers
+__host__ __device__ __forceinline__ constexpr bool w8_hybrid(int mode) { return mode == 3 || w8_parked(mode); }
+// (forced: once the kernel had grown by the round-5 output loops the inliner left this one out of line -- 80 calls per layer, the launch 3.7 x as long)
+__host__ __device__ __forceinline__ constexpr bool w8_slot_lds(int mode, int j) { return mode == 0 || (mode == 3 && j < W8_NL) || (w8_parked(mode) && j < ldpc_park_nl(mode)); }
 
 // development knobs of the SPA layer (tools/build_variant.sh): suffix values kept every SPA_BS-th slot; next layer's messages
 // requested under the current layer's stores; cache policy of the message traffic
@@ -103,6 +105,12 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #ifndef W8_FAST_OUT       // output loops of their own for the bits socket alone and for the fused chain (buffer descriptors per frame, scalar descrambling)
 #define W8_FAST_OUT 1
 #endif
+#ifndef W8_OUT_BAR_LGKM   // output phase of the production forms: the barriers wait for the LDS traffic only (same-box A/B: no difference, 6.28 / 6.32 ms under the profiler)
+#define W8_OUT_BAR_LGKM 1
+#endif
+#ifndef W8_OUT_GFIRST     // ... and the rows of the workgroup's global slot are emitted before the LDS rows
+#define W8_OUT_GFIRST 1
+#endif
 #ifndef W8_KEEP_NOWAIT    // the row-keeping waves take a layer's inner barriers without draining their exchanges
 #define W8_KEEP_NOWAIT 1
 #endif
@@ -110,9 +118,17 @@ __host__ __device__ constexpr bool w8_slot_lds(int mode, int j) { return mode ==
 #define W8_IDX_E32 0
 #endif
 #ifdef LDPC_PHASE_PROF
-#define PROF_MARK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[i] += (uint32_t)(n_ - pt_); pt_ = n_; } while (0)
+#define PROF_MARK_(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[i] += (uint32_t)(n_ - pt_); pt_ = n_; } while (0)
+#ifdef LDPC_PROF_OUT      // the six layer slots show the parts of the OUTPUT phase instead: global rows, LDS rows, the hand-over barriers, parked rows, the wave's fold, the end barrier
+#define PROF_MARK(i) do { if ((i) >= 6) PROF_MARK_(i); } while (0)
+#define PROF_MARK_O(i) PROF_MARK_(i)
+#else
+#define PROF_MARK(i) PROF_MARK_(i)
+#define PROF_MARK_O(i)
+#endif
 #else
 #define PROF_MARK(i)
+#define PROF_MARK_O(i)
 #endif
 
 // LDS word at byte offset a of the workgroup's allocation (see the kernel's note on `smem`)
@@ -178,12 +194,12 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_int *co
     const bool on = el < LDPC_Z / 3;
     const uint32_t a0 = (uint32_t)el * 4u;
     constexpr uint32_t A1 = LDPC_Z / 3 * 4u, A2 = 2u * A1;
-    auto lst = [&](uint32_t a, float v) { *w8_lds(a) = v; };
+    auto lst = [&](uint32_t a, float v) __attribute__((always_inline)) { *w8_lds(a) = v; };
     // one ds_wrxchg_rtn_b32 swaps a register with an LDS word (no temporaries: the rows take 3 NR of the wave's 128 registers)
-    auto lxc = [&](uint32_t a, float v) -> float { return __hip_atomic_exchange(w8_lds(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto lxc = [&](uint32_t a, float v) __attribute__((always_inline)) -> float { return __hip_atomic_exchange(w8_lds(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     float R[NR][3];
     int nvote = 0;
-    auto vote0 = [&]() -> bool {                    // the working waves' vote (ldpc_wg8_kernel), with nothing to report
+    auto vote0 = [&]() __attribute__((always_inline)) -> bool {                    // the working waves' vote (ldpc_wg8_kernel), with nothing to report
         lds_int *const w = s_misc + 10;
         const int k = nvote % 3;
         nvote++;
@@ -195,7 +211,7 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_int *co
     // test per slot, every register index and LDS offset a compile-time constant.  The per-slot table entries of round 3 were 39 dependent scalar loads per layer
     // (~3000 cycles of a layer's ~6800), which put these two waves last at the layer's first barrier.
     const const_u32 swm = srv + q * NR;
-    auto moves = [&](int r) {
+    auto moves = [&](int r) __attribute__((always_inline)) {
         const uint32_t mlo = swm[2 * r], mhi = swm[2 * r + 1];
         if (on)
 #pragma unroll
@@ -208,11 +224,11 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_int *co
         }
     };
 #if W8_KEEP_NOWAIT
-    auto bar_inner = [&]() { __builtin_amdgcn_s_barrier(); };      // inside a layer: no wait for the exchanges in flight (nobody looks at the rows being swapped before the layer's end barrier)
+    auto bar_inner = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_barrier(); };      // inside a layer: no wait for the exchanges in flight (nobody looks at the rows being swapped before the layer's end barrier)
 #else
-    auto bar_inner = [&]() { __syncthreads(); };
+    auto bar_inner = [&]() __attribute__((always_inline)) { __syncthreads(); };
 #endif
-    auto layer_barriers = [&](int r) {              // the barriers of one min-sum layer, as the working waves take them
+    auto layer_barriers = [&](int r) __attribute__((always_inline)) {              // the barriers of one min-sum layer, as the working waves take them
         const const_u32 T = tab + r * LDPC_FAST_STRIDE;
         const uint32_t cinfo = T[28];
         const int ncf = (int)(cinfo & 0xFFu);
@@ -231,7 +247,8 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_int *co
     // (wave priority 1 / 2 / 3 for these two waves: no difference, 6.00-6.04 ms for every setting, same box)
     for (int f = blockIdx.x; f < p.n_frames; ) {
         const float *Y = p.llr + (size_t)f * p.N;
-        const int elc = on ? el : 0;                // (the eight lanes without elements load something harmless)
+        const int eln = sidx * 64 + w8_lane_now();  // (re-formed per frame: as a loop invariant the compiler keeps it, widened to 64 bits, across the layer loop -- in registers these waves do not have)
+        const int elc = eln < LDPC_Z / 3 ? eln : 0; // (the eight lanes without elements load something harmless)
 #pragma unroll
         for (int k = 0; k < NR; k++) {
             const uint32_t g = srow[k];
@@ -280,7 +297,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
     // LDS is addressed by plain byte offsets (w8_lds): the kernel has no static LDS, so its dynamic block starts at 0.  Through the symbol every address the
     // layer loop keeps in a register would carry an "+ smem" that the compiler resolves to an add of 0 only at link time -- one vector instruction per access.
     if ((uint32_t)(size_t)(lds_float *)smem != 0u) __builtin_trap();
-    lds_int *const s_misc = (lds_int *)w8_lds((uint32_t)p.w8.lds_bytes - 64u);      // [0..7] SIMD of wave w, [8] F
+    lds_int *const s_misc = (lds_int *)w8_lds((uint32_t)p.w8.lds_bytes - (uint32_t)LDPC_W8_MISC_BYTES);      // [0..7] SIMD of wave w, [8] F, .. (LDPC_W8_MISC_BYTES)
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
     const uint32_t hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);            // HW_REG_HW_ID
     const int simd = (int)((hw >> 4) & 3u);
@@ -290,6 +307,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
         const uint32_t key = (xcc & 15u) << 8 | ((hw >> 13) & 7u) << 5 | ((hw >> 12) & 1u) << 4 | ((hw >> 8) & 15u);
         s_misc[8] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[key], 1u) & 1u) : 0;
         s_misc[10] = 0; s_misc[11] = 0; s_misc[12] = 0;      // SPA: the three vote words
+        for (int k = 16; k < 22; k++) s_misc[k] = 0;         // fused chain: the frame's BCH remainder (zeroed again by the thread that reads it)
     }
     int nvote = 0;                                           // SPA: votes taken so far (rotation of the vote words)
     __syncthreads();
@@ -338,13 +356,13 @@ ldpc_wg8_kernel(const LdpcKParams p)
     // the next instruction may overwrite the store's data registers at once (the rule of the first GCN parts); on gfx950 that corrupts the stored data -- found when a variant of
     // the sum-product layer without branches behind its 16-byte message stores decoded differently from call to call.  With the field zero the compiler's hazard recognizer
     // puts the wait state in itself (one vector add per store is the price; the opaque copy keeps instruction selection from moving the scalar part back).
-    auto wide_off = [&](uint32_t voff, uint32_t soff) -> uint32_t { uint32_t o = voff + soff; asm volatile("" : "+v"(o)); return o; };
-    auto gld = [&](uint32_t voff, uint32_t soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0)); };
-    auto gst = [&](uint32_t voff, uint32_t soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, 0); };
-    auto gld1 = [&](uint32_t voff, uint32_t soff) { if (W8_ABL & 2) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(voff | 0x3F000000u)); return r; } return gld(voff, soff); };
-    auto gst2 = [&](uint32_t voff, uint32_t soff, float v) { if (W8_ABL & 1) { asm volatile("" :: "v"(v), "v"(voff), "s"(soff)); return; } gst(voff, soff, v); };
-    auto mld = [&](uint32_t voff, uint32_t soff) { if (SPA_ABL & 2) return __uint_as_float(voff & 0x3F000000u); return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, SPA_AUX)); };      // SPA messages
-    auto mst = [&](uint32_t voff, uint32_t soff, float v) { if (SPA_ABL & 1) { asm volatile("" :: "v"(v)); return; } __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, SPA_AUX); };
+    auto wide_off = [&](uint32_t voff, uint32_t soff) __attribute__((always_inline)) -> uint32_t { uint32_t o = voff + soff; asm volatile("" : "+v"(o)); return o; };
+    auto gld = [&](uint32_t voff, uint32_t soff) __attribute__((always_inline)) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0)); };
+    auto gst = [&](uint32_t voff, uint32_t soff, float v) __attribute__((always_inline)) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, 0); };
+    auto gld1 = [&](uint32_t voff, uint32_t soff) __attribute__((always_inline)) { if (W8_ABL & 2) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(voff | 0x3F000000u)); return r; } return gld(voff, soff); };
+    auto gst2 = [&](uint32_t voff, uint32_t soff, float v) __attribute__((always_inline)) { if (W8_ABL & 1) { asm volatile("" :: "v"(v), "v"(voff), "s"(soff)); return; } gst(voff, soff, v); };
+    auto mld = [&](uint32_t voff, uint32_t soff) __attribute__((always_inline)) { if (SPA_ABL & 2) return __uint_as_float(voff & 0x3F000000u); return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, SPA_AUX)); };      // SPA messages
+    auto mst = [&](uint32_t voff, uint32_t soff, float v) __attribute__((always_inline)) { if (SPA_ABL & 1) { asm volatile("" :: "v"(v)); return; } __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, voff, soff, SPA_AUX); };
     // SPA_MSG4: the messages of a layer as [slot / 4][360][4 slots] (the last group holds DEG mod 4 of them): a lane's messages of four consecutive slots are 16
     // consecutive bytes, a wave's access 1 KB -- whole lines written and read by ONE instruction instead of four 256-byte pieces of four rows
     // (the per-edge message stream, HBM by construction, is what the sum-product kernel is bound by: docs/negative_results.md's ablations).  Same bytes per layer.
@@ -352,7 +370,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
     typedef uint32_t m_u32x3 __attribute__((ext_vector_type(3)));
     typedef uint32_t m_u32x2 __attribute__((ext_vector_type(2)));
     constexpr int MG4 = DEG / 4, MR = DEG % 4;                                            // whole groups of four slots, slots in the last group
-    auto mgrp_ld = [&](float *dst, uint32_t tb, uint32_t lbase) {                         // all DEG messages of this lane; tb = 4 t (bytes of one dword per lane)
+    auto mgrp_ld = [&](float *dst, uint32_t tb, uint32_t lbase) __attribute__((always_inline)) {                         // all DEG messages of this lane; tb = 4 t (bytes of one dword per lane)
 #pragma unroll
         for (int g = 0; g < MG4; g++) {
             m_u32x4 v = {0u, 0u, 0u, 0u};
@@ -366,12 +384,12 @@ ldpc_wg8_kernel(const LdpcKParams p)
                        dst[4 * MG4] = __uint_as_float(v.x); dst[4 * MG4 + 1] = __uint_as_float(v.y); }
         if (MR == 1) dst[4 * MG4] = mld(tb, tbase);
     };
-    auto mone_ld = [&](uint32_t slot, uint32_t tb, uint32_t lbase) -> float {             // one message (wave-uniform slot): the duplicate edges' old values
+    auto mone_ld = [&](uint32_t slot, uint32_t tb, uint32_t lbase) __attribute__((always_inline)) -> float {             // one message (wave-uniform slot): the duplicate edges' old values
         const uint32_t g = slot >> 2, k = slot & 3u;
         return g < (uint32_t)MG4 ? mld(tb * 4u, lbase + g * (W8_ROW * 4u) + k * 4u) : mld(tb * (uint32_t)(MR ? MR : 1), lbase + (uint32_t)MG4 * (W8_ROW * 4u) + k * 4u);
     };
-    auto lld = [&](uint32_t a) -> float { return *w8_lds(a); };
-    auto lst = [&](uint32_t a, float v) { *w8_lds(a) = v; };
+    auto lld = [&](uint32_t a) __attribute__((always_inline)) -> float { return *w8_lds(a); };
+    auto lst = [&](uint32_t a, float v) __attribute__((always_inline)) { *w8_lds(a) = v; };
     const int nl_info = p.w8.nl_info, nl = p.w8.nl, ng_info = p.w8.ng_info, ng = p.w8.ng;
     const uint32_t grow0 = 2u * W8_ROW;                      // global image: [junk row][+inf row][group rows ..]
     // (LDS-only image only: on the hybrid image of the normal frames the table's loads queue behind the global rows' and the kernel is 19 % SLOWER, 6.73 against 5.65 ms)
@@ -465,7 +483,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
         constexpr int NW4 = (DEG + 3) / 4;
         uint32_t w[4 * NW4];                        // (loop-carried: the addresses of the current layer until its stores have been issued, then the next layer's)
         constexpr int AT_NS = MODE == 0 ? DEG : (MODE == 3 ? W8_NL : w8_parked(MODE) ? ldpc_park_nl(MODE) : 0);      // slots whose address the table supplies (hybrid: the LDS slots, the first ones)
-        auto at_request = [&](int rl) {
+        auto at_request = [&](int rl) __attribute__((always_inline)) {
             typedef uint32_t at_u32x4 __attribute__((ext_vector_type(4)));
             typedef uint32_t at_u32x3 __attribute__((ext_vector_type(3)));
             typedef uint32_t at_u32x2 __attribute__((ext_vector_type(2)));
@@ -510,9 +528,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     // from holding 27 of them across the arithmetic: registers, not instructions, are what this layer is short of)
                     uint32_t t4s = t4, MAGM = 0x7FFFFFFFu;
                     asm volatile("" : "+s"(MAGM));                // the magnitude mask as an SGPR operand (VOP3 takes no literal)
-                    auto woff = [&](int j) { const uint32_t d = t4 - (E[j] & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
-                    auto woff_s = [&](int j) { const uint32_t d = t4s - (E[j] & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
-                    auto dup_slot = [&](int i) -> uint32_t { return i == 0 ? (cinfo >> 8) & 31u : i == 1 ? (cinfo >> 16) & 31u : T[48 + i] & 31u; };
+                    auto woff = [&](int j) __attribute__((always_inline)) { const uint32_t d = t4 - (E[j] & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
+                    auto woff_s = [&](int j) __attribute__((always_inline)) { const uint32_t d = t4s - (E[j] & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
+                    auto dup_slot = [&](int i) __attribute__((always_inline)) -> uint32_t { return i == 0 ? (cinfo >> 8) & 31u : i == 1 ? (cinfo >> 16) & 31u : T[48 + i] & 31u; };
                     // suffix values are kept for every BS-th slot only and rebuilt from there on the way forward (one or two steps off the
                     // critical path): the full array does not fit the 128-VGPR budget of two workgroups per CU beside x[] and u[]
                     constexpr int BS = DEG > 13 ? SPA_BS : 1, NB = (DEG + BS - 1) / BS;      // (the 11- and 13-slot codes have the registers for every suffix value)
@@ -525,7 +543,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     float od[LDPC_SPA_MAXC];                        // old c->v of the duplicate edges, then new - old (what such an edge adds)
                     float mn1 = INFINITY, kap = 1.f, cln = 0.f, key = 0.f;
                     uint32_t sx = 0u;
-                    auto comb = [&](float a, float b) { return __builtin_fmaf(b, __builtin_fmaf(-kap, a, 1.f), a); };      // Q'_ab
+                    auto comb = [&](float a, float b) __attribute__((always_inline)) { return __builtin_fmaf(b, __builtin_fmaf(-kap, a, 1.f), a); };      // Q'_ab
 #pragma unroll
                     for (int i = 0; i < LDPC_SPA_MAXC; i++) od[i] = 0.f;
                     if (act) {
@@ -860,8 +878,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 // ---- duplicate edges of a bit-group inside this layer: ordered delta updates, level by level.  The
                 //      first two (nearly always all of them, both of level 1) travel with the layer table.
                 if (ncf > 0) {
-                    auto addr_of = [&](uint32_t e) { const uint32_t d = t4 - (e & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
-                    auto delta_of = [&](uint32_t j) { return w8_unpack<DEG>(cst1, cst2, pkn, j, SB) - w8_unpack<DEG>(c1o, c2o, pko, j, SB); };
+                    auto addr_of = [&](uint32_t e) __attribute__((always_inline)) { const uint32_t d = t4 - (e & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
+                    auto delta_of = [&](uint32_t j) __attribute__((always_inline)) { return w8_unpack<DEG>(cst1, cst2, pkn, j, SB) - w8_unpack<DEG>(c1o, c2o, pko, j, SB); };
                     const uint32_t j0 = (cinfo >> 8) & 31u, j1 = (cinfo >> 16) & 31u, lvl1 = (cinfo >> 21) & 3u;
                     const bool two = ncf > 1 && lvl1 == 1u;         // entry 1 commutes with entry 0 (another bit-group)
                     // (round 4, LDS-only image) addresses and deltas of the first two entries are ready BEFORE the barrier: behind it only load, add, store remain
@@ -922,7 +940,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 // the workgroup's vote as a ballot per wave + one LDS word out of three in rotation (zeroed two votes ahead), one barrier per vote
                 // (__syncthreads_or brings 256 bytes of static LDS: the dynamic block then starts at 0x100 and every LDS address the layer loop keeps in
                 // a register needs that offset added on the vector unit; it also keeps the 64-bit thread index alive across the layer loop)
-                auto vote = [&](int b) -> bool {
+                auto vote = [&](int b) __attribute__((always_inline)) -> bool {
                     const bool any = __ballot(b != 0) != 0ull;
                     lds_int *const w = s_misc + 10;
                     const int k = nvote % 3;
@@ -975,7 +993,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
         }
         const int n_words = (p.K + 31) / 32;
         const const_u32 prbs_c = (const_u32)p.info_prbs;
-        auto emit = [&](int g, float Lv) {
+        auto emit = [&](int g, float Lv) __attribute__((always_inline)) {
             if (p.info_out && role >= 0 && g < p.n_info) {
                 // fused chain: descrambled info bits as int32, the BCH stage's output for a frame it leaves alone.  The 64 PRBS bits
                 // of this wave's stretch of the row (bit 360 g + 64 role onwards) come in as ONE wave-uniform 64-bit scalar word of a
@@ -1017,10 +1035,10 @@ ldpc_wg8_kernel(const LdpcKParams p)
         const int nb_w = role * 64 + 64 <= LDPC_Z ? 8 : (LDPC_Z - role * 64) / 8;      // whole bytes of a row this wave's ballot holds
         const uint32_t pk_vo = (role >= 0 && lo < nb_w) ? (uint32_t)(role * 8 + lo) : W8_OOB, pk_sh = (uint32_t)(lo & 3) * 8u;
         const bool pk_hi = lo >= 4;
-        auto emit_plain = [&](int g, float Lv) {       // bits socket alone (dvbs2hip_ldpc_decode_siho*, the bench line)
+        auto emit_plain = [&](int g, float Lv) __attribute__((always_inline)) {       // bits socket alone (dvbs2hip_ldpc_decode_siho*, the bench line)
             __builtin_amdgcn_raw_buffer_store_b32(Lv < 0.f ? 1u : 0u, rs_bits, vo_out, (uint32_t)g * (uint32_t)W8_ROW, 2);
         };
-        auto emit_chain = [&](int g, float Lv) {       // fused chain: packed hard decisions for the BCH stage + descrambled information bits as int32 (rows of information groups only)
+        auto emit_chain = [&](int g, float Lv) __attribute__((always_inline)) {       // fused chain: packed hard decisions for the BCH stage + descrambled information bits as int32 (rows of information groups only)
             const unsigned long long m = __ballot(Lv < 0.f);                      // (inactive lanes hold 0.f)
             const const_u32 pq = prbs_c + 2 * (g * 6 + role);
             const unsigned long long d = m ^ ((unsigned long long)pq[0] | ((unsigned long long)pq[1] << 32));
@@ -1031,7 +1049,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
             const uint32_t half = pk_hi ? (uint32_t)(m >> 32) : (uint32_t)m;
             if (!(W8_ABL & 16)) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(half >> pk_sh), rs_pack, pk_vo, (uint32_t)g * (uint32_t)(LDPC_Z / 8), 0);
         };
-        auto run_out = [&](auto &&em) {
+        auto run_out = [&](auto &&em) __attribute__((always_inline)) {
             if (role >= 0) {
                 for (int l0 = 0; l0 < nl_out; l0 += W8_IO) {
                     float v[W8_IO];
@@ -1063,14 +1081,188 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 }
             }
         };
-#if W8_FAST_OUT
-        if (out_plain) run_out(emit_plain);
-        else if (out_chain) run_out(emit_chain);
-        else
+        // (round 5) Fused chain with the BCH verification in this kernel (`syn_tab`): a frame is a BCH codeword iff r(x) mod g(x) = 0, and the remainder is linear in the
+        // bits.  Bit t of row g is the coefficient of x^(360 (G - 1 - g)) x^(359 - t) (G rows of 360 information bits): the first factor A_g = x^(360 (G - 1 - g)) mod g(x)
+        // depends on the row alone -- 4 or 6 words that arrive as wave-uniform scalars, like the PRBS bits -- so a lane XORs A_g into its accumulator for every row whose
+        // hard decision it holds set (one mask + one and-xor per word: no vector-memory access, nothing in the way of the row loads), and the second factor is applied ONCE
+        // per frame: the wave folds its lanes Horner-fashion (block of s lanes times x^s, plus the next block: six shuffle steps) into V_w = sum_l acc_l x^(63 - l),
+        // reduces V_w x^(64 (5 - w)) with a small table of x^k mod g(x) and XORs the result into the workgroup's words.  What is tested is the remainder times x^24 (the
+        // last wave holds 40 checks); g(0) = 1, so it is zero iff the remainder is.  The BCH stage then runs over the flagged frames only (> 99 % of the frames behind a
+        // converged LDPC decoder are codewords) and rebuilds their bit image from the information bits written here plus the last row's packed bytes (the BCH parity
+        // bits): the packed bytes of the other rows are not written any more.
+        const bool out_syn = out_chain && p.syn_tab && p.bch_flag;
+        const bool syn6 = p.syn_words > 4;
+        // Per row in STORAGE order (LDS rows, global rows, register slots: the order the rows are emitted in) the plan supplies one 32-byte record {byte offset of the row in
+        // the int32 socket (beyond every socket: an empty register slot), last-row flag, A_g[0 .. 5]} and the PRBS words by (storage row, wave): every scalar of a row comes
+        // from an address known before the batch starts, nothing waits for the row number first (round 4's form: row number, then the PRBS word at an address formed from it).
+        const const_u32 syn_rec = (const_u32)p.syn_tab;                       // [rows emitted][8]
+        const const_u32 prbs_s = (const_u32)p.info_prbs_s;                     // [rows emitted][6 waves][2]
+        typedef uint32_t o_u32x4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t o_u32x2 __attribute__((ext_vector_type(2)));
+        uint32_t sacc[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        const unsigned long long actm = __ballot(act);                              // the lanes that hold a check
+        auto emit_syn = [&](int ks, float Lv, bool repeat, auto nw_c) __attribute__((always_inline)) {      // ks: storage row; repeat (wave-uniform): a row that was emitted already
+            constexpr int NW = decltype(nw_c)::value;
+            const const_u32 rec = syn_rec + ks * 8;
+            const uint32_t off = repeat ? W8_OOB : rec[0];
+            const unsigned long long m = __ballot(Lv < 0.f) & (off == W8_OOB ? 0ull : actm);     // (the lanes without a check hold anything)
+            const const_u32 pq = prbs_s + 2 * (ks * 6 + role);
+            const unsigned long long d = m ^ ((unsigned long long)pq[0] | ((unsigned long long)pq[1] << 32));
+            uint32_t bit, mk;
+            asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(bit) : "s"(d));
+            asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(mk) : "s"(m));            // all ones where the hard decision is 1 (Lv < 0, as the stored bit: not the sign bit -- a posterior of -0.f decides 0)
+            // (the whole offset in the vector register: the range check that drops the bits behind K_info, the lanes without a check and a skipped row then sees all of it)
+            __builtin_amdgcn_raw_buffer_store_b32(bit, rs_info, vo_out + off, 0u, 2);
+#pragma unroll
+            for (int i = 0; i < NW; i++)      // acc ^= mask & A_g[i] as ONE instruction that takes the scalar where it is (written as `acc ^= mk & ag[i]` the compiler forms the 64 products of a batch first -- to let go of the scalar registers -- and spills them)
+                asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x78" : "+v"(sacc[i]) : "v"(mk), "s"(rec[2 + i]));
+            if (rec[1] && !repeat) {                                                // the row that holds the BCH parity bits: its packed bytes for the BCH stage (row g at byte 45 g = offset / 32)
+                const uint32_t half = pk_hi ? (uint32_t)(m >> 32) : (uint32_t)m;
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(half >> pk_sh), rs_pack, pk_vo, off >> 5, 0);
+            }
+        };
+        auto fold_syn = [&](auto nw_c) __attribute__((always_inline)) {
+            constexpr int NW = decltype(nw_c)::value, NU = NW + 2;
+            const int los = w8_lane_now();
+            // the value of lane (l ^ sh): ds_bpermute by the opaque lane index (__shfl_xor goes through __lane_id(), which the compiler computes once at the kernel's start and keeps)
+            auto shx = [&](uint32_t x, int sh) __attribute__((always_inline)) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((los ^ sh) << 2, (int)x); };      // (re-formed here: every per-lane constant of this once-per-frame stretch would otherwise be hoisted out of the frame loop and live across the layer loop)
+            // V_w = sum over the wave's lanes of acc_l x^(63 - l): a block of s lanes holds the sum of its lanes with the block's last lane at x^0; two neighbouring
+            // blocks merge as (lower block) x^s + (upper block).  NU words hold the 32 NW + 63 bits.
+            // (the reduction table's entries are requested first: their addresses do not depend on V_w, they travel under the shuffles)
+            const __amdgpu_buffer_rsrc_t rs_red = __builtin_amdgcn_make_buffer_rsrc((void *)(p.syn_tab + p.syn_rows * 8), 0, LDPC_SYN_RED * NW * 4, 0x00020000);
+            o_u32x4 ta[NU / 2]; o_u32x2 tb[NU / 2];
+#pragma unroll
+            for (int j = 0; j < NU / 2; j++) {
+                const uint32_t vo = (uint32_t)(los + 64 * (j + 5 - role)) * (uint32_t)(NW * 4);
+                ta[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_red, vo, 0u, 0);
+                tb[j] = o_u32x2{0u, 0u};
+                if (NW > 4) tb[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_red, vo + 16u, 0u, 0);
+            }
+            uint32_t U[NU];
+#pragma unroll
+            for (int i = 0; i < NU; i++) U[i] = i < NW ? sacc[i] : 0u;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                const bool lower = (los & sh) == 0;
+                uint32_t X[NU], Y[NU];
+#pragma unroll
+                for (int i = 0; i < NU; i++) {
+                    const uint32_t P = shx(U[i], sh);
+                    X[i] = lower ? U[i] : P;      // the lower block's value: times x^s
+                    Y[i] = lower ? P : U[i];
+                }
+#pragma unroll
+                for (int i = NU - 1; i >= 0; i--) {
+                    const uint32_t hi = X[i], lw = i > 0 ? X[i - 1] : 0u;
+                    U[i] = (sh == 32 ? lw : ((hi << sh) | (lw >> (32 - sh)))) ^ Y[i];
+                }
+            }
+            // V_w x^(64 (5 - w)) mod g(x): bit n = lo + 64 j of V_w (word 2 j + (lo >> 5): the same words in every lane now) selects the table's entry x^k mod g(x), k = n + 64 (5 - w)
+            uint32_t part[NW];
+#pragma unroll
+            for (int i = 0; i < NW; i++) part[i] = 0u;
+#pragma unroll
+            for (int j = 0; j < NU / 2; j++) {
+                const uint32_t hsel = (uint32_t)((int32_t)((uint32_t)los << 26) >> 31);                     // all ones in the lanes 32 .. 63: they look at the odd word
+                const uint32_t wsel = U[2 * j] ^ ((U[2 * j] ^ U[2 * j + 1]) & hsel);                  // (bitwise: a select of two array elements becomes a dynamically indexed array in private memory)
+                const uint32_t mk = (uint32_t)((int32_t)(wsel << (31 - (los & 31))) >> 31);
+                part[0] ^= ta[j].x & mk; part[1] ^= ta[j].y & mk; part[2] ^= ta[j].z & mk; part[3] ^= ta[j].w & mk;
+                if (NW > 4) { part[NW > 4 ? 4 : 0] ^= tb[j].x & mk; part[NW > 4 ? 5 : 0] ^= tb[j].y & mk; }
+            }
+            // the wave's XOR over its lanes, then into the workgroup's words (zero at the start of every frame)
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                uint32_t x = part[k];
+                for (int o = 32; o > 0; o >>= 1) x ^= shx(x, o);
+                if (los == 0 && x) __hip_atomic_fetch_xor(s_misc + 16 + k, (int)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        const uint32_t t4o = SPA ? (uint32_t)to * 4u : t4;      // (sum-product kernel: re-formed from the opaque lane index, like the frame input's -- t4 kept alive across the layer loop costs the register it does not have)
+        auto out_bar = [&]() __attribute__((always_inline)) {      // a barrier of the output phase: LDS traffic only (what the row-keeping waves hand over); the stores in flight are not waited for
+#if W8_OUT_BAR_LGKM
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+            __syncthreads();
 #endif
-            run_out(emit);
+        };
+        auto run_out_fast = [&](auto nw_c) __attribute__((always_inline)) {
+            constexpr int NW = decltype(nw_c)::value;                  // words of the BCH remainder: 0 (bits socket alone: no verification), 4 or 6
+            constexpr bool SYN = NW > 0;
+            constexpr int IOS = (SPA || SYN) ? 8 : W8_IO;                // rows per batch
+            const const_u32 srow = rows + nl + ng + q;
+            constexpr int NRP = w8_parked(MODE) ? ldpc_park_nr(MODE) : 0;
+            // kind 0: LDS rows, 1: global rows, 2: the parked rows handed over through LDS positions 0 .. NR-1
+            auto grp = [&](int kind, int l) __attribute__((always_inline)) -> uint32_t { return kind == 0 ? rows[l] : kind == 1 ? rows[nl + l] : srow[l]; };
+            // A batch of B rows without a branch in it: the lanes without a check read a valid address (LDS) or beyond the slot (global rows: the access returns 0) and
+            // store beyond their socket; the segment's remainder is its LAST B rows once more (`ldone`: rows below it were emitted by the batch before -- stored twice,
+            // which the bits socket does not mind, and masked out of the BCH remainder).  With per-row tests every row was a basic block of its own: its row number, PRBS
+            // word and buffer descriptor (spilled to a lane of a vector register) were fetched, and waited for, row by row.
+            const uint32_t t4l = act ? t4o : 0u, t4g = act ? t4o : W8_OOB;
+            auto body = [&](int kind, int l0, int ldone, auto b_c) __attribute__((always_inline)) {
+                constexpr int B = decltype(b_c)::value;
+                float v[B];
+#pragma unroll
+                for (int k = 0; k < B; k++) v[k] = kind == 1 ? gld(t4g, grow0 + (uint32_t)(l0 + k) * W8_ROW) : lld((uint32_t)(l0 + k) * W8_ROW + t4l);
+#pragma unroll
+                for (int k = 0; k < B; k++) {
+                    // (the rows' scalars -- row number, PRBS word, A_g -- four rows at a time: hoisted for the whole batch they are 7 x 16 SGPRs that the kernel does not have)
+                    if (k > 0 && k % (SYN ? 4 : 8) == 0) __builtin_amdgcn_sched_barrier(0);
+                    if (SYN) { emit_syn((kind == 0 ? 0 : kind == 1 ? nl_info : nl_info + ng_info) + l0 + k, v[k], l0 + k < ldone, nw_c); continue; }
+                    const uint32_t gk = grp(kind, l0 + k);
+                    if (kind == 2) { if (gk != 0xFFFFFFFFu) emit_plain((int)gk, v[k]); }      // (an empty register slot: the plan of the DVB-S2 codes leaves none)
+                    else emit_plain((int)gk, v[k]);
+                }
+            };
+            auto seg = [&](int kind, int n) __attribute__((always_inline)) {
+                int l0 = 0;
+                for (; l0 + IOS <= n; l0 += IOS) body(kind, l0, 0, std::integral_constant<int, IOS>{});
+                if (l0 < n) {
+                    if (n >= IOS) body(kind, n - IOS, l0, std::integral_constant<int, IOS>{});
+                    else for (; l0 < n; l0++) body(kind, l0, 0, std::integral_constant<int, 1>{});
+                }
+            };
+            if (role >= 0) {
+#if W8_OUT_GFIRST
+                seg(1, ng_info);      // the global rows first: their loads are issued while nothing of this phase is in the wave's memory queue yet
+                PROF_MARK_O(0);
+                seg(0, nl_info);
+                PROF_MARK_O(1);
+#else
+                seg(0, nl_info);
+                PROF_MARK_O(1);
+                seg(1, ng_info);
+                PROF_MARK_O(0);
+#endif
+            }
+            if (w8_parked(MODE)) {
+                out_bar();      // every LDS row has been read
+                out_bar();      // the parked rows are in positions 0 .. NR-1
+                PROF_MARK_O(2);
+                if (role >= 0) seg(2, NRP);
+                PROF_MARK_O(3);
+            }
+            if constexpr (SYN) { if (role >= 0) fold_syn(nw_c); }
+        };
+        bool fast_out = false;
+#if W8_FAST_OUT
+        if (out_plain) { run_out_fast(std::integral_constant<int, 0>{}); fast_out = true; }
+        else if (out_syn && syn6) { run_out_fast(std::integral_constant<int, 6>{}); fast_out = true; }
+        else if (out_syn) { run_out_fast(std::integral_constant<int, 4>{}); fast_out = true; }
+        else if (out_chain) { run_out(emit_chain); fast_out = true; }
+#endif
+        if (!fast_out) run_out(emit);
+        PROF_MARK_O(4);
         if (first) s_misc[9] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[LDPC_FRAME_CTR], 1u) + gridDim.x) : f + (int)gridDim.x;
-        __syncthreads();     // the posterior image is reused by the next frame of this workgroup
+        // the posterior image is reused by the next frame of this workgroup: every load of this phase has been consumed, the stores in flight touch the sockets only
+        if (fast_out) out_bar(); else __syncthreads();
+        PROF_MARK_O(5);
+        if (out_syn && first) {
+            int nz = 0;
+#pragma unroll
+            for (int k = 16; k < 22; k++) { nz |= s_misc[k]; s_misc[k] = 0; }      // (the next frame's first XOR is a frame input and a barrier away)
+            p.bch_flag[fu] = nz ? 1 : 0;
+            if (p.cwd_bch && !nz) p.cwd_bch[fu] = 1;
+        }
         f = SPA ? __builtin_amdgcn_readfirstlane(s_misc[9]) : s_misc[9];      // (uniform: the frame's base addresses stay on the scalar unit)
         PROF_MARK(7);
 #ifdef LDPC_PHASE_PROF
@@ -1109,7 +1301,11 @@ static hipError_t wg8_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t
         (void)hipMemcpy(hbuf.data(), p.cu_ctr + LDPC_CU_CTR_WORDS, hbuf.size() * 4, hipMemcpyDeviceToHost);
         double acc[12] = {0}; int nw = 0;
         for (int w = 0; w < grid * 8; w++) { if (!hbuf[(size_t)w * 12 + 11]) continue; nw++; for (int i = 0; i < 12; i++) acc[i] += hbuf[(size_t)w * 12 + i]; }
+        #ifdef LDPC_PROF_OUT
+        static const char *nm[12] = {"out: global rows", "out: LDS rows", "out: hand-over", "out: parked rows", "out: fold", "out: end barrier", "syndrome", "output (rest)", "input", "-frames", "-", "TOTAL"};
+#else
         static const char *nm[12] = {"1a issue", "1b", "mid barrier", "pass 2", "replay", "end barrier", "syndrome", "output", "input", "-frames", "-", "TOTAL"};
+#endif
         fprintf(stderr, "[ldpc phase prof] %d working waves\n", nw);
         {   // frames per workgroup and busy time: how evenly the work queue feeds the persistent grid
             std::vector<int> hist(64, 0); double tmin = 1e30, tmax = 0;
@@ -1119,7 +1315,7 @@ static hipError_t wg8_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t
             for (int i = 0; i < 64; i++) if (hist[i]) fprintf(stderr, "  %d frames: %d WGs", i, hist[i]);
             fprintf(stderr, "\n  busy ticks per wave: min %.0f max %.0f\n", tmin, tmax);
         }
-        for (int i = 0; i < 12; i++) if (nm[i][0] != '-') fprintf(stderr, "  %-12s %12.0f ticks/wave  %5.1f %%\n", nm[i], acc[i] / (nw ? nw : 1), 100.0 * acc[i] / (acc[11] > 0 ? acc[11] : 1));
+        for (int i = 0; i < 12; i++) if (nm[i][0] != '-') fprintf(stderr, "  %-18s %12.0f ticks/wave  %5.1f %%\n", nm[i], acc[i] / (nw ? nw : 1), 100.0 * acc[i] / (acc[11] > 0 ? acc[11] : 1));
     }
 #endif
     return hipGetLastError();

@@ -310,6 +310,44 @@ def test_lr_waiting_workgroup_that_gives_up_is_reported_and_the_call_repaired(O,
     rx.close()
 
 
+def test_lr_timeouts_of_several_outstanding_device_calls_are_each_repaired_with_their_own_estimates(O, Rx, monkeypatch):
+    """the repair of a device-form L&R call that timed out needs THAT launch's estimates and THAT launch's error word.  Sequences that used to
+    corrupt Y silently (one error word, one `lr_last`, estimates in a buffer shared with the next call): lr_dev(A) -> lr_dev(B) -> freq_phase_dev(C) -> a host-form L&R call
+    -> dvbs2hip_synchronize, every L&R launch forced to time out.  Every output must equal the three-kernel path's (state carried call to call), bit for bit."""
+    import torch
+    modcod, F = "QPSK-S_8/9", 48
+    _, pl, _, _ = make_pl_frames(O, modcod, 4, 10.0, seed=14)
+    n = pl.shape[1] // 2
+    rng = np.random.default_rng(8)
+    xs = [np.stack([_rot(O, pl[(f + k) % pl.shape[0]], 2e-4 * ((f + k) % 7 + 1), 0.05 * f + 0.3 * k) for f in range(F)])
+          + (0.05 * rng.standard_normal((F, 2 * n))).astype(np.float32) for k in range(4)]
+    monkeypatch.setenv("DVBS2HIP_LR", "unfused")
+    rx = Rx(modcod, max_frames=F); rx.sync_lr_set_alpha(0.9)
+    ref = [rx.sync_lr_synchronize(xs[0]), rx.sync_lr_synchronize(xs[1]), rx.sync_freq_phase_synchronize(xs[2]), rx.sync_lr_synchronize(xs[3])]
+    rx.close()
+    monkeypatch.delenv("DVBS2HIP_LR")
+    monkeypatch.setenv("DVBS2HIP_LR_TIMEOUT_US", "0")
+    rx = Rx(modcod, max_frames=F); rx.sync_lr_set_alpha(0.9)
+    dev = []
+    for k in range(3):
+        xd = torch.from_numpy(xs[k]).cuda(); yd = torch.empty_like(xd); fd = torch.empty(F, dtype=torch.float32, device="cuda"); pd = torch.empty_like(fd)
+        dev.append((xd, yd, fd, pd))
+    torch.cuda.synchronize()
+    for k in range(3):
+        xd, yd, fd, pd = dev[k]
+        fn = rx.L.dvbs2hip_sync_lr_synchronize_dev if k < 2 else rx.L.dvbs2hip_sync_freq_phase_synchronize_dev
+        rx._chk(fn(rx.h, xd.data_ptr(), fd.data_ptr(), pd.data_ptr(), yd.data_ptr(), F))
+    host = rx.sync_lr_synchronize(xs[3])           # a host-form call in between: must not swallow the device calls' error words
+    rx.synchronize()
+    assert rx.sync_lr_timeouts() >= 2
+    for k in range(3):
+        _, yd, fd, _ = dev[k]
+        assert np.array_equal(fd.cpu().numpy(), ref[k][0]), k
+        assert np.array_equal(yd.cpu().numpy().reshape(F, -1), ref[k][2].reshape(F, -1)), k
+    assert np.array_equal(host[0], ref[3][0]) and np.array_equal(host[2].reshape(F, -1), ref[3][2].reshape(F, -1))
+    rx.close()
+
+
 def test_lr_one_launch_form_under_another_handles_persistent_kernel():
     """The rotating workgroups of sff_lr_fused_kernel wait for words that workgroup 0 publishes, which is safe because workgroup 0 is placed first.  Issued while another
     handle's persistent LDPC launch owns every CU (tools/lr_soak.py), the synchronizer's workgroups are placed a few at a time as LDPC workgroups retire: every call must
