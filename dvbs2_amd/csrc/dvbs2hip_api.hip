@@ -1788,6 +1788,50 @@ int dvbs2hip_timing_get(dvbs2hip_t *h, int32_t k, double *total_ms, int64_t *n)
     *total_ms = tot; *n = (int64_t)h->ev[k].size();
     return 0;
 }
+// a plain streaming copy: 16 bytes per lane and access, 8 accesses in flight per lane, non-temporal stores; grid-stride over a persistent grid
+typedef float copy_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) device_copy_kernel(const copy_f4 *__restrict__ src, copy_f4 *__restrict__ dst, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        copy_f4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(&src[i + k * stride]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) __builtin_nontemporal_store(v[k], &dst[i + k * stride]);
+    }
+    for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
+}
+
+int dvbs2hip_device_copy_bandwidth(dvbs2hip_t *h, size_t bytes, int32_t reps, double *GBps)
+{
+    if (!h || !GBps || reps < 1 || bytes < 16) return DVBS2HIP_EINVAL;
+    int r0 = enter(h); if (r0) return r0;
+    const size_t n4 = bytes / 16;
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, n4 * 16) != hipSuccess) return fail(h, DVBS2HIP_ENOMEM, "hipMalloc of " + std::to_string(n4 * 16) + " bytes failed");
+    if (hipMalloc(&b, n4 * 16) != hipSuccess) { (void)hipFree(a); return fail(h, DVBS2HIP_ENOMEM, "hipMalloc of " + std::to_string(n4 * 16) + " bytes failed"); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    float ms = 0.f;
+    const int grid = h->n_cus * 8;
+    if (hipMemsetAsync(a, 0x3c, n4 * 16, h->stream) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = DVBS2HIP_EHIP;
+    if (!rc) {
+        hipLaunchKernelGGL(device_copy_kernel, dim3(grid), dim3(256), 0, h->stream, (const copy_f4 *)a, (copy_f4 *)b, n4);      // warm-up
+        (void)hipEventRecord(e0, h->stream);
+        for (int i = 0; i < reps; i++) hipLaunchKernelGGL(device_copy_kernel, dim3(grid), dim3(256), 0, h->stream, (const copy_f4 *)a, (copy_f4 *)b, n4);
+        (void)hipEventRecord(e1, h->stream);
+        if (hipStreamSynchronize(h->stream) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = DVBS2HIP_EHIP;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
+    if (rc) return fail(h, rc, "device copy measurement failed");
+    *GBps = 2.0 * (double)(n4 * 16) * reps / ((double)ms * 1e-3) / 1e9;
+    return 0;
+}
+
 int dvbs2hip_malloc(dvbs2hip_t *h, void **d, size_t bytes)
 {
     if (!h || !d) return DVBS2HIP_EINVAL;

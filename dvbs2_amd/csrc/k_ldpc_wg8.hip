@@ -105,6 +105,9 @@ __host__ __device__ __forceinline__ constexpr bool w8_slot_lds(int mode, int j) 
 #ifndef W8_FAST_OUT       // output loops of their own for the bits socket alone and for the fused chain (buffer descriptors per frame, scalar descrambling)
 #define W8_FAST_OUT 1
 #endif
+#ifndef W8_IN_FAST        // frame input of the information rows, LDS-only image: branch-free batches through a buffer descriptor (see there)
+#define W8_IN_FAST 1
+#endif
 #ifndef W8_OUT_BAR_LGKM   // output phase of the production forms: the barriers wait for the LDS traffic only (same-box A/B: no difference, 6.28 / 6.32 ms under the profiler)
 #define W8_OUT_BAR_LGKM 1
 #endif
@@ -298,10 +301,10 @@ ldpc_wg8_kernel(const LdpcKParams p)
     // layer loop keeps in a register would carry an "+ smem" that the compiler resolves to an add of 0 only at link time -- one vector instruction per access.
     if ((uint32_t)(size_t)(lds_float *)smem != 0u) __builtin_trap();
     lds_int *const s_misc = (lds_int *)w8_lds((uint32_t)p.w8.lds_bytes - (uint32_t)LDPC_W8_MISC_BYTES);      // [0..7] SIMD of wave w, [8] F, .. (LDPC_W8_MISC_BYTES)
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane0 = (int)threadIdx.x & 63;
     const uint32_t hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);            // HW_REG_HW_ID
     const int simd = (int)((hw >> 4) & 3u);
-    if (lane == 0) s_misc[wave] = simd;
+    if (lane0 == 0) s_misc[wave] = simd;
     if (threadIdx.x == 0) {
         const uint32_t xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);        // HW_REG_XCC_ID
         const uint32_t key = (xcc & 15u) << 8 | ((hw >> 13) & 7u) << 5 | ((hw >> 12) & 1u) << 4 | ((hw >> 8) & 15u);
@@ -335,11 +338,12 @@ ldpc_wg8_kernel(const LdpcKParams p)
             }
             w8_park_server<DEG, ldpc_park_nr(MODE)>(p, s_misc, wave, __builtin_amdgcn_readfirstlane(sidx));
 #ifdef LDPC_PHASE_PROF
-            if (lane == 0 && p.cu_ctr) for (int i = 0; i < 12; i++) p.cu_ctr[LDPC_CU_CTR_WORDS + ((int)blockIdx.x * 8 + wave) * 12 + i] = 0u;
+            if (lane0 == 0 && p.cu_ctr) for (int i = 0; i < 12; i++) p.cu_ctr[LDPC_CU_CTR_WORDS + ((int)blockIdx.x * 8 + wave) * 12 + i] = 0u;
 #endif
             return;
         }
     }
+    const int lane = w8_lane_now() & 63;      // (re-formed behind the role split: the row-keeping waves' branch reuses the register, and the one from the kernel's start was spilled around it)
     const int t = role * 64 + lane;
     const bool act = role >= 0 && t < LDPC_Z;
     const uint32_t t4 = (uint32_t)t * 4u;
@@ -412,10 +416,39 @@ ldpc_wg8_kernel(const LdpcKParams p)
         const float *Y = p.llr + (size_t)f * p.N;
         // the frame I/O addresses are formed per frame from an opaque copy of the lane's index: hoisted out of the frame loop they are
         // ~10 64-bit pointers per lane that the layer loop has no registers for (they were spilled)
-        const int lio = SPA ? w8_lane_now() : lane, tio = SPA ? role * 64 + lio : t;
-        const uint32_t tio4 = SPA ? (uint32_t)tio * 4u : t4;
+        // (same-box A/B of the branch-free input form below: LDS-only image 4.43 -> 4.40 ms per 16384 short frames, hybrid image 5.755 -> 5.81 ms per 4096 normal frames -- its
+        // input phase is 14 % shorter there too, and the launch longer: the burst of 16 back-to-back loads lands on the fabric the CU's other workgroup is decoding through)
+        constexpr bool INF = W8_IN_FAST && MODE == 0;
+        const int lio = (SPA || INF) ? w8_lane_now() : lane, tio = (SPA || INF) ? role * 64 + lio : t;
+        const uint32_t tio4 = (SPA || INF) ? (uint32_t)tio * 4u : t4;
         __builtin_amdgcn_s_setprio(3);                       // frame I/O: short bursts of loads that the other workgroup's arithmetic should not delay
-        if (act) {
+        if (INF && act) {
+            // info groups: coalesced rows of 360, streamed in once (non-temporal).  (round 5) Batches without a branch or a clamp in them -- the segment's remainder is its last
+            // W8_IO rows once more, copied twice -- through a buffer descriptor of the frame: the row numbers of a batch arrive as one wide scalar load and a row's load is ONE
+            // instruction (row offset in the scalar field).  With a clamped index per row the compiler fetched every row number by itself and waited for it in front of the
+            // row's load (16 scalar round trips per batch between loads that are meant to go out back to back), and formed a 64-bit address per lane and row.
+            const int fin = __builtin_amdgcn_readfirstlane(f);
+            const __amdgpu_buffer_rsrc_t rs_llr = __builtin_amdgcn_make_buffer_rsrc((void *)(p.llr + (size_t)fin * p.N), 0, p.N * 4, 0x00020000);
+            auto in_body = [&](int rb, int l0, bool lds, auto b_c) __attribute__((always_inline)) {
+                constexpr int B = decltype(b_c)::value;
+                float v[B];
+#pragma unroll
+                for (int k = 0; k < B; k++) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_llr, tio4, rows[rb + l0 + k] * (uint32_t)W8_ROW, 2));
+#pragma unroll
+                for (int k = 0; k < B; k++) { if (lds) lst((uint32_t)(l0 + k) * W8_ROW + tio4, v[k]); else gst(tio4, grow0 + (uint32_t)(l0 + k) * W8_ROW, v[k]); }
+            };
+            auto in_seg = [&](int rb, int n, bool lds) __attribute__((always_inline)) {
+                int l0 = 0;
+                for (; l0 + W8_IO <= n; l0 += W8_IO) in_body(rb, l0, lds, std::integral_constant<int, W8_IO>{});
+                if (l0 < n) {
+                    if (n >= W8_IO) in_body(rb, n - W8_IO, lds, std::integral_constant<int, W8_IO>{});
+                    else for (; l0 < n; l0++) in_body(rb, l0, lds, std::integral_constant<int, 1>{});
+                }
+            };
+            in_seg(0, nl_info, true);
+            in_seg(nl, ng_info, false);
+        }
+        if (!INF && act) {
             // info groups: coalesced rows of 360, streamed in once (non-temporal)
             for (int l0 = 0; l0 < nl_info; l0 += W8_IO) {
                 float v[W8_IO];

@@ -127,6 +127,7 @@ ABI = {
     "dvbs2hip_timing_enable": (C.c_int, [_vp, _i]),
     "dvbs2hip_timing_reset": (C.c_int, [_vp]),
     "dvbs2hip_timing_get": (C.c_int, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "dvbs2hip_device_copy_bandwidth": (C.c_int, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
     "dvbs2hip_malloc": (C.c_int, [_vp, C.POINTER(_vp), C.c_size_t]),
     "dvbs2hip_free": (C.c_int, [_vp, _vp]),
     "dvbs2hip_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

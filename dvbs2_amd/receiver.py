@@ -404,6 +404,12 @@ class Dvbs2Hip:
     def timing_reset(self):
         self._chk(self.L.dvbs2hip_timing_reset(self.h))
 
+    def device_copy_GBps(self, nbytes=1 << 30, reps=5) -> float:
+        """read + written GB/s of the library's own streaming copy kernel on this GPU (a measurement aid: dvbs2hip_device_copy_bandwidth)"""
+        g = C.c_double()
+        self._chk(self.L.dvbs2hip_device_copy_bandwidth(self.h, int(nbytes), int(reps), C.byref(g)))
+        return g.value
+
     def timing_get(self, k):
         ms, n = C.c_double(), C.c_int64()
         self._chk(self.L.dvbs2hip_timing_get(self.h, k, C.byref(ms), C.byref(n)))

@@ -7,6 +7,7 @@
  * Compiled with -ffp-contract=off so the fp32 results do not depend on FMA fusion.
  * All path:line citations are relative to /root/reference.
  */
+#define _GNU_SOURCE      /* sched_setaffinity, CPU_SET (the CPU baseline's pinned threads) */
 #include "dvbs2_oracle.h"
 #include <math.h>
 #include <stdlib.h>
@@ -14,6 +15,7 @@
 #include <float.h>
 #include <time.h>
 #ifdef _OPENMP
+#include <sched.h>
 #include <omp.h>
 #endif
 
@@ -371,6 +373,134 @@ double orc_ldpc_decode_batch_inter(const orc_ldpc *c, const float *llr, int F, i
     clock_gettime(CLOCK_MONOTONIC, &t1);
     (void)threads;
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* ---- CPU baseline, the form bench.py times (round 5): every thread pinned to a CPU of the caller's list, its work buffers AND a private copy of its share of the
+ * LLRs first-touched by itself (NUMA-local pages), the blocks dealt statically (thread t takes blocks t, t + T, ..); the timed region starts behind a barrier, when every
+ * copy is in place, and ends when the slowest thread is done.  flavour 0: scalar decoder (sched = natural), 1: inter-frame SIMD.  Same arithmetic as the functions above.
+ * Returns seconds; *per_thread_max / *per_thread_min (may be NULL) get the slowest / fastest thread's own time. */
+double orc_ldpc_decode_batch_pinned(const orc_ldpc *c, const float *llr, int F, int flavour, int n_ite, float alpha, int32_t *bits, int threads,
+                                    const int *cpus, int n_cpus, double *tmax, double *tmin)
+{
+    const int W = flavour ? ORC_W : 1, nb = (F + W - 1) / W;
+    double t_start = 0.0, t_end = 0.0, hi = 0.0, lo = 1e30;
+    if (threads < 1) threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+        const int tid = 0, T = 1;
+#endif
+        cpu_set_t old, one;
+        int pinned = 0;
+        if (cpus && n_cpus > 0 && sched_getaffinity(0, sizeof old, &old) == 0) {
+            CPU_ZERO(&one); CPU_SET(cpus[tid % n_cpus], &one);
+            pinned = sched_setaffinity(0, sizeof one, &one) == 0;
+        }
+        inter_ws iw = {0, 0, 0};
+        ldpc_ws sw = {0, 0, 0, 0};
+        if (flavour) inter_ws_alloc(c, &iw); else ldpc_ws_alloc(c, &sw);
+        int mine = 0;
+        for (int blk = tid; blk < nb; blk += T) mine++;
+        float *own = (float *)malloc(sizeof(float) * (size_t)(mine > 0 ? mine : 1) * W * c->N);
+        int k = 0;
+        for (int blk = tid; blk < nb; blk += T, k++) {
+            const int f0 = blk * W, nf = F - f0 < W ? F - f0 : W;
+            memcpy(own + (size_t)k * W * c->N, llr + (size_t)f0 * c->N, sizeof(float) * (size_t)nf * c->N);
+        }
+        if (flavour) { memset(iw.L, 0, sizeof(float) * (size_t)c->N * ORC_W); memset(iw.msg, 0, sizeof(float) * (size_t)c->E * ORC_W); }      /* pages touched before the clock starts */
+        else { memset(sw.L, 0, sizeof(float) * c->N); memset(sw.msg, 0, sizeof(float) * c->E); }
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+#endif
+        { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); t_start = (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+#ifdef _OPENMP
+#pragma omp barrier
+#endif
+        struct timespec a, b;
+        clock_gettime(CLOCK_MONOTONIC, &a);
+        k = 0;
+        for (int blk = tid; blk < nb; blk += T, k++) {
+            const int f0 = blk * W, nf = F - f0 < W ? F - f0 : W;
+            if (flavour) decode_inter_block(c, own + (size_t)k * W * c->N, nf, n_ite, alpha, bits ? bits + (size_t)f0 * c->K : NULL, &iw);
+            else ldpc_decode_ws(c, own + (size_t)k * c->N, ORC_NMS, ORC_SCHED_NATURAL, n_ite, alpha, 0, bits ? bits + (size_t)f0 * c->K : NULL, NULL, NULL, &sw);
+        }
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        const double mine_s = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        { if (mine > 0 && mine_s > hi) hi = mine_s; if (mine > 0 && mine_s < lo) lo = mine_s; }
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+#endif
+        { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); t_end = (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+        free(own);
+        if (flavour) inter_ws_free(&iw); else ldpc_ws_free(&sw);
+        if (pinned) sched_setaffinity(0, sizeof old, &old);
+    }
+    if (tmax) *tmax = hi;
+    if (tmin) *tmin = lo;
+    return t_end - t_start;
+}
+
+/* STREAM triad a[i] = b[i] + s c[i] on `threads` pinned threads, every thread on arrays it first-touched itself: the host's sustainable DRAM bandwidth in GB/s
+ * (3 x 4 bytes per element; write-allocate traffic not counted, as STREAM does), best of `reps` passes.  Beside the CPU baseline it says whether the inter-frame
+ * flavour -- 16 frames x (N + E) floats = 16.6 MB of state per thread, swept once per iteration -- is bound by the cores or by the memory they share. */
+double orc_stream_triad_GBps(int threads, size_t floats_per_thread, int reps, const int *cpus, int n_cpus)
+{
+    double best = 0.0;
+    if (threads < 1) threads = 1;
+    double t0 = 0.0, t1 = 0.0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+        const int tid = 0, T = 1;
+#endif
+        cpu_set_t old, one;
+        int pinned = 0;
+        if (cpus && n_cpus > 0 && sched_getaffinity(0, sizeof old, &old) == 0) {
+            CPU_ZERO(&one); CPU_SET(cpus[tid % n_cpus], &one);
+            pinned = sched_setaffinity(0, sizeof one, &one) == 0;
+        }
+        float *a = (float *)aligned_alloc(64, sizeof(float) * floats_per_thread), *b = (float *)aligned_alloc(64, sizeof(float) * floats_per_thread),
+              *cc = (float *)aligned_alloc(64, sizeof(float) * floats_per_thread);
+        for (size_t i = 0; i < floats_per_thread; i++) { a[i] = 0.f; b[i] = 1.f; cc[i] = 2.f; }
+        for (int r = 0; r < reps; r++) {
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+#endif
+            { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); t0 = (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+#ifdef _OPENMP
+#pragma omp barrier
+#endif
+            const float sc = 3.0f + (float)r;
+            for (size_t i = 0; i < floats_per_thread; i++) a[i] = b[i] + sc * cc[i];
+            __asm__ volatile("" :: "r"(a) : "memory");
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+#endif
+            {
+                struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); t1 = (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+                const double g = 12.0 * (double)floats_per_thread * (double)T / (t1 - t0) / 1e9;
+                if (g > best) best = g;
+            }
+        }
+        free(a); free(b); free(cc);
+        if (pinned) sched_setaffinity(0, sizeof old, &old);
+    }
+    return best;
 }
 
 /* ======================================================================== BCH */

@@ -19,6 +19,7 @@
 #ifndef DVBS2_ORACLE_H
 #define DVBS2_ORACLE_H
 #include <stdint.h>
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -147,6 +148,12 @@ double orc_ldpc_decode_batch(const orc_ldpc *c, const float *llr, int F, int sch
 int orc_ldpc_inter_width(void);
 double orc_ldpc_decode_batch_inter(const orc_ldpc *c, const float *llr, int F, int n_ite, float alpha,
                                    int32_t *bits, int threads);
+/* the CPU baseline's form (bench.py): threads pinned to the caller's CPU list, work buffers and a private copy of each thread's share of the LLRs first-touched by the
+ * thread itself, static deal of the blocks; flavour 0 = scalar (natural order), 1 = inter-frame SIMD; returns the seconds between the barriers around the decode */
+double orc_ldpc_decode_batch_pinned(const orc_ldpc *c, const float *llr, int F, int flavour, int n_ite, float alpha, int32_t *bits, int threads,
+                                    const int *cpus, int n_cpus, double *per_thread_max, double *per_thread_min);
+/* STREAM triad on pinned threads over first-touched arrays: sustainable DRAM GB/s of the host (3 x 4 bytes per element) */
+double orc_stream_triad_GBps(int threads, size_t floats_per_thread, int reps, const int *cpus, int n_cpus);
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,10 @@ def _bind(path):
         L.orc_ldpc_decode_batch_inter.restype = C.c_double
         L.orc_ldpc_decode_batch_inter.argtypes = [vp, vp, ci, ci, cf, vp, ci]
         L.orc_ldpc_inter_width.restype = ci
+        L.orc_ldpc_decode_batch_pinned.restype = C.c_double
+        L.orc_ldpc_decode_batch_pinned.argtypes = [vp, vp, ci, ci, ci, cf, vp, ci, vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_stream_triad_GBps.restype = C.c_double
+        L.orc_stream_triad_GBps.argtypes = [ci, C.c_size_t, ci, vp, ci]
         _libs[path] = L
     return _libs[path]
 
@@ -96,6 +100,20 @@ class NativeLdpc:
         llr = _f32(llr).reshape(-1, self.N)
         bits = np.empty((llr.shape[0], self.K), dtype=np.int32)
         return bits, self.L.orc_ldpc_decode_batch_inter(self.h, _p(llr), llr.shape[0], n_ite, alpha, _p(bits), threads)
+
+    def decode_batch_pinned(self, llr, flavour, n_ite=10, alpha=1.0, threads=1, cpus=None, want_bits=False):
+        """bench.py's CPU baseline: pinned threads, first-touched private buffers, static deal -> (seconds, slowest thread's seconds, fastest thread's seconds[, bits])"""
+        llr = _f32(llr).reshape(-1, self.N)
+        bits = np.empty((llr.shape[0], self.K), dtype=np.int32) if want_bits else None
+        cp = _i32(cpus) if cpus is not None and len(cpus) else None
+        hi, lo = C.c_double(), C.c_double()
+        sec = self.L.orc_ldpc_decode_batch_pinned(self.h, _p(llr), llr.shape[0], int(flavour), n_ite, alpha, _p(bits) if want_bits else None, threads,
+                                                  _p(cp) if cp is not None else None, len(cp) if cp is not None else 0, C.byref(hi), C.byref(lo))
+        return (sec, hi.value, lo.value, bits) if want_bits else (sec, hi.value, lo.value)
+
+    def stream_triad_GBps(self, threads, floats_per_thread=1 << 24, reps=3, cpus=None):
+        cp = _i32(cpus) if cpus is not None and len(cpus) else None
+        return self.L.orc_stream_triad_GBps(threads, floats_per_thread, reps, _p(cp) if cp is not None else None, len(cp) if cp is not None else 0)
 
 
 def lib():

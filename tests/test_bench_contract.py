@@ -26,6 +26,19 @@ def test_committed_pmc_traffic_belongs_to_the_kernel_in_the_tree():
     assert bench._pmc_traffic(d["kernel"], bench.FRAMES_PER_GPU + 1, bench.N_ITE)[0] is None          # another workload: no figure
 
 
+def test_committed_ablation_run_belongs_to_the_kernel_in_the_tree():
+    """profiles/ldpc_ablation.json (tools/build_ablations.sh, tools/run_ablations.sh, tools/summarize_ablations.py) carries the hash of the kernel + plan sources it was
+    measured on; bench.py's `roofline.bound` / `chain_floor_ms` come from it only while it matches, so an edit of the kernel without a new ablation run fails here."""
+    sys.path.insert(0, ROOT)
+    import bench
+    d = json.load(open(os.path.join(ROOT, "profiles", "ldpc_ablation.json")))
+    assert d["kernel_sha"] == bench.kernel_sha(), "re-run tools/run_ablations.sh: the LDPC kernel / plan changed since profiles/ldpc_ablation.json was measured"
+    assert d["frames"] == bench.FRAMES_PER_GPU and d["n_ite"] == bench.N_ITE and set(d["ablations"]) >= {"3", "12", "15"}
+    assert 0.4 * d["production_ms"] < d["chain_floor_ms"] < d["production_ms"]
+    a = bench._ablation(bench.FRAMES_PER_GPU, bench.N_ITE)
+    assert a["chain_floor_ms"] == d["chain_floor_ms"] and bench._ablation(bench.FRAMES_PER_GPU + 1, bench.N_ITE) is None
+
+
 def test_committed_kernel_counters_belong_to_the_kernels_in_the_tree():
     """profiles/<round>_kernels_pmc.md (rocprofv3 counters of every non-LDPC kernel, tools/profile_kernels.sh + tools/summarize_kernels_pmc.py) is
     stamped with the hash of the kernel sources it was measured on (profiles/kernels_pmc_stamp.json): editing k_front / k_bch / k_sync* / k_fir* /
@@ -55,18 +68,29 @@ def test_bench_line_on_the_gpu():
     ro = d["roofline"]
     assert ro["avg_launch_ms"] <= d["ms_per_step"] * 1.02
     assert 0.0 < ro["hbm_true"]["frac"] < 0.1
-    assert ro["binding_resource"] in ("fabric", "vector issue") and ro["bound"] == ro["binding_resource"]
+    assert ro["binding_resource"] in ("fabric", "vector issue", "dependent chain (latency)") and ro["bound"] == ro["binding_resource"]
     assert abs(ro["algorithmic_frac"] - ro["algorithmic_GBps"] / 8000.0) < 1e-9            # SURVEY 8(d)'s effective figure, kept beside the bounded one
     assert d["per_rank"]["fec_frames_per_s"] and d["per_rank"]["min"] <= d["fec_frames_per_s"] * 1.001 <= d["per_rank"]["max"] * 1.002
     assert d["self_check"]["steps"] == 20 and 0.5 * d["ms_per_step"] < d["self_check"]["ms_per_step"] < 1.5 * d["ms_per_step"]
     if ro["traffic"] is not None:                                          # the committed PMC file matches the running kernel
-        b = ro["bounded"]
-        assert 0.0 < ro["frac"] <= 1.0 and ro["frac"] == ro["bounded_frac"] and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9      # a fraction of a real ceiling
-        assert ro["bounded_frac"] == max(b["frac"], b["valu"]["frac"]) and (ro["binding_resource"] == "fabric") == (b["frac"] >= b["valu"]["frac"])
-        assert 0.0 < b["frac"] <= 1.0 and abs(b["achieved"] - ro["traffic"] / (ro["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * b["achieved"]
-        assert 0.0 < b["valu"]["frac"] <= 1.0
+        b, rs = ro["bounded"], ro["resources"]
+        assert 0.0 < ro["frac"] <= 1.0 and ro["frac"] == ro["bounded_frac"]
+        # the two measured resource fractions stay in the line whatever `bound` says
+        assert 0.0 < rs["fabric"]["frac"] <= 1.0 and abs(rs["fabric"]["achieved_GBps"] - ro["traffic"] / (ro["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * rs["fabric"]["achieved_GBps"]
+        assert 0.0 < rs["vector_issue"]["frac"] <= 1.0 and "upper" in rs["vector_issue"]["estimate"]
+        assert rs["closest_frac"] == max(rs["fabric"]["frac"], rs["vector_issue"]["frac"]) and b["frac"] == rs["fabric"]["frac"]
+        if ro["bound"] == "dependent chain (latency)":
+            # neither resource binds while removing its work gives back less than half of what is removed (committed, sha-stamped ablation run);
+            # frac = the measured time of the chain alone over this run's launch
+            a = ro["ablation"]
+            assert a is not None and max(a["elasticity"]["vector_issue"], a["elasticity"]["global_slot_traffic"]) < 0.5
+            assert ro["chain_floor_ms"] == a["chain_floor_ms"] == ro["peak"] and abs(ro["achieved"] - ro["avg_launch_ms"]) < 1e-9
+            assert abs(ro["frac"] - min(1.0, ro["chain_floor_ms"] / ro["avg_launch_ms"])) < 1e-9 and 0.4 < ro["frac"] <= 1.0
+        else:
+            assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and ro["frac"] == rs["closest_frac"]
     else:
-        assert ro["bounded"] is None and ro["bounded_frac"] is None and ro["frac"] is None
+        assert ro["bounded"] is None and ro["resources"]["fabric"]["frac"] is None
+    assert ro["hbm_copy_GBps_measured"] > 3000.0 and "dvbs2hip_device_copy_bandwidth" in ro["hbm_copy_kernel"]      # the library's own copy kernel, not a torch copy_
     # the fabric bytes are re-measured in the run itself (rocprofv3 --pmc child runs of bench.py) and agree with the committed, sha-stamped passes
     # (a profiler that cannot run on this box is reported in the line, not a failure: the committed figures then stand alone, as asserted above)
     lp = ro["live_pmc"]

@@ -299,6 +299,37 @@ def test_ldpc_headline_config_at_size_matches_oracle(O, Rx, n_ite, F, ebn0s):
     assert (CWD[0::2] if len(ebn0s) == 2 else CWD).mean() < 0.5      # 3.0 dB: most frames fail, which is the point
 
 
+def test_ldpc_baseline_batch_of_exactly_4096_frames_matches_oracle(O, Rx):
+    """BASELINE configs[1] AT ITS STATED SIZE: 4096 QPSK-N 8/9 frames in ONE call, 10 fixed iterations -- the batch bench.py times -- at 3.0 dB (nothing
+    converges) and 4.2 dB interleaved: 16 random frames + the last 8 against the oracle by posterior BIT PATTERN, hard decisions and CWD; then the same batch in the
+    reference's own sweep order (SCHED_NATURAL, AFF3CT's BP_HORIZONTAL_LAYERED over the rows of H as built, DVBS2.cpp:428), 8 frames against the oracle's natural schedule.
+    Size-independent over the whole batch: a detected codeword is the sent word, the 4.2 dB half decodes, the 3.0 dB half does not."""
+    modcod, F = "QPSK-N_8/9", 4096
+    ch, sent, llr = _big_batch(O, modcod, F, (3.0, 4.2), seed=4096, n_cw=8)
+    rng = np.random.default_rng(40)
+    pick = np.unique(np.concatenate([np.arange(F - 8, F), rng.choice(F - 8, 16, replace=False)]))
+    rx = Rx(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=False)
+    assert rx.ldpc_kernel_name() == "ldpc_wg8_kernel<27,%d>" % DEFAULT_NMS_MODE
+    V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+    Vo, posto, cwdo, iteso = ch.ldpc.decode(llr[pick], n_ite=10, alpha=1.0, sched=O.QC, early_stop=False)
+    assert np.array_equal(post[pick].view(np.uint32), posto.view(np.uint32)), "posterior bit patterns (QC-layer order)"
+    assert np.array_equal(V[pick], Vo) and np.array_equal(CWD[pick], cwdo) and (ites == 10).all()
+    okf = CWD == 1
+    assert np.array_equal(V[okf], sent[okf]) and okf[1::2].mean() > 0.99 and okf[0::2].mean() < 0.05
+    Vb, CWDb = rx.decode_siho(llr)                      # the bits socket alone (the bench line's step): same decisions
+    assert np.array_equal(Vb, V) and np.array_equal(CWDb, CWD)
+    from dvbs2_amd import lib_binding as B
+    rx.set_ldpc_schedule(B.SCHED_NATURAL)
+    pick_n = pick[-8:]
+    Vn, CWDn, postn, _ = rx.decode_siho(llr, with_post=True)
+    Vno, postno, cwdno, _ = ch.ldpc.decode(llr[pick_n], n_ite=10, alpha=1.0, sched=O.NATURAL, early_stop=False)
+    assert np.array_equal(postn[pick_n].view(np.uint32), postno.view(np.uint32)), "posterior bit patterns (natural row order)"
+    assert np.array_equal(Vn[pick_n], Vno) and np.array_equal(CWDn[pick_n], cwdno)
+    okn = CWDn == 1
+    assert np.array_equal(Vn[okn], sent[okn]) and okn[1::2].mean() > 0.99
+    rx.close()
+
+
 @pytest.mark.parametrize("implem", ["NMS", "SPA"])
 @pytest.mark.parametrize("mode,kernel_mode", [("", None), ("cu1", 6), ("park", 5), ("park4", 4), ("static", 3), ("global", 1)])
 def test_ldpc_normal_frame_image_modes_agree_with_the_oracle(O, Rx, monkeypatch, mode, kernel_mode, implem):
