@@ -708,6 +708,9 @@ def cpu_baseline(mc, llr, target_s):
             "one_thread_frames_per_s": one, "inter_over_scalar_per_core": one["inter"] / one["scalar"],
             "threads_curve_frames_per_s": {k: {str(t): r for t, r in v.items()} for k, v in curve.items()},
             "parallel_efficiency": rate / (cores * one[best]),
+            "effective_cores": min(float(cores), quota) if quota else float(cores),
+            "parallel_efficiency_vs_effective_cores": rate / ((min(float(cores), quota) if quota else float(cores)) * one[best]),
+            "parallel_efficiency_note": "rate / (cores x one pinned thread's rate); `effective_cores` = min(threads, cgroup CPU quota): a job that sees 256 CPUs in its affinity mask may own the time of 16",
             "slowest_over_fastest_thread": t_hi / t_lo if t_lo > 0 else None,
             "stream_triad_GBps": triad, "stream_triad": "a[i] = b[i] + s c[i], 64 MiB per array and thread, the same %d pinned threads, first-touched arrays (oracle/dvbs2_oracle.c, orc_stream_triad_GBps)" % cores,
             "dram_traffic_estimate_GBps": rate * 8.0 * E * N_ITE / 1e9 if best == "inter" else None,

@@ -151,6 +151,9 @@ __host__ __device__ __forceinline__ constexpr int ldpc_cu1_nrg() { return 36; }
 #ifndef LDPC_CU1_DEFAULT
 #define LDPC_CU1_DEFAULT 0
 #endif
+#ifndef LDPC_CU1_SPA_DEFAULT      // the sum-product decoder on normal frames: mode 6 (one frame per CU, two lanes per check, messages inside the Infinity Cache) as the default
+#define LDPC_CU1_SPA_DEFAULT 1
+#endif
 constexpr int LDPC_W8_MISC_BYTES = 96;  // k_ldpc_wg8.hip: words behind the image -- [0..7] SIMD of wave w, [8] first / second workgroup of the CU, [9] next frame, [10..12] vote words, [16..21] BCH remainder of the frame
 constexpr int LDPC_SYN_RED = 640;       // entries x^k mod g(x), k = 0 .. 639, of the BCH verification's reduction table (k <= 64 * 5 + 32 * 8 + 63)
 constexpr int LDPC_SPA_MAXC = 6;       // SPA: duplicate edges per layer whose old messages a lane keeps in registers (the DVB-S2 codes have at most 6)

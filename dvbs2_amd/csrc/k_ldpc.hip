@@ -362,7 +362,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             // pair like information groups (the 160 information rows of the N = 64800 8/9 code have a maximum matching of 71 pairs, 72 are needed): a parity row
             // that starts an iteration in a register slot is loaded by its row-keeping wave (a stride-q gather), the others by the working waves' scatter.
             const bool env_cu1 = env_mode && !strcmp(env_mode, "cu1");
-            if ((env_cu1 || (!env_mode && LDPC_CU1_DEFAULT)) && pl.fast_mode == 1 && pl.fast_deg == 27 && !pl.fast_pad && !spa) {
+            if ((env_cu1 || (!env_mode && LDPC_CU1_DEFAULT && !spa) || (!env_mode && spa && LDPC_CU1_SPA_DEFAULT)) && pl.fast_mode == 1 && pl.fast_deg == 27 && !pl.fast_pad) {
                 const int n_pos = ((int)lds_limit - LDPC_CU1_XCHG_BYTES - 128) / (int)grp_bytes - 1;      // [positions | junk row | exchange area | misc]
                 std::vector<std::vector<int>> mult(pl.n_groups, std::vector<int>(q, 0));
                 for (int r = 0; r < q; r++) for (const Slot &sl : layers[r]) mult[sl.group][r]++;
@@ -633,6 +633,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                     pl.cu1_pairs = park.n_pairs;
                 }
                 if (spa) pl.w8_gwork_words = (2 + pl.w8_ng) * LDPC_Z + pl.fast_deg * M;      // SPA: one fp32 message per edge slot, [layer][slot][360]
+                if (spa && cu1) pl.w8_gwork_words = pl.fast_deg * M;                          // mode 6: the messages alone, [layer][half][group of 4 slots][360][4]
                 {   // DVBS2HIP_LDPC_SLOT_ALIGN / _PAD (bytes): where a workgroup's slot starts -- measured without effect (docs/negative_results.md), kept for experiments
                     const char *ea = getenv("DVBS2HIP_LDPC_SLOT_ALIGN"), *ep = getenv("DVBS2HIP_LDPC_SLOT_PAD");
                     const size_t al = ea ? (size_t)atoi(ea) / 4 : 1, pad = ep ? (size_t)atoi(ep) / 4 : 0;

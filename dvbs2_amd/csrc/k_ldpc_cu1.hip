@@ -31,10 +31,23 @@ typedef const __attribute__((address_space(4))) uint32_t *const_u32;
 constexpr int C1_ROW = LDPC_Z * 4;           // bytes per bit-group row
 constexpr int C1_IO = 16;                    // independent loads per lane in flight during frame I/O
 constexpr int C1_HA = LDPC_CU1_HA;           // slots of half A
+#ifndef LDPC_CU1_HA_SPA_V
+#define LDPC_CU1_HA_SPA_V 13
+#endif
+constexpr int C1_HA_SPA = LDPC_CU1_HA_SPA_V;    // ... in the sum-product kernel (half A also keeps the duplicate edges' deltas: 13 + 14 balances the registers)
 constexpr int C1_WAVES = 16, C1_THREADS = C1_WAVES * 64;
 
 // development knobs (tools/build_variant_tus.sh): the row-keeping waves swap with ds_wrxchg_rtn (0) or with a read and a write per word (1); they swap right behind the
 // end-of-layer barrier (0) or behind the layer's first barrier (1), when the working waves' loads are out of the way
+#ifndef C1_SPA_BS        // sum-product layer: suffix values kept for every C1_SPA_BS-th slot
+#define C1_SPA_BS 2
+#endif
+#ifndef C1_SPA_KEEPW     // sum-product layer: a slot's LDS address is kept from its load to its store (1) or formed twice (0)
+#define C1_SPA_KEEPW 1
+#endif
+#ifndef C1_SPA_FENCE
+#define C1_SPA_FENCE 2
+#endif
 #ifndef C1_KEEP_RW
 #define C1_KEEP_RW 0
 #endif
@@ -67,7 +80,7 @@ __device__ __forceinline__ float c1_unpack(float c1, float c2, uint32_t pk, uint
 // ---- the row-keeping waves: group `grp` (two waves, 120 of their 128 lanes hold elements e, e + 120, e + 240 of NRG rows) follows the working waves barrier for
 // barrier and swaps rows with LDS positions by the plan's table (w8_park_server of k_ldpc_wg8.hip, for a workgroup with two such groups and the barrier
 // sequence of this kernel's layer: one barrier always, then the duplicate-edge barriers, then the end barrier)
-template <int NRG>
+template <int NRG, bool SPA>
 __device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const s_misc, const int grp, const int sidx, const int lane, const bool vote_writer
 #ifdef LDPC_PHASE_PROF
                                            , uint32_t *prof, unsigned long long &pt_
@@ -123,6 +136,7 @@ __device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const 
         const uint32_t cinfo = T[28];
         const int ncf = (int)(cinfo & 0xFFu);
         bar_nowait();                               // the halves' partial minima are in the exchange area; every read of the layer precedes its writes
+        if (SPA) bar_nowait();                      // sum-product layer: the halves' products are in the exchange area
 #if C1_KEEP_LATE
         moves(r);
 #endif
@@ -192,14 +206,14 @@ __device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const 
 }
 
 // ---- one half-check's lanes.  HALF 0: slots 0 .. 13 (duplicate edges among the first ones, replayed by these lanes); HALF 1: slots 14 .. 26 (25 = p_c, 26 = p_{c-1})
-template <int DEG, int HALF>
+template <int DEG, int HALF, bool SPA, int HA>
 __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_misc, const int cb, const int lane, const int wave, const bool vote_writer, const bool first_wave
 #ifdef LDPC_PHASE_PROF
                                          , uint32_t *prof, unsigned long long &pt_
 #endif
                                          )
 {
-    constexpr int NS = HALF == 0 ? C1_HA : DEG - C1_HA, J0 = HALF == 0 ? 0 : C1_HA;      // local slot i is the layer's slot J0 + i
+    constexpr int NS = HALF == 0 ? HA : DEG - HA, J0 = HALF == 0 ? 0 : HA;      // local slot i is the layer's slot J0 + i
     constexpr bool FWD = HALF == 1;                  // parity chain forwarded in a register: p_c at local slot NS-2, p_{c-1} at NS-1
     const int t = cb * 64 + lane;
     const bool act = t < LDPC_Z;
@@ -214,9 +228,9 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
     const uint32_t xmine = xch + (uint32_t)HALF * (LDPC_Z * 8u) + (uint32_t)t * 8u, xother = xch + (uint32_t)(1 - HALF) * (LDPC_Z * 8u) + (uint32_t)t * 8u;
     uint32_t SB = 0x80000000u;
     asm volatile("" : "+s"(SB));
-    auto wide_off = [&](uint32_t voff, uint32_t soff) -> uint32_t { uint32_t o = voff + soff; asm volatile("" : "+v"(o)); return o; };      // (see k_ldpc_wg8.hip: stores of more than 8 bytes)
-    auto lld = [&](uint32_t a) -> float { return *c1_lds(a); };
-    auto lst = [&](uint32_t a, float v) { *c1_lds(a) = v; };
+    auto wide_off = [&](uint32_t voff, uint32_t soff) __attribute__((always_inline)) -> uint32_t { uint32_t o = voff + soff; asm volatile("" : "+v"(o)); return o; };      // (see k_ldpc_wg8.hip: stores of more than 8 bytes)
+    auto lld = [&](uint32_t a) __attribute__((always_inline)) -> float { return *c1_lds(a); };
+    auto lst = [&](uint32_t a, float v) __attribute__((always_inline)) { *c1_lds(a) = v; };
     const int nl_info = p.w8.nl_info, nl = p.w8.nl;
     int nvote = 0;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -269,18 +283,196 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
         bool ok = false;
         float nx1 = 0.f, nx2 = 0.f, nxk = 0.f;           // packed state of the next layer (prefetched): c1, c2, this half's signs | position
         float pfw = 0.f;                                 // HALF 1: posterior of parity bit q t + r after layer r, on its way to layer r + 1
+        float onx[SPA ? NS : 1];                         // SPA: old messages of the NEXT layer, requested while this layer's stores drain
+#pragma unroll
+        for (int j = 0; j < (SPA ? NS : 1); j++) onx[j] = 0.f;
         uint32_t TE[32];                                 // layer table of the NEXT layer, fetched under the end-of-layer barrier
 #pragma unroll
-        for (int j = 0; j < 32; j++) TE[j] = tab[j];
+        for (int j = 0; j < 32; j++) TE[j] = SPA ? 0u : tab[j];
+        // sum-product kernel: the next layer's table travels in ONE vector register (lane j holds entry j, read back with v_readlane where an entry is needed): carried as 32
+        // scalars across the layer's barriers it does not fit the scalar file beside this layer's, and the compiler parks it in 32 VECTOR registers (and spills others)
+        uint32_t tev = SPA ? p.w8.tab[lane & 31] : 0u;
         while (it < p.n_ite) {
             for (int r = 0; r < q; r++) {
                 const const_u32 T = tab + r * LDPC_FAST_STRIDE;
                 uint32_t E[NS];
 #pragma unroll
-                for (int j = 0; j < NS; j++) E[j] = TE[J0 + j];
-                const uint32_t prim = TE[27] >> J0, cinfo = TE[28], ce0 = TE[29], ce1 = TE[30];
+                for (int j = 0; j < NS; j++) E[j] = SPA ? (uint32_t)__builtin_amdgcn_readlane((int)tev, J0 + j) : TE[J0 + j];
+                const uint32_t prim = (SPA ? (uint32_t)__builtin_amdgcn_readlane((int)tev, 27) : TE[27]) >> J0, cinfo = SPA ? (uint32_t)__builtin_amdgcn_readlane((int)tev, 28) : TE[28],
+                               ce0 = SPA ? (uint32_t)__builtin_amdgcn_readlane((int)tev, 29) : TE[29], ce1 = SPA ? (uint32_t)__builtin_amdgcn_readlane((int)tev, 30) : TE[30];
                 const int ncf = (int)(cinfo & 0xFFu);
                 const bool mask0 = HALF == 1 && (r == 0) && (t == 0);        // p_{c-1} of check 0 does not exist
+                if constexpr (SPA) {
+                    // ================= sum-product layer, two lanes per check (round 5) =================
+                    // The check node in the complement-product domain (k_ldpc_wg8.hip, SPA layer: |out_j| = ln((2 - Q_j) / Q_j), Q_j = 1 - prod_{i != j} (1 - u_i),
+                    // u_i = 2 / (e^a_i + 1), carried as Q' = 2^s2 Q with s2 from the check's SECOND smallest magnitude) splits cleanly over the two halves of a check:
+                    // Q_ab = Q_a + Q_b (1 - kap Q_a) is associative and commutative, so a half forms the prefix / suffix values of its own 13 / 14 slots and its own
+                    // total, and an edge's Q_j is comb(comb(prefix_j, suffix_j), the OTHER half's total).  Two exchanges through the 8 bytes per half-check of the
+                    // min-sum form: {min1 | parity of the signs, min2} behind the loads (the scale s2 and the overflow rule need the two smallest magnitudes of the
+                    // WHOLE check; this barrier is also "every read of the layer precedes its writes"), then the half's total -- written into the OTHER half's
+                    // slot, whose content this lane has just consumed, so the area needs no second copy.  The c->v messages, one fp32 per edge, live in the
+                    // workgroup's global slot as [layer][half][group of 4 slots][360][4]: 778 KB per frame, 199 MB for the 256 workgroups of a launch -- inside
+                    // the 256 MB Infinity Cache, which the 512 x 778 KB of the two-frames-per-CU kernel are not (there the messages are an HBM stream).
+                    constexpr int NG4 = NS / 4, NT = NS % 4;
+                    constexpr uint32_t HB = HALF == 0 ? 0u : (uint32_t)((HA / 4) * (C1_ROW * 4) + (HA % 4) * C1_ROW), LB = (uint32_t)(DEG * C1_ROW);
+                    typedef uint32_t m_u32x4 __attribute__((ext_vector_type(4)));
+                    typedef uint32_t m_u32x2 __attribute__((ext_vector_type(2)));
+                    typedef uint32_t m_u32x3 __attribute__((ext_vector_type(3)));
+                    auto msg_ld = [&](float *dst, uint32_t lbase) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int g = 0; g < NG4; g++) {
+                            const m_u32x4 q4 = __builtin_amdgcn_raw_buffer_load_b128(rs, t4 * 4u, lbase + HB + (uint32_t)g * (C1_ROW * 4u), 0);
+                            dst[4 * g] = __uint_as_float(q4.x); dst[4 * g + 1] = __uint_as_float(q4.y); dst[4 * g + 2] = __uint_as_float(q4.z); dst[4 * g + 3] = __uint_as_float(q4.w);
+                        }
+                        const uint32_t tb = lbase + HB + (uint32_t)NG4 * (C1_ROW * 4u);
+                        if (NT == 3) { const m_u32x3 q3 = __builtin_amdgcn_raw_buffer_load_b96(rs, t4 * 3u, tb, 0); dst[4 * NG4] = __uint_as_float(q3.x); dst[4 * NG4 + 1] = __uint_as_float(q3.y); dst[(NT == 3 ? 4 * NG4 + 2 : 0)] = __uint_as_float(q3.z); }
+                        if (NT == 2) { const m_u32x2 q2 = __builtin_amdgcn_raw_buffer_load_b64(rs, t4 * 2u, tb, 0); dst[4 * NG4] = __uint_as_float(q2.x); dst[(NT >= 2 ? 4 * NG4 + 1 : 0)] = __uint_as_float(q2.y); }
+                        if (NT == 1) dst[4 * NG4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t4, tb, 0));
+                    };
+                    uint32_t MAGM = 0x7FFFFFFFu;
+                    asm volatile("" : "+s"(MAGM));
+                    // registers: the suffix values are kept for every second slot and rebuilt from there on the way forward; the circulant offsets are formed twice (loads,
+                    // stores) through an opaque copy of the lane's offset so that the compiler does not hold them across the arithmetic (as in k_ldpc_wg8.hip's SPA layer)
+                    constexpr int BS = C1_SPA_BS, NB = (NS + BS - 1) / BS;
+                    float x[NS], u[NS], Bs[NB], od[LDPC_SPA_MAXC];
+                    uint32_t t4s = t4;
+                    uint32_t wk[C1_SPA_KEEPW ? NS : 1];
+                    auto woff = [&](int j, uint32_t tt) __attribute__((always_inline)) { const uint32_t d = tt - (E[j] & 0x7FFu); return min(d, d + (uint32_t)C1_ROW) + ((E[j] >> 11) & 0x3FFFFu); };
+                    float mn1 = INFINITY, mn2 = INFINITY, kap = 1.f, cln = 0.f, key = 0.f, Qown = 0.f;
+                    uint32_t sx = 0u;
+                    auto comb = [&](float a, float b) __attribute__((always_inline)) { return __builtin_fmaf(b, __builtin_fmaf(-kap, a, 1.f), a); };      // Q'_ab
+#pragma unroll
+                    for (int i = 0; i < LDPC_SPA_MAXC; i++) od[i] = 0.f;
+                    if (act) {
+#pragma unroll
+                        for (int j = 0; j < NS; j++) {
+#if C1_SPA_KEEPW
+                            wk[j] = woff(j, t4);
+                            if (FWD && j == NS - 1 && r > 0) x[j] = pfw; else x[j] = lld(wk[j]);
+#else
+                            if (FWD && j == NS - 1 && r > 0) x[j] = pfw;         // p_{c-1}: handed over by layer r - 1
+                            else x[j] = lld(woff(j, t4));
+#endif
+                        }
+                        if (HALF == 0) {
+#pragma unroll
+                            for (int j = 0; j < LDPC_SPA_MAXC; j++) od[j] = onx[j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < NS; j++) x[j] = x[j] - onx[j];      // zeros in the first iteration
+                        if (HALF == 1 && mask0) x[NS - 1] = INFINITY;
+#pragma unroll
+                        for (int j = 0; j < NS; j++) {
+                            const float a = fabsf(x[j]);
+                            mn2 = __builtin_amdgcn_fmed3f(mn1, mn2, a);
+                            mn1 = fminf(mn1, a);
+                            sx ^= __float_as_uint(x[j]);
+                        }
+                        f32x2 mine;
+                        mine.x = __uint_as_float(__float_as_uint(mn1) | (sx & 0x80000000u)); mine.y = mn2;      // (+inf | sign bit: the magnitude bits stay those of +inf)
+                        *(lds_f32x2 *)(size_t)xmine = mine;
+                    }
+                    C1_MARK(1);
+                    __syncthreads();         // the halves' minima are in place; every read of the layer precedes its writes
+                    C1_MARK(2);
+                    uint32_t SXT = 0u;
+                    if (act) {
+                        const f32x2 oth = *(lds_f32x2 *)(size_t)xother;
+                        const float o1 = fabsf(oth.x), o2 = oth.y;
+                        SXT = (sx ^ __float_as_uint(oth.x)) & 0x80000000u;      // the parity of ALL the check's signs, in bit 31
+                        const float hi = fmaxf(mn1, o1);
+                        mn1 = fminf(mn1, o1);
+                        mn2 = fminf(fminf(mn2, o2), hi);
+                        const float s2 = fmaxf(0.f, (mn2 - 16.f) * 1.44269504088896341f);
+                        kap = __builtin_amdgcn_exp2f(-s2);
+                        cln = s2 * 0.693147180559945309f;
+                        const float s2p1 = s2 + 1.f, hk = 0.5f * kap;
+                        key = (mn2 - mn1 > 60.f) ? mn1 : __builtin_nanf("");
+#pragma unroll
+                        for (int j = 0; j < NS; j++) {
+                            const float ea = __builtin_fmaf(fabsf(x[j]), 1.44269504088896341f, -s2p1);
+                            u[j] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(ea) + hk);
+                        }
+                        float b = 0.f;      // B_j = Q' of this half's slots behind j; Bs[k] = B_{BS k + BS - 1} (clipped to the last slot)
+#pragma unroll
+                        for (int j = NS - 1; j >= 0; j--) { if (j % BS == BS - 1 || j == NS - 1) Bs[j / BS] = b; b = comb(b, u[j]); }
+                        Qown = b;
+                        *c1_lds(xother) = Qown;      // into the other half's slot (its content has been consumed above); that half reads its own slot behind the barrier
+                    }
+                    __syncthreads();         // the halves' totals are in place
+                    if (act) {
+                        // the prefix recursion STARTS from the other half's total: A_j then holds "the other half and this half's slots before j", and Q_j = comb(A_j, B_j)
+                        // needs no third operand (two fused multiply-adds per slot less than comb(comb(A_j, B_j), Q_other))
+                        float A = *c1_lds(xmine);
+                        const bool anykey = __ballot(key == key) != 0ull;      // some check of this wave is in the overflow case (min2 - min1 > 60): rare, and wave-uniform
+                        float mq[4] = {0.f, 0.f, 0.f, 0.f};
+                        const uint32_t mrow = (uint32_t)r * LB;
+                        asm volatile("" : "+v"(t4s));
+#pragma unroll
+                        for (int j = 0; j < NS; j++) {
+                            // (a scheduling fence every C1_SPA_FENCE slots: left alone the scheduler interleaves all 13 / 14 slots' reciprocal / logarithm chains and needs
+                            // ~30 registers more than the kernel has)
+                            if (C1_SPA_FENCE > 0 && j > 0 && j % C1_SPA_FENCE == 0) __builtin_amdgcn_sched_barrier(0);
+                            const float wA = __builtin_fmaf(-kap, A, 1.f);
+                            float Bj;
+                            {
+                                const int js = (j / BS) * BS + BS - 1 < NS - 1 ? (j / BS) * BS + BS - 1 : NS - 1;      // the kept slot at or behind j
+                                Bj = Bs[j / BS];
+#pragma unroll
+                                for (int i = js; i > j; i--) Bj = comb(Bj, u[i]);
+                            }
+                            const float Q = __builtin_fmaf(Bj, wA, A);                    // every slot of the check but j
+                            const float lg = __builtin_amdgcn_logf(__builtin_fmaf(2.f, __builtin_amdgcn_rcpf(Q), -kap));
+                            float o = __builtin_fmaf(lg, 0.693147180559945309f, cln);
+                            if (anykey) { asm volatile("" ::: "memory"); o = __builtin_islessgreater(fabsf(x[j]), key) ? mn1 : o; }      // (the empty asm keeps the compiler from turning the wave-uniform branch back into two selects per slot)      // (ordered "not equal": false against the NaN that stands for "no overflow")
+                            float nw;
+                            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(nw) : "s"(MAGM), "v"(o), "v"(SXT ^ __float_as_uint(x[j])));
+                            A = __builtin_fmaf(u[j], wA, A);
+                            uint32_t a = C1_SPA_KEEPW ? wk[C1_SPA_KEEPW ? j : 0] : woff(j, t4s);
+                            if (HALF == 1 && j == NS - 1 && mask0) a = ljunk + t4s;
+                            if (FWD && j == NS - 2 && r + 1 < q) pfw = x[j] + nw;                    // p_c: kept for layer r + 1
+                            else if (HALF == 0 && j < ldpc_w8_kd(DEG)) { if (((prim >> j) & 1u) != 0u) lst(a, x[j] + nw); }      // a duplicate edge's plain store is left out
+                            else lst(a, x[j] + nw);
+                            mq[j & 3] = nw;
+                            if ((j & 3) == 3)
+                                __builtin_amdgcn_raw_buffer_store_b128(m_u32x4{__float_as_uint(mq[0]), __float_as_uint(mq[1]), __float_as_uint(mq[2]), __float_as_uint(mq[3])}, rs,
+                                                                       wide_off(t4s * 4u, mrow + HB + (uint32_t)(j >> 2) * (C1_ROW * 4u)), 0u, 0);
+                            else if (j == NS - 1) {
+                                const uint32_t tb = mrow + HB + (uint32_t)NG4 * (C1_ROW * 4u);
+                                if (NT == 3) __builtin_amdgcn_raw_buffer_store_b96(m_u32x3{__float_as_uint(mq[0]), __float_as_uint(mq[1]), __float_as_uint(mq[2])}, rs, wide_off(t4s * 3u, tb), 0u, 0);
+                                if (NT == 2) __builtin_amdgcn_raw_buffer_store_b64(m_u32x2{__float_as_uint(mq[0]), __float_as_uint(mq[1])}, rs, t4s * 2u, tb, 0);
+                                if (NT == 1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mq[0]), rs, t4s, tb, 0);
+                            }
+                            if (HALF == 0 && j < LDPC_SPA_MAXC) od[j] = nw - od[j];
+                        }
+                        // the next layer's messages: requested now, they travel while this layer's stores drain at the barriers
+                        __builtin_amdgcn_sched_barrier(0);
+                        if ((it > 0 || r + 1 == q) && !(r + 1 == q && it + 1 >= p.n_ite)) msg_ld(onx, (uint32_t)(r + 1 < q ? r + 1 : 0) * LB);
+                        else {
+#pragma unroll
+                            for (int j = 0; j < NS; j++) onx[j] = 0.f;
+                        }
+                    }
+                    tev = p.w8.tab[(r + 1 < q ? r + 1 : 0) * LDPC_FAST_STRIDE + (lane & 31)];      // the next layer's table (see `tev`)
+                    C1_MARK(3);
+                    // duplicate edges: ordered delta updates, level by level, by half A's lanes (conflict entry i is slot i: what it adds is od[i] = new - old)
+                    if (ncf > 0) {
+                        auto addr_of = [&](uint32_t e) __attribute__((always_inline)) { const uint32_t d = t4 - (e & 0x7FFu); return min(d, d + (uint32_t)C1_ROW) + ((e >> 11) & 0x3FFFFu); };
+                        uint32_t prev_lvl = 0u;
+#pragma unroll
+                        for (int i = 0; i < LDPC_SPA_MAXC; i++) {
+                            if (i >= ncf) break;
+                            const uint32_t e = i == 0 ? ce0 : i == 1 ? ce1 : T[32 + i];
+                            const uint32_t lvl = i == 0 ? 1u : i == 1 ? (cinfo >> 21) & 3u : T[48 + i] >> 8;
+                            if (lvl != prev_lvl) { __syncthreads(); prev_lvl = lvl; }
+                            if (HALF == 0 && act) { const uint32_t a = addr_of(e); const float Lv = lld(a); lst(a, Lv + od[i]); }
+                        }
+                    }
+                    C1_MARK(4);
+                    __syncthreads();
+                    C1_MARK(5);
+                    continue;
+                }
                 float v[NS];
                 uint32_t w[NS];
                 const float c1o = nx1, c2o = nx2;
@@ -523,7 +715,7 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
     }
 }
 
-template <int DEG>
+template <int DEG, bool SPA>
 __global__ void __launch_bounds__(C1_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 ldpc_cu1_kernel(const LdpcKParams p)
 {
@@ -560,27 +752,27 @@ ldpc_cu1_kernel(const LdpcKParams p)
 #endif
     if (role < 0) {
 #ifdef LDPC_PHASE_PROF
-        cu1_keeper<ldpc_cu1_nrg()>(p, s_misc, keeper >> 1, keeper & 1, lane, keeper == 0, prof, pt_);
+        cu1_keeper<ldpc_cu1_nrg(), SPA>(p, s_misc, keeper >> 1, keeper & 1, lane, keeper == 0, prof, pt_);
         if (lane == 0 && p.cu_ctr) {
             prof[10] = 1u; prof[11] = (uint32_t)(__builtin_amdgcn_s_memtime() - prof_t0);
             for (int i = 0; i < 12; i++) p.cu_ctr[LDPC_CU_CTR_WORDS + ((int)blockIdx.x * C1_WAVES + wave) * 12 + i] = prof[i];
         }
 #else
-        cu1_keeper<ldpc_cu1_nrg()>(p, s_misc, keeper >> 1, keeper & 1, lane, keeper == 0);
+        cu1_keeper<ldpc_cu1_nrg(), SPA>(p, s_misc, keeper >> 1, keeper & 1, lane, keeper == 0);
 #endif
         return;
     }
     // (the vote words are zeroed by keeper 0's lane 0; the frame counter and the flags are written by working role 0's lane 0)
 #ifdef LDPC_PHASE_PROF
-    if (role & 1) cu1_work<DEG, 1>(p, s_misc, role >> 1, lane, wave, false, false, prof, pt_);
-    else cu1_work<DEG, 0>(p, s_misc, role >> 1, lane, wave, false, role == 0, prof, pt_);
+    if (role & 1) cu1_work<DEG, 1, SPA, SPA ? C1_HA_SPA : C1_HA>(p, s_misc, role >> 1, lane, wave, false, false, prof, pt_);
+    else cu1_work<DEG, 0, SPA, SPA ? C1_HA_SPA : C1_HA>(p, s_misc, role >> 1, lane, wave, false, role == 0, prof, pt_);
     if (lane == 0 && p.cu_ctr) {
         prof[10] = 0x100u + (uint32_t)role; prof[11] = (uint32_t)(__builtin_amdgcn_s_memtime() - prof_t0);
         for (int i = 0; i < 12; i++) p.cu_ctr[LDPC_CU_CTR_WORDS + ((int)blockIdx.x * C1_WAVES + wave) * 12 + i] = prof[i];
     }
 #else
-    if (role & 1) cu1_work<DEG, 1>(p, s_misc, role >> 1, lane, wave, false, false);
-    else cu1_work<DEG, 0>(p, s_misc, role >> 1, lane, wave, false, role == 0);
+    if (role & 1) cu1_work<DEG, 1, SPA, SPA ? C1_HA_SPA : C1_HA>(p, s_misc, role >> 1, lane, wave, false, false);
+    else cu1_work<DEG, 0, SPA, SPA ? C1_HA_SPA : C1_HA>(p, s_misc, role >> 1, lane, wave, false, role == 0);
 #endif
 }
 
@@ -593,11 +785,11 @@ hipError_t ldpc_cu1_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.gwork_words = pl.w8_gwork_words;
     if (pl.fast_deg != 27 || pl.cu1_pairs != 2 * ldpc_cu1_nrg()) return hipErrorInvalidValue;
-    auto kern = ldpc_cu1_kernel<27>;
-    static size_t configured_dev[64] = {0};
+    auto kern = pl.spa ? ldpc_cu1_kernel<27, true> : ldpc_cu1_kernel<27, false>;
+    static size_t configured_dev[2][64] = {{0}, {0}};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    size_t &configured = configured_dev[dev & 63];
+    size_t &configured = configured_dev[pl.spa ? 1 : 0][dev & 63];
     const size_t lds = (size_t)pl.w8_lds_bytes;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

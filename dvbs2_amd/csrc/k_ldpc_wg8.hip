@@ -105,6 +105,9 @@ __host__ __device__ __forceinline__ constexpr bool w8_slot_lds(int mode, int j) 
 #ifndef W8_FAST_OUT       // output loops of their own for the bits socket alone and for the fused chain (buffer descriptors per frame, scalar descrambling)
 #define W8_FAST_OUT 1
 #endif
+#ifndef W8_SPA_TEV        // sum-product layer: the next layer's table in one vector register (what made k_ldpc_cu1.hip's sum-product kernel 12 % faster: there the compiler had parked
+#define W8_SPA_TEV 0      // the 32 scalars in vector registers).  Here, same-box A/B: QPSK-S 8/9 1712 -> 1655 k, 3/5 1190 -> 1092 k frames/s, normal frames (mode 4) 315 -> 307 k: off
+#endif
 #ifndef W8_IN_FAST        // frame input of the information rows, LDS-only image: branch-free batches through a buffer descriptor (see there)
 #define W8_IN_FAST 1
 #endif
@@ -510,8 +513,10 @@ ldpc_wg8_kernel(const LdpcKParams p)
         for (int j = 0; j < (SPA ? DEG : 1); j++) onx[j] = 0.f;
         // layer table of the NEXT layer, fetched under the end-of-layer barrier: 27 slots | prim | conflict info | 2 conflict entries
         uint32_t TE[32];
+        constexpr bool TEV = SPA && W8_SPA_TEV;      // sum-product kernel: the next layer's table in ONE vector register (lane j = entry j, read back with v_readlane) instead of 32 scalars carried across the layer's barriers (k_ldpc_cu1.hip: the compiler parked them in vector registers)
 #pragma unroll
-        for (int j = 0; j < 32; j++) TE[j] = tab[j];
+        for (int j = 0; j < 32; j++) TE[j] = TEV ? 0u : tab[j];
+        uint32_t tev = TEV ? p.w8.tab[w8_lane_now() & 31] : 0u;
         // (round 4) the slots' addresses of the NEXT layer, 16 bytes (four slots) per load from the per-lane table
         constexpr int NW4 = (DEG + 3) / 4;
         uint32_t w[4 * NW4];                        // (loop-carried: the addresses of the current layer until its stores have been issued, then the next layer's)
@@ -538,8 +543,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 const const_u32 T = tab + r * LDPC_FAST_STRIDE;
                 uint32_t E[DEG];
 #pragma unroll
-                for (int j = 0; j < DEG; j++) E[j] = TE[j];
-                const uint32_t prim = TE[27], cinfo = TE[28], ce0 = TE[29], ce1 = TE[30];
+                for (int j = 0; j < DEG; j++) E[j] = TEV ? (uint32_t)__builtin_amdgcn_readlane((int)tev, j) : TE[j];
+                const uint32_t prim = TEV ? (uint32_t)__builtin_amdgcn_readlane((int)tev, 27) : TE[27], cinfo = TEV ? (uint32_t)__builtin_amdgcn_readlane((int)tev, 28) : TE[28],
+                               ce0 = TEV ? (uint32_t)__builtin_amdgcn_readlane((int)tev, 29) : TE[29], ce1 = TEV ? (uint32_t)__builtin_amdgcn_readlane((int)tev, 30) : TE[30];
                 const int ncf = (int)(cinfo & 0xFFu);
                 const bool mask0 = (r == 0) && (t == 0);        // p_{c-1} of check 0 does not exist
                 if (SPA) {
@@ -556,7 +562,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     // on the way out and ~20 full-rate operations, against 2.8 boxplus x (2 exp + 2 log + 12) of the forward / backward form.
                     constexpr uint32_t mpitch = W8_ROW;      // message rows packed like the image's (a run-time pitch costs two scalar instructions per access; 1536-byte rows -- whole lines -- measured SLOWER, docs/negative_results.md)
                     const uint32_t mrow = st_base + (uint32_t)(r * DEG) * mpitch;       // messages of this layer: [slot][360 of mpitch / 4]
-                    const uint32_t dupmask = TE[31];
+                    const uint32_t dupmask = TEV ? (uint32_t)__builtin_amdgcn_readlane((int)tev, 31) : TE[31];
                     // the circulant offsets are formed twice, for the loads and again for the stores (an opaque copy of t4 keeps the compiler
                     // from holding 27 of them across the arithmetic: registers, not instructions, are what this layer is short of)
                     uint32_t t4s = t4, MAGM = 0x7FFFFFFFu;
@@ -731,7 +737,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             else { const float Lv = gld(off, base); gst(off, base, Lv + od[i]); }
                         }
                     }
-                    {
+                    if (TEV) tev = p.w8.tab[(r + 1 < q ? r + 1 : 0) * LDPC_FAST_STRIDE + (w8_lane_now() & 31)];
+                    else {
                         const const_u32 Tn = tab + (r + 1 < q ? r + 1 : 0) * LDPC_FAST_STRIDE;
 #pragma unroll
                         for (int j = 0; j < 32; j++) TE[j] = Tn[j];

@@ -377,9 +377,8 @@ int dvbs2hip_timing_enable(dvbs2hip_t *h, int32_t on);
 int dvbs2hip_timing_reset(dvbs2hip_t *h);
 /* synchronises, then returns the summed device ms and the number of launches of kernel k */
 int dvbs2hip_timing_get(dvbs2hip_t *h, int32_t k, double *total_ms, int64_t *n_launches);
-/* what a plain device-to-device copy reaches on this GPU with a kernel of this library (16 bytes per lane and access, non-temporal stores, the
- * loop shape of the front end and the synchronizers' rotation): read + written bytes over the hipEvent time of `reps` copies of `bytes` bytes
- * in scratch memory of the handle, in GB/s.  A measurement aid for the roofline figures (bench.py: `roofline.hbm_copy_GBps_measured`); the
+/* what a plain device-to-device copy reaches on this GPU with a kernel of this library (16 bytes per lane and access; the best of 1 / 4 accesses
+ * in flight per lane, plain / non-temporal): read + written bytes over the hipEvent time of `reps` copies of `bytes` bytes in scratch memory, in GB/s.  A measurement aid for the roofline figures (bench.py: `roofline.hbm_copy_GBps_measured`); the
  * reference has no counterpart.                                                        */
 int dvbs2hip_device_copy_bandwidth(dvbs2hip_t *h, size_t bytes, int32_t reps, double *GBps);
 /* device memory helpers so non-HIP hosts (ctypes, cgo, JNI) can own device buffers */

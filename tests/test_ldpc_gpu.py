@@ -246,6 +246,7 @@ def test_natural_order_in_the_fused_chain(O, Rx):
 
 
 DEFAULT_NMS_MODE = 5       # image mode the planner picks for the min-sum decoder on normal frames (6 = one frame per CU, k_ldpc_cu1.hip)
+DEFAULT_SPA_MODE = 6       # ... for the sum-product decoder (round 5: one frame per CU, two lanes per check, the messages inside the Infinity Cache)
 
 
 def _big_batch(O, modcod, F, ebn0s, seed, n_cw=8):
@@ -347,10 +348,10 @@ def test_ldpc_normal_frame_image_modes_agree_with_the_oracle(O, Rx, monkeypatch,
     for early in (False, True):
         n_ite = 3 if spa and not early else 10
         rx = Rx(modcod, max_frames=F, n_ite=n_ite, alpha=1.0, early_stop=early, implem=implem)
-        want = kernel_mode if kernel_mode is not None else (4 if spa else DEFAULT_NMS_MODE)
-        if spa and want >= 5:
-            want = 4                    # (the sum-product kernel has neither the one-frame-per-CU form nor the registers for 39 parked rows)
-        name = "ldpc_cu1_kernel<27>" if want == 6 else "ldpc_wg8_kernel<27,%d%s>" % (want, ",true" if spa else "")
+        want = kernel_mode if kernel_mode is not None else (DEFAULT_SPA_MODE if spa else DEFAULT_NMS_MODE)
+        if spa and want == 5:
+            want = 4                    # (the sum-product kernel has no registers for 39 parked rows)
+        name = ("ldpc_cu1_kernel<27,true>" if spa else "ldpc_cu1_kernel<27>") if want == 6 else "ldpc_wg8_kernel<27,%d%s>" % (want, ",true" if spa else "")
         assert rx.ldpc_kernel_name() == name, rx.ldpc_kernel_name()
         V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
         Vo, posto, cwdo, iteso = ch.ldpc.decode(llr[pick], n_ite=n_ite, alpha=1.0, implem=O.SPA if spa else O.NMS, sched=O.QC, early_stop=early)
