@@ -131,7 +131,7 @@ int fail(dvbs2hip_t *h, int code, const std::string &msg)
     } while (0)
 
 enum BufId { B_IN = 0, B_OUT, B_AUX0, B_AUX1, B_AUX2, B_AUX3, B_LLR, B_PACKED, B_EST, B_CWD0, B_CWD1, B_INFO, B_SIG, B_TXBCH, B_TXLDPC,
-             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY, B_SFM_DTAB, B_SFF_TMP, B_SFF_OUT, B_FLT2, B_MON_BE, B_MON_OUT, B_BCHFLAG, B_LR_TMP0, B_LR_TMP1, B_LR_TMP2, B_LR_TMP3 };
+             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY, B_SFM_DTAB, B_SFF_TMP, B_SFF_OUT, B_FLT2, B_MON_BE, B_MON_OUT, B_BCHFLAG, B_LR_TMP0, B_LR_TMP1, B_LR_TMP2, B_LR_TMP3, B_SFM_SCR, B_SFM_NEED };
 
 int ensure(dvbs2hip_t *h, int id, size_t bytes, void **out)
 {
@@ -474,18 +474,24 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
                     for (int w = 0; w < 3; w++) { const int lo = 64 * w; if (r <= lo) v[w] = 0; else if (r < lo + 64) v[w] &= (1ull << (r - lo)) - 1ull; }
                     if (fb) { v[0] ^= gl[0]; v[1] ^= gl[1]; v[2] ^= gl[2]; }
                 }
-                std::vector<uint32_t> ps((size_t)rows * 6 * 2, 0u);
+                // the descrambler's bits per (first row of a batch, lane): bit k of entry [ks][t] = PRBS bit of information bit 360 g + t, g the row emitted at ks + k (k < 16)
+                std::vector<uint32_t> ps((size_t)rows * LDPC_AT_LANES, 0u);
                 for (int k = 0; k < rows; k++) {
                     uint32_t *d = &sp[(size_t)k * 8];
                     const int g = order[k];
                     if (g < 0) { d[0] = 0x7FFFF000u; continue; }
                     d[0] = (uint32_t)g * 1440u; d[1] = g == G - 1 ? 1u : 0u;
                     for (int i = 0; i < 6; i++) d[2 + i] = ag[(size_t)g * 6 + i];
-                    for (int e = 0; e < 360; e++) {
-                        const int i = g * 360 + e;
-                        if (i < cfg->K_bch && ((prbs[i >> 5] >> (i & 31)) & 1u)) { const int w = e >> 6, l = e & 63; ps[(size_t)(k * 6 + w) * 2 + (l >> 5)] |= 1u << (l & 31); }
-                    }
                 }
+                for (int ks = 0; ks < rows; ks++)
+                    for (int k = 0; k < 16 && ks + k < rows; k++) {
+                        const int g = order[ks + k];
+                        if (g < 0) continue;
+                        for (int e = 0; e < 360; e++) {
+                            const int i = g * 360 + e;
+                            if (i < cfg->K_bch && ((prbs[i >> 5] >> (i & 31)) & 1u)) ps[(size_t)ks * LDPC_AT_LANES + e] |= 1u << k;
+                        }
+                    }
                 if (upload(h, &h->d_syn_pos, sp.data(), sp.size()) || upload(h, &h->d_prbs_s, ps.data(), ps.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
                 h->syn_words = nsw; h->syn_rows = rows;
             }
@@ -1155,12 +1161,12 @@ int dvbs2hip_sync_frame_synchronize1_dev(dvbs2hip_t *h, const float *X_N1, float
 }
 
 // synchronize2, or (cor_SOF == cor_PLSC == null) the whole one-task synchronize with the correlators fused into the metric
-static int sfm_sync2(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, const float *cor_PLSC, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t F)
+static int sfm_sync2(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, const float *cor_PLSC, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t F, const float **SRC = nullptr)
 {
     int r = check_frames(h, F); if (r) return r;
     int32_t *delay = DEL;
     const bool fused = !cor_SOF && !cor_PLSC;
-    if (!X_N1 || (!fused && (!cor_SOF || !cor_PLSC)) || !delay || !Y_N2) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    if (!X_N1 || (!fused && (!cor_SOF || !cor_PLSC)) || !delay || (!Y_N2 && !SRC)) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
     if ((r = sfm_ready(h))) return r;
     auto &S = h->sfm;
     const int n = h->pl_frame;
@@ -1179,8 +1185,14 @@ static int sfm_sync2(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, con
         HIPCHK(h, sync_metric_launch(cor_SOF, S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], cor_PLSC, S.cv, (float *)corr, tail, n, F, S.alpha, S.vec_width, h->stream));
     S.sofh_cur ^= 1;
     // the delay line is a recurrence from frame to frame made of copies only: resolved per output sample, one launch (k_sync.hip)
+    void *need = nullptr;
+    if (SRC) {      // located form: only the frames that are not a run of the input stream are materialized (into the handle's scratch); SRC[f] says where frame f starts
+        void *scr;
+        if ((r = ensure(h, B_SFM_SCR, sizeof(float) * 2 * (size_t)n * F, &scr)) || (r = ensure(h, B_SFM_NEED, sizeof(int32_t) * ((size_t)F + 2), &need))) return r;
+        Y_N2 = (float *)scr;
+    }
     HIPCHK(h, sync_vdelay_launch(X_N1, S.yprev[S.yp_cur], S.yprev[S.yp_cur ^ 1], Y_N2, S.buff2[S.od_cur], S.buff2[S.od_cur ^ 1], S.st[S.od_cur], S.st[S.od_cur ^ 1],
-                                 (const int32_t *)dtab, n, S.nbuff2, F, h->stream));
+                                 (const int32_t *)dtab, n, S.nbuff2, F, h->stream, (int32_t *)need, SRC));
     S.od_cur ^= 1;
     S.yp_cur ^= 1;
     return 0;
@@ -1204,6 +1216,15 @@ int dvbs2hip_sync_frame_synchronize_dev(dvbs2hip_t *h, const float *X_N1, int32_
     if ((r = ensure(h, B_SFM_SOF, nb, &cs)) || (r = ensure(h, B_SFM_PLSC, nb, &cp))) return r;
     if ((r = dvbs2hip_sync_frame_synchronize1_dev(h, X_N1, (float *)cs, (float *)cp, F))) return r;
     return dvbs2hip_sync_frame_synchronize2_dev(h, X_N1, (const float *)cs, (const float *)cp, DEL, FLG, TRI, Y_N2, F);
+}
+
+// (round 5) the frame synchronizer for a consumer of this library: instead of the delayed copy Y_N2 it returns, per frame, WHERE the aligned frame starts -- inside X_N1 for a
+// frame that is one run of the input stream (every frame in lock but the first and the last of a call), inside the handle's scratch for the others.  X_N1 and the table stay
+// valid until the next synchronizer call on this handle; the frames are 8-byte aligned.  DEL / FLG / TRI and the synchronizer's state are those of `synchronize`.
+int dvbs2hip_sync_frame_locate_dev(dvbs2hip_t *h, const float *X_N1, int32_t *DEL, int32_t *FLG, float *TRI, const float **SRC, int32_t F)
+{
+    if (h && !SRC) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    return sfm_sync2(h, X_N1, nullptr, nullptr, DEL, FLG, TRI, nullptr, F, SRC);
 }
 
 int dvbs2hip_sync_frame_synchronize1(dvbs2hip_t *h, const float *X_N1, float *cor_SOF, float *cor_PLSC, int32_t F)
@@ -1668,10 +1689,10 @@ int dvbs2hip_monitor_reset(dvbs2hip_t *h)
 }
 
 // ------------------------------------------------------------------ fused RX baseband chain
-int dvbs2hip_rx_bb_dev(dvbs2hip_t *h, const float *pl, const float *sigma, int32_t *info, int8_t *cwd_l, int8_t *cwd_b, int32_t F)
+static int rx_bb_any_dev(dvbs2hip_t *h, const float *pl, const float *const *src, const float *sigma, int32_t *info, int8_t *cwd_l, int8_t *cwd_b, int32_t F)
 {
     int r = check_frames(h, F); if (r) return r;
-    if (!pl || !info) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    if ((!pl && !src) || !info) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
     void *dllr, *dpk, *dest;
     const size_t nwords = (size_t)(h->K_ldpc + 31) / 32;
     if ((r = ensure(h, B_LLR, (size_t)F * h->N_ldpc * 4, &dllr)) || (r = ensure(h, B_PACKED, (size_t)F * nwords * 4, &dpk)) ||
@@ -1679,7 +1700,9 @@ int dvbs2hip_rx_bb_dev(dvbs2hip_t *h, const float *pl, const float *sigma, int32
         return r;
     {
         Timer tm(h, DVBS2HIP_K_FRONT);
-        HIPCHK(h, front_rx_launch(front_params(h, pl, sigma, (float *)dllr, (float *)dest, F), h->stream));
+        FrontKParams fp = front_params(h, pl, sigma, (float *)dllr, (float *)dest, F);
+        fp.src = src;
+        HIPCHK(h, front_rx_launch(fp, h->stream));
     }
     // the LDPC kernel writes the descrambled info bits of every frame straight into the output socket (what the BCH stage outputs for a
     // frame it does not correct: nearly all of them behind a converged LDPC decoder); the BCH stage then only checks the syndromes of the
@@ -1691,6 +1714,19 @@ int dvbs2hip_rx_bb_dev(dvbs2hip_t *h, const float *pl, const float *sigma, int32
     if (fused_out && ldpc_verifies_bch(h) && (r = ensure(h, B_BCHFLAG, (size_t)F, &dflag))) return r;
     if ((r = ldpc_dev(h, (const float *)dllr, cwd_l, nullptr, (uint32_t *)dpk, nullptr, nullptr, F, fused_out ? info : nullptr, (uint8_t *)dflag, cwd_b))) return r;
     return bch_dev(h, nullptr, (const uint32_t *)dpk, cwd_b, info, true, F, fused_out, (const uint8_t *)dflag);
+}
+
+int dvbs2hip_rx_bb_dev(dvbs2hip_t *h, const float *pl, const float *sigma, int32_t *info, int8_t *cwd_l, int8_t *cwd_b, int32_t F)
+{
+    if (h && !pl) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    return rx_bb_any_dev(h, pl, nullptr, sigma, info, cwd_l, cwd_b, F);
+}
+
+// (round 5) the fused chain behind dvbs2hip_sync_frame_locate_dev: frame f is read where SRC[f] points (device table of device pointers)
+int dvbs2hip_rx_bb_located_dev(dvbs2hip_t *h, const float *const *SRC, const float *sigma, int32_t *info, int8_t *cwd_l, int8_t *cwd_b, int32_t F)
+{
+    if (h && !SRC) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    return rx_bb_any_dev(h, nullptr, SRC, sigma, info, cwd_l, cwd_b, F);
 }
 
 int dvbs2hip_rx_bb(dvbs2hip_t *h, const float *pl, const float *sigma, int32_t *info, int8_t *cwd_l, int8_t *cwd_b, int32_t F)

@@ -56,7 +56,7 @@ struct LdpcKParams {
     const uint32_t *syn_tab;    // [syn_rows][8]: per row in STORAGE order (the order k_ldpc_wg8.hip emits the rows in: LDS rows, global rows, register slots) {byte offset 1440 g of the row in the int32
                                 // socket (0x7FFFF000: an empty register slot), 1 = the last information row, A_g[0 .. 5] = x^(360 (n_info - 1 - g)) mod g(x)}, then [LDPC_SYN_RED][syn_words]: x^k mod g(x),
                                 // little-endian 32-bit words; or null (no verification)
-    const uint32_t *info_prbs_s;   // the PRBS words of info_prbs by (storage row, wave)
+    const uint32_t *info_prbs_s;   // [syn_rows][LDPC_AT_LANES]: bit k of entry [ks][t] = the BB descrambler's bit of information bit 360 g + t, g the row emitted at storage position ks + k (k < 16)
     int32_t syn_words;          // 4 (deg g <= 128) or 6 (<= 192)
     int32_t syn_rows;           // rows the kernel emits (information rows + empty register slots)
     uint8_t *bch_flag;          // [F]: 1 = remainder not zero (the BCH stage decodes this frame), 0 = codeword
@@ -203,6 +203,7 @@ hipError_t bch_launch(const BchPlan &pl, BchKParams p, hipStream_t s);
 // ---------------------------------------------------------------- front end (a3, a4, a6, a7)
 struct FrontKParams {
     const float *in;        // pl frames [F][2*pl_frame] or xfec frames [F][2*n_sym]
+    const float *const *src;   // (round 5) per-frame start of the PL frame (8-byte aligned) instead of in + f * 2 * pl_frame: the located form of the frame synchronizer; or null
     const float *sigma_in;  // [F] or null
     float *llr;             // [F][N_ldpc]
     float *est;             // [F][3] sigma, ebn0, esn0 (may be null)
@@ -287,6 +288,6 @@ hipError_t sff_lr_launch(const float *X, float *Y, float *R_l, float *tmp, float
 hipError_t sff_lr_recover(const float *X, float *Y, float *tmp, int n, int F, hipStream_t s);
 hipError_t sff_fp_launch(const float *X, float *Y, float *tmp, float *FRQ, float *PHS, int n, int F, hipStream_t s);
 hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Yprev_new, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
-                              const int32_t *Dtab, int n, int nbuff2, int F, hipStream_t s);
+                              const int32_t *Dtab, int n, int nbuff2, int F, hipStream_t s, int32_t *list = nullptr, const float **src = nullptr);
 
 }  // namespace dvbs2

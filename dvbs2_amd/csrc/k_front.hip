@@ -283,7 +283,7 @@ front_kernel(const FrontKParams p)
     const int tid = threadIdx.x, f = blockIdx.x;
     const int n_sym = p.n_sym, n_pil = n_sym / (PL_SLOTS * PL_M);
     const size_t in_stride = FROM_PL ? 2 * (size_t)p.pl_frame : 2 * (size_t)n_sym;
-    const float2 *in = reinterpret_cast<const float2 *>(p.in + (size_t)f * in_stride);
+    const float2 *in = reinterpret_cast<const float2 *>((FROM_PL && p.src) ? p.src[f] : p.in + (size_t)f * in_stride);
     float sigma;
     if (FROM_PL && p.sigma_in == nullptr) {
         float m2 = 0.f, m4 = 0.f;
@@ -381,7 +381,7 @@ front_reg_kernel(const FrontKParams p)
     __shared__ float red[2][WIDE / 64];
     const int tid = threadIdx.x, f = blockIdx.x;
     const int n_sym = p.n_sym, n_pil = n_sym / (PL_SLOTS * PL_M);
-    const float2 *in = reinterpret_cast<const float2 *>(p.in + (size_t)f * 2 * (size_t)p.pl_frame);
+    const float2 *in = reinterpret_cast<const float2 *>(p.src ? p.src[f] : p.in + (size_t)f * 2 * (size_t)p.pl_frame);
     float2 y[SPT];
     // 32-bit offsets through buffer descriptors (a 64-bit address per load in flight would not fit the register budget);
     // an offset past the frame returns zero, which is what the padding lanes have to hold
@@ -480,7 +480,7 @@ front_reg2_kernel(const FrontKParams p)
     __shared__ float red[2][FRONT_WIDE / 64];
     const int tid = threadIdx.x, f = blockIdx.x;
     const int n_sym = p.n_sym, n_pil = n_sym / (PL_SLOTS * PL_M), n_pairs = n_sym / 2;
-    const float2 *in = reinterpret_cast<const float2 *>(p.in + (size_t)f * 2 * (size_t)p.pl_frame);
+    const float2 *in = reinterpret_cast<const float2 *>(p.src ? p.src[f] : p.in + (size_t)f * 2 * (size_t)p.pl_frame);
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(in), 0, 8 * p.pl_frame, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.pl_seq), 0, p.pl_frame, 0x00020000);
     front_f4 y[PPT];
@@ -534,7 +534,7 @@ static bool front_reg_try(const FrontKParams &p, hipStream_t s)
     dim3 g(p.n_frames), b(FRONT_WIDE);
     const bool small = p.n_sym <= 8 * FRONT_WIDE, mid = p.n_sym <= 22 * FRONT_WIDE, big = p.n_sym <= 32 * FRONT_WIDE;
     const bool pair_ok = p.bps == 2 && p.sep && p.itl_cols <= 1 && p.n_sym % 2 == 0 && p.pl_frame % 2 == 0 && !getenv("DVBS2HIP_FRONT_SINGLE") &&
-                         ((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.llr)) & 15) == 0;
+                         ((reinterpret_cast<uintptr_t>(p.src ? nullptr : p.in) | reinterpret_cast<uintptr_t>(p.llr)) & 15) == 0;      // (a located frame starts on 8 bytes: the pair kernel reads it through a buffer descriptor, which takes any dword address)
     if (pair_ok && small) hipLaunchKernelGGL((front_reg2_kernel<4>), g, b, 0, s, p);
     else if (pair_ok && big) hipLaunchKernelGGL((front_reg2_kernel<16>), g, b, 0, s, p);
     // one symbol per lane and access: short frames (8 symbols per lane) and the 8PSK normal frame (21600 symbols: 22 per lane = 44 registers

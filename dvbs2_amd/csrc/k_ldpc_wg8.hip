@@ -1135,28 +1135,40 @@ ldpc_wg8_kernel(const LdpcKParams p)
         // Per row in STORAGE order (LDS rows, global rows, register slots: the order the rows are emitted in) the plan supplies one 32-byte record {byte offset of the row in
         // the int32 socket (beyond every socket: an empty register slot), last-row flag, A_g[0 .. 5]} and the PRBS words by (storage row, wave): every scalar of a row comes
         // from an address known before the batch starts, nothing waits for the row number first (round 4's form: row number, then the PRBS word at an address formed from it).
-        const const_u32 syn_rec = (const_u32)p.syn_tab;                       // [rows emitted][8]
-        const const_u32 prbs_s = (const_u32)p.info_prbs_s;                     // [rows emitted][6 waves][2]
         typedef uint32_t o_u32x4 __attribute__((ext_vector_type(4)));
         typedef uint32_t o_u32x2 __attribute__((ext_vector_type(2)));
         uint32_t sacc[6] = {0u, 0u, 0u, 0u, 0u, 0u};
         const unsigned long long actm = __ballot(act);                              // the lanes that hold a check
-        auto emit_syn = [&](int ks, float Lv, bool repeat, auto nw_c) __attribute__((always_inline)) {      // ks: storage row; repeat (wave-uniform): a row that was emitted already
+        // (round 5, second form) The rows' scalars do not come through the scalar memory path at all: for a batch of B <= 16 rows lane l (mod 16) loads row l's 32-byte record
+        // and every lane ONE dword of PRBS bits (bit k = the descrambler's bit of this lane's information bit in row k of the batch) -- three vector loads per batch, issued with
+        // the batch's row loads -- and a row's scalars are read out of those registers with v_readlane.  With s_load per row (four rows' worth requested at a time: the scalar
+        // file has no room for more) every group of four rows waited for a scalar round trip, the chain's output rows cost 325 cycles against the bits socket's 100.
+        const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc(out_syn ? (void *)p.syn_tab : (void *)gwork, 0, out_syn ? p.syn_rows * 32 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_pl = __builtin_amdgcn_make_buffer_rsrc(out_syn ? (void *)p.info_prbs_s : (void *)gwork, 0, out_syn ? p.syn_rows * LDPC_AT_LANES * 4 : 0, 0x00020000);
+        const uint32_t rec_vo = (uint32_t)(lo & 15) * 32u, pl_vo = act ? (uint32_t)to * 4u : W8_OOB;
+        auto emit_syn = [&](int kk, float Lv, bool repeat, const o_u32x4 r0, const o_u32x4 r1, const uint32_t pw, auto nw_c) __attribute__((always_inline)) {      // kk: row of the batch; repeat (wave-uniform): a row that was emitted already
             constexpr int NW = decltype(nw_c)::value;
-            const const_u32 rec = syn_rec + ks * 8;
-            const uint32_t off = repeat ? W8_OOB : rec[0];
+            const uint32_t off = repeat ? W8_OOB : (uint32_t)__builtin_amdgcn_readlane((int)r0.x, kk);
             const unsigned long long m = __ballot(Lv < 0.f) & (off == W8_OOB ? 0ull : actm);     // (the lanes without a check hold anything)
-            const const_u32 pq = prbs_s + 2 * (ks * 6 + role);
-            const unsigned long long d = m ^ ((unsigned long long)pq[0] | ((unsigned long long)pq[1] << 32));
-            uint32_t bit, mk;
-            asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(bit) : "s"(d));
+            uint32_t hd, mk;
+            asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(hd) : "s"(m));
             asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(mk) : "s"(m));            // all ones where the hard decision is 1 (Lv < 0, as the stored bit: not the sign bit -- a posterior of -0.f decides 0)
+            const uint32_t bit = hd ^ ((pw >> kk) & 1u);
             // (the whole offset in the vector register: the range check that drops the bits behind K_info, the lanes without a check and a skipped row then sees all of it)
             __builtin_amdgcn_raw_buffer_store_b32(bit, rs_info, vo_out + off, 0u, 2);
-#pragma unroll
-            for (int i = 0; i < NW; i++)      // acc ^= mask & A_g[i] as ONE instruction that takes the scalar where it is (written as `acc ^= mk & ag[i]` the compiler forms the 64 products of a batch first -- to let go of the scalar registers -- and spills them)
-                asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x78" : "+v"(sacc[i]) : "v"(mk), "s"(rec[2 + i]));
-            if (rec[1] && !repeat) {                                                // the row that holds the BCH parity bits: its packed bytes for the BCH stage (row g at byte 45 g = offset / 32)
+            const uint32_t A0 = (uint32_t)__builtin_amdgcn_readlane((int)r0.z, kk), A1 = (uint32_t)__builtin_amdgcn_readlane((int)r0.w, kk),
+                           A2 = (uint32_t)__builtin_amdgcn_readlane((int)r1.x, kk), A3 = (uint32_t)__builtin_amdgcn_readlane((int)r1.y, kk);
+            // acc ^= mask & A_g[i] as ONE instruction that takes the scalar where it is (written as `acc ^= mk & a` the compiler forms the products of a whole batch first and spills them)
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x78" : "+v"(sacc[0]) : "v"(mk), "s"(A0));
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x78" : "+v"(sacc[1]) : "v"(mk), "s"(A1));
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x78" : "+v"(sacc[2]) : "v"(mk), "s"(A2));
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x78" : "+v"(sacc[3]) : "v"(mk), "s"(A3));
+            if (NW > 4) {
+                const uint32_t A4 = (uint32_t)__builtin_amdgcn_readlane((int)r1.z, kk), A5 = (uint32_t)__builtin_amdgcn_readlane((int)r1.w, kk);
+                asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x78" : "+v"(sacc[NW > 4 ? 4 : 0]) : "v"(mk), "s"(A4));
+                asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x78" : "+v"(sacc[NW > 4 ? 5 : 0]) : "v"(mk), "s"(A5));
+            }
+            if (__builtin_amdgcn_readlane((int)r0.y, kk) && !repeat) {               // the row that holds the BCH parity bits: its packed bytes for the BCH stage (row g at byte 45 g = offset / 32)
                 const uint32_t half = pk_hi ? (uint32_t)(m >> 32) : (uint32_t)m;
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(half >> pk_sh), rs_pack, pk_vo, off >> 5, 0);
             }
@@ -1228,7 +1240,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
         auto run_out_fast = [&](auto nw_c) __attribute__((always_inline)) {
             constexpr int NW = decltype(nw_c)::value;                  // words of the BCH remainder: 0 (bits socket alone: no verification), 4 or 6
             constexpr bool SYN = NW > 0;
-            constexpr int IOS = (SPA || SYN) ? 8 : W8_IO;                // rows per batch
+            constexpr int IOS = SPA ? 8 : W8_IO;                         // rows per batch
             const const_u32 srow = rows + nl + ng + q;
             constexpr int NRP = w8_parked(MODE) ? ldpc_park_nr(MODE) : 0;
             // kind 0: LDS rows, 1: global rows, 2: the parked rows handed over through LDS positions 0 .. NR-1
@@ -1243,11 +1255,18 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 float v[B];
 #pragma unroll
                 for (int k = 0; k < B; k++) v[k] = kind == 1 ? gld(t4g, grow0 + (uint32_t)(l0 + k) * W8_ROW) : lld((uint32_t)(l0 + k) * W8_ROW + t4l);
+                o_u32x4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+                uint32_t pw = 0u;
+                if (SYN) {      // the batch's records (lane l mod 16: row l) and this lane's PRBS bits of its rows
+                    const uint32_t ks0 = (uint32_t)((kind == 0 ? 0 : kind == 1 ? nl_info : nl_info + ng_info) + l0);
+                    r0 = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, rec_vo, ks0 * 32u, 0);
+                    r1 = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, rec_vo + 16u, ks0 * 32u, 0);
+                    pw = __builtin_amdgcn_raw_buffer_load_b32(rs_pl, pl_vo, ks0 * (uint32_t)(LDPC_AT_LANES * 4), 0);
+                }
 #pragma unroll
                 for (int k = 0; k < B; k++) {
-                    // (the rows' scalars -- row number, PRBS word, A_g -- four rows at a time: hoisted for the whole batch they are 7 x 16 SGPRs that the kernel does not have)
-                    if (k > 0 && k % (SYN ? 4 : 8) == 0) __builtin_amdgcn_sched_barrier(0);
-                    if (SYN) { emit_syn((kind == 0 ? 0 : kind == 1 ? nl_info : nl_info + ng_info) + l0 + k, v[k], l0 + k < ldone, nw_c); continue; }
+                    if (k > 0 && k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+                    if (SYN) { emit_syn(k, v[k], l0 + k < ldone, r0, r1, pw, nw_c); continue; }
                     const uint32_t gk = grp(kind, l0 + k);
                     if (kind == 2) { if (gk != 0xFFFFFFFFu) emit_plain((int)gk, v[k]); }      // (an empty register slot: the plan of the DVB-S2 codes leaves none)
                     else emit_plain((int)gk, v[k]);

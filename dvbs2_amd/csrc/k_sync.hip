@@ -602,10 +602,14 @@ typedef float vd_f4 __attribute__((ext_vector_type(4), aligned(4)));     // a pa
 // run of the input stream, X[f N - D ...)), and the pair then moves as 16 bytes.
 __global__ void sync_vdelay_batch_kernel(const float *__restrict__ X, const float *__restrict__ yprev0, float *__restrict__ yprev_new, float *__restrict__ Y,
                                          const float *__restrict__ buff_old, float *__restrict__ buff_new, const int *__restrict__ st_old,
-                                         int *__restrict__ st_new, const int32_t *__restrict__ delay_f, int n, int nbuff2, int F)
+                                         int *__restrict__ st_new, const int32_t *__restrict__ delay_f, int n, int nbuff2, int F, const int32_t *__restrict__ list)
 {
-    const int N = 2 * n, f = blockIdx.y;
+    const int N = 2 * n;
     __shared__ int red[256];
+    // located form (sync_locate_kernel): `list` = {count, frames to materialize .. (F = the state row among them)}; row y of the grid takes entries y, y + gridDim.y, ..
+    const int n_list = list ? list[0] : 1;
+    for (int li = list ? (int)blockIdx.y : 0; li < n_list; li += list ? (int)gridDim.y : 1) {
+    const int f = list ? list[1 + li] : (int)blockIdx.y;
     int dmax = 0;
     if (f == F) {                                                     // the largest D of the call (a few thousand ints out of L2)
         for (int g = threadIdx.x; g < F; g += 256) dmax = delay_f[g] > dmax ? delay_f[g] : dmax;
@@ -616,11 +620,13 @@ __global__ void sync_vdelay_batch_kernel(const float *__restrict__ X, const floa
     }
     const int lim = f < F ? N : nbuff2;
     const VdU u = vd_uniform(st_old, delay_f, f < F ? f : F - 1, n, nbuff2);
+    {
+    const int bx = blockIdx.x;
     const float *sa[VD_SPL], *sb[VD_SPL];
     int jj[VD_SPL];
 #pragma unroll
     for (int i = 0; i < VD_SPL; i++) {
-        const int j = 4 * ((blockIdx.x * VD_SPL + i) * (int)blockDim.x + (int)threadIdx.x);      // first float of a pair of complex samples
+        const int j = 4 * ((bx * VD_SPL + i) * (int)blockDim.x + (int)threadIdx.x);      // first float of a pair of complex samples
         jj[i] = j; sa[i] = nullptr; sb[i] = nullptr;
         if (f < F) {
             if (j < lim) sa[i] = vd_source_fast(u, X, yprev0, buff_old, st_old, delay_f, f, j, n, nbuff2);
@@ -652,7 +658,10 @@ __global__ void sync_vdelay_batch_kernel(const float *__restrict__ X, const floa
             if (f == F - 1) *reinterpret_cast<float2 *>(yprev_new + j) = make_float2(v[i].x, v[i].y);
         }
     }
+    }
     if (f == F && blockIdx.x == 0 && threadIdx.x == 0) { st_new[0] = vd_D(delay_f, F - 1, n); st_new[1] = 0; }
+    __syncthreads();      // (`red` is reused by the next entry of the list)
+    }
 }
 
 // ================================================================ fine frequency / phase synchronizers
@@ -1069,13 +1078,41 @@ hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float 
     return hipGetLastError();
 }
 
-// all F frames of a call; Dtab (F ints) comes from sync_finalize_kernel; Yprev_new = the last output frame for the next call
+// (round 5) The LOCATED form of the frame synchronizer: Variable_delay_cc_naive's output frame f is, whenever the delay did not move between f - 1 and f, ONE run of the
+// input stream -- X[f N - D_f, f N - D_f + N) (vd_source_fast: samples j >= D come from input f, samples j < D from the tail of input f - 1, which the delay line holds) --
+// so a consumer of ours can read it THERE and the shifted copy (a third of the synchronizer's time, a pure copy at 5.9 TB/s) is not made.  need[f] = 1 marks the frames
+// that are NOT such a run -- frame 0 (its head is state of the previous call), a frame whose delay differs from its predecessor's, a delay beyond the line's length --
+// and the last frame (the next call's `yprev`): those are materialized by sync_vdelay_batch_kernel into `scratch` (frame f at scratch + f N), src[f] points there.
+__global__ void sync_locate_kernel(const float *X, float *scratch, const int32_t *__restrict__ Dtab, int n, int nbuff2, int F, int32_t *__restrict__ list, const float **__restrict__ src)
+{
+    // one workgroup; list[0] = count (zeroed by the host side of the launch), list[1 ..] = the frames to materialize in any order, then F (the delay line's state row)
+    const size_t N = 2 * (size_t)n;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const int D = Dtab[f];
+        const bool run = f > 0 && f < F - 1 && D == Dtab[f - 1] && D <= nbuff2;
+        src[f] = run ? X + (size_t)f * N - (size_t)D : scratch + (size_t)f * N;
+        if (!run) list[1 + atomicAdd(&list[0], 1)] = f;
+    }
+    if (threadIdx.x == 0) list[1 + atomicAdd(&list[0], 1)] = F;
+}
+
+// all F frames of a call; Dtab (F ints) comes from sync_finalize_kernel; Yprev_new = the last output frame for the next call.  need / src != null: the located form
+// (Y = scratch for the frames that are materialized)
 hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Yprev_new, float *Y, const float *buff_old, float *buff_new, const int *st_old, int *st_new,
-                              const int32_t *Dtab, int n, int nbuff2, int F, hipStream_t s)
+                              const int32_t *Dtab, int n, int nbuff2, int F, hipStream_t s, int32_t *list, const float **src)
 {
     const int tot = ((nbuff2 > 2 * n ? nbuff2 : 2 * n) + 3) / 4;     // pairs of complex samples
-    hipLaunchKernelGGL(sync_vdelay_batch_kernel, dim3((tot + 256 * VD_SPL - 1) / (256 * VD_SPL), F + 1), dim3(256), 0, s, X, Yprev, Yprev_new, Y, buff_old, buff_new, st_old,
-                       st_new, Dtab, n, nbuff2, F);
+    const int gx = (tot + 256 * VD_SPL - 1) / (256 * VD_SPL);
+    if (list) {
+        hipError_t e = hipMemsetAsync(list, 0, sizeof(int32_t), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(sync_locate_kernel, dim3(1), dim3(1024), 0, s, X, Y, Dtab, n, nbuff2, F, list, src);
+        // rows of the grid share the list's entries: in lock three of them have work (first frame, last frame, state row), while the synchronizer acquires all do
+        const int gy = F + 1 < 64 ? F + 1 : 64;
+        hipLaunchKernelGGL(sync_vdelay_batch_kernel, dim3(gx, gy), dim3(256), 0, s, X, Yprev, Yprev_new, Y, buff_old, buff_new, st_old, st_new, Dtab, n, nbuff2, F, (const int32_t *)list);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(sync_vdelay_batch_kernel, dim3(gx, F + 1), dim3(256), 0, s, X, Yprev, Yprev_new, Y, buff_old, buff_new, st_old, st_new, Dtab, n, nbuff2, F, (const int32_t *)nullptr);
     return hipGetLastError();
 }
 

@@ -73,6 +73,7 @@ ABI = {
     "dvbs2hip_sync_frame_synchronize2_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_sync_frame_synchronize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_sync_frame_synchronize_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "dvbs2hip_sync_frame_locate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_sync_frame_get_metric": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "dvbs2hip_set_ldpc_params": (C.c_int, [_vp, _i, _f, _i]),
     "dvbs2hip_get_stream": (_vp, [_vp]),
@@ -117,6 +118,7 @@ ABI = {
     "dvbs2hip_monitor_reduce_finalize": (C.c_int, [_vp]),
     "dvbs2hip_rx_bb": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_rx_bb_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "dvbs2hip_rx_bb_located_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_tx_bb": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _i]),
     "dvbs2hip_tx_bb_dev": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _i]),
     "dvbs2hip_shape_filter": (C.c_int, [_vp, _vp, _vp, _i, _i]),

@@ -357,6 +357,13 @@ class Dvbs2Hip:
     def sync_frame_synchronize_dev(self, X, DEL, FLG, TRI, Y, n_frames):
         self._chk(self.L.dvbs2hip_sync_frame_synchronize_dev(self.h, X, DEL, FLG, TRI, Y, n_frames))
 
+    def sync_frame_locate_dev(self, X, DEL, FLG, TRI, SRC, n_frames):
+        """chained device form: SRC (device table of n_frames device pointers) <- where each aligned frame starts (inside X or the handle's scratch)"""
+        self._chk(self.L.dvbs2hip_sync_frame_locate_dev(self.h, X, DEL, FLG, TRI, SRC, n_frames))
+
+    def rx_bb_located_dev(self, SRC, sigma, info, cwd_ldpc, cwd_bch, n_frames):
+        self._chk(self.L.dvbs2hip_rx_bb_located_dev(self.h, SRC, _ptr(sigma), _ptr(info), _ptr(cwd_ldpc), _ptr(cwd_bch), n_frames))
+
     def sync_frame_metric(self):
         m, fl = C.c_float(), C.c_int32()
         self._chk(self.L.dvbs2hip_sync_frame_get_metric(self.h, C.byref(m), C.byref(fl)))

@@ -285,6 +285,8 @@ int dvbs2hip_rx_bb(dvbs2hip_t *h, const float *pl_frames, const float *sigma_in,
                    int8_t *cwd_ldpc, int8_t *cwd_bch, int32_t n_frames);
 int dvbs2hip_rx_bb_dev(dvbs2hip_t *h, const float *pl_frames, const float *sigma_in, int32_t *info_bits,
                        int8_t *cwd_ldpc, int8_t *cwd_bch, int32_t n_frames);
+/* the fused chain reading frame f where SRC[f] points (the table dvbs2hip_sync_frame_locate_dev fills): same outputs as dvbs2hip_rx_bb_dev on the delayed copy */
+int dvbs2hip_rx_bb_located_dev(dvbs2hip_t *h, const float *const *SRC, const float *sigma, int32_t *info_bits, int8_t *cwd_ldpc, int8_t *cwd_bch, int32_t n_frames);
 
 /* ------------------------------------------------------------------ N1: TX mirror + AWGN channel (test-signal side)
  * One call = the TX half + channel of TX_RX_BB/main.cpp:75-82 on the device:
@@ -343,6 +345,13 @@ int dvbs2hip_sync_frame_synchronize2_dev(dvbs2hip_t *h, const float *X_N1, const
                                          float *TRI, float *Y_N2, int32_t n_frames);
 int dvbs2hip_sync_frame_synchronize(dvbs2hip_t *h, const float *X_N1, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t n_frames);
 int dvbs2hip_sync_frame_synchronize_dev(dvbs2hip_t *h, const float *X_N1, int32_t *DEL, int32_t *FLG, float *TRI, float *Y_N2, int32_t n_frames);
+/* (round 5) CHAINED device form for a consumer of this library (Synchronizer_frame_DVBS2_fast.cpp:296-299 materializes Y_N2 only because the next task is a separate
+ * module): the same synchronizer -- same DEL / FLG / TRI, same state for the next call -- but instead of the delayed copy it returns where each aligned frame STARTS:
+ * SRC[f] (device table of n_frames device pointers, 8-byte aligned frames of 2 * pl_frame floats) points into X_N1 when the frame is one run of the input stream (the
+ * delay did not move from frame f - 1: every frame in lock but the first and the last of a call) and into scratch of the handle otherwise.  X_N1 and the table must stay
+ * untouched until their consumer -- dvbs2hip_rx_bb_located_dev, on the same handle and stream -- has run; the next synchronizer call reuses the scratch.  Bit-exact by
+ * construction: the delay line only copies.                                                    */
+int dvbs2hip_sync_frame_locate_dev(dvbs2hip_t *h, const float *X_N1, int32_t *DEL, int32_t *FLG, float *TRI, const float **SRC, int32_t n_frames);
 int dvbs2hip_sync_frame_get_metric(dvbs2hip_t *h, float *max_corr, int32_t *packet_flag);
 
 /* ------------------------------------------------------------------ N4: fine frequency / phase synchronizers

@@ -355,3 +355,55 @@ def test_lr_one_launch_form_under_another_handles_persistent_kernel():
     import subprocess, sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lr_soak.py"), "25"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "225 calls, 0 bad" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("modcod,F,ebn0", [("QPSK-S_8/9", 24, 6.0), ("8PSK-S_8/9", 10, 9.0), ("32APSK-S_3/4", 17, 14.0), ("QPSK-N_8/9", 6, 6.0)])
+def test_located_form_feeds_the_fused_chain_what_the_delayed_copy_would(O, Rx, modcod, F, ebn0):
+    """VERDICT r4 item 5, the chained device form: dvbs2hip_sync_frame_locate_dev returns WHERE every aligned frame starts (inside the input stream when the frame is one run
+    of it, inside scratch otherwise) and dvbs2hip_rx_bb_located_dev reads the frames there -- against dvbs2hip_sync_frame_synchronize_dev + dvbs2hip_rx_bb_dev on the delayed
+    copy: same DEL / FLG / TRI, same information bits and CWD flags, frame for frame, over four calls on a stream that starts mid-frame (the delay moves while the synchronizer
+    acquires: those frames are materialized; in lock every frame but the first and last of a call is read in place) and whose offset JUMPS in the third call.  Two handles
+    run the two forms side by side: the synchronizer's state (delay line, last output frame) carries from call to call in both.  QPSK (pair kernel, frames on 8-byte
+    addresses), 8PSK (frame in registers), 32APSK (two-sweep kernel), QPSK normal frames."""
+    import torch
+    info, pl, _, sigma = make_pl_frames(O, modcod, min(F, 6), ebn0, seed=31)
+    n = pl.shape[1] // 2
+    reps = -(-4 * F // pl.shape[0]) + 2
+    flat = np.tile(pl.reshape(-1), reps)
+    # calls 0, 1: offset 1501 symbols; from call 2 on the stream has slipped by 77 symbols more (a new alignment: the delay moves again)
+    base = np.concatenate([np.zeros(2 * 1501, np.float32), flat])
+    slipped = np.concatenate([np.zeros(2 * (1501 + 77), np.float32), flat])
+    a, b = Rx(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=True), Rx(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=True)
+    dev = torch.device("cuda")
+    K = a.K_bch
+    sg = torch.full((F,), float(sigma), dtype=torch.float32, device=dev) if a.bps >= 4 else None
+    in_place = 0
+    for call in range(4):
+        src_stream = base if call < 2 else slipped
+        x = torch.from_numpy(src_stream[call * F * 2 * n:(call + 1) * F * 2 * n].copy()).to(dev)
+        out = {}
+        for form, rx in (("copy", a), ("located", b)):
+            DEL = torch.empty(F, dtype=torch.int32, device=dev); FLG = torch.empty_like(DEL); TRI = torch.empty(F, dtype=torch.float32, device=dev)
+            bits = torch.empty((F, K), dtype=torch.int32, device=dev); c0 = torch.empty(F, dtype=torch.int8, device=dev); c1 = torch.empty_like(c0)
+            torch.cuda.synchronize()
+            if form == "copy":
+                Y = torch.empty_like(x)
+                rx.sync_frame_synchronize_dev(x.data_ptr(), DEL.data_ptr(), FLG.data_ptr(), TRI.data_ptr(), Y.data_ptr(), F)
+                rx.rx_bb_dev(Y.data_ptr(), sg.data_ptr() if sg is not None else None, bits.data_ptr(), c0.data_ptr(), c1.data_ptr(), F)
+            else:
+                SRC = torch.zeros(F, dtype=torch.int64, device=dev)
+                rx.sync_frame_locate_dev(x.data_ptr(), DEL.data_ptr(), FLG.data_ptr(), TRI.data_ptr(), SRC.data_ptr(), F)
+                rx.rx_bb_located_dev(SRC.data_ptr(), sg.data_ptr() if sg is not None else None, bits.data_ptr(), c0.data_ptr(), c1.data_ptr(), F)
+            rx.synchronize()
+            out[form] = (DEL.cpu().numpy(), FLG.cpu().numpy(), TRI.cpu().numpy(), bits.cpu().numpy(), c0.cpu().numpy(), c1.cpu().numpy())
+            if form == "located":
+                p = SRC.cpu().numpy()
+                inside = (p >= x.data_ptr()) & (p < x.data_ptr() + x.numel() * 4)
+                in_place += int(inside.sum())
+                assert (p % 8 == 0).all() and not inside[0] and not inside[-1]           # the first and the last frame of a call are materialized
+        for u, v in zip(out["copy"], out["located"]):
+            assert np.array_equal(u, v), call
+        if call in (1, 3):      # in lock: the payloads come out, and nearly every frame was read in place
+            assert (out["located"][1][2:] == 1).all() and out["located"][5][3:].all()
+    assert in_place >= 2 * (F - 2) - 4, in_place
+    a.close(); b.close()
