@@ -31,7 +31,7 @@ for cfg in sorted(glob.glob(os.path.join(OUT, "lv_*.cfg")), key=lambda s: int(s.
     ks = first(t + "_stats/*/*_kernel_stats.csv")
     if ks:
         for row in csv.DictReader(open(ks)):
-            if "ldpc_wg8_kernel" in row["Name"]:
+            if "ldpc_wg8_kernel" in row["Name"] or "ldpc_cu1_kernel" in row["Name"]:
                 r["kernel"] = row["Name"].replace("void dvbs2::", "").split("(")[0]
                 r["calls"] = int(row["Calls"]); r["avg_ms"] = float(row["AverageNs"]) / 1e6; r["min_ms"] = float(row["MinNs"]) / 1e6
     pmc = {}
@@ -41,7 +41,7 @@ for cfg in sorted(glob.glob(os.path.join(OUT, "lv_*.cfg")), key=lambda s: int(s.
             continue
         acc = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
-            if "ldpc_wg8_kernel" in row["Kernel_Name"]:
+            if "ldpc_wg8_kernel" in row["Kernel_Name"] or "ldpc_cu1_kernel" in row["Kernel_Name"]:
                 acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
                 r["vgpr"] = int(row["VGPR_Count"]); r["lds"] = int(row["LDS_Block_Size"]); r["grid"] = int(row["Grid_Size"]) // int(row["Workgroup_Size"])
         for k, v in acc.items():

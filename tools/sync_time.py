@@ -1,4 +1,4 @@
-"""Wall time per call of the three N4 synchronizers (sync_case of tools/bench_kernels.py) for one MODCOD: one line (tools/r04_sync_ab.sh).
+"""Wall time per call of the three N4 synchronizers (sync_case of tools/bench_kernels.py) for one MODCOD: one line (tools/archive/r04_sync_ab.sh).
 usage: python tools/sync_time.py [modcod] [frames]"""
 import os, re, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
