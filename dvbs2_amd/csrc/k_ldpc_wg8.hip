@@ -105,6 +105,9 @@ __host__ __device__ __forceinline__ constexpr bool w8_slot_lds(int mode, int j) 
 #ifndef W8_FAST_OUT       // output loops of their own for the bits socket alone and for the fused chain (buffer descriptors per frame, scalar descrambling)
 #define W8_FAST_OUT 1
 #endif
+#ifndef W8_SPA_ANYKEY      // sum-product layer: the overflow rule behind a wave-uniform branch per slot (k_ldpc_cu1.hip has it): same-box A/B here QPSK-S 8/9 1697 -> 1654 k,
+#define W8_SPA_ANYKEY 0      // 3/5 1178 -> 1151 k frames/s -- 27 scalar branches per layer cut the unrolled slot loop into scheduling regions; off
+#endif
 #ifndef W8_SPA_TEV        // sum-product layer: the next layer's table in one vector register (what made k_ldpc_cu1.hip's sum-product kernel 12 % faster: there the compiler had parked
 #define W8_SPA_TEV 0      // the 32 scalars in vector registers).  Here, same-box A/B: QPSK-S 8/9 1712 -> 1655 k, 3/5 1190 -> 1092 k frames/s, normal frames (mode 4) 315 -> 307 k: off
 #endif
@@ -646,6 +649,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     if (ncf > 0) __syncthreads();         // every read of the layer precedes its writes
                     if (act) {
                         float A = 0.f;
+                        const bool anykey = __ballot(key == key) != 0ull;      // (NaN stands for "no overflow in this check")
                         float mq[4] = {0.f, 0.f, 0.f, 0.f};
                         if (DEG > 13) asm volatile("" : "+v"(t4s));      // (the short codes keep their offsets: 70 registers in all)
                         __builtin_amdgcn_s_setprio(2);
@@ -664,7 +668,13 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             // cancellation; same deviation from the oracle, 3.3e-6 max(1, |L|) at most; short frames +1.0-1.6 %, same-box A/B)
                             const float lg = (SPA_ABL & 8) ? Q : __builtin_amdgcn_logf(__builtin_fmaf(2.f, __builtin_amdgcn_rcpf(Q), -kap));
                             float o = __builtin_fmaf(lg, 0.693147180559945309f, cln);
+#if W8_SPA_ANYKEY
+                            // (round 5) the overflow rule behind a wave-uniform branch: it applies to a check whose two smallest magnitudes differ by more than 60, which no
+                            // wave of a frame near the waterfall holds; as two compares, an or and a select per slot it was 4 of the layer's ~34 vector instructions per edge
+                            if (anykey) { asm volatile("" ::: "memory"); o = __builtin_islessgreater(fabsf(x[j]), key) ? mn1 : o; }
+#else
                             o = (fabsf(x[j]) < key || fabsf(x[j]) > key) ? mn1 : o;
+#endif
                             float nw;                                 // magnitude bits of o under the sign of (all signs) ^ (own sign): one v_bfi_b32
                             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(nw) : "s"(MAGM), "v"(o), "v"(sx ^ __float_as_uint(x[j])));
                             A = __builtin_fmaf(u[j], wA, A);
