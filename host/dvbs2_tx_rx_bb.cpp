@@ -15,6 +15,11 @@
 // across the reference's threads (main.cpp:123-125,155-161); every rank stops on the REDUCED frame-error count; rank 0
 // prints the table.  A rank that fails leaves with a non-zero exit code; the collectives of the others do not time out, so the
 // launcher has to end the job when one process dies (torchrun does).
+//
+// Clones: the reference runs its chain in hardware_concurrency() clones, each with its own -F frames in flight (main.cpp:19,96 -- spu::runtime::Sequence with
+// n_threads; seeds per clone main.cpp:118-120; the monitors summed by Monitor_reduction, main.cpp:123-125).  --clones C (default 3) is that on one GPU: C handles = C
+// streams, batches dealt to them in turn, the host waiting on a clone's counters only when that clone's turn comes again.  With the syndrome early stop a batch of the
+// LDPC kernel ends with a few frames running to the iteration limit on a few CUs; the next clone's kernels fill the others (one clone: --clones 1, the loop of rounds 2-4).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -30,7 +35,7 @@ int main(int argc, char **argv)
 {
     std::string modcod = "QPSK-S_8/9", implem = "SPA", est = "DVBS2";
     double ebn0_min = 3.2, ebn0_max = 6.0, step = 0.1;     // DVBS2.cpp:121-123
-    int F = 512, n_ite = 50, max_fe = 100;                 // DVBS2.cpp:135-142 (implem SPA, 50 ite, 100 frame errors)
+    int F = 512, n_ite = 50, max_fe = 100, n_clones = 3;   // DVBS2.cpp:135-142 (implem SPA, 50 ite, 100 frame errors)
     long long max_frames = 10000000;
     float alpha = 1.0f;
     auto env_int = [](const char *n, int d) { const char *v = std::getenv(n); return v && *v ? std::atoi(v) : d; };
@@ -50,6 +55,7 @@ int main(int argc, char **argv)
         else if (a == "--dec-alpha") alpha = (float)std::atof(next());
         else if (a == "--est-type") est = next();
         else if (a == "--max-frames") max_frames = std::atoll(next());
+        else if (a == "--clones") n_clones = std::atoi(next());
         else if (a == "--world") world = std::atoi(next());
         else if (a == "--rank") rank = std::atoi(next());
         else if (a == "--local-rank") local_rank = std::atoi(next());
@@ -65,19 +71,26 @@ int main(int argc, char **argv)
     cfg.device = local_rank >= 0 ? local_rank : (n_gpus > 0 ? rank % n_gpus : rank);      // a global rank only: ranks are dealt to the node's GPUs in order
     cfg.ldpc_implem = implem == "SPA" ? DVBS2HIP_IMPLEM_SPA : implem == "MS" ? DVBS2HIP_IMPLEM_MS : DVBS2HIP_IMPLEM_NMS;
     if (implem != "SPA" && implem != "MS" && implem != "NMS") { std::fprintf(stderr, "--dec-implem has to be SPA, MS or NMS\n"); return 2; }
-    if (dvbs2hip_create(&cfg, &h)) { std::fprintf(stderr, "%s\n", dvbs2hip_last_error(nullptr)); return 3; }
+    if (n_clones < 1 || n_clones > 8) { std::fprintf(stderr, "--clones has to be 1 .. 8\n"); return 2; }
+    struct Clone { dvbs2hip_t *h = nullptr; void *d_pl = nullptr, *d_sent = nullptr, *d_got = nullptr, *d_sig = nullptr; uint64_t c[3] = {0, 0, 0}; bool busy = false; };
+    std::vector<Clone> cl((size_t)n_clones);
     dvbs2hip_sizes sz;
-    CHK(dvbs2hip_get_sizes(h, &sz));
-    if (world > 1 || std::getenv("DVBS2HIP_FORCE_RCCL")) CHK(dvbs2hip_monitor_reduce_init(h, rank, world, rendezvous.c_str(), 120000));
+    const bool reduce = world > 1 || std::getenv("DVBS2HIP_FORCE_RCCL");
+    for (int k = 0; k < n_clones; k++) {
+        if (dvbs2hip_create(&cfg, &cl[k].h)) { std::fprintf(stderr, "%s\n", dvbs2hip_last_error(nullptr)); return 3; }
+        h = cl[k].h;
+        CHK(dvbs2hip_get_sizes(h, &sz));
+        // one communicator per clone (its all-reduce runs on the clone's stream); every rank calls them in the same order
+        if (reduce) CHK(dvbs2hip_monitor_reduce_init(h, rank, world, (rendezvous + (k ? ".c" + std::to_string(k) : "")).c_str(), 120000));
+        CHK(dvbs2hip_malloc(h, &cl[k].d_pl, (size_t)F * 2 * sz.pl_frame_sym * sizeof(float)));
+        CHK(dvbs2hip_malloc(h, &cl[k].d_sent, (size_t)F * sz.K_bch * sizeof(int32_t)));
+        CHK(dvbs2hip_malloc(h, &cl[k].d_got, (size_t)F * sz.K_bch * sizeof(int32_t)));
+        CHK(dvbs2hip_malloc(h, &cl[k].d_sig, (size_t)F * sizeof(float)));
+    }
     const bool chief = rank == 0;
-    void *d_pl, *d_sent, *d_got, *d_sig;
-    CHK(dvbs2hip_malloc(h, &d_pl, (size_t)F * 2 * sz.pl_frame_sym * sizeof(float)));
-    CHK(dvbs2hip_malloc(h, &d_sent, (size_t)F * sz.K_bch * sizeof(int32_t)));
-    CHK(dvbs2hip_malloc(h, &d_got, (size_t)F * sz.K_bch * sizeof(int32_t)));
-    CHK(dvbs2hip_malloc(h, &d_sig, (size_t)F * sizeof(float)));
 
     if (chief) std::printf("# * DVB-S2 (HIP) ------------------------------------\n#    ** Modulation and coding = %s\n#    ** LDPC implem           = %s\n"
-                "#    ** LDPC n iterations     = %d\n#    ** Frames per batch (-F)  = %d\n#    ** Processes (1 per GPU)  = %d\n", modcod.c_str(), implem.c_str(), n_ite, F, world);
+                "#    ** LDPC n iterations     = %d\n#    ** Frames per batch (-F)  = %d\n#    ** Clones per process     = %d\n#    ** Processes (1 per GPU)  = %d\n", modcod.c_str(), implem.c_str(), n_ite, F, n_clones, world);
     if (chief) std::printf("# ----------|----------||----------|----------|----------|----------|----------||----------|----------\n"
                 "#     Es/N0 |    Eb/N0 ||      FRA |       BE |       FE |      BER |      FER ||  SIM_THR |    ET/RT\n"
                 "#      (dB) |     (dB) ||          |          |          |          |          ||   (Mb/s) | (hhmmss)\n"
@@ -88,16 +101,28 @@ int main(int argc, char **argv)
         const double esn0 = ebn0 + 10.0 * std::log10(R * sz.bps);         // main.cpp:143-146
         const float sigma = (float)std::sqrt(1.0 / (2.0 * std::pow(10.0, esn0 / 10.0)));
         std::vector<float> sig(F, sigma);
-        CHK(dvbs2hip_memcpy_h2d(h, d_sig, sig.data(), sig.size() * sizeof(float)));
-        CHK(dvbs2hip_monitor_reset(h));
+        for (auto &k : cl) { h = k.h; CHK(dvbs2hip_memcpy_h2d(h, k.d_sig, sig.data(), sig.size() * sizeof(float))); CHK(dvbs2hip_monitor_reset(h)); k.c[0] = k.c[1] = k.c[2] = 0; k.busy = false; }
         uint64_t c[3] = {0, 0, 0};
+        // a clone's counters run on the device from the reset above; the sum over the clones of what each one last reported is what the stopping rule sees
+        auto collect = [&](Clone &k) -> int {
+            h = k.h;
+            CHK(dvbs2hip_monitor_reduce(h, k.c));                             // Monitor_reduction::is_done_all: every rank sees the same sum
+            k.busy = false;
+            for (int i = 0; i < 3; i++) { c[i] = 0; for (auto &o : cl) c[i] += o.c[i]; }
+            return 0;
+        };
         const auto t0 = std::chrono::steady_clock::now();
-        while (c[2] < (uint64_t)max_fe && (long long)c[0] < max_frames) {     // Monitor_BFER: stop at max_fe (DVBS2.cpp:136)
-            CHK(dvbs2hip_tx_bb_dev(h, nullptr, (batch++ << 8), (const float *)d_sig, (int32_t *)d_sent, (float *)d_pl, F));
-            CHK(dvbs2hip_rx_bb_dev(h, (const float *)d_pl, est == "PERFECT" ? (const float *)d_sig : nullptr, (int32_t *)d_got, nullptr, nullptr, F));
-            CHK(dvbs2hip_monitor_check_errors_dev(h, (const int32_t *)d_sent, (const int32_t *)d_got, F));
-            CHK(dvbs2hip_monitor_reduce(h, c));                               // Monitor_reduction::is_done_all: every rank sees the same sum
+        for (size_t turn = 0;; turn++) {
+            Clone &k = cl[turn % cl.size()];
+            if (k.busy) { const int rc = collect(k); if (rc) return rc; }
+            if (c[2] >= (uint64_t)max_fe || (long long)c[0] >= max_frames) break;     // Monitor_BFER: stop at max_fe (DVBS2.cpp:136)
+            h = k.h;
+            CHK(dvbs2hip_tx_bb_dev(h, nullptr, (batch++ << 8), (const float *)k.d_sig, (int32_t *)k.d_sent, (float *)k.d_pl, F));
+            CHK(dvbs2hip_rx_bb_dev(h, (const float *)k.d_pl, est == "PERFECT" ? (const float *)k.d_sig : nullptr, (int32_t *)k.d_got, nullptr, nullptr, F));
+            CHK(dvbs2hip_monitor_check_errors_dev(h, (const int32_t *)k.d_sent, (const int32_t *)k.d_got, F));
+            k.busy = true;
         }
+        for (auto &k : cl) if (k.busy) { const int rc = collect(k); if (rc) return rc; }      // the batches still in flight count (the reference's threads finish theirs)
         const double et = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const int hh = (int)(et / 3600), mm = (int)(et / 60) % 60, ss = (int)et % 60;
         if (chief) std::printf("  %9.2f | %8.2f || %8llu | %8llu | %8llu | %8.2e | %8.2e || %8.3f | %02dh%02d'%02d\n", esn0, ebn0, (unsigned long long)c[0],
@@ -106,7 +131,6 @@ int main(int argc, char **argv)
         std::fflush(stdout);
     }
     if (chief) std::printf("# End of the simulation\n");
-    dvbs2hip_free(h, d_pl); dvbs2hip_free(h, d_sent); dvbs2hip_free(h, d_got); dvbs2hip_free(h, d_sig);
-    dvbs2hip_destroy(h);
+    for (auto &k : cl) { dvbs2hip_free(k.h, k.d_pl); dvbs2hip_free(k.h, k.d_sent); dvbs2hip_free(k.h, k.d_got); dvbs2hip_free(k.h, k.d_sig); dvbs2hip_destroy(k.h); }
     return 0;
 }

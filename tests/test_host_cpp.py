@@ -67,12 +67,14 @@ def test_host_frame_sync_task_in_front_of_the_graph(O, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_tx_rx_bb_reproduces_a_reference_row():
-    """The C++ work-alike of dvbs2_tx_rx_bb (C ABI only) on one row of refs/TX_RX_BB/QPSK_8_9.txt."""
+@pytest.mark.parametrize("clones", [1, 2, 3])
+def test_cpp_tx_rx_bb_reproduces_a_reference_row(clones):
+    """The C++ work-alike of dvbs2_tx_rx_bb (C ABI only) on one row of refs/TX_RX_BB/QPSK_8_9.txt, with one clone of the chain and with several in flight
+    (the reference's Sequence runs n_threads clones, TX_RX_BB/main.cpp:19,96)."""
     import json
     build()
     exe = os.path.join(ROOT, "host", "dvbs2_tx_rx_bb")
-    r = subprocess.run([exe, "--mod-cod", "QPSK-S_8/9", "-m", "3.7", "-M", "3.71", "--dec-implem", "SPA", "--dec-ite", "50", "-F", "2048"],
+    r = subprocess.run([exe, "--mod-cod", "QPSK-S_8/9", "-m", "3.7", "-M", "3.71", "--dec-implem", "SPA", "--dec-ite", "50", "-F", "2048", "--clones", str(clones)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     row = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("#")][0]
@@ -130,7 +132,8 @@ def test_cpp_tx_rx_bb_reduces_its_monitor_over_rccl(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_tx_rx_bb_two_processes_reduce_and_stop_together(tmp_path):
+@pytest.mark.parametrize("clones", [1, 2])
+def test_cpp_tx_rx_bb_two_processes_reduce_and_stop_together(tmp_path, clones):
     """VERDICT r4 item 4, the C++ half: `host/dvbs2_tx_rx_bb --world 2` as two processes -- rendezvous through files, communicator, one all-reduce of {FRA, BE, FE} per
     batch, both ranks stopping on the REDUCED frame-error count, rank 0 printing -- on the ONE GPU of this box.  RCCL refuses a communicator with a duplicate device, so the
     library's dlopen finds tests/stub_rccl/librccl.so.1 (a test-side stand-in that sums through a shared mapping; LD_LIBRARY_PATH points at it for these two processes only).
@@ -141,13 +144,13 @@ def test_cpp_tx_rx_bb_two_processes_reduce_and_stop_together(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "tests", "stub_rccl") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     F, max_fe = 256, 100
     cmd = [exe, "--mod-cod", "QPSK-S_8/9", "-m", "3.6", "-M", "3.61", "--dec-implem", "NMS", "--dec-ite", "10", "-F", str(F), "--world", "2", "--local-rank", "0",
-           "--rendezvous", str(tmp_path / "rdv")]
+           "--rendezvous", str(tmp_path / "rdv"), "--clones", str(clones)]         # (two clones: two handles, streams and communicators per process, called in the same order on both ranks)
     procs = [subprocess.Popen(cmd + ["--rank", str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in (1, 0)]
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     out1, out0 = outs[0][0], outs[1][0]
     assert "||" not in out1                                                                     # rank 1 prints nothing of the table
-    assert "Processes (1 per GPU)  = 2" in out0
+    assert "Processes (1 per GPU)  = 2" in out0 and "Clones per process     = %d" % clones in out0
     row = [l for l in out0.splitlines() if "||" in l and not l.startswith("#")][0]
     f = [x.strip() for x in row.replace("||", "|").split("|")]
     fra, fe = int(f[2]), int(f[4])

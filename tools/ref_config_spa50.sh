@@ -9,3 +9,7 @@ run qpsk_3_5   --mod-cod QPSK-S_3/5   -m 1.3 -M 1.51 -s 0.1
 run 8psk_3_5   --mod-cod 8PSK-S_3/5   -m 2.7 -M 3.01 -s 0.1
 run 8psk_8_9   --mod-cod 8PSK-S_8/9   -m 6.2 -M 6.51 -s 0.1
 run 16apsk_8_9 --mod-cod 16APSK-S_8/9 -m 7.1 -M 7.51 -s 0.1 --est-type PERFECT
+# one clone of the chain (the loop of rounds 2-4: the same batches seed for seed) and four, on the rows the rounds have tracked
+run c1_qpsk_8_9 --mod-cod QPSK-S_8/9   -m 3.6 -M 3.81 -s 0.1 --clones 1
+run c2_qpsk_8_9 --mod-cod QPSK-S_8/9   -m 3.6 -M 3.81 -s 0.1 --clones 2
+run c4_qpsk_8_9 --mod-cod QPSK-S_8/9   -m 3.6 -M 3.81 -s 0.1 --clones 4
