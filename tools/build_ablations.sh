@@ -5,5 +5,6 @@
 set -e
 cd "$(dirname "$0")/.."
 rm -f tools/bin/lib_abl*.so tools/bin/k_ldpc_wg8_abl*.o
-for a in 1 2 3 4 8 12 15; do bash tools/build_variant.sh abl$a k_ldpc_wg8 -DW8_ABL=$a > /dev/null 2>&1 & done; wait
+# (one after the other: seven hipcc runs of this file at once lose some of them in this 8-CPU container)
+for a in 1 2 3 4 8 12 15; do bash tools/build_variant.sh abl$a k_ldpc_wg8 -DW8_ABL=$a > /dev/null 2>&1; test -f tools/bin/lib_abl$a.so || { echo "lib_abl$a.so did not build"; exit 1; }; done
 ls tools/bin/lib_abl*.so
