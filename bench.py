@@ -690,18 +690,29 @@ def cpu_baseline(mc, llr, target_s):
                 best_thr, best_rate = thr, rate
             if thr > 1 and rate < 0.6 * best_rate:       # far past the knee: more threads only lose (and the probe's time is bounded)
                 break
-        n = int(min(x_all.shape[0], max(quantum * best_thr, 0.5 * target_s * best_rate)))
-        n -= n % (quantum * best_thr) if n >= quantum * best_thr else 0
-        rounds = int(max(1, min(32, round(0.5 * target_s * best_rate / n))))       # the sample again and again up to ~target_s / 2
-        secs = [code.decode_batch_pinned(x_all[:n], fl, n_ite=N_ITE, alpha=1.0, threads=best_thr, cpus=cpus_for(best_thr)) for _ in range(rounds)]
-        res[kind] = (n * rounds, sum(s[0] for s in secs), best_thr, max(s[1] for s in secs), min(s[2] for s in secs))
+        # the sustained run.  Under a cgroup CPU quota the short probes of counts above the quota run on burst credit that a longer run does not have (driver box, round 5: 32 threads
+        # probed 37.9 k frames/s, sustained 20.2 k, with a quota of 16 CPUs): the largest probed count inside the quota is timed as well and the faster of the two is reported.
+        cands = [best_thr]
+        if quota and best_thr > quota:
+            inside = [t for t in curve[kind] if t <= quota]
+            if inside:
+                cands.append(max(inside))
+        for thr in cands:
+            r_thr = curve[kind][thr]
+            n = int(min(x_all.shape[0], max(quantum * thr, 0.5 * target_s * r_thr / len(cands))))
+            n -= n % (quantum * thr) if n >= quantum * thr else 0
+            rounds = int(max(1, min(32, round(0.5 * target_s * r_thr / len(cands) / n))))       # the sample again and again up to ~target_s / 2 per flavour
+            secs = [code.decode_batch_pinned(x_all[:n], fl, n_ite=N_ITE, alpha=1.0, threads=thr, cpus=cpus_for(thr)) for _ in range(rounds)]
+            got = (n * rounds, sum(s[0] for s in secs), thr, max(s[1] for s in secs), min(s[2] for s in secs))
+            if kind not in res or got[0] / got[1] > res[kind][0] / res[kind][1]:
+                res[kind] = got
     best = max(res, key=lambda k: res[k][0] / res[k][1])
     n, sec, cores, t_hi, t_lo = res[best]
     rate = n / sec
     triad = code.stream_triad_GBps(cores, 1 << 24, 3, cpus_for(cores))
     return {"value": rate * mc.K_bch, "unit": "bit/s", "fec_frames_per_s": rate, "cores": cores, "kind": "port",
             "sample": "%d frames of the same batch, oracle layered NMS (natural row order, fp32, 10 ite, %s flavour), %d pinned threads with first-touched private buffers -- "
-                      "the fastest of the probed counts %s of the %d CPUs in this job's affinity mask (%d hardware threads on the host, cgroup CPU quota %s), %.1f s"
+                      "the fastest sustained of the probed counts %s of the %d CPUs in this job's affinity mask (%d hardware threads on the host, cgroup CPU quota %s), %.1f s"
                       % (n, best, cores, sorted(curve[best]), naff, ncpu, ("%.1f CPUs" % quota) if quota else "none", sec),
             "build": build, "isa": isa, "frames_per_vector": width, "sched_affinity_cpus": naff, "os_cpu_count": ncpu, "cgroup_cpu_quota": quota,
             "cpu_list": cpus_for(cores) if cores <= 64 else cpus_for(cores)[:64] + ["..."],
