@@ -30,7 +30,7 @@ def probe(tmp_path_factory):
 
 
 @pytest.mark.parametrize("spa,mode,want,lds_slots,parked,glob_rows", [
-    (False, None, 5, 15, 39, 180 - 55 - 39), (True, None, 4, 14, 32, 180 - 55 - 32), (False, "park4", 4, 14, 32, 93), (False, "static", 3, 9, 0, 125)])
+    (False, None, 5, 15, 39, 180 - 55 - 39), (True, "park4", 4, 14, 32, 180 - 55 - 32), (False, "park4", 4, 14, 32, 93), (False, "static", 3, 9, 0, 125)])
 def test_normal_frame_plan(probe, spa, mode, want, lds_slots, parked, glob_rows):
     out = probe("QPSK-N_8/9", spa, mode)
     head = out.splitlines()[0]
@@ -53,13 +53,13 @@ def test_mode6_one_frame_per_cu_plan(probe):
     replays one cycle of the tables the way the kernel reads them: every slot of every layer is an LDS access whose base is the position that holds its row in THAT layer, the
     duplicate edges are the first slots (conflict entry i = slot i), p_c / p_{c-1} the last two, no swap touches a row the current layer uses, the cycle closes, and the
     start-of-frame placement of the parity groups (position or register slot) is consistent."""
+    assert probe("QPSK-N_8/9", True, None).splitlines()[0] == probe("QPSK-N_8/9", True, "cu1").splitlines()[0]      # (round 5) the sum-product decoder's default on normal frames
+    assert "gwork words %d" % (27 * 7200) in probe("QPSK-N_8/9", True, None).splitlines()[0]                          # its messages: one word per edge, inside the Infinity Cache
     out = probe("QPSK-N_8/9", False, "cu1")
     head = out.splitlines()[0]
     assert "plan: ''" in head and "mode 6 wg8 1 dups_in_lds 1" in head and "LDS rows 108 (info 108) global rows 0" in head, head
     cu1 = [l for l in out.splitlines() if l.startswith("cu1:")][0]
     assert cu1 == "cu1: positions 108 pairs 72 swaps per iteration 144 max duplicate edges per layer 3 tables ok", cu1
-    # the sum-product decoder has no such mode: the request falls back to the parked-row hybrid
-    assert "mode 4 wg8 1" in probe("QPSK-N_8/9", True, "cu1").splitlines()[0]
 
 
 def test_natural_order_hazard_planes_are_empty_for_the_dvbs2_codes(probe):
