@@ -360,6 +360,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
         CREATE_HIP(hipMemset(lp.d_cu_ctr, 0, LDPC_CU_CTR_WORDS * sizeof(uint32_t)));
     }
     lp.grid_max = ldpc_blocks_per_cu(lp) * h->n_cus;
+    lp.n_cus = h->n_cus;
     if (const char *ev = getenv("DVBS2HIP_LDPC_GRID_MAX")) { const int g = atoi(ev); if (g >= 1 && g < lp.grid_max) lp.grid_max = g; }   // scaling experiments
     if (lp.gwork_words > 0) CREATE_HIP(hipMalloc((void **)&h->d_gwork, (size_t)lp.grid_max * lp.gwork_words * sizeof(float)));
 
@@ -631,7 +632,7 @@ const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
     if (!h) return "";
     if (h->ldpc_sched == DVBS2HIP_SCHED_NATURAL) {      // one lane per frame from 32768 frames on, a check's edges over 4 / 8 lanes below (k_ldpc_nat.hip: ldpc_nat_launch)
         const std::string d = std::to_string(h->ldpc.fast_deg);
-        const_cast<dvbs2hip_t *>(h)->ldpc_name = "ldpc_nat_kernel<" + d + "> / ldpc_nat_part_kernel<" + d + ",4|8> / ldpc_nat_ck_kernel<" + d + ",8|4> by batch size";
+        const_cast<dvbs2hip_t *>(h)->ldpc_name = "ldpc_nat_kernel<" + d + "> / ldpc_nat_part_kernel<" + d + ",4|8> / ldpc_nat_ck_kernel<" + d + ",8|4,2|4> by batch size";
         return h->ldpc_name.c_str();
     }
     {

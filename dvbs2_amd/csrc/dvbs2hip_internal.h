@@ -94,6 +94,7 @@ struct LdpcPlan {             // host-side description, built once per handle
     int lds_post_words = 0, glb_post_words = 0, gwork_words = 0;
     size_t lds_bytes = 0;
     int grid_max = 1;         // persistent grid: resident workgroups on the device
+    int n_cus = 256;          // compute units of the device (k_ldpc_nat.hip: the natural order's workgroup shape by batch size)
     std::vector<LdpcEntry> entries;
     std::vector<int32_t> layer_deg, layer_lvl;
     std::vector<LdpcGroup> groups;

@@ -679,24 +679,26 @@ hipError_t ldpc_nat_launch(const LdpcPlan &pl, const LdpcKParams &kp, float *wor
     p.bits = kp.bits; p.packed = kp.packed; p.cwd = kp.cwd; p.post = kp.post; p.ites = kp.ites;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.F = kp.n_frames; p.n_ite = kp.n_ite; p.early_stop = kp.early_stop; p.alpha = kp.alpha;
     // Form by the size of the batch.  Codes whose second hazard plane is empty and whose check count divides by eight (every DVB-S2 code of the library) run CONSECUTIVE CHECKS
-    // side by side (ldpc_nat_ck_kernel): 8 checks x 8 frames per wave, four waves per 32-frame workgroup, below 3072 frames (1024 normal frames: 32 against 35 ms),
-    // 4 checks x 16 frames, two waves per workgroup, from there on (the BASELINE batch of 4096: 78 -> 111-115 k normal frames/s; 16384+ frames: 245-253 k; one lane per frame
-    // reached 171 k at 32768).  Any other code: one lane per
-    // frame when that alone gives every SIMD a wave, else a check's edges over 4 or 8 lanes.  DVBS2HIP_NAT_PARTS = 1 | 4 | 8 (those forms), 88 | 44 (the two above) overrides.
+    // side by side (ldpc_nat_ck_kernel).  (round 5) While the batch gives every CU at most ONE workgroup of 16 frames (4096 frames on 256 CUs: the BASELINE batch): 8 checks x 8
+    // frames per wave, TWO waves per workgroup -- the sweep's step time follows the number of cache lines the waves of a CU touch per group of checks (every slot of every check
+    // is one line access per wave whatever the row holds), and rows of 32 frames (the two forms below) put four waves on half the CUs at this size: 4096 normal frames 35.3 -> 24.9-26.8
+    // ms = 115 -> 153-165 k frames/s, 1024 frames 31.4 -> 19.3 ms; with two such workgroups on a CU the time doubles (6144 frames: 47.5 against 36.5 ms), so from there on
+    // 4 checks x 16 frames, two waves per workgroup = rows of 32 frames (8192 frames: 217 k; 16384+: 245-260 k; one lane per frame reached 171 k at 32768).  Any other code: one lane per
+    // frame when that alone gives every SIMD a wave, else a check's edges over 4 or 8 lanes.  DVBS2HIP_NAT_PARTS = 1 | 4 | 8 (those forms), 88 | 44 | 82 | 81 | 41 | 48 (side by side) overrides.
     bool clean = pl.M % 8 == 0;
     for (size_t i = pl.nat_haz.size() / 2; i < pl.nat_haz.size(); i++) clean &= pl.nat_haz[i] == 0u;
-    int parts = clean ? (kp.n_frames >= 3072 ? 44 : 88) : kp.n_frames >= 32768 ? 1 : kp.n_frames > 6144 ? 4 : 8;
-    if (const char *ev = getenv("DVBS2HIP_NAT_PARTS")) { const int v = atoi(ev); if (v == 1 || v == 4 || v == 8 || ((v == 88 || v == 44) && clean)) parts = v; }
-    if (parts == 88) {
-        if (pl.fast_deg == 27) return nat_ck_launch<27, 8, 4>(pl, p, s);
-        if (pl.fast_deg == 13) return nat_ck_launch<13, 8, 4>(pl, p, s);
-        return nat_ck_launch<11, 8, 4>(pl, p, s);
+    int parts = clean ? (kp.n_frames <= 8 * pl.n_cus ? 81 : kp.n_frames <= 16 * pl.n_cus ? 82 : kp.n_frames >= 3072 ? 44 : 88)      // (one wave per CU while that holds the batch: 2048 normal frames 20.9 -> 19.4 ms)
+                     : kp.n_frames >= 32768 ? 1 : kp.n_frames > 6144 ? 4 : 8;
+    if (const char *ev = getenv("DVBS2HIP_NAT_PARTS")) { const int v = atoi(ev); if (v == 1 || v == 4 || v == 8 || ((v == 88 || v == 44 || v == 82 || v == 81 || v == 48 || v == 41) && clean)) parts = v; }
+    // (two digits: checks side by side, waves per workgroup -- 88 and 44 are the forms above, whose rows hold 32 frames; 82 = <8, 2> and 41 = <4, 1>: rows of 16 frames, twice the workgroups; 81 = <8, 1>: rows of 8; 48 = <4, 4>: rows of 64)
+#define NAT_CK_CASE(code, CKv, WVv) \
+    if (parts == code) { \
+        if (pl.fast_deg == 27) return nat_ck_launch<27, CKv, WVv>(pl, p, s); \
+        if (pl.fast_deg == 13) return nat_ck_launch<13, CKv, WVv>(pl, p, s); \
+        return nat_ck_launch<11, CKv, WVv>(pl, p, s); \
     }
-    if (parts == 44) {
-        if (pl.fast_deg == 27) return nat_ck_launch<27, 4, 2>(pl, p, s);
-        if (pl.fast_deg == 13) return nat_ck_launch<13, 4, 2>(pl, p, s);
-        return nat_ck_launch<11, 4, 2>(pl, p, s);
-    }
+    NAT_CK_CASE(88, 8, 4) NAT_CK_CASE(44, 4, 2) NAT_CK_CASE(82, 8, 2) NAT_CK_CASE(81, 8, 1) NAT_CK_CASE(48, 4, 4) NAT_CK_CASE(41, 4, 1)
+#undef NAT_CK_CASE
     if (parts > 1) {
         if (pl.fast_deg == 27) return parts == 4 ? nat_part_launch<27, 4>(pl, p, s) : nat_part_launch<27, 8>(pl, p, s);
         if (pl.fast_deg == 13) return parts == 4 ? nat_part_launch<13, 4>(pl, p, s) : nat_part_launch<13, 8>(pl, p, s);

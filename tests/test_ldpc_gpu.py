@@ -202,13 +202,13 @@ NAT_CASES = [("QPSK-S_8/9", 4.4, 5), ("QPSK-S_8/9", 3.2, 70), ("QPSK-S_3/5", 1.2
 
 @pytest.mark.parametrize("modcod,ebn0,F", NAT_CASES)
 @pytest.mark.parametrize("early", [False, True])
-@pytest.mark.parametrize("parts", [1, 4, 8, 88, 44])
+@pytest.mark.parametrize("parts", [1, 4, 8, 88, 44, 82, 81, 41, 48])
 def test_ldpc_natural_order_matches_oracle(O, Rx, monkeypatch, modcod, ebn0, F, early, parts):
     """dvbs2hip_set_ldpc_schedule(NATURAL): the reference's sweep order (checks in row order) against the oracle's ORC_SCHED_NATURAL -- hard decisions, iteration
     counts and posteriors bit for bit -- in its forms: one lane per frame (64 frames per wave), a check's edges split over 4 / 8 adjacent lanes (16 / 8 frames per
     wave: the merged minima, the sign word and the forwarded parity posterior come from exchanges inside the wave), and 8 / 4 CONSECUTIVE checks of a frame in adjacent
-    lanes (88 / 44: the parity chain as a scan over the lanes, four / two waves per workgroup sharing the image's rows; the default); more frames than one wave or
-    workgroup holds, a ragged last group."""
+    lanes (two digits = checks side by side, waves per workgroup: the parity chain as a scan over the lanes, the waves of a workgroup sharing the image's rows of 8 to 64 frames;
+    82 is the default up to 16 frames per CU, 44 beyond); more frames than one wave or workgroup holds, a ragged last group."""
     from dvbs2_amd import lib_binding as B
     monkeypatch.setenv("DVBS2HIP_NAT_PARTS", str(parts))
     ch = chain(O, modcod)

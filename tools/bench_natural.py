@@ -3,7 +3,8 @@ sys.path.insert(0, "/root/repo")
 from dvbs2_amd.receiver import Dvbs2Hip
 from dvbs2_amd import lib_binding as B
 dev = torch.device("cuda", 0)
-for modcod, F in (("QPSK-N_8/9", 4096), ("QPSK-N_8/9", 32768), ("QPSK-S_8/9", 65024)):
+cases = [("QPSK-S_8/9", int(a[1:])) if a[0] == "S" else ("QPSK-N_8/9", int(a)) for a in sys.argv[1:]] or [("QPSK-N_8/9", 4096), ("QPSK-N_8/9", 32768), ("QPSK-S_8/9", 65024)]      # usage: python tools/bench_natural.py [normal-frame counts | S<short-frame count> ..]
+for modcod, F in cases:
     rx = Dvbs2Hip(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=False)
     N, K = rx.N_ldpc, rx.K_ldpc
     llr = (2.0 * (1.0 + 0.35 * torch.randn((F, N), device=dev, dtype=torch.float32)) / 0.35 ** 2)
