@@ -129,6 +129,13 @@ struct LdpcPlan {             // host-side description, built once per handle
 constexpr int LDPC_PROF_WORDS = 1024 * 64;   // development aid (LDPC_PHASE_PROF builds): per-wave phase timers
 constexpr int LDPC_CU_CTR_WORDS = 4096 + 64;   // [0, 4096): arrivals per CU, key = XCC_ID << 8 | SE_ID << 5 | SH_ID << 4 | CU_ID; [4096]: frames handed out (work queue)
 constexpr int LDPC_FRAME_CTR = 4096;
+#ifndef LDPC_SPA_AT16
+#define LDPC_SPA_AT16 1      // sum-product layer, LDS-only image: the slots' LDS addresses from a per-lane table of 16-bit entries (k_ldpc.hip plan, k_ldpc_wg8.hip W8_SPA_AT16) ...
+#endif
+#ifndef LDPC_SPA_AT16_MAXDEG
+#define LDPC_SPA_AT16_MAXDEG 13      // ... for the 11- and 13-slot codes only (QPSK-S 3/5: 14.33 -> 13.47 ms per 16384 frames).  The 27-slot layer runs at the 128-register budget of two workgroups
+#endif                               // per CU: the 14 registers that carry the table do not exist there (23 / 19 / 8 spilled registers with suffix values every 3rd / 4th / 6th slot: QPSK-S 8/9
+                                     // 9.63 -> 13.0 / 11.9 / 11.2 ms, docs/negative_results.md)
 constexpr int LDPC_AT_LANES = 384;      // lanes per row of the address table (6 waves; lanes 360 .. 383 hold the junk row / an offset that is dropped)
 constexpr int LDPC_FAST_STRIDE = 64;   // dwords per layer: 27 entries | prim mask | conflict info | conflict entries 0, 1 | slots with a duplicate edge | 16 conf entries | 16 conf meta
 constexpr int LDPC_FAST_MAXC = 16;

@@ -560,6 +560,32 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                         }
                 }
             }
+            if (spa && !cu1 && pl.fast_mode == 0 && LDPC_SPA_AT16 && pl.fast_deg <= LDPC_SPA_AT16_MAXDEG) {
+                // (round 5) per-lane address table of the SUM-PRODUCT layer on the LDS-only image (k_ldpc_wg8.hip, W8_SPA_AT16): two 16-bit LDS byte addresses per dword (slot 2 k in the low
+                // half), [q][pieces of 16 bytes][LDPC_AT_LANES][4] -- the image's 45 rows end at byte 64800, so every address of a real slot fits; a NULL slot reads the +inf WORD the
+                // kernel keeps at junk row + 4 (the +inf row itself lies beyond 64 KB; the junk row is written at its word 0 only in this form), and the slot of check 0's absent
+                // p_{c-1} points at the junk row's word 0 (its value is replaced by +inf, its store lands there)
+                const int ND = (pl.fast_deg + 1) / 2, NP = (ND + 3) / 4;
+                const uint32_t junk = (uint32_t)(w8_lrows * LDPC_Z * 4), infw = junk + 4u, inf_row = (uint32_t)((w8_lrows + 1) * LDPC_Z * 4);
+                bool fits = junk + 8u <= 65536u;
+                pl.w8_atab.assign((size_t)q * NP * LDPC_AT_LANES * 4, 0u);
+                for (int r = 0; r < q && fits; r++) {
+                    const uint32_t *T8 = &pl.w8_tab[(size_t)r * LDPC_FAST_STRIDE];
+                    for (int j = 0; j < pl.fast_deg; j++)
+                        for (int t = 0; t < LDPC_AT_LANES; t++) {
+                            const uint32_t e = T8[j], shift = e & 0x7FFu, base = (e >> 11) & 0x3FFFFu;
+                            uint32_t v = junk;                                                   // idle lanes: never accessed (`act`)
+                            if (t < LDPC_Z) {
+                                if (base == inf_row) v = infw;
+                                else if (j == pl.fast_deg - 1 && r == 0 && t == 0) v = junk;
+                                else v = ((uint32_t)t * 4u + (uint32_t)LDPC_Z * 4u - shift) % ((uint32_t)LDPC_Z * 4u) + base;
+                            }
+                            if (v >= 65536u) fits = false;
+                            pl.w8_atab[(((size_t)r * NP + (j / 2) / 4) * LDPC_AT_LANES + t) * 4 + ((j / 2) & 3)] |= v << (16 * (j & 1));
+                        }
+                }
+                if (!fits) return PLAN_RETRY_GENERIC;      // (no DVB-S2 code: an LDS-only image is 45 rows)
+            }
             {   // image rows in storage order: LDS rows then global rows (bit-groups ascend inside each: info first)
                 std::vector<int> lrow, grow;
                 for (int g = 0; g < pl.n_groups; g++) ((pl.fast_mode == 0 || (hyb && glds[g])) ? lrow : grow).push_back(g);

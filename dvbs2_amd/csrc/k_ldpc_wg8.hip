@@ -105,6 +105,9 @@ __host__ __device__ __forceinline__ constexpr bool w8_slot_lds(int mode, int j) 
 #ifndef W8_FAST_OUT       // output loops of their own for the bits socket alone and for the fused chain (buffer descriptors per frame, scalar descrambling)
 #define W8_FAST_OUT 1
 #endif
+#ifndef W8_SPA_AT16        // sum-product layer, LDS-only image, the 11- and 13-slot codes: the slots' LDS addresses come from a per-lane table of 16-bit entries (two per register) instead of
+#define W8_SPA_AT16 LDPC_SPA_AT16      // being formed on the vector ALU (4 instructions per edge, two of them with an SGPR operand); the 27-slot layer has no registers for it (dvbs2hip_internal.h)
+#endif
 #ifndef W8_SPA_ANYKEY      // sum-product layer: the overflow rule behind a wave-uniform branch per slot (k_ldpc_cu1.hip has it): same-box A/B here QPSK-S 8/9 1697 -> 1654 k,
 #define W8_SPA_ANYKEY 0      // 3/5 1178 -> 1151 k frames/s -- 27 scalar branches per layer cut the unrolled slot loop into scheduling regions; off
 #endif
@@ -404,7 +407,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
     const uint32_t grow0 = 2u * W8_ROW;                      // global image: [junk row][+inf row][group rows ..]
     // (LDS-only image only: on the hybrid image of the normal frames the table's loads queue behind the global rows' and the kernel is 19 % SLOWER, 6.73 against 5.65 ms)
     constexpr bool ATAB = W8_ATAB && !SPA && (MODE == 0 || (W8_ATAB_HYB && w8_hybrid(MODE)));
-    const __amdgpu_buffer_rsrc_t rs_at = __builtin_amdgcn_make_buffer_rsrc((void *)(ATAB ? p.w8.atab : (const uint32_t *)p.w8.tab), 0, ATAB ? p.q * ((DEG + 3) / 4) * (LDPC_AT_LANES * 16) : 0, 0x00020000);
+    constexpr bool AT16 = W8_SPA_AT16 && SPA && MODE == 0 && DEG <= LDPC_SPA_AT16_MAXDEG;      // (the plan builds the table for exactly this case: k_ldpc.hip, LDPC_SPA_AT16)
+    constexpr int ND16 = (DEG + 1) / 2, NP16 = (ND16 + 3) / 4;
+    const __amdgpu_buffer_rsrc_t rs_at = __builtin_amdgcn_make_buffer_rsrc((void *)((ATAB || AT16) ? p.w8.atab : (const uint32_t *)p.w8.tab), 0, ATAB ? p.q * ((DEG + 3) / 4) * (LDPC_AT_LANES * 16) : AT16 ? p.q * NP16 * (LDPC_AT_LANES * 16) : 0, 0x00020000);
     const uint32_t at_vo = (uint32_t)(role >= 0 ? t : 0) * 16u;
     constexpr bool FWD = w8_hybrid(MODE);                    // parity chain forwarded in a register (plan: p_c at slot DEG-2, p_{c-1} at DEG-1, both global)
 #ifdef LDPC_PHASE_PROF
@@ -501,6 +506,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
             // the c->v state is NOT zeroed: a layer's state is first read one iteration after it was first written, and the
             // reads of the first iteration are replaced by zeros where they happen (nx* / dl[] below)
             if (p.w8.pad) { if (MODE == 0) lst(ljunk + W8_ROW + t4, INFINITY); else gst(t4, W8_ROW, INFINITY); }     // what NULL slots read
+            if (AT16 && t == 0) lst(ljunk + 4u, INFINITY);      // ... through the 16-bit address table: one word inside the first 64 KB (the junk row is written at its word 0 only)
         }
         if (p.packed && (SPA ? wave == 0 && lio == 0 : threadIdx.x == 0) && (p.K & 31)) p.packed[(size_t)f * ((p.K + 31) / 32) + p.K / 32] = 0u;     // the bits behind K in the last word
         __builtin_amdgcn_s_setprio(0);
@@ -541,6 +547,24 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #pragma unroll
         for (int j = 0; j < 4 * NW4; j++) w[j] = 0u;
         if (ATAB && role >= 0) at_request(0);
+        uint32_t w16[AT16 ? 4 * NP16 : 1];          // (sum-product, LDS-only image) the 16-bit addresses of the current layer's slots, two per register; the next layer's once this one's stores are out
+        auto at16_request = [&](int rl) __attribute__((always_inline)) {
+            typedef uint32_t at_u32x4 __attribute__((ext_vector_type(4)));
+            typedef uint32_t at_u32x3 __attribute__((ext_vector_type(3)));
+            typedef uint32_t at_u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int g4 = 0; g4 < NP16; g4++) {
+                const uint32_t so = (uint32_t)((rl * NP16 + g4) * (LDPC_AT_LANES * 16));
+                const int left = ND16 - 4 * g4;
+                if (left >= 4) { const at_u32x4 q4 = __builtin_amdgcn_raw_buffer_load_b128(rs_at, at_vo, so, 0); w16[4 * g4] = q4.x; w16[4 * g4 + 1] = q4.y; w16[4 * g4 + 2] = q4.z; w16[4 * g4 + 3] = q4.w; }
+                else if (left == 3) { const at_u32x3 q3 = __builtin_amdgcn_raw_buffer_load_b96(rs_at, at_vo, so, 0); w16[4 * g4] = q3.x; w16[4 * g4 + 1] = q3.y; w16[4 * g4 + 2] = q3.z; }
+                else if (left == 2) { const at_u32x2 q2 = __builtin_amdgcn_raw_buffer_load_b64(rs_at, at_vo, so, 0); w16[4 * g4] = q2.x; w16[4 * g4 + 1] = q2.y; }
+                else w16[4 * g4] = __builtin_amdgcn_raw_buffer_load_b32(rs_at, at_vo, so, 0);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < (AT16 ? 4 * NP16 : 1); j++) w16[j] = 0u;
+        if (AT16 && role >= 0) at16_request(0);
         while (it < p.n_ite) {
             for (int r = 0; r < q; r++) {
                 const const_u32 T = tab + r * LDPC_FAST_STRIDE;
@@ -572,6 +596,11 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     asm volatile("" : "+s"(MAGM));                // the magnitude mask as an SGPR operand (VOP3 takes no literal)
                     auto woff = [&](int j) __attribute__((always_inline)) { const uint32_t d = t4 - (E[j] & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
                     auto woff_s = [&](int j) __attribute__((always_inline)) { const uint32_t d = t4s - (E[j] & 0x7FFu); return min(d, d + (uint32_t)W8_ROW); };
+                    // (round 5, LDS-only image) ... or read from the per-lane table: slot j's LDS address is one half of a register (a v_and with 0xFFFF or a shift by 16)
+                    uint32_t M16 = 0xFFFFu;
+                    asm volatile("" : "+v"(M16));                 // in a vector register: the plain two-register v_and_b32 issues every 2.07 cycles, with a literal 2.6, with an SGPR 4.25
+                    auto a16 = [&](int j) __attribute__((always_inline)) -> uint32_t { const uint32_t wv = w16[AT16 ? j / 2 : 0]; return (j & 1) ? wv >> 16 : wv & M16; };
+                    constexpr int KDS = ldpc_w8_kd(DEG);          // (plan contract, LDS-only image: from this slot on every slot is a primary edge)
                     auto dup_slot = [&](int i) __attribute__((always_inline)) -> uint32_t { return i == 0 ? (cinfo >> 8) & 31u : i == 1 ? (cinfo >> 16) & 31u : T[48 + i] & 31u; };
                     // suffix values are kept for every BS-th slot only and rebuilt from there on the way forward (one or two steps off the
                     // critical path): the full array does not fit the 128-VGPR budget of two workgroups per CU beside x[] and u[]
@@ -592,6 +621,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         __builtin_amdgcn_s_setprio(3);            // as in the min-sum layer: load issue first, the long arithmetic last ((3, 1) / (2, 1) in and behind pass 2 instead of (2, 0): within 0.4 %)
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
+                            if (AT16) { x[j] = lld(a16(j)); continue; }
                             const uint32_t base = (E[j] >> 11) & 0x3FFFFu, wj = woff(j);
                             if (FWD && j == DEG - 1 && r > 0) x[j] = pfw;                  // p_{c-1}: handed over by layer r - 1
                             else x[j] = w8_slot_lds(MODE, j) ? lld(wj + base) : gld(wj, base);
@@ -652,6 +682,10 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         const bool anykey = __ballot(key == key) != 0ull;      // (NaN stands for "no overflow in this check")
                         float mq[4] = {0.f, 0.f, 0.f, 0.f};
                         if (DEG > 13) asm volatile("" : "+v"(t4s));      // (the short codes keep their offsets: 70 registers in all)
+                        if (AT16 && DEG > 13) {      // (the halves are taken apart again for the stores: 27 addresses kept across the arithmetic do not fit)
+#pragma unroll
+                            for (int k = 0; k < ND16; k++) asm volatile("" : "+v"(w16[k]));
+                        }
                         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
@@ -679,6 +713,11 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(nw) : "s"(MAGM), "v"(o), "v"(sx ^ __float_as_uint(x[j])));
                             A = __builtin_fmaf(u[j], wA, A);
                             const bool pr = ((prim >> j) & 1u) != 0u;
+                            if (AT16) {
+                                // the table's address is where the value came from (check 0's absent p_{c-1}: the junk row's word 0); a duplicate edge's or a NULL slot's plain store
+                                // (redirected to the junk row in the other form) is left out -- those are the first slots only
+                                if (j >= KDS || pr) lst(a16(j), x[j] + nw);
+                            } else {
                             const uint32_t base = (E[j] >> 11) & 0x3FFFFu, wj = woff_s(j);
                             if (w8_slot_lds(MODE, j)) {
                                 uint32_t a = wj + (pr ? base : ljunk);
@@ -690,6 +729,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                                 if (FWD && j == DEG - 2 && r + 1 < q) pfw = x[j] + nw;      // p_c: kept for layer r + 1
                                 else if (SPA_ABL & 4) asm volatile("" :: "v"(x[j] + nw), "v"(vo), "s"(sb));
                                 else gst(vo, sb, x[j] + nw);
+                            }
                             }
 #if SPA_MSG4
                             mq[j & 3] = nw;                     // four slots' messages leave as one 16-byte piece (the last group: what is left)
@@ -712,6 +752,10 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #pragma unroll
                                 for (int i = 0; i < LDPC_SPA_MAXC; i++) if (i < ncf && dup_slot(i) == (uint32_t)j) od[i] = nw - od[i];
                             }
+                        }
+                        if (AT16) {      // the next layer's addresses: this layer's stores have read theirs; they travel under the replay and the end barrier
+                            __builtin_amdgcn_sched_barrier(0);
+                            at16_request(r + 1 < q ? r + 1 : 0);
                         }
 #if SPA_PREFETCH
                         // the messages of the next layer do not depend on this one: their loads (HBM misses, the message store is

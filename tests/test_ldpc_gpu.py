@@ -368,13 +368,14 @@ def test_ldpc_normal_frame_image_modes_agree_with_the_oracle(O, Rx, monkeypatch,
         rx.close()
 
 
-@pytest.mark.parametrize("modcod,F", [("QPSK-N_8/9", 1100), ("QPSK-S_8/9", 2600)])
-def test_ldpc_spa_at_size_matches_oracle(O, Rx, modcod, F):
+@pytest.mark.parametrize("modcod,F,dbs", [("QPSK-N_8/9", 1100, (3.2, 4.4)), ("QPSK-S_8/9", 2600, (3.2, 4.4)),
+                                           ("QPSK-S_3/5", 1300, (0.8, 2.8)), ("32APSK-S_3/4", 1100, (2.4, 3.8))])      # (the last two: the 11- / 13-slot layers with the 16-bit address table)
+def test_ldpc_spa_at_size_matches_oracle(O, Rx, modcod, F, dbs):
     """The reference's default decoder (--dec-implem SPA) with more frames than the persistent grid holds: the per-edge message store
     of a workgroup is reused frame after frame (its first-iteration reads are replaced by zeros, like the packed state of the NMS
-    kernel).  Two fixed iterations at 3.2 / 4.4 dB: posteriors of the last 6 frames and 6 random ones within the SPA bar of the oracle
+    kernel).  Two fixed iterations at two Eb/N0 (3.2 / 4.4 dB for rate 8/9): posteriors of the last 6 frames and 6 random ones within the SPA bar of the oracle
     (1e-4 max(1, |L|)); then the converging half with the early stop: hard decisions = the sent word."""
-    ch, sent, llr = _big_batch(O, modcod, F, (3.2, 4.4), seed=77, n_cw=4)
+    ch, sent, llr = _big_batch(O, modcod, F, dbs, seed=77, n_cw=4)
     rng = np.random.default_rng(6)
     pick = np.unique(np.concatenate([np.arange(F - 6, F), rng.choice(F - 6, 6, replace=False)]))
     rx = Rx(modcod, max_frames=F, n_ite=2, early_stop=False, implem="SPA")
