@@ -129,6 +129,9 @@ struct LdpcPlan {             // host-side description, built once per handle
 constexpr int LDPC_PROF_WORDS = 1024 * 64;   // development aid (LDPC_PHASE_PROF builds): per-wave phase timers
 constexpr int LDPC_CU_CTR_WORDS = 4096 + 64;   // [0, 4096): arrivals per CU, key = XCC_ID << 8 | SE_ID << 5 | SH_ID << 4 | CU_ID; [4096]: frames handed out (work queue)
 constexpr int LDPC_FRAME_CTR = 4096;
+#ifndef LDPC_ATAB_HYB
+#define LDPC_ATAB_HYB 0          // the min-sum layer's per-lane address table for the LDS slots of the hybrid images too (k_ldpc_wg8.hip W8_ATAB_HYB: measured and left off); 0: the plan builds
+#endif                           // and uploads the table for the LDS-only image alone (0.9-6 MB per handle that no normal-frame kernel reads)
 #ifndef LDPC_SPA_AT16
 #define LDPC_SPA_AT16 1      // sum-product layer, LDS-only image: the slots' LDS addresses from a per-lane table of 16-bit entries (k_ldpc.hip plan, k_ldpc_wg8.hip W8_SPA_AT16) ...
 #endif

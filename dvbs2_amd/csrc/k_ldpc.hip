@@ -542,7 +542,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 if (nc > 0 && (T8[48] >> 8) != 1u) return "LDPC: internal: first conflict entry is not of level 1";
                 if (pl.fast_mode == 0 || spa || cu1) for (int i = 0; i < nc; i++) if ((T8[48 + i] & 31u) != (uint32_t)i) return "LDPC: internal: conflict entry i is not slot i";
             }
-            if (!spa && !cu1) {      // per-lane address table of the min-sum layer (k_ldpc_wg8.hip, W8_ATAB: every slot of the LDS-only image; -DW8_ATAB_HYB: the LDS slots of the hybrid images)
+            if (!spa && !cu1 && (pl.fast_mode == 0 || LDPC_ATAB_HYB)) {      // per-lane address table of the min-sum layer (k_ldpc_wg8.hip, W8_ATAB: every slot of the LDS-only image; -DW8_ATAB_HYB: the LDS slots of the hybrid images)
                 const int NW4 = (pl.fast_deg + 3) / 4;
                 pl.w8_atab.assign((size_t)q * NW4 * LDPC_AT_LANES * 4, 0u);
                 for (int r = 0; r < q; r++) {

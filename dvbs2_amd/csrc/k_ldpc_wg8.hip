@@ -97,7 +97,7 @@ __host__ __device__ __forceinline__ constexpr bool w8_slot_lds(int mode, int j) 
 #endif
 #ifndef W8_ATAB_HYB       // the table for the LDS slots of the hybrid images too: measured and left off (docs/negative_results.md: 2 % slower with the request in front of the global stores, 19 % behind them --
                           // the table's loads share the fabric the image's global rows already keep 0.64 busy)
-#define W8_ATAB_HYB 0
+#define W8_ATAB_HYB LDPC_ATAB_HYB      // (dvbs2hip_internal.h: the plan builds the table for the hybrid images only with this set)
 #endif
 #ifndef W8_DELTA_REG      // LDS-only image: new - old of the duplicate-edge slots kept from the passes instead of rebuilt behind the barrier
 #define W8_DELTA_REG 1
@@ -805,6 +805,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
                 // (LDS-only image only.  On the hybrid images -- global slots' loads first, LDS slots' behind them, barrier once the LDS data are back -- it is 2.5-5.7 % SLOWER, same-box
                 // A/B 5.94-6.04 against 5.62-5.70 ms: a barrier at the layer's start keeps the waves in phase, and in-phase waves want the issue port at the same moment)
                 constexpr bool EARLY_B1 = W8_EARLY_B1 && MODE == 0;
+                // (the early barrier is an s_barrier inside the block of the active lanes, matched by a hand-written one for the waves without checks: every WORKING wave has to have
+                //  an active lane -- a wave whose lanes are all idle would skip the block, and the barrier with it)
+                static_assert(LDPC_Z > 64 * 5 && LDPC_Z <= 64 * 6, "six working waves, the last one with active lanes (W8_EARLY_B1's barrier sits inside `if (act)`)");
                 constexpr bool ABSF = W8_ABS_FOLD && MODE == 0, SGNA = W8_SIGN_ADD && MODE == 0;
                 constexpr int KD = MODE == 0 ? ldpc_w8_kd(DEG) : DEG;       // LDS-only image: duplicate edges sit in slots < KD (plan), the others are primary
                 // (round 4) LDS-only image: conflict entry i is slot i < KDD (plan), so what a duplicate edge adds in the replay, new - old message, is kept from the passes
