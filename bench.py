@@ -402,7 +402,7 @@ def _chain_bytes(rx, n_ite):
 
 def _chain_config(Dvbs2Hip, torch, B, modcod, n_ite, ebn0, F, dev, local_rank, rank, rx=None, reps=5):
     """BASELINE configs[2] / [3] on one GPU: the fused RX chain (a7 a6 a3 a4 a1 a2 a8: PL frames of the on-device TX mirror -> information
-    bits), fixed iterations like `value`; wall time per call over `reps` back-to-back calls, and the LDPC kernel's share from hipEvents."""
+    bits), fixed iterations like `value`; wall time per call over `reps` back-to-back calls, and the LDPC kernel's share from hipEvents (the same calls once more with the timers on)."""
     from dvbs2_amd import params as P
     mc = P.get_modcod(modcod)
     own = rx is None
@@ -417,12 +417,15 @@ def _chain_config(Dvbs2Hip, torch, B, modcod, n_ite, ebn0, F, dev, local_rank, r
     def once():
         rx.rx_bb_dev(pl.data_ptr(), sg, got.data_ptr(), None, None, F)
     once(); once(); rx.synchronize()
-    rx.timing_enable(True); rx.timing_reset()
-    t = time.perf_counter()
+    t = time.perf_counter()             # (the library's per-kernel timers stay off in the timed calls: two hipEvents per kernel are ~10 us of idle stream each, tools/r05_chain_trace.sh)
     for _ in range(reps):
         once()
     rx.synchronize()
     dt = (time.perf_counter() - t) / reps
+    rx.timing_enable(True); rx.timing_reset()
+    for _ in range(reps):
+        once()
+    rx.synchronize()
     k_ms, k_n = rx.timing_get(B.K_LDPC)
     rx.timing_enable(False)
     nb = _chain_bytes(rx, n_ite)
