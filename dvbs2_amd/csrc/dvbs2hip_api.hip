@@ -49,6 +49,8 @@ struct dvbs2hip_handle {
     float *d_taps_rev = nullptr;
     uint16_t *d_fir_afrag = nullptr, *d_upfir_afrag = nullptr;       // Toeplitz fragments of the split taps for the matrix-core FIR (T <= 81)
     float *d_hist[2] = {nullptr, nullptr};
+    void *d_hist_all = nullptr;      // one allocation behind d_hist[] and d_uphist[]
+    size_t hist_stride = 0;
     int hist_cur = 0;
     float *d_taps = nullptr;            // natural order (shaping filter)
     float *d_uphist[2] = {nullptr, nullptr};
@@ -565,13 +567,17 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
             if (upload(h, &h->d_fir_afrag, af.data(), af.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
         }
         const size_t hb = sizeof(float) * 2 * (size_t)(h->fir_T > 1 ? h->fir_T - 1 : 1);
-        for (int i = 0; i < 2; i++) { CREATE_HIP(hipMalloc((void **)&h->d_hist[i], hb)); CREATE_HIP(hipMemset(h->d_hist[i], 0, hb)); }
+        // the four history buffers in ONE allocation, [hist 0 | uphist 0 | hist 1 | uphist 1]: dvbs2hip_filter_reset is then one memset of the first two (it makes them the current
+        // ones) instead of four fill kernels -- ~50 us of the 250 us a one-frame call sequence takes (tools/r05_latency_trace.sh)
+        h->hist_stride = (hb + 255) / 256 * 256;
+        CREATE_HIP(hipMalloc((void **)&h->d_hist_all, 4 * h->hist_stride));
+        CREATE_HIP(hipMemset(h->d_hist_all, 0, 4 * h->hist_stride));
+        for (int i = 0; i < 2; i++) { h->d_hist[i] = (float *)((char *)h->d_hist_all + (size_t)(2 * i) * h->hist_stride); h->d_uphist[i] = (float *)((char *)h->d_hist_all + (size_t)(2 * i + 1) * h->hist_stride); }
         if (upload(h, &h->d_taps, cfg->fir_taps, (size_t)h->fir_T)) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
         if (h->fir_osf == 2) {
             const std::vector<uint16_t> af2 = upfir_mfma_afrag(cfg->fir_taps, h->fir_T);
             if (!af2.empty() && upload(h, &h->d_upfir_afrag, af2.data(), af2.size())) CREATE_FAIL(DVBS2HIP_EHIP, h->err);
         }
-        for (int i = 0; i < 2; i++) { CREATE_HIP(hipMalloc((void **)&h->d_uphist[i], hb)); CREATE_HIP(hipMemset(h->d_uphist[i], 0, hb)); }
     }
     CREATE_HIP(hipMalloc((void **)&h->d_ctr, 3 * sizeof(unsigned long long)));
     CREATE_HIP(hipMemset(h->d_ctr, 0, 3 * sizeof(unsigned long long)));
@@ -600,7 +606,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     if (h->lr_err_host) (void)hipHostFree(h->lr_err_host);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_atab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
-                    h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist[0], h->d_hist[1], h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_syn_pos, h->d_prbs_s, h->d_taps, h->d_uphist[0], h->d_uphist[1]};
+                    h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist_all, h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_syn_pos, h->d_prbs_s, h->d_taps};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1022,11 +1028,10 @@ int dvbs2hip_filter2(dvbs2hip_t *h, const float *X, const float *Yh, float *Y, i
 int dvbs2hip_filter_reset(dvbs2hip_t *h)
 {
     int r0 = enter(h); if (r0) return r0;
-    if (h->fir_T > 1)
-        for (int i = 0; i < 2; i++) {
-            HIPCHK(h, hipMemsetAsync(h->d_hist[i], 0, sizeof(float) * 2 * (h->fir_T - 1), h->stream));
-            HIPCHK(h, hipMemsetAsync(h->d_uphist[i], 0, sizeof(float) * 2 * (h->fir_T - 1), h->stream));
-        }
+    if (h->fir_T > 1 && h->d_hist_all) {      // buffers 0 become the current ones, zeroed by one memset (they are adjacent); buffers 1 are written before they are read
+        HIPCHK(h, hipMemsetAsync(h->d_hist_all, 0, 2 * h->hist_stride, h->stream));
+        h->hist_cur = 0; h->uphist_cur = 0;
+    }
     return 0;
 }
 

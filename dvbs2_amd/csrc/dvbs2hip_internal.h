@@ -221,6 +221,7 @@ struct FrontKParams {
     const float *cstl;      // normalised constellation, 2^bps points
     const uint8_t *pl_seq;  // PL scrambling sequence R(i), 66420 entries
     int32_t n_sym, pl_frame, bps, itl_cols, itl_order, n_frames;
+    int32_t slice_chunk;    // front_kernel: symbols per workgroup when a frame is dealt to several (blockIdx.y), 0 = the whole frame (set by the launcher: small batches)
     float code_rate;
     // separable 2-bit constellation (plan time): L_b = c (y[sep_ax[b]] * sep_g[b] + sep_h[b]); sep = 0: general demapper
     int32_t sep, sep_ax[2];

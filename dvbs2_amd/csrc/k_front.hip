@@ -297,12 +297,12 @@ front_kernel(const FrontKParams p)
         m4 = block_sum(m4, red);
         float ebn0, esn0;
         m2m4_finish(m2, m4, n_sym, p.code_rate, p.bps, sigma, ebn0, esn0);
-        if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = ebn0; p.est[3 * f + 2] = esn0; }
+        if (tid == 0 && p.est && blockIdx.y == 0) { p.est[3 * f] = sigma; p.est[3 * f + 1] = ebn0; p.est[3 * f + 2] = esn0; }
     } else {
         if (tid == 0) s_sigma = p.sigma_in[f];
         __syncthreads();
         sigma = s_sigma;
-        if (tid == 0 && p.est) { p.est[3 * f] = sigma; p.est[3 * f + 1] = 0.f; p.est[3 * f + 2] = 0.f; }
+        if (tid == 0 && p.est && blockIdx.y == 0) { p.est[3 * f] = sigma; p.est[3 * f + 1] = 0.f; p.est[3 * f + 2] = 0.f; }
     }
     const float inv2s2 = 1.0f / (2.0f * sigma * sigma);
     if (tid < (1 << BPS)) tab[tid] = demap_table_entry(p.cstl, tid, inv2s2);
@@ -335,8 +335,11 @@ front_kernel(const FrontKParams p)
             }
         }
     };
-    fetch(tid);
-    for (int k0 = tid; k0 < n_sym; k0 += U * FRONT_THREADS) {
+    // (round 5) small batches: a frame's symbols are dealt to gridDim.y workgroups in pieces of slice_chunk (a multiple of what a workgroup takes per trip), every one of which forms
+    // sigma from the whole frame for itself -- one workgroup walking a short 32APSK frame alone was 42 us of the 250 us a one-frame call sequence takes (tools/r05_latency_trace.sh)
+    const int k_lo = p.slice_chunk ? (int)blockIdx.y * p.slice_chunk : 0, k_hi = p.slice_chunk ? min(n_sym, k_lo + p.slice_chunk) : n_sym;
+    fetch(k_lo + tid);
+    for (int k0 = k_lo + tid; k0 < k_hi; k0 += U * FRONT_THREADS) {
         float2 y[U];
 #pragma unroll
         for (int i = 0; i < U; i++) y[i] = FROM_PL ? pl_derotate(yn[i], Rn[i]) : yn[i];
@@ -553,9 +556,18 @@ static bool front_reg_try(const FrontKParams &p, hipStream_t s)
 }
 
 template <bool FROM_PL, bool DEITL>
-static hipError_t front_dispatch(const FrontKParams &p, hipStream_t s)
+static hipError_t front_dispatch(const FrontKParams &p_in, hipStream_t s)
 {
+    FrontKParams p = p_in;
+    p.slice_chunk = 0;
     dim3 g(p.n_frames), b(FRONT_THREADS);
+    if (p.n_frames < 512) {      // fewer workgroups than the chip holds: several per frame
+        const int trip = (p.bps <= 3 ? 4 : FRONT_U_APSK) * FRONT_THREADS;      // symbols a workgroup takes per trip of its loop (front_kernel's U)
+        int slices = (p.n_sym + trip - 1) / trip;
+        const int cap = 1024 / p.n_frames;
+        if (slices > cap) slices = cap;
+        if (slices > 1) { p.slice_chunk = ((p.n_sym + slices - 1) / slices + trip - 1) / trip * trip; g.y = (unsigned)((p.n_sym + p.slice_chunk - 1) / p.slice_chunk); }
+    }
     switch (p.bps) {
         case 1: hipLaunchKernelGGL((front_kernel<1, FROM_PL, DEITL>), g, b, 0, s, p); break;
         case 2: hipLaunchKernelGGL((front_kernel<2, FROM_PL, DEITL>), g, b, 0, s, p); break;
