@@ -1085,15 +1085,21 @@ hipError_t sync_metric_launch(const float *cor_sof, const float *sofh_in, float 
 // and the last frame (the next call's `yprev`): those are materialized by sync_vdelay_batch_kernel into `scratch` (frame f at scratch + f N), src[f] points there.
 __global__ void sync_locate_kernel(const float *X, float *scratch, const int32_t *__restrict__ Dtab, int n, int nbuff2, int F, int32_t *__restrict__ list, const float **__restrict__ src)
 {
-    // one workgroup; list[0] = count (zeroed by the host side of the launch), list[1 ..] = the frames to materialize in any order, then F (the delay line's state row)
+    // one workgroup; list[0] = count, list[1 ..] = the frames to materialize in any order, then F (the delay line's state row).  The count is kept in LDS while the list is
+    // built (no memset of list[0] in front of the launch: a fill kernel of its own in every call).  (Doing this loop in the last workgroup of sync_finalize_kernel to leave
+    // instead -- one launch less -- was measured: the F arrivals on one counter word cost 25 ns each, 4096 frames 0.100 -> 0.203 ms: docs/negative_results.md)
+    __shared__ int cnt;
     const size_t N = 2 * (size_t)n;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
     for (int f = threadIdx.x; f < F; f += blockDim.x) {
         const int D = Dtab[f];
         const bool run = f > 0 && f < F - 1 && D == Dtab[f - 1] && D <= nbuff2;
         src[f] = run ? X + (size_t)f * N - (size_t)D : scratch + (size_t)f * N;
-        if (!run) list[1 + atomicAdd(&list[0], 1)] = f;
+        if (!run) list[1 + atomicAdd(&cnt, 1)] = f;
     }
-    if (threadIdx.x == 0) list[1 + atomicAdd(&list[0], 1)] = F;
+    __syncthreads();
+    if (threadIdx.x == 0) { list[1 + cnt] = F; list[0] = cnt + 1; }
 }
 
 // all F frames of a call; Dtab (F ints) comes from sync_finalize_kernel; Yprev_new = the last output frame for the next call.  need / src != null: the located form
@@ -1104,8 +1110,6 @@ hipError_t sync_vdelay_launch(const float *X, const float *Yprev, float *Yprev_n
     const int tot = ((nbuff2 > 2 * n ? nbuff2 : 2 * n) + 3) / 4;     // pairs of complex samples
     const int gx = (tot + 256 * VD_SPL - 1) / (256 * VD_SPL);
     if (list) {
-        hipError_t e = hipMemsetAsync(list, 0, sizeof(int32_t), s);
-        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(sync_locate_kernel, dim3(1), dim3(1024), 0, s, X, Y, Dtab, n, nbuff2, F, list, src);
         // rows of the grid share the list's entries: in lock three of them have work (first frame, last frame, state row), while the synchronizer acquires all do
         const int gy = F + 1 < 64 ? F + 1 : 64;
