@@ -35,6 +35,10 @@ def build_parser():
     ap.add_argument("--est-type", default="DVBS2", choices=["DVBS2", "PERFECT"])
     ap.add_argument("--max-frames", type=int, default=10_000_000, help="cap on frames per noise point (all ranks)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--clones", type=int, default=1,
+                    help="clones of the chain per process, each with its own handle, stream and -F frames in flight (the reference's Sequence runs n_threads of them, "
+                         "TX_RX_BB/main.cpp:19,96; host/dvbs2_tx_rx_bb --clones): batches are dealt to them in turn and a clone's counters are read when its turn comes again, "
+                         "so the next clone's kernels fill the CUs that a batch's last frames leave idle under the early stop.  1 = one batch at a time (the loop every committed sweep used)")
     ap.add_argument("--filtered", action="store_true",
                     help="TX shaping filter -> AWGN at the sample rate -> matched filter -> perfect-timing extraction "
                          "(the filtered loop of src/mains/TX_RX/main.cpp with --perfect-sync); the last frame of every batch "
@@ -64,16 +68,38 @@ def run(args, out=sys.stdout):
     mc = P.get_modcod(args.mod_cod)
     F = args.sim_inter_fra
     alpha = 1.0 if args.dec_implem == "MS" else args.dec_alpha
-    rx = Dvbs2Hip(mc.name, max_frames=F, n_ite=args.dec_ite, alpha=alpha, early_stop=not args.no_early_stop, device=local_rank,
-                  implem=args.dec_implem)
-    pl = torch.empty((F, 2 * rx.pl_frame), dtype=torch.float32, device=dev)
-    sent = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev)
-    got = torch.empty((F, rx.K_bch), dtype=torch.int32, device=dev)
-    sig = torch.empty((F,), dtype=torch.float32, device=dev)
+    if not 1 <= args.clones <= 8:
+        raise SystemExit("--clones has to be 1 .. 8")
     osf, delay = 2, 80                       # Shaping_filter.hpp:24-28: osf 2, two group delays of 20 symbols
-    if args.filtered:
-        up = torch.empty((F, 2 * rx.pl_frame * osf), dtype=torch.float32, device=dev)
-        up2 = torch.empty_like(up)
+
+    class Clone:
+        def __init__(self):
+            self.rx = Dvbs2Hip(mc.name, max_frames=F, n_ite=args.dec_ite, alpha=alpha, early_stop=not args.no_early_stop, device=local_rank, implem=args.dec_implem)
+            self.pl = torch.empty((F, 2 * self.rx.pl_frame), dtype=torch.float32, device=dev)
+            self.sent = torch.empty((F, self.rx.K_bch), dtype=torch.int32, device=dev)
+            self.got = torch.empty((F, self.rx.K_bch), dtype=torch.int32, device=dev)
+            self.sig = torch.empty((F,), dtype=torch.float32, device=dev)
+            if args.filtered:
+                self.up = torch.empty((F, 2 * self.rx.pl_frame * osf), dtype=torch.float32, device=dev)
+                self.up2 = torch.empty_like(self.up)
+            self.count, self.busy = [0, 0, 0], False
+
+        def issue(self, seed):
+            rx = self.rx
+            if args.filtered:
+                rx.tx_bb_dev(None, seed, None, self.sent.data_ptr(), self.pl.data_ptr(), F)
+                rx.shape_filter_dev(self.pl.data_ptr(), self.up.data_ptr(), rx.pl_frame, F)
+                rx.add_noise_dev(self.sig.data_ptr(), self.up.data_ptr(), self.up2.data_ptr(), seed, 2 * rx.pl_frame * osf, F)
+                rx.filter_dev(self.up2.data_ptr(), self.up.data_ptr(), rx.pl_frame * osf, F)
+                rx.extract_dev(self.up.data_ptr(), self.pl.data_ptr(), rx.pl_frame, osf, delay, F)
+            else:
+                rx.tx_bb_dev(None, seed, self.sig.data_ptr(), self.sent.data_ptr(), self.pl.data_ptr(), F)
+            rx.rx_bb_dev(self.pl.data_ptr(), self.sig.data_ptr() if args.est_type == "PERFECT" else None, self.got.data_ptr(), None, None, F)
+            rx.check_errors_dev(self.sent.data_ptr(), self.got.data_ptr(), F - 1 if args.filtered else F)
+            self.busy = True
+
+    clones = [Clone() for _ in range(args.clones)]
+    rx = clones[0].rx
     torch.cuda.synchronize()
 
     rows = []
@@ -84,6 +110,8 @@ def run(args, out=sys.stdout):
         print("#    ** LDPC n iterations     = %d" % args.dec_ite, file=out)
         print("#    ** Estimator             = %s" % args.est_type, file=out)
         print("#    ** Frames per batch      = %d x %d" % (F, world), file=out)
+        if args.clones > 1:
+            print("#    ** Clones per process     = %d" % args.clones, file=out)
         print("# ----------|----------||----------|----------|----------|----------|----------||----------|----------", file=out)
         print("#     Es/N0 |    Eb/N0 ||      FRA |       BE |       FE |      BER |      FER ||  SIM_THR |    ET/RT", file=out)
         print("#      (dB) |     (dB) ||          |          |          |          |          ||   (Mb/s) | (hhmmss)", file=out)
@@ -93,25 +121,32 @@ def run(args, out=sys.stdout):
     while ebn0 < args.sim_noise_max - 1e-9:
         esn0 = P.ebn0_to_esn0(ebn0, mc.code_rate, mc.bps)          # main.cpp:142-146
         sigma = P.esn0_to_sigma(esn0)
-        sig.fill_(sigma)
-        rx.monitor_reset()
+        for c in clones:
+            c.sig.fill_(sigma)
+            c.rx.monitor_reset()
+            c.count, c.busy = [0, 0, 0], False
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         tot = [0, 0, 0]
-        while tot[2] < args.max_fe and tot[0] < args.max_frames:
-            seed = (args.seed << 40) + (batch_id << 8) + rank
+
+        def collect(c):
+            # a clone's counters run on the device from the reset above; the stopping rule sees the sum over the clones of what each last reported, reduced over the ranks
+            c.count, c.busy = list(c.rx.monitor_get()), False       # syncs that clone's stream only
+            return reduce_counters([sum(k.count[i] for k in clones) for i in range(3)], dev)      # 24-byte all-reduce
+
+        turn = 0
+        while True:
+            c = clones[turn % len(clones)]
+            turn += 1
+            if c.busy:
+                tot = collect(c)
+            if tot[2] >= args.max_fe or tot[0] >= args.max_frames:
+                break
+            c.issue((args.seed << 40) + (batch_id << 8) + rank)
             batch_id += 1
-            if args.filtered:
-                rx.tx_bb_dev(None, seed, None, sent.data_ptr(), pl.data_ptr(), F)
-                rx.shape_filter_dev(pl.data_ptr(), up.data_ptr(), rx.pl_frame, F)
-                rx.add_noise_dev(sig.data_ptr(), up.data_ptr(), up2.data_ptr(), seed, 2 * rx.pl_frame * osf, F)
-                rx.filter_dev(up2.data_ptr(), up.data_ptr(), rx.pl_frame * osf, F)
-                rx.extract_dev(up.data_ptr(), pl.data_ptr(), rx.pl_frame, osf, delay, F)
-            else:
-                rx.tx_bb_dev(None, seed, sig.data_ptr(), sent.data_ptr(), pl.data_ptr(), F)
-            rx.rx_bb_dev(pl.data_ptr(), sig.data_ptr() if args.est_type == "PERFECT" else None, got.data_ptr(), None, None, F)
-            rx.check_errors_dev(sent.data_ptr(), got.data_ptr(), F - 1 if args.filtered else F)
-            tot = reduce_counters(list(rx.monitor_get()), dev)       # syncs the stream; 24-byte all-reduce
+        for c in clones:                                             # the batches still in flight count (the reference's threads finish theirs)
+            if c.busy:
+                tot = collect(c)
         et = reduce_max(time.perf_counter() - t0, dev)
         fra, be, fe = tot
         row = dict(esn0=esn0, ebn0=ebn0, fra=fra, be=be, fe=fe, ber=be / max(1, fra * mc.K_bch), fer=fe / max(1, fra),
@@ -127,7 +162,8 @@ def run(args, out=sys.stdout):
         if args.json:
             with open(args.json, "w") as fh:
                 json.dump(dict(args=vars(args), n_gpus=world, rows=rows), fh, indent=1)
-    rx.close()
+    for c in clones:
+        c.rx.close()
     return rows
 
 

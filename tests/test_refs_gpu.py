@@ -34,6 +34,24 @@ def test_gpu_spa50_fer_inside_reference_band(ref, ebn0):
     assert abs(r["esn0"] - row["esn0"]) < 0.0051
 
 
+@pytest.mark.parametrize("clones", [2, 3])
+def test_gpu_sim_with_clones_counts_what_one_clone_counts(clones):
+    """--clones C (the reference's Sequence with n_threads clones, TX_RX_BB/main.cpp:19,96): the batches are the same batches -- dealt to C handles in turn -- so the counters after
+    the same number of batches are the one-clone loop's: a run capped at 6 batches (no row reaches 100 frame errors before) gives FRA / BE / FE equal to the one-clone run's."""
+    from dvbs2_amd import sim
+    def run(c):
+        argv = ["--mod-cod", "QPSK-S_8/9", "-m", "3.90", "-M", "3.91", "--dec-implem", "NMS", "--dec-ite", "10", "-F", "1024", "--max-frames", str(6 * 1024), "-e", "1000000",
+                "--clones", str(c)]
+        return sim.run(sim.build_parser().parse_args(argv), out=io.StringIO())[0]
+    one, many = run(1), run(clones)
+    # with C clones the loop stops when the collected total reaches the cap: batches issued = 6 + (C - 1) in flight at that moment, all counted
+    assert one["fra"] == 6 * 1024 and many["fra"] == (6 + clones - 1) * 1024
+    assert many["fe"] >= one["fe"] > 0 and many["be"] >= one["be"]
+    capped = ["--mod-cod", "QPSK-S_8/9", "-m", "3.90", "-M", "3.91", "--dec-implem", "NMS", "--dec-ite", "10", "-F", "1024", "--max-frames", str((6 + clones - 1) * 1024), "-e", "1000000"]
+    same = sim.run(sim.build_parser().parse_args(capped), out=io.StringIO())[0]
+    assert (same["fra"], same["be"], same["fe"]) == (many["fra"], many["be"], many["fe"])      # the same batches, seed for seed
+
+
 @pytest.mark.parametrize("modcod,anchor_db", [("QPSK-N_8/9", 6.20), ("8PSK-N_8/9", 10.69), ("16APSK-N_8/9", 12.89)])
 def test_normal_frame_waterfall_sits_at_the_etsi_anchor(modcod, anchor_db):
     """The N = 64800 codes are an extension beyond the reference (their LDPC table is entered from ETSI EN 302 307 Annex B): the only
