@@ -10,7 +10,7 @@ files = [("QPSK_8_9.txt", "QPSK-S_8/9", "qpsk_8_9"), ("QPSK_3_5.txt", "QPSK-S_3/
 rows = []
 for ref_file, modcod, name in files:
     gpu = {}
-    for l in open(os.path.join(ROOT, "gpurun_out", "ref_config_%s.txt" % name)):
+    for l in open(os.path.join(ROOT, "gpurun_out", os.environ.get("REF_CONFIG_PREFIX", "ref_config_") + "%s.txt" % name)):      # REF_CONFIG_PREFIX=ref1000_: the -e 1000 runs of tools/ref_config_e1000.sh
         if re.match(r"^ +[0-9]", l):
             f = [x.strip() for x in l.replace("||", "|").split("|")]
             gpu[round(float(f[1]), 2)] = dict(fra=int(f[2]), fe=int(f[4]), ber=float(f[5]), fer=float(f[6]), thr=float(f[7]))
