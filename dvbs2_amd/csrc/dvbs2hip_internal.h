@@ -105,6 +105,7 @@ struct LdpcPlan {             // host-side description, built once per handle
     // regular-code fast path (k_ldpc_wg8.hip): every layer has exactly fast_deg slots
     bool fast = false;
     bool spa = false;             // sum-product check node: per-edge fp32 messages instead of the packed min-sum state
+    int spa_rule = 0;             // 0: not sum-product, 1: exact (complement-product domain), 2: AFF3CT's saturating tanh-product form, bit for bit the oracle's ORC_SPA_TANH
     int fast_deg = 0;             // slots per layer in the unrolled kernel (11, 13 or 27)
     bool fast_pad = false;        // layers padded with NULL slots (irregular code)
     int fast_inf_row = -1;        // byte offset of the +inf row the NULL slots read, or -1
@@ -141,6 +142,8 @@ constexpr int LDPC_FRAME_CTR = 4096;
                                      // 9.63 -> 13.0 / 11.9 / 11.2 ms, docs/negative_results.md)
 constexpr int LDPC_AT_LANES = 384;      // lanes per row of the address table (6 waves; lanes 360 .. 383 hold the junk row / an offset that is dropped)
 constexpr int LDPC_FAST_STRIDE = 64;   // dwords per layer: 27 entries | prim mask | conflict info | conflict entries 0, 1 | slots with a duplicate edge | 16 conf entries | 16 conf meta
+                                       // (sum-product plans, at most LDPC_SPA_MAXC conflict entries: dwords LDPC_TANH_ORDER .. +4 = the slots in the ORACLE's edge order, 5 bits each, 6 per dword)
+constexpr int LDPC_TANH_ORDER = 56;
 constexpr int LDPC_FAST_MAXC = 16;
 // modes 4 / 5 (k_ldpc_wg8.hip): bit-group rows parked in the registers of a workgroup's two idle waves (3 VGPRs per row and lane) and LDS slots per
 // layer (the static hybrid without parked rows, mode 3, has 9).  Mode 5 (min-sum kernel only: the sum-product kernel has no registers for it) parks 39.
@@ -178,7 +181,7 @@ int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl);
 
 // builds the layer tables; returns empty string on success, else the error text
 std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,
-                            const int32_t *addr, int lds_groups_req, size_t lds_limit_bytes, bool spa = false);
+                            const int32_t *addr, int lds_groups_req, size_t lds_limit_bytes, int spa_rule = 0);      // spa_rule: LdpcPlan::spa_rule
 hipError_t ldpc_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
 int ldpc_blocks_per_cu(const LdpcPlan &pl);
 

@@ -253,9 +253,10 @@ static bool plan_parked(const std::vector<std::vector<int>> &mult, const std::ve
 }
 
 static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,
-                                   const int32_t *addr, int lds_groups_req, size_t lds_limit, bool spa, bool allow_fast)
+                                   const int32_t *addr, int lds_groups_req, size_t lds_limit, int spa_rule, bool allow_fast)
 {
-    pl.spa = spa;
+    const bool spa = spa_rule != 0;
+    pl.spa = spa; pl.spa_rule = spa_rule;
     if (N <= 0 || K <= 0 || K >= N) return "LDPC: need 0 < K < N";
     const int M = N - K;
     if (M % LDPC_Z || K % LDPC_Z) return "LDPC: N-K and K must be multiples of 360";
@@ -362,7 +363,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             // pair like information groups (the 160 information rows of the N = 64800 8/9 code have a maximum matching of 71 pairs, 72 are needed): a parity row
             // that starts an iteration in a register slot is loaded by its row-keeping wave (a stride-q gather), the others by the working waves' scatter.
             const bool env_cu1 = env_mode && !strcmp(env_mode, "cu1");
-            if ((env_cu1 || (!env_mode && LDPC_CU1_DEFAULT && !spa) || (!env_mode && spa && LDPC_CU1_SPA_DEFAULT)) && pl.fast_mode == 1 && pl.fast_deg == 27 && !pl.fast_pad) {
+            if ((env_cu1 || (!env_mode && LDPC_CU1_DEFAULT && !spa) || (!env_mode && spa_rule == 1 && LDPC_CU1_SPA_DEFAULT)) && spa_rule != 2 && pl.fast_mode == 1 && pl.fast_deg == 27 && !pl.fast_pad) {
                 const int n_pos = ((int)lds_limit - LDPC_CU1_XCHG_BYTES - 128) / (int)grp_bytes - 1;      // [positions | junk row | exchange area | misc]
                 std::vector<std::vector<int>> mult(pl.n_groups, std::vector<int>(q, 0));
                 for (int r = 0; r < q; r++) for (const Slot &sl : layers[r]) mult[sl.group][r]++;
@@ -541,6 +542,18 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
                 }
                 if (nc > 0 && (T8[48] >> 8) != 1u) return "LDPC: internal: first conflict entry is not of level 1";
                 if (pl.fast_mode == 0 || spa || cu1) for (int i = 0; i < nc; i++) if ((T8[48 + i] & 31u) != (uint32_t)i) return "LDPC: internal: conflict entry i is not slot i";
+                if (spa) {
+                    // the oracle's edge order of a check (information bits in address-table order, p_c, p_{c-1} = layers[r] as built above) as slots: the tanh-product
+                    // rule multiplies in THAT order (fp32 products do not commute bit for bit); NULL slots (tanh(inf / 2) = 1, exact) fill the tail
+                    std::vector<int> perm;
+                    std::vector<char> used(ord.size(), 0);
+                    for (const Slot &sl : layers[r])
+                        for (size_t j = 0; j < ord.size(); j++)
+                            if (!used[j] && ord[j].group == sl.group && ord[j].t0 == sl.t0) { perm.push_back((int)j); used[j] = 1; break; }
+                    if ((int)perm.size() != pl.layer_deg[r] || nc > LDPC_TANH_ORDER - 48) return "LDPC: internal: edge-order table";
+                    for (size_t j = 0; j < ord.size(); j++) if (!used[j]) perm.push_back((int)j);
+                    for (size_t c = 0; c < perm.size(); c++) T8[LDPC_TANH_ORDER + c / 6] |= (uint32_t)perm[c] << (5 * (c % 6));
+                }
             }
             if (!spa && !cu1 && (pl.fast_mode == 0 || LDPC_ATAB_HYB)) {      // per-lane address table of the min-sum layer (k_ldpc_wg8.hip, W8_ATAB: every slot of the LDS-only image; -DW8_ATAB_HYB: the LDS slots of the hybrid images)
                 const int NW4 = (pl.fast_deg + 3) / 4;
@@ -749,10 +762,10 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
 }
 
 std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,
-                            const int32_t *addr, int lds_groups_req, size_t lds_limit, bool spa)
+                            const int32_t *addr, int lds_groups_req, size_t lds_limit, int spa_rule)
 {
-    std::string e = build_plan_impl(pl, N, K, n_rows, row_ptr, addr, lds_groups_req, lds_limit, spa, true);
-    if (e == PLAN_RETRY_GENERIC) { pl = LdpcPlan(); e = build_plan_impl(pl, N, K, n_rows, row_ptr, addr, lds_groups_req, lds_limit, spa, false); }
+    std::string e = build_plan_impl(pl, N, K, n_rows, row_ptr, addr, lds_groups_req, lds_limit, spa_rule, true);
+    if (e == PLAN_RETRY_GENERIC) { pl = LdpcPlan(); e = build_plan_impl(pl, N, K, n_rows, row_ptr, addr, lds_groups_req, lds_limit, spa_rule, false); }
     return e;
 }
 

@@ -105,6 +105,9 @@ __host__ __device__ __forceinline__ constexpr bool w8_slot_lds(int mode, int j) 
 #ifndef W8_FAST_OUT       // output loops of their own for the bits socket alone and for the fused chain (buffer descriptors per frame, scalar descrambling)
 #define W8_FAST_OUT 1
 #endif
+// the fused chain trusts the per-frame BCH flags (dvbs2hip_api.hip: ldpc_verifies_bch), which only the run_out_fast<4|6> output loops write: a build without them would leave
+// bch_flag / cwd_bch unwritten while bch_decode_kernel skips frames on those bytes
+static_assert(W8_FAST_OUT, "W8_FAST_OUT=0 never writes bch_flag / cwd_bch, which the fused chain's BCH stage reads");
 #ifndef W8_SPA_AT16        // sum-product layer, LDS-only image, the 11- and 13-slot codes: the slots' LDS addresses come from a per-lane table of 16-bit entries (two per register) instead of
 #define W8_SPA_AT16 LDPC_SPA_AT16      // being formed on the vector ALU (4 instructions per edge, two of them with an SGPR operand); the 27-slot layer has no registers for it (dvbs2hip_internal.h)
 #endif
@@ -188,6 +191,61 @@ __device__ __forceinline__ float w8_boxplus(float a, float b)
     if (!CHECKED) return r;
     return a == INFINITY ? b : (b == INFINITY ? a : r);
 }
+
+// `--dec-implem SPA_TANH`: the check node in the form AFF3CT's Update_rule_SPA evaluates [UPSTREAM-RECALL, oracle/dvbs2_oracle.c chk_update_spa_tanh]:
+//     t_j = tanh(|v_j| / 2) in fp32 (1.0f beyond 18.02),  P = prod t_j in the oracle's edge order,  val = P / t_j clamped to 1 - 2^-23,  |out_j| = 2 atanh(val).
+// Near the cap the quotient moves in steps of 2^-24 = the message in steps of 0.1 .. 0.7: a twin of the oracle has to agree bit for bit.  tanh, the quotients and
+// log1p are therefore made of operations whose IEEE-754 result is correctly rounded (add, multiply, fma, divide, v_rndne) in exactly the oracle's order -- no
+// v_exp / v_log / v_rcp here (the build has no fast-math flag and -ffp-contract=off: `/` is the correctly rounded division sequence).
+__device__ __forceinline__ float w8_det_expm1(float y)            // e^y - 1, -2.1 <= y <= 45
+{
+    const float n = __builtin_rintf(y * 1.44269502f);
+    float r = __builtin_fmaf(-n, 0.693145751953125f, y);
+    r = __builtin_fmaf(-n, 1.42860677e-6f, r);
+    float q = 1.98412701e-4f;
+    q = __builtin_fmaf(q, r, 1.38888892e-3f);
+    q = __builtin_fmaf(q, r, 8.33333377e-3f);
+    q = __builtin_fmaf(q, r, 4.16666679e-2f);
+    q = __builtin_fmaf(q, r, 1.66666672e-1f);
+    q = __builtin_fmaf(q, r, 0.5f);
+    const float pm1 = __builtin_fmaf(q * r, r, r);
+    const float sc = __uint_as_float((uint32_t)((int)n + 127) << 23);
+    return __builtin_fmaf(sc, pm1, sc - 1.0f);
+}
+__device__ __forceinline__ float w8_det_tanh_half(float a)        // tanh(a / 2), a >= 0 (+inf: absent / NULL slots -> exactly 1); one expm1 and one division on either branch of the oracle's
+{
+    const bool big = a >= 2.0f;
+    const float ac = fminf(a, 44.0f);
+    const float t = w8_det_expm1(big ? ac : -ac);
+    const float d = (big ? 2.0f : -t) / (t + 2.0f);
+    const float r = big ? 1.0f - d : d;
+    return (a < 44.0f) ? r : 1.0f;
+}
+__device__ __forceinline__ float w8_det_log1p(float w)            // log(1 + w), 0 <= w < 2^26
+{
+    const float u = 1.0f + w;
+    const float c = w - (u - 1.0f);
+    const uint32_t iu = __float_as_uint(u);
+    int e = (int)(iu >> 23) - 127;
+    uint32_t im = (iu & 0x007FFFFFu) | 0x3F800000u;
+    const bool up = im >= 0x3FB504F3u;
+    im = up ? im - 0x00800000u : im;
+    e = up ? e + 1 : e;
+    const float f = __builtin_fmaf(c, __uint_as_float((uint32_t)(127 - e) << 23), __uint_as_float(im) - 1.0f);
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    float q = 0.111111112f;
+    q = __builtin_fmaf(q, z, 0.142857149f);
+    q = __builtin_fmaf(q, z, 0.2f);
+    q = __builtin_fmaf(q, z, 0.333333343f);
+    const float s2 = s + s;
+    const float lm = __builtin_fmaf(s2 * z, q, s2);
+    const float fe = (float)e;
+    float r = __builtin_fmaf(fe, 0.693145751953125f, lm);
+    r = __builtin_fmaf(fe, 1.42860677e-6f, r);
+    return r;
+}
+typedef float w8_f32x32 __attribute__((ext_vector_type(32)));
 
 // MODE 4 / 5: what the two waves of a workgroup that hold no check do instead of idling -- they keep NR = 32 / 39 bit-group rows of the frame in
 // their registers (3 VGPRs per row and lane: lane e of 128 holds elements e, e + 128, e + 256) and swap rows with LDS by the static, cyclic
@@ -299,10 +357,11 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_int *co
     }
 }
 
-// SPA = false: normalised min-sum with the packed per-check state.  SPA = true: sum-product check node, the c->v
-// messages kept per edge (fp32, [layer][slot][360] after the image in the workgroup's global slot).
-template <int DEG, int MODE, bool SPA = false>      // MODE 0: image in LDS, 1: in the workgroup's global slot, 3: static hybrid
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// SPA = 0: normalised min-sum with the packed per-check state.  SPA = 1: sum-product check node (exact, complement-product domain), the c->v
+// messages kept per edge (fp32, [layer][slot][360] after the image in the workgroup's global slot).  SPA = 2: the same layer with the check node as
+// AFF3CT's Update_rule_SPA evaluates it (tanh product in fp32, saturating), bit for bit the oracle's ORC_SPA_TANH (w8_det_*).
+template <int DEG, int MODE, int SPA = 0>      // MODE 0: image in LDS, 1: in the workgroup's global slot, 3: static hybrid
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((SPA == 2 && DEG > 13) ? 2 : 4, 4)))      // (the tanh-product rule on 27 slots: one workgroup per CU, 256 registers -- a parity mode, not a throughput one)
 ldpc_wg8_kernel(const LdpcKParams p)
 {
     extern __shared__ float smem[];
@@ -614,6 +673,8 @@ ldpc_wg8_kernel(const LdpcKParams p)
                     float od[LDPC_SPA_MAXC];                        // old c->v of the duplicate edges, then new - old (what such an edge adds)
                     float mn1 = INFINITY, kap = 1.f, cln = 0.f, key = 0.f;
                     uint32_t sx = 0u;
+                    w8_f32x32 tv;                                    // SPA = 2: tanh(|v->c| / 2) per slot (a vector: read by wave-uniform index for the ordered product)
+                    float tprod = 1.f;
                     auto comb = [&](float a, float b) __attribute__((always_inline)) { return __builtin_fmaf(b, __builtin_fmaf(-kap, a, 1.f), a); };      // Q'_ab
 #pragma unroll
                     for (int i = 0; i < LDPC_SPA_MAXC; i++) od[i] = 0.f;
@@ -648,6 +709,16 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #pragma unroll
                         for (int j = 0; j < DEG; j++) x[j] = x[j] - onx[j];      // zeros in the first iteration
                         if (mask0) x[DEG - 1] = INFINITY;
+                        if constexpr (SPA == 2) {
+                            // the slots in the oracle's edge order, 5 bits each (k_ldpc.hip): wave-uniform indices into the lane's tanh values
+                            uint32_t pw[5];
+#pragma unroll
+                            for (int k = 0; k < 5; k++) pw[k] = T[LDPC_TANH_ORDER + k];
+#pragma unroll
+                            for (int j = 0; j < DEG; j++) { sx ^= __float_as_uint(x[j]); tv[j] = w8_det_tanh_half(fabsf(x[j])); }
+#pragma unroll
+                            for (int c = 0; c < DEG; c++) tprod = tprod * tv[(pw[c / 6] >> (5 * (c % 6))) & 31u];
+                        } else {
                         float mn2 = INFINITY;
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
@@ -675,6 +746,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
                                 b = comb(b, u[j]);
                             }
                         }
+                        }
                     }
                     if (ncf > 0) __syncthreads();         // every read of the layer precedes its writes
                     if (act) {
@@ -689,6 +761,13 @@ ldpc_wg8_kernel(const LdpcKParams p)
                         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                         for (int j = 0; j < DEG; j++) {
+                            float nw;                                 // magnitude bits of o under the sign of (all signs) ^ (own sign): one v_bfi_b32
+                            if constexpr (SPA == 2) {
+                                float val = tprod / tv[j];              // 0 / 0 = NaN takes the cap, as in the oracle
+                                val = (val < 1.0f) ? val : __uint_as_float(0x3F7FFFFEu);      // 1 - FLT_EPSILON
+                                const float o = w8_det_log1p((val + val) / (1.0f - val));
+                                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(nw) : "s"(MAGM), "v"(o), "v"(sx ^ __float_as_uint(x[j])));
+                            } else {
                             const float wA = __builtin_fmaf(-kap, A, 1.f);
                             float Bj;
                             {
@@ -709,9 +788,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #else
                             o = (fabsf(x[j]) < key || fabsf(x[j]) > key) ? mn1 : o;
 #endif
-                            float nw;                                 // magnitude bits of o under the sign of (all signs) ^ (own sign): one v_bfi_b32
                             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(nw) : "s"(MAGM), "v"(o), "v"(sx ^ __float_as_uint(x[j])));
                             A = __builtin_fmaf(u[j], wA, A);
+                            }
                             const bool pr = ((prim >> j) & 1u) != 0u;
                             if (AT16) {
                                 // the table's address is where the value came from (check 0's absent p_{c-1}: the junk row's word 0); a duplicate edge's or a NULL slot's plain store
@@ -1393,7 +1472,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #endif
 }
 
-template <int DEG, int MODE, bool SPA = false>
+template <int DEG, int MODE, int SPA = 0>
 static hipError_t wg8_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t s)
 {
     auto kern = ldpc_wg8_kernel<DEG, MODE, SPA>;
@@ -1437,7 +1516,7 @@ static hipError_t wg8_inst(const LdpcPlan &pl, const LdpcKParams &p, hipStream_t
     return hipGetLastError();
 }
 
-template <int DEG, int MODE, bool SPA = false>
+template <int DEG, int MODE, int SPA = 0>
 static int wg8_occ(const LdpcPlan &pl)
 {
     auto kern = ldpc_wg8_kernel<DEG, MODE, SPA>;
@@ -1455,11 +1534,16 @@ static int wg8_occ(const LdpcPlan &pl)
                          : (pl.fast_mode == 0 ? FN<11, 0>(__VA_ARGS__) : FN<11, 1>(__VA_ARGS__)))
 
 #define WG8_SPA_DISPATCH(FN, ...)                                                                                                                          \
-    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, true>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3, true>(__VA_ARGS__) : pl.fast_mode == 4 ? FN<27, 4, true>(__VA_ARGS__) : FN<27, 1, true>(__VA_ARGS__)) \
-     : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0, true>(__VA_ARGS__) : FN<13, 1, true>(__VA_ARGS__))                                                 \
-                         : (pl.fast_mode == 0 ? FN<11, 0, true>(__VA_ARGS__) : FN<11, 1, true>(__VA_ARGS__)))
+    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, 1>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3, 1>(__VA_ARGS__) : pl.fast_mode == 4 ? FN<27, 4, 1>(__VA_ARGS__) : FN<27, 1, 1>(__VA_ARGS__)) \
+     : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0, 1>(__VA_ARGS__) : FN<13, 1, 1>(__VA_ARGS__))                                                 \
+                         : (pl.fast_mode == 0 ? FN<11, 0, 1>(__VA_ARGS__) : FN<11, 1, 1>(__VA_ARGS__)))
 
-int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl) { return pl.spa ? WG8_SPA_DISPATCH(wg8_occ, pl) : WG8_DISPATCH(wg8_occ, pl); }
+#define WG8_TANH_DISPATCH(FN, ...)                                                                                                                         \
+    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, 2>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3, 2>(__VA_ARGS__) : pl.fast_mode == 4 ? FN<27, 4, 2>(__VA_ARGS__) : FN<27, 1, 2>(__VA_ARGS__)) \
+     : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0, 2>(__VA_ARGS__) : FN<13, 1, 2>(__VA_ARGS__))                                                       \
+                         : (pl.fast_mode == 0 ? FN<11, 0, 2>(__VA_ARGS__) : FN<11, 1, 2>(__VA_ARGS__)))
+
+int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl) { return pl.spa_rule == 2 ? WG8_TANH_DISPATCH(wg8_occ, pl) : pl.spa ? WG8_SPA_DISPATCH(wg8_occ, pl) : WG8_DISPATCH(wg8_occ, pl); }
 
 hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
@@ -1469,7 +1553,7 @@ hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
     p.w8.nl_info = pl.w8_nl_info; p.w8.nl = pl.w8_nl; p.w8.ng_info = pl.w8_ng_info; p.w8.ng = pl.w8_ng;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.gwork_words = pl.w8_gwork_words;
-    return pl.spa ? WG8_SPA_DISPATCH(wg8_inst, pl, p, s) : WG8_DISPATCH(wg8_inst, pl, p, s);
+    return pl.spa_rule == 2 ? WG8_TANH_DISPATCH(wg8_inst, pl, p, s) : pl.spa ? WG8_SPA_DISPATCH(wg8_inst, pl, p, s) : WG8_DISPATCH(wg8_inst, pl, p, s);
 }
 
 }  // namespace dvbs2

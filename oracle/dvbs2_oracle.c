@@ -178,6 +178,94 @@ static void chk_update_spa(const float *v2c, int d, float *out)
     for (int j = 0; j < d; j++) out[j] = boxplus(fw[j], bw[j]);
 }
 
+/* ---- the check node as AFF3CT's Update_rule_SPA evaluates it [UPSTREAM-RECALL: lib/aff3ct is an empty submodule; the rule the reference
+ * selects with `--dec-implem SPA`, its default: DVBS2.cpp:135,418-449; every refs/TX_RX_BB trace says "LDPC implem = SPA", "LDPC simd = "]:
+ *     in :  t_j = tanh(|v_j| / 2) in fp32 (exactly 1.0f beyond |v_j| ~ 18),  P = t_0 t_1 .. t_{d-1} multiplied in fp32 in edge order,
+ *           sign = xor of the sign bits
+ *     out:  val = P / t_j ;  val = (val < 1) ? val : 1 - FLT_EPSILON  (a NaN from 0 / 0 takes the second branch) ;
+ *           |c->v_j| = 2 atanh(val) ;  sign = (all signs) ^ (own sign)
+ * Unlike the exact boxplus above this SATURATES: no message exceeds 2 atanh(1 - 2^-23) = 16.64, and near that cap the quotient moves in steps of
+ * 2^-24, i.e. the message in steps of 0.1 .. 0.7.  Because of those steps a faithful GPU twin has to agree BIT FOR BIT, not to 1e-4: every operation
+ * below is one whose IEEE-754 result is correctly rounded (add, multiply, fma, divide, round-to-nearest-integer) -- tanh and log1p are written out with those
+ * (the structure of the usual libm routines: tanh through expm1, 2 atanh(x) = log1p(2 x / (1 - x))) instead of calling libm, whose results differ from
+ * one library to the next by an ulp.  tests/test_oracle.py holds them to libm within 4 ulp.  Edge order = the order the checks' edges are built in above:
+ * information bits in the order of the standard's address table, then p_k, then p_(k-1). */
+static inline float det_scale2(int n) { uint32_t u = (uint32_t)(n + 127) << 23; float f; memcpy(&f, &u, 4); return f; }     /* 2^n, -126 <= n <= 127 */
+/* e^y - 1, -2.1 <= y <= 45 */
+static inline float det_expm1(float y)
+{
+    const float n = rintf(y * 1.44269502f);
+    float r = fmaf(-n, 0.693145751953125f, y);              /* ln 2 = hi + lo, hi with 11 trailing zero bits: n hi is exact */
+    r = fmaf(-n, 1.42860677e-6f, r);
+    float q = 1.98412701e-4f;                               /* 1/5040 .. 1/2: e^r - 1 = r + r^2 (1/2 + r (1/6 + ...)), |r| <= 0.347 */
+    q = fmaf(q, r, 1.38888892e-3f);
+    q = fmaf(q, r, 8.33333377e-3f);
+    q = fmaf(q, r, 4.16666679e-2f);
+    q = fmaf(q, r, 1.66666672e-1f);
+    q = fmaf(q, r, 0.5f);
+    const float pm1 = fmaf(q * r, r, r);
+    const float sc = det_scale2((int)n);
+    return fmaf(sc, pm1, sc - 1.0f);
+}
+/* tanh(a / 2), a >= 0 (+inf allowed) */
+static inline float det_tanh_half(float a)
+{
+    if (!(a < 44.0f)) return 1.0f;
+    if (a >= 2.0f) { const float t = det_expm1(a); return 1.0f - 2.0f / (t + 2.0f); }
+    const float t = det_expm1(-a);
+    return -t / (t + 2.0f);
+}
+/* log(1 + w), 0 <= w < 2^26 */
+static inline float det_log1p(float w)
+{
+    const float u = 1.0f + w;
+    const float c = w - (u - 1.0f);                         /* what the rounding of 1 + w lost (u - 1 is exact) */
+    uint32_t iu; memcpy(&iu, &u, 4);
+    int e = (int)(iu >> 23) - 127;
+    uint32_t im = (iu & 0x007FFFFFu) | 0x3F800000u;         /* mantissa in [1, 2) */
+    if (im >= 0x3FB504F3u) { im -= 0x00800000u; e += 1; }   /* ... in [sqrt(1/2), sqrt 2) */
+    float m; memcpy(&m, &im, 4);
+    const float f = fmaf(c, det_scale2(-e), m - 1.0f);      /* 1 + w = 2^e (m + c 2^-e): the lost part goes back in at the mantissa's scale (no second division) */
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    float q = 0.111111112f;                                 /* log m = 2 atanh(s) = 2 s (1 + z / 3 + z^2 / 5 + z^3 / 7 + z^4 / 9), z <= 0.0295 */
+    q = fmaf(q, z, 0.142857149f);
+    q = fmaf(q, z, 0.2f);
+    q = fmaf(q, z, 0.333333343f);
+    const float s2 = s + s;
+    const float lm = fmaf(s2 * z, q, s2);
+    const float fe = (float)e;
+    float r = fmaf(fe, 0.693145751953125f, lm);
+    r = fmaf(fe, 1.42860677e-6f, r);
+    return r;
+}
+static void chk_update_spa_tanh(const float *v2c, int d, float *out)
+{
+    float t[64], P = 1.0f;
+    int sign = 0;
+    for (int j = 0; j < d; j++) {
+        t[j] = det_tanh_half(fabsf(v2c[j]));
+        sign ^= f_signbit(v2c[j]);
+        P = P * t[j];
+    }
+    for (int j = 0; j < d; j++) {
+        float val = P / t[j];
+        val = (val < 1.0f) ? val : 1.0f - FLT_EPSILON;
+        const float mag = det_log1p((val + val) / (1.0f - val));
+        out[j] = (sign ^ f_signbit(v2c[j])) ? -mag : mag;
+    }
+}
+/* test hooks: the two written-out functions against libm */
+float orc_det_tanh_half(float a) { return det_tanh_half(a); }
+float orc_det_log1p(float w) { return det_log1p(w); }
+static inline void chk_update(int implem, float alpha, const float *v2c, int d, float *out)
+{
+    if (implem == ORC_NMS) chk_update_nms(v2c, d, alpha, out);
+    else if (implem == ORC_SPA_TANH) chk_update_spa_tanh(v2c, d, out);
+    else chk_update_spa(v2c, d, out);
+}
+void orc_chk_update(int implem, float alpha, const float *v2c, int d, float *out) { chk_update(implem, alpha, v2c, d, out); }
+
 /* work buffers of one decoder instance (a thread of the CPU baseline keeps its own across frames:
  * allocating ~1 MB per frame from 256 threads at once serialises them in the allocator) */
 typedef struct { float *L, *msg, *v2c, *nw; } ldpc_ws;
@@ -205,7 +293,7 @@ static int ldpc_decode_ws(const orc_ldpc *c, const float *llr, int implem, int s
             for (int k = 0; k < M; k++) {
                 int b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
                 for (int j = 0; j < d; j++) v2c[j] = L[c->chk_var[b + j]] - msg[b + j];
-                if (implem == ORC_NMS) chk_update_nms(v2c, d, alpha, nw); else chk_update_spa(v2c, d, nw);
+                chk_update(implem, alpha, v2c, d, nw);
                 for (int j = 0; j < d; j++) { msg[b + j] = nw[j]; L[c->chk_var[b + j]] = v2c[j] + nw[j]; }
             }
         } else {
@@ -218,8 +306,7 @@ static int ldpc_decode_ws(const orc_ldpc *c, const float *llr, int implem, int s
                 for (int t = 0; t < 360; t++) {
                     int k = q * t + r, b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
                     for (int j = 0; j < d; j++) v2c[t * D + j] = L[c->chk_var[b + j]] - msg[b + j];
-                    if (implem == ORC_NMS) chk_update_nms(v2c + t * D, d, alpha, nw + t * D);
-                    else chk_update_spa(v2c + t * D, d, nw + t * D);
+                    chk_update(implem, alpha, v2c + t * D, d, nw + t * D);
                 }
                 for (int t = 0; t < 360; t++) {
                     int k = q * t + r, b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;

@@ -38,11 +38,13 @@ void      orc_ldpc_encode(const orc_ldpc *c, const int32_t *info, int32_t *cw);
 /* syndrome weight of a hard word */
 int       orc_ldpc_syndrome_weight(const orc_ldpc *c, const int32_t *cw);
 
-enum { ORC_NMS = 0, ORC_SPA = 1 };
+/* ORC_SPA: exact boxplus (no saturation).  ORC_SPA_TANH: the tanh-product form with fp32 saturation as AFF3CT's Update_rule_SPA evaluates it
+ * [UPSTREAM-RECALL], written with correctly rounded IEEE operations only so that the HIP kernels match it bit for bit (dvbs2_oracle.c). */
+enum { ORC_NMS = 0, ORC_SPA = 1, ORC_SPA_TANH = 2 };
 enum { ORC_SCHED_NATURAL = 0, ORC_SCHED_QC = 1 };
 /*
  * Horizontal-layered BP (dec type "BP_HORIZONTAL_LAYERED", DVBS2.cpp:428), implem
- * NMS (alpha; alpha = 1 gives plain MS) or SPA.
+ * NMS (alpha; alpha = 1 gives plain MS), SPA (exact) or SPA_TANH (AFF3CT's saturating form).
  *   sched NATURAL: checks swept in natural row order of H  (AFF3CT order)
  *   sched QC     : q layers of 360 independent checks (c mod q == layer), the schedule
  *                  the HIP kernel runs; same-layer double edges resolved by ordered
@@ -53,6 +55,11 @@ enum { ORC_SCHED_NATURAL = 0, ORC_SCHED_QC = 1 };
  */
 int orc_ldpc_decode(const orc_ldpc *c, const float *llr, int implem, int sched, int n_ite,
                     float alpha, int early_stop, int32_t *bits_K, float *post, int8_t *cwd);
+
+/* test hooks */
+float orc_det_tanh_half(float a);
+float orc_det_log1p(float w);
+void  orc_chk_update(int implem, float alpha, const float *v2c, int d, float *out);
 
 /* ---------------------------------------------------------------- BCH (a2) */
 typedef struct orc_bch orc_bch;

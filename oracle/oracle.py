@@ -131,6 +131,11 @@ def lib():
         L.orc_ldpc_encode.argtypes = [vp, vp, vp]
         L.orc_ldpc_syndrome_weight.argtypes = [vp, vp]
         L.orc_ldpc_decode.argtypes = [vp, vp, ci, ci, ci, cf, ci, vp, vp, vp]
+        L.orc_det_tanh_half.restype = cf
+        L.orc_det_tanh_half.argtypes = [cf]
+        L.orc_det_log1p.restype = cf
+        L.orc_det_log1p.argtypes = [cf]
+        L.orc_chk_update.argtypes = [ci, cf, vp, ci, vp]
         L.orc_ldpc_decode_batch.restype = C.c_double
         L.orc_ldpc_decode_batch.argtypes = [vp, vp, ci, ci, ci, cf, vp, ci]
         L.orc_ldpc_decode_batch_inter.restype = C.c_double
@@ -195,8 +200,25 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
-NMS, SPA = 0, 1
+NMS, SPA, SPA_TANH = 0, 1, 2      # SPA: exact boxplus; SPA_TANH: the saturating tanh-product form of AFF3CT's Update_rule_SPA (dvbs2_oracle.c)
 NATURAL, QC = 0, 1
+
+
+def det_tanh_half(a):
+    """tanh(a / 2) as the SPA_TANH rule evaluates it (correctly rounded operations only)"""
+    return float(lib().orc_det_tanh_half(float(a)))
+
+
+def det_log1p(w):
+    return float(lib().orc_det_log1p(float(w)))
+
+
+def chk_update(v2c, implem=SPA_TANH, alpha=1.0):
+    """one check node: v->c messages in, c->v messages out"""
+    v2c = _f32(v2c)
+    out = np.empty_like(v2c)
+    lib().orc_chk_update(implem, alpha, _p(v2c), v2c.size, _p(out))
+    return out
 
 
 class Ldpc:

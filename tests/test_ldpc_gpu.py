@@ -176,6 +176,46 @@ def test_ldpc_spa_matches_oracle(O, Rx, modcod, ebn0):
     rx.close()
 
 
+TANH_CASES = [("QPSK-S_8/9", 3.9, 4), ("QPSK-S_8/9", 3.2, 3), ("QPSK-S_3/5", 1.5, 4), ("8PSK-S_3/5", 3.0, 3), ("16APSK-S_8/9", 7.4, 3), ("32APSK-S_3/4", 3.2, 3), ("QPSK-N_8/9", 3.9, 2)]
+
+
+@pytest.mark.parametrize("modcod,ebn0,F", TANH_CASES)
+def test_ldpc_spa_tanh_is_the_oracles_rule_bit_for_bit(O, Rx, modcod, ebn0, F):
+    """--dec-implem SPA_TANH: the check node as AFF3CT's Update_rule_SPA evaluates it (tanh product in fp32, quotient clamped to 1 - FLT_EPSILON, 2 atanh) -- messages
+    cap at 16.64 and, near the cap, move in steps of 0.1 .. 0.7, so "within 1e-4" is not a bar a twin of the oracle can be held to: both sides are written with
+    correctly rounded operations only (oracle/dvbs2_oracle.c chk_update_spa_tanh, k_ldpc_wg8.hip w8_det_*), the kernel multiplies a check's tanh values in the
+    oracle's edge order, and the bar is the min-sum family's: posteriors BIT-IDENTICAL after 1, 2 and 50 iterations (every frame of the 50-iteration runs is deep
+    in the saturated regime), same iteration counts with the stopping rule."""
+    ch = chain(O, modcod)
+    _, llr, cw = make_llrs(O, modcod, F, ebn0, seed=31)
+    for n_ite, early in ((1, False), (2, False), (50, False), (50, True)):
+        rx = Rx(modcod, max_frames=F, n_ite=n_ite, early_stop=early, implem="SPA_TANH")
+        assert rx.ldpc_kernel_name().endswith(",2>")
+        V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+        Vo, posto, cwdo, iteso = ch.ldpc.decode(llr, n_ite=n_ite, implem=O.SPA_TANH, sched=O.QC, early_stop=early)
+        assert not np.isnan(post).any()
+        assert np.array_equal(post.view(np.uint32), posto.view(np.uint32)), "%d posteriors differ after %d iterations, max %g" % (int((post.view(np.uint32) != posto.view(np.uint32)).sum()), n_ite, float(np.abs(post - posto).max()))
+        assert np.array_equal(V, Vo) and np.array_equal(CWD, cwdo) and np.array_equal(ites, iteso)
+        if n_ite == 50 and not early:
+            assert float(np.abs(posto).max()) > 20.0          # beyond one capped message: several saturated messages per bit
+        rx.close()
+
+
+def test_ldpc_spa_tanh_saturates_where_the_exact_rule_does_not(O, Rx):
+    """What the two sum-product rules differ by: scaled-up LLRs drive the exact rule's posteriors to thousands, the tanh-product rule's messages stop at
+    2 atanh(1 - 2^-23) = 16.64 each -- a bit of column weight w cannot exceed |channel| + 16.64 w."""
+    modcod = "QPSK-S_8/9"
+    ch = chain(O, modcod)
+    _, llr, cw = make_llrs(O, modcod, 2, 9.0, seed=23)
+    llr = (llr * 4.0).astype(np.float32)
+    rx = Rx(modcod, max_frames=2, n_ite=20, early_stop=False, implem="SPA_TANH")
+    V, CWD, post, _ = rx.decode_siho(llr, with_post=True)
+    Vo, posto, cwdo, _ = ch.ldpc.decode(llr, n_ite=20, implem=O.SPA_TANH, sched=O.QC, early_stop=False)
+    assert np.array_equal(post.view(np.uint32), posto.view(np.uint32)) and CWD.all()
+    assert np.all(np.abs(post) <= np.abs(llr) + 16.636 * 4 + 1e-3)           # (the columns of the short 8/9 code have at most 4 edges: SURVEY 7 H1)
+    rx.close()
+
+
 @pytest.mark.parametrize("modcod,ebn0,n_ite,scale", [("QPSK-S_8/9", 5.0, 10, 1.0), ("QPSK-S_8/9", 9.0, 20, 4.0), ("QPSK-S_3/5", 6.0, 10, 1.0), ("32APSK-S_3/4", 8.0, 10, 1.0),
                                                      ("QPSK-N_8/9", 6.0, 10, 1.0), ("QPSK-N_8/9", 9.0, 10, 3.0)])
 def test_ldpc_spa_far_beyond_the_saturation_of_tanh(O, Rx, modcod, ebn0, n_ite, scale):

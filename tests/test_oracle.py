@@ -233,3 +233,48 @@ def test_spa50_fer_within_reference_band(O, ref, ebn0):
     assert fe >= 100
     assert row["fer"] / 2.5 <= fer <= row["fer"] * 2.5, (fer, row["fer"])
     assert row["ber"] / 2.5 <= ber <= row["ber"] * 2.5, (ber, row["ber"])
+
+
+# ---- the saturating sum-product rule (ORC_SPA_TANH): AFF3CT's Update_rule_SPA as recalled, written with correctly rounded operations only
+def test_spa_tanh_building_blocks_follow_libm(O):
+    """tanh(a / 2) and log(1 + w) of the rule are written out (expm1 / log1p structure of the usual libm routines, only +, x, fma, / and round-to-integer) so that the HIP
+    kernels can match them bit for bit; against double-precision libm they stay within 4 ulp, tanh saturates to exactly 1.0f where glibc's tanhf does (|v| > 18.02),
+    and the rule's cap is 2 atanh(1 - FLT_EPSILON) = 16.6355."""
+    import math
+    rng = np.random.default_rng(0)
+    a = np.concatenate([np.float32(10.0) ** rng.uniform(-8, 1.7, 20000).astype(np.float32), rng.uniform(0, 50, 20000).astype(np.float32)])
+    for x in a:
+        t, ref = np.float32(O.det_tanh_half(x)), math.tanh(float(x) / 2)
+        assert abs(float(t) - ref) <= 4 * np.spacing(np.float32(ref)), (x, t, ref)
+    assert O.det_tanh_half(0.0) == 0.0 and O.det_tanh_half(1e-30) > 0.0 and O.det_tanh_half(np.inf) == 1.0
+    assert O.det_tanh_half(18.0) < 1.0 and O.det_tanh_half(18.03) == 1.0
+    w = np.float32(10.0) ** rng.uniform(-9, 7.5, 40000).astype(np.float32)
+    for x in w:
+        r, ref = np.float32(O.det_log1p(x)), math.log1p(float(x))
+        assert abs(float(r) - ref) <= 4 * np.spacing(np.float32(ref)), (x, r, ref)
+    assert O.det_log1p(0.0) == 0.0 and O.det_log1p(1e-30) == np.float32(1e-30)
+    v = np.float32(1.0) - np.float32(2.0 ** -23)
+    assert abs(O.det_log1p((v + v) / (np.float32(1.0) - v)) - 2 * math.atanh(float(v))) < 1e-5 and abs(2 * math.atanh(float(v)) - 16.6355) < 1e-3
+
+
+def test_spa_tanh_check_node(O):
+    """The rule against its definition evaluated in double precision where nothing saturates; its cap, its quantisation near the cap, and the 0 / 0 case
+    (a zero input: AFF3CT's `val < 1 ? val : 1 - eps` sends the NaN to the cap)."""
+    rng = np.random.default_rng(1)
+    for d in (3, 11, 13, 27):
+        v = (rng.standard_normal(d) * 3).astype(np.float32)
+        out = O.chk_update(v, O.SPA_TANH)
+        ex = O.chk_update(v, O.SPA)
+        t = np.tanh(np.abs(v.astype(np.float64)) / 2)
+        for j in range(d):
+            ref = 2 * np.arctanh(np.prod(np.delete(t, j))) * np.prod(np.sign(np.delete(v, j)))
+            assert abs(out[j] - ref) <= 2e-5 * max(1.0, abs(ref)), (d, j, out[j], ref)
+            assert abs(ex[j] - ref) <= 2e-5 * max(1.0, abs(ref))
+    big = np.float32([25.0, -30.0, 40.0, 22.0])
+    out = O.chk_update(big, O.SPA_TANH)
+    assert np.allclose(np.abs(out), 16.6355, atol=1e-3) and (np.sign(out) == [-1, 1, -1, -1]).all()      # every tanh is 1.0f: all four at the cap
+    assert np.allclose(np.abs(O.chk_update(big, O.SPA)), [22, 22, 22, 25], atol=0.2)                      # the exact rule: the minimum of the others
+    steps = sorted({float(abs(O.chk_update(np.float32([x, 50.0, 50.0]), O.SPA_TANH)[1])) for x in np.arange(14.0, 18.0, 0.01, dtype=np.float32)})
+    assert 4 < len(steps) < 40 and max(np.diff(steps)) > 0.3          # a staircase: 2^-24 steps of the quotient
+    z = O.chk_update(np.float32([0.0, 3.0, -2.0]), O.SPA_TANH)
+    assert abs(abs(z[0]) - 16.6355) < 1e-3 and z[1] == 0.0 and z[2] == 0.0
