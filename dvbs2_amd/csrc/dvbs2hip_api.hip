@@ -307,8 +307,8 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
     if (cfg->bps < 1 || cfg->bps > 5 || !cfg->cstl) return fail(nullptr, DVBS2HIP_EINVAL, "'bps' has to be in [1,5] with a constellation");
     if (cfg->N_ldpc <= 0 || cfg->N_ldpc % cfg->bps) return fail(nullptr, DVBS2HIP_EINVAL, "'N_ldpc' has to be a positive multiple of 'bps'");
     if (cfg->itl_cols > 1 && cfg->N_ldpc % cfg->itl_cols) return fail(nullptr, DVBS2HIP_EINVAL, "'N_ldpc' has to be a multiple of 'itl_cols'");
-    if (cfg->ldpc_implem != DVBS2HIP_IMPLEM_NMS && cfg->ldpc_implem != DVBS2HIP_IMPLEM_MS && cfg->ldpc_implem != DVBS2HIP_IMPLEM_SPA && cfg->ldpc_implem != DVBS2HIP_IMPLEM_SPA_TANH)
-        return fail(nullptr, DVBS2HIP_EUNSUPPORTED, "LDPC implem not supported (NMS, MS, SPA and SPA_TANH only)");
+    if (cfg->ldpc_implem != DVBS2HIP_IMPLEM_NMS && cfg->ldpc_implem != DVBS2HIP_IMPLEM_MS && cfg->ldpc_implem != DVBS2HIP_IMPLEM_SPA && cfg->ldpc_implem != DVBS2HIP_IMPLEM_SPA_TANH && cfg->ldpc_implem != DVBS2HIP_IMPLEM_SPA_EXACT)
+        return fail(nullptr, DVBS2HIP_EUNSUPPORTED, "LDPC implem not supported (NMS, MS, SPA, SPA_TANH and SPA_EXACT only)");
     if (!cfg->ldpc_row_ptr || !cfg->ldpc_addr || !cfg->bch_prim) return fail(nullptr, DVBS2HIP_EINVAL, "missing code tables");
     if (cfg->ldpc_n_ite < 1) return fail(nullptr, DVBS2HIP_EINVAL, "'ldpc_n_ite' has to be greater than 0");
     if (cfg->fir_n_taps < 0 || cfg->fir_n_taps > 257 || (cfg->fir_n_taps > 0 && !cfg->fir_taps))
@@ -347,7 +347,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
     if (lds_limit < 32 * 1024) lds_limit = 32 * 1024;
     lds_limit -= 512;                                    // static LDS of the kernel + slack
     std::string e = ldpc_build_plan(h->ldpc, cfg->N_ldpc, cfg->K_ldpc, cfg->ldpc_n_rows, cfg->ldpc_row_ptr, cfg->ldpc_addr,
-                                    cfg->ldpc_lds_groups, lds_limit, cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA ? 1 : cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA_TANH ? 2 : 0);
+                                    cfg->ldpc_lds_groups, lds_limit, cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA ? 3 : cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA_TANH ? 2 : cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA_EXACT ? 1 : 0);
     if (!e.empty()) CREATE_FAIL(DVBS2HIP_EINVAL, e);
     LdpcPlan &lp = h->ldpc;
     if (upload(h, &lp.d_entries, lp.entries.data(), lp.entries.size()) ||
@@ -646,7 +646,7 @@ const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
         char buf[96];
         if (!pl.fast) snprintf(buf, sizeof buf, "ldpc_layered_nms_kernel<%d,%s,%s>", pl.ent_stride, pl.hybrid ? "true" : "false", pl.c2v_lds ? "true" : "false");
         else if (pl.fast_cu1) snprintf(buf, sizeof buf, pl.spa ? "ldpc_cu1_kernel<%d,true>" : "ldpc_cu1_kernel<%d>", pl.fast_deg);
-        else if (pl.spa) snprintf(buf, sizeof buf, "ldpc_wg8_kernel<%d,%d,%d>", pl.fast_deg, pl.fast_mode, pl.spa_rule);
+        else if (pl.spa) snprintf(buf, sizeof buf, "ldpc_wg8_kernel<%d,%d,%d>", pl.fast_deg, pl.fast_mode, pl.spa_rule == 2 ? 2 : 1);
         else snprintf(buf, sizeof buf, "ldpc_wg8_kernel<%d,%d>", pl.fast_deg, pl.fast_mode);
         const_cast<dvbs2hip_t *>(h)->ldpc_name = buf;
     }

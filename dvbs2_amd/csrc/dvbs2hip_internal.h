@@ -73,6 +73,7 @@ struct LdpcKParams {
     int32_t gwork_words;     // global words per frame in total (posteriors + c2v state)
     int32_t n_frames, n_ite, early_stop;
     float alpha;
+    float spa_cap;                // sum-product, exact check node: |c->v| is clipped to this (LDPC_SPA_CAP: the reference's results; +inf: no clip)
     int32_t inf_row;           // fast path: byte offset of the +inf row (padded layers) or -1
     uint32_t *cu_ctr;          // 8-wave workgroups: per-CU arrival counter (zeroed before the launch) or null
     struct {                   // k_ldpc_wg8.hip
@@ -105,7 +106,7 @@ struct LdpcPlan {             // host-side description, built once per handle
     // regular-code fast path (k_ldpc_wg8.hip): every layer has exactly fast_deg slots
     bool fast = false;
     bool spa = false;             // sum-product check node: per-edge fp32 messages instead of the packed min-sum state
-    int spa_rule = 0;             // 0: not sum-product, 1: exact (complement-product domain), 2: AFF3CT's saturating tanh-product form, bit for bit the oracle's ORC_SPA_TANH
+    int spa_rule = 0;             // 0: not sum-product, 1: exact (complement-product domain), 2: AFF3CT's saturating tanh-product form, bit for bit the oracle's ORC_SPA_TANH, 3: the exact rule with every message clipped to LDPC_SPA_CAP (same kernels as 1, LdpcKParams::spa_cap)
     int fast_deg = 0;             // slots per layer in the unrolled kernel (11, 13 or 27)
     bool fast_pad = false;        // layers padded with NULL slots (irregular code)
     int fast_inf_row = -1;        // byte offset of the +inf row the NULL slots read, or -1
@@ -144,6 +145,7 @@ constexpr int LDPC_AT_LANES = 384;      // lanes per row of the address table (6
 constexpr int LDPC_FAST_STRIDE = 64;   // dwords per layer: 27 entries | prim mask | conflict info | conflict entries 0, 1 | slots with a duplicate edge | 16 conf entries | 16 conf meta
                                        // (sum-product plans, at most LDPC_SPA_MAXC conflict entries: dwords LDPC_TANH_ORDER .. +4 = the slots in the ORACLE's edge order, 5 bits each, 6 per dword)
 constexpr int LDPC_TANH_ORDER = 56;
+constexpr float LDPC_SPA_CAP = 16.6355324f;      // 2 atanh(1 - FLT_EPSILON): where the messages of AFF3CT's tanh-product rule stop (spa_rule 2 by construction, 3 by a clip)
 constexpr int LDPC_FAST_MAXC = 16;
 // modes 4 / 5 (k_ldpc_wg8.hip): bit-group rows parked in the registers of a workgroup's two idle waves (3 VGPRs per row and lane) and LDS slots per
 // layer (the static hybrid without parked rows, mode 3, has 9).  Mode 5 (min-sum kernel only: the sum-product kernel has no registers for it) parks 39.

@@ -363,7 +363,7 @@ static std::string build_plan_impl(LdpcPlan &pl, int N, int K, int n_rows, const
             // pair like information groups (the 160 information rows of the N = 64800 8/9 code have a maximum matching of 71 pairs, 72 are needed): a parity row
             // that starts an iteration in a register slot is loaded by its row-keeping wave (a stride-q gather), the others by the working waves' scatter.
             const bool env_cu1 = env_mode && !strcmp(env_mode, "cu1");
-            if ((env_cu1 || (!env_mode && LDPC_CU1_DEFAULT && !spa) || (!env_mode && spa_rule == 1 && LDPC_CU1_SPA_DEFAULT)) && spa_rule != 2 && pl.fast_mode == 1 && pl.fast_deg == 27 && !pl.fast_pad) {
+            if ((env_cu1 || (!env_mode && LDPC_CU1_DEFAULT && !spa) || (!env_mode && spa && LDPC_CU1_SPA_DEFAULT)) && spa_rule != 2 && pl.fast_mode == 1 && pl.fast_deg == 27 && !pl.fast_pad) {
                 const int n_pos = ((int)lds_limit - LDPC_CU1_XCHG_BYTES - 128) / (int)grp_bytes - 1;      // [positions | junk row | exchange area | misc]
                 std::vector<std::vector<int>> mult(pl.n_groups, std::vector<int>(q, 0));
                 for (int r = 0; r < q; r++) for (const Slot &sl : layers[r]) mult[sl.group][r]++;

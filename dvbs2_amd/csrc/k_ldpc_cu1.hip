@@ -425,6 +425,7 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
                             const float lg = __builtin_amdgcn_logf(__builtin_fmaf(2.f, __builtin_amdgcn_rcpf(Q), -kap));
                             float o = __builtin_fmaf(lg, 0.693147180559945309f, cln);
                             if (anykey) { asm volatile("" ::: "memory"); o = __builtin_islessgreater(fabsf(x[j]), key) ? mn1 : o; }      // (the empty asm keeps the compiler from turning the wave-uniform branch back into two selects per slot)      // (ordered "not equal": false against the NaN that stands for "no overflow")
+                            o = fminf(o, p.spa_cap);      // (`--dec-implem SPA`: the cap of AFF3CT's tanh-product rule; SPA_EXACT: +inf)
                             float nw;
                             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(nw) : "s"(MAGM), "v"(o), "v"(SXT ^ __float_as_uint(x[j])));
                             A = __builtin_fmaf(u[j], wA, A);
@@ -782,6 +783,7 @@ hipError_t ldpc_cu1_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
     p.w8.tab = pl.d_w8_tab; p.w8.rows = pl.d_w8_rows; p.w8.atab = nullptr;
     p.w8.st_base = pl.w8_st_base; p.w8.lds_junk = pl.w8_lds_junk; p.w8.lds_bytes = pl.w8_lds_bytes; p.w8.pad = 0;
     p.w8.nl_info = pl.w8_nl_info; p.w8.nl = pl.w8_nl; p.w8.ng_info = pl.w8_ng_info; p.w8.ng = pl.w8_ng;
+    p.spa_cap = pl.spa_rule == 3 ? LDPC_SPA_CAP : INFINITY;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.gwork_words = pl.w8_gwork_words;
     if (pl.fast_deg != 27 || pl.cu1_pairs != 2 * ldpc_cu1_nrg()) return hipErrorInvalidValue;

@@ -788,6 +788,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #else
                             o = (fabsf(x[j]) < key || fabsf(x[j]) > key) ? mn1 : o;
 #endif
+                            o = fminf(o, p.spa_cap);      // (`--dec-implem SPA`: clipped where the messages of AFF3CT's tanh-product rule saturate; SPA_EXACT: +inf)
                             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(nw) : "s"(MAGM), "v"(o), "v"(sx ^ __float_as_uint(x[j])));
                             A = __builtin_fmaf(u[j], wA, A);
                             }
@@ -1533,17 +1534,15 @@ static int wg8_occ(const LdpcPlan &pl)
      : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0>(__VA_ARGS__) : FN<13, 1>(__VA_ARGS__))                                           \
                          : (pl.fast_mode == 0 ? FN<11, 0>(__VA_ARGS__) : FN<11, 1>(__VA_ARGS__)))
 
-#define WG8_SPA_DISPATCH(FN, ...)                                                                                                                          \
-    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, 1>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3, 1>(__VA_ARGS__) : pl.fast_mode == 4 ? FN<27, 4, 1>(__VA_ARGS__) : FN<27, 1, 1>(__VA_ARGS__)) \
-     : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0, 1>(__VA_ARGS__) : FN<13, 1, 1>(__VA_ARGS__))                                                 \
-                         : (pl.fast_mode == 0 ? FN<11, 0, 1>(__VA_ARGS__) : FN<11, 1, 1>(__VA_ARGS__)))
+#define WG8_RULE_DISPATCH(RULE, FN, ...)                                                                                                                   \
+    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, RULE>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3, RULE>(__VA_ARGS__) : pl.fast_mode == 4 ? FN<27, 4, RULE>(__VA_ARGS__) : FN<27, 1, RULE>(__VA_ARGS__)) \
+     : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0, RULE>(__VA_ARGS__) : FN<13, 1, RULE>(__VA_ARGS__))                                                 \
+                         : (pl.fast_mode == 0 ? FN<11, 0, RULE>(__VA_ARGS__) : FN<11, 1, RULE>(__VA_ARGS__)))
+#define WG8_ANY_DISPATCH(FN, ...)                                                                                  \
+    (pl.spa_rule == 2 ? WG8_RULE_DISPATCH(2, FN, __VA_ARGS__)                                                     \
+     : pl.spa ? WG8_RULE_DISPATCH(1, FN, __VA_ARGS__) : WG8_DISPATCH(FN, __VA_ARGS__))
 
-#define WG8_TANH_DISPATCH(FN, ...)                                                                                                                         \
-    (pl.fast_deg == 27 ? (pl.fast_mode == 0 ? FN<27, 0, 2>(__VA_ARGS__) : pl.fast_mode == 3 ? FN<27, 3, 2>(__VA_ARGS__) : pl.fast_mode == 4 ? FN<27, 4, 2>(__VA_ARGS__) : FN<27, 1, 2>(__VA_ARGS__)) \
-     : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0, 2>(__VA_ARGS__) : FN<13, 1, 2>(__VA_ARGS__))                                                       \
-                         : (pl.fast_mode == 0 ? FN<11, 0, 2>(__VA_ARGS__) : FN<11, 1, 2>(__VA_ARGS__)))
-
-int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl) { return pl.spa_rule == 2 ? WG8_TANH_DISPATCH(wg8_occ, pl) : pl.spa ? WG8_SPA_DISPATCH(wg8_occ, pl) : WG8_DISPATCH(wg8_occ, pl); }
+int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl) { return WG8_ANY_DISPATCH(wg8_occ, pl); }
 
 hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
 {
@@ -1553,7 +1552,8 @@ hipError_t ldpc_wg8_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
     p.w8.nl_info = pl.w8_nl_info; p.w8.nl = pl.w8_nl; p.w8.ng_info = pl.w8_ng_info; p.w8.ng = pl.w8_ng;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.gwork_words = pl.w8_gwork_words;
-    return pl.spa_rule == 2 ? WG8_TANH_DISPATCH(wg8_inst, pl, p, s) : pl.spa ? WG8_SPA_DISPATCH(wg8_inst, pl, p, s) : WG8_DISPATCH(wg8_inst, pl, p, s);
+    p.spa_cap = pl.spa_rule == 3 ? LDPC_SPA_CAP : INFINITY;
+    return WG8_ANY_DISPATCH(wg8_inst, pl, p, s);
 }
 
 }  // namespace dvbs2

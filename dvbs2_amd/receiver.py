@@ -40,9 +40,9 @@ class Dvbs2Hip:
         cfg.max_frames = int(max_frames)
         cfg.ldpc_n_ite = int(n_ite)
         cfg.ldpc_alpha = float(alpha)
-        if implem not in ("NMS", "MS", "SPA", "SPA_TANH"):
-            raise ValueError("implem has to be NMS, MS, SPA or SPA_TANH")
-        cfg.ldpc_implem = {"NMS": 0, "MS": 1, "SPA": 2, "SPA_TANH": 3}[implem]
+        if implem not in ("NMS", "MS", "SPA", "SPA_TANH", "SPA_EXACT"):
+            raise ValueError("implem has to be NMS, MS, SPA, SPA_TANH or SPA_EXACT")
+        cfg.ldpc_implem = {"NMS": 0, "MS": 1, "SPA": 2, "SPA_TANH": 3, "SPA_EXACT": 4}[implem]
         cfg.ldpc_early_stop = 1 if early_stop else 0
         cfg.device = int(device)
         cfg.stream = stream

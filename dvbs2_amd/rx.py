@@ -30,7 +30,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--rad-rx-file-path", required=True)
     ap.add_argument("--rad-rx-no-loop", action="store_true")
     ap.add_argument("--max-frames", type=int, default=0)
-    ap.add_argument("--dec-implem", default="SPA", choices=["NMS", "MS", "SPA", "SPA_TANH"])    # the reference's defaults (DVBS2.cpp:135-138)
+    ap.add_argument("--dec-implem", default="SPA", choices=["NMS", "MS", "SPA", "SPA_TANH", "SPA_EXACT"])    # the reference's defaults (DVBS2.cpp:135-138)
     ap.add_argument("--dec-ite", type=int, default=50)
     ap.add_argument("--dec-alpha", type=float, default=1.0)
     ap.add_argument("--dec-simd", default="", help="accepted and ignored (the GPU batches frames with -F)")

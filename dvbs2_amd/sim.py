@@ -29,7 +29,7 @@ def build_parser():
     ap.add_argument("-e", "--max-fe", type=int, default=100)
     ap.add_argument("-F", "--sim-inter-fra", type=int, default=512, help="frames per batch per GPU (grid width)")
     ap.add_argument("--dec-ite", type=int, default=50)
-    ap.add_argument("--dec-implem", default="SPA", choices=["NMS", "MS", "SPA", "SPA_TANH"])    # the reference's defaults: SPA, 50 ite (DVBS2.cpp:135-138)
+    ap.add_argument("--dec-implem", default="SPA", choices=["NMS", "MS", "SPA", "SPA_TANH", "SPA_EXACT"])    # the reference's defaults: SPA, 50 ite (DVBS2.cpp:135-138)
     ap.add_argument("--dec-alpha", type=float, default=1.0)
     ap.add_argument("--no-early-stop", action="store_true")
     ap.add_argument("--est-type", default="DVBS2", choices=["DVBS2", "PERFECT"])

@@ -69,8 +69,8 @@ int main(int argc, char **argv)
     int32_t n_gpus = 0;
     (void)dvbs2hip_device_count(&n_gpus);
     cfg.device = local_rank >= 0 ? local_rank : (n_gpus > 0 ? rank % n_gpus : rank);      // a global rank only: ranks are dealt to the node's GPUs in order
-    cfg.ldpc_implem = implem == "SPA" ? DVBS2HIP_IMPLEM_SPA : implem == "SPA_TANH" ? DVBS2HIP_IMPLEM_SPA_TANH : implem == "MS" ? DVBS2HIP_IMPLEM_MS : DVBS2HIP_IMPLEM_NMS;
-    if (implem != "SPA" && implem != "SPA_TANH" && implem != "MS" && implem != "NMS") { std::fprintf(stderr, "--dec-implem has to be SPA, SPA_TANH, MS or NMS\n"); return 2; }
+    cfg.ldpc_implem = implem == "SPA" ? DVBS2HIP_IMPLEM_SPA : implem == "SPA_TANH" ? DVBS2HIP_IMPLEM_SPA_TANH : implem == "SPA_EXACT" ? DVBS2HIP_IMPLEM_SPA_EXACT : implem == "MS" ? DVBS2HIP_IMPLEM_MS : DVBS2HIP_IMPLEM_NMS;
+    if (implem != "SPA" && implem != "SPA_TANH" && implem != "SPA_EXACT" && implem != "MS" && implem != "NMS") { std::fprintf(stderr, "--dec-implem has to be SPA, SPA_TANH, SPA_EXACT, MS or NMS\n"); return 2; }
     if (n_clones < 1 || n_clones > 8) { std::fprintf(stderr, "--clones has to be 1 .. 8\n"); return 2; }
     struct Clone { dvbs2hip_t *h = nullptr; void *d_pl = nullptr, *d_sent = nullptr, *d_got = nullptr, *d_sig = nullptr; uint64_t c[3] = {0, 0, 0}; bool busy = false; };
     std::vector<Clone> cl((size_t)n_clones);

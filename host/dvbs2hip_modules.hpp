@@ -30,9 +30,9 @@ public:
         dvbs2hip_cfg cfg;
         if (dvbs2hip_cfg_from_modcod(modcod.c_str(), &cfg) != DVBS2HIP_OK)
             throw spu::tools::invalid_argument(__FILE__, __LINE__, __func__, dvbs2hip_last_error(nullptr));   // DVBS2.cpp:319
-        if (ldpc_implem != "SPA" && ldpc_implem != "SPA_TANH" && ldpc_implem != "NMS" && ldpc_implem != "MS")
-            throw spu::tools::invalid_argument(__FILE__, __LINE__, __func__, "'ldpc_implem' has to be SPA, SPA_TANH, NMS or MS");
-        cfg.ldpc_implem = ldpc_implem == "SPA" ? DVBS2HIP_IMPLEM_SPA : ldpc_implem == "SPA_TANH" ? DVBS2HIP_IMPLEM_SPA_TANH : ldpc_implem == "MS" ? DVBS2HIP_IMPLEM_MS : DVBS2HIP_IMPLEM_NMS;
+        if (ldpc_implem != "SPA" && ldpc_implem != "SPA_TANH" && ldpc_implem != "SPA_EXACT" && ldpc_implem != "NMS" && ldpc_implem != "MS")
+            throw spu::tools::invalid_argument(__FILE__, __LINE__, __func__, "'ldpc_implem' has to be SPA, SPA_TANH, SPA_EXACT, NMS or MS");
+        cfg.ldpc_implem = ldpc_implem == "SPA" ? DVBS2HIP_IMPLEM_SPA : ldpc_implem == "SPA_TANH" ? DVBS2HIP_IMPLEM_SPA_TANH : ldpc_implem == "SPA_EXACT" ? DVBS2HIP_IMPLEM_SPA_EXACT : ldpc_implem == "MS" ? DVBS2HIP_IMPLEM_MS : DVBS2HIP_IMPLEM_NMS;
         cfg.max_frames = n_frames; cfg.ldpc_n_ite = ldpc_n_ite; cfg.ldpc_alpha = ldpc_alpha;
         cfg.ldpc_early_stop = early_stop ? 1 : 0; cfg.device = device;
         const int rc = dvbs2hip_create(&cfg, &h);

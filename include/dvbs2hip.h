@@ -44,9 +44,13 @@ typedef struct dvbs2hip_handle dvbs2hip_t;
 
 /* LDPC check-node rule (--dec-implem, DVBS2.cpp:117-149; the reference's default is SPA) */
 enum { DVBS2HIP_IMPLEM_NMS = 0, DVBS2HIP_IMPLEM_MS = 1,
-       DVBS2HIP_IMPLEM_SPA = 2,          /* sum-product, exact check node (no saturation): within 1e-4 max(1, |L|) of the oracle's ORC_SPA */
-       DVBS2HIP_IMPLEM_SPA_TANH = 3 };   /* sum-product as AFF3CT's Update_rule_SPA evaluates it [UPSTREAM-RECALL]: tanh product in fp32, messages capped at
+       DVBS2HIP_IMPLEM_SPA = 2,          /* sum-product as the reference decodes it: the exact check node with every message clipped at 2 atanh(1 - FLT_EPSILON) = 16.64, where
+                                            the messages of AFF3CT's Update_rule_SPA saturate (fp32 tanh product) -- frame for frame the decisions of SPA_TANH on 99.9 % of the
+                                            frames near the waterfall (results/r06/spa_rules.md); within 1e-4 max(1, |L|) of the oracle's ORC_SPA_CLIP */
+       DVBS2HIP_IMPLEM_SPA_TANH = 3,   /* sum-product as AFF3CT's Update_rule_SPA evaluates it [UPSTREAM-RECALL]: tanh product in fp32, messages capped at
                                             2 atanh(1 - FLT_EPSILON) = 16.64; BIT-EXACT against the oracle's ORC_SPA_TANH (every operation correctly rounded) */
+       DVBS2HIP_IMPLEM_SPA_EXACT = 4 };  /* the exact check node without the clip (rounds 1-5's SPA): within 1e-4 max(1, |L|) of the oracle's ORC_SPA; loses 20-50 % more frames than the
+                                            reference at the low-FER end of the rate-3/5 traces */
 /* Order in which the layered decoder visits the checks of a frame (dvbs2hip_set_ldpc_schedule) */
 enum { DVBS2HIP_SCHED_QC = 0,        /* quasi-cyclic layers of 360 independent checks: the throughput path */
        DVBS2HIP_SCHED_NATURAL = 1 }; /* natural row order of H, what AFF3CT's BP_HORIZONTAL_LAYERED runs: one lane per frame */

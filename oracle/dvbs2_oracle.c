@@ -262,6 +262,10 @@ static inline void chk_update(int implem, float alpha, const float *v2c, int d, 
 {
     if (implem == ORC_NMS) chk_update_nms(v2c, d, alpha, out);
     else if (implem == ORC_SPA_TANH) chk_update_spa_tanh(v2c, d, out);
+    else if (implem == ORC_SPA_CLIP) {      /* the exact rule, every message clipped to the cap of the tanh-product rule: 2 atanh(1 - FLT_EPSILON) */
+        chk_update_spa(v2c, d, out);
+        for (int j = 0; j < d; j++) if (fabsf(out[j]) > 16.6355324f) out[j] = copysignf(16.6355324f, out[j]);
+    }
     else chk_update_spa(v2c, d, out);
 }
 void orc_chk_update(int implem, float alpha, const float *v2c, int d, float *out) { chk_update(implem, alpha, v2c, d, out); }

@@ -200,7 +200,7 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
-NMS, SPA, SPA_TANH = 0, 1, 2      # SPA: exact boxplus; SPA_TANH: the saturating tanh-product form of AFF3CT's Update_rule_SPA (dvbs2_oracle.c)
+NMS, SPA, SPA_TANH, SPA_CLIP = 0, 1, 2, 3      # SPA: exact boxplus; SPA_TANH: the saturating tanh-product form of AFF3CT's Update_rule_SPA (dvbs2_oracle.c)
 NATURAL, QC = 0, 1
 
 

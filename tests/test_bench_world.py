@@ -30,7 +30,7 @@ def _rank(rank, world, port, outdir, extras):
     import bench
     import bench_stub
     sys.stdout = open(os.path.join(outdir, "out.%d" % rank), "w")
-    argv = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--frames", str(FRAMES), "--quad-launches", "1", "--self-check-steps", "2", "--no-cpu-baseline"]
+    argv = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--frames", str(FRAMES), "--quad-launches", "1", "--self-check-steps", "2", "--self-check-seconds", "0", "--no-cpu-baseline"]
     bench.main(argv + ([] if extras else ["--no-extras"]), runtime=bench_stub.StubRuntime)
     sys.stdout.flush()
     with open(os.path.join(outdir, "calls.%d" % rank), "w") as fh:
@@ -67,7 +67,7 @@ def test_bench_control_path_with_n_ranks(world, tmp_path):
     # what belongs to the N = 1 line is named, not silently dropped
     assert d["cpu_baseline"] == "N=1 line only" and d["roofline"]["live_pmc"] == "N=1 line only"
     ex = d["extra"]
-    assert "N=1 line only" in ex["host_socket_form"] and "N=1 line only" in ex["configs"]["4"] and set(ex["skipped_at_this_n"]) == {"configs.4", "host_socket_form"}
+    assert "N=1 line only" in ex["host_socket_form"] and "N=1 line only" in ex["configs"]["4"] and set(ex["skipped_at_this_n"]) == {"configs.4", "host_socket_form", "ref_config", "sync_located"} and ex["spa"]["QPSK-N_8/9"]["frames"] == FRAMES
     assert ex["configs"]["2"]["bit_errors"] == 0 and ex["configs"]["3"]["n_ite"] == 20 and ex["natural_order"]["frames"] == FRAMES
     assert set(ex["four_way"]["variants"]) == {"4.0dB_fixed", "3.0dB_fixed", "4.0dB_stop", "3.0dB_stop"}
     # every rank went through the same extras in the same order (lock step: none of them holds a collective, so a rank that skipped one would not hang the others -- it would

@@ -18,7 +18,7 @@ def test_no_kernel_spills_vector_registers():
     import kernel_regs
     ks = kernel_regs.kernels()
     names = {k["name"] for k in ks}
-    assert len(ks) >= 80 and any("ldpc_wg8_kernel<27, 4, true>" in n for n in names) and any("ldpc_cu1_kernel<27, true>" in n for n in names) and any("ldpc_wg8_kernel<27, 5, false>" in n for n in names) and any("fir_mfma_kernel<2>" in n for n in names)
+    assert len(ks) >= 80 and any("ldpc_wg8_kernel<27, 4, 1>" in n for n in names) and any("ldpc_cu1_kernel<27, true>" in n for n in names) and any("ldpc_wg8_kernel<27, 5, 0>" in n for n in names) and any("fir_mfma_kernel<2>" in n for n in names)
     assert not any("ldpc_fast2" in n for n in names), "stale object of a removed translation unit in dvbs2_amd/lib"
     bad = [(k["name"], k["vgpr_spill"]) for k in ks if k["vgpr_spill"] > 0]
     assert not bad, bad
@@ -26,7 +26,7 @@ def test_no_kernel_spills_vector_registers():
     scratch = [(k["name"], k["scratch"]) for k in ks if k["scratch"] > 0]
     # ... and a 20-byte slot the backend reserves in the LDS-only min-sum kernels since their layer loop carries the address table's 28 registers (W8_ATAB; gone with -DW8_ATAB=0):
     # no instruction of the kernels touches it -- checked here in the disassembly -- so it is a frame-size entry, not a spill
-    dead = [n for n, b in scratch if "ldpc_wg8_kernel<" in n and ", 0, false>" in n and b <= 32]
+    dead = [n for n, b in scratch if "ldpc_wg8_kernel<" in n and ", 0, 0>" in n and b <= 32]
     assert all("sync_vdelay_batch_kernel" in n or n in dead for n, _ in scratch), scratch
     if dead:
         import subprocess
@@ -88,5 +88,5 @@ def test_layer_loop_instruction_mix_is_read_from_the_code_object():
     assert how["scope"] == "layer loop" and how["mix"]["trans"] == 0 and 3.8 < cpi < 4.1, (cpi, how)
     n = sum(how["mix"].values())
     assert 500 < n < 800 and 0.40 < how["mix"]["vop3"] / n < 0.55 and how["mix"]["plain"] / n < 0.12
-    cpi_spa, how_spa = KM.price_kernel("ldpc_wg8_kernel<27,0,true>")
+    cpi_spa, how_spa = KM.price_kernel("ldpc_wg8_kernel<27,0,1>")
     assert how_spa["mix"]["trans"] >= 100 and cpi_spa < cpi + 0.5

@@ -149,9 +149,13 @@ def test_ldpc_ties_zeros_and_extremes_match_oracle(O, Rx, modcod):
     assert np.array_equal(V[1], info[0])      # 1 % erasures are filled in
 
 
+SPA_RULES = [("SPA", "SPA_CLIP"), ("SPA_EXACT", "SPA")]      # (--dec-implem, the oracle's rule): SPA = the exact check node with AFF3CT's message cap, SPA_EXACT = without
+
+
+@pytest.mark.parametrize("implem,orule", SPA_RULES)
 @pytest.mark.parametrize("modcod,ebn0", [("QPSK-S_8/9", 3.9), ("QPSK-S_3/5", 1.8), ("32APSK-S_3/4", 3.0), ("QPSK-N_8/9", 3.9)])
-def test_ldpc_spa_matches_oracle(O, Rx, modcod, ebn0):
-    """--dec-implem SPA (the reference's default): exact boxplus check node.  The GPU evaluates the
+def test_ldpc_spa_matches_oracle(O, Rx, modcod, ebn0, implem, orule):
+    """--dec-implem SPA (the reference's default) / SPA_EXACT: exact boxplus check node, with / without the cap at 2 atanh(1 - FLT_EPSILON).  The GPU evaluates the
     exp/log terms on the hardware exp2/log2 units, the oracle with libm, so the parity bar is the
     soft one: |posterior difference| <= 1e-4 * max(1, |posterior|) after 1 and 2 iterations (before
     rounding differences can be amplified), and identical hard decisions / iteration counts for
@@ -160,15 +164,15 @@ def test_ldpc_spa_matches_oracle(O, Rx, modcod, ebn0):
     F = 4
     _, llr, cw = make_llrs(O, modcod, F, ebn0, seed=17)
     for n_ite in (1, 2):
-        rx = Rx(modcod, max_frames=F, n_ite=n_ite, early_stop=False, implem="SPA")
+        rx = Rx(modcod, max_frames=F, n_ite=n_ite, early_stop=False, implem=implem)
         V, CWD, post, _ = rx.decode_siho(llr, with_post=True)
-        Vo, posto, cwdo, _ = ch.ldpc.decode(llr, n_ite=n_ite, implem=O.SPA, sched=O.QC, early_stop=False)
+        Vo, posto, cwdo, _ = ch.ldpc.decode(llr, n_ite=n_ite, implem=getattr(O, orule), sched=O.QC, early_stop=False)
         assert np.all(np.abs(post - posto) <= 1e-4 * np.maximum(1.0, np.abs(posto))), float(np.abs(post - posto).max())
         assert (V != Vo).mean() < 1e-4
         rx.close()
-    rx = Rx(modcod, max_frames=F, n_ite=50, early_stop=True, implem="SPA")
+    rx = Rx(modcod, max_frames=F, n_ite=50, early_stop=True, implem=implem)
     V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
-    Vo, posto, cwdo, iteso = ch.ldpc.decode(llr, n_ite=50, implem=O.SPA, sched=O.QC, early_stop=True)
+    Vo, posto, cwdo, iteso = ch.ldpc.decode(llr, n_ite=50, implem=getattr(O, orule), sched=O.QC, early_stop=True)
     conv = (CWD == 1) & (cwdo == 1)
     assert conv.sum() >= F - 1
     assert np.array_equal(V[conv], Vo[conv]) and np.all(np.abs(ites[conv] - iteso[conv]) <= 1)
@@ -227,12 +231,30 @@ def test_ldpc_spa_far_beyond_the_saturation_of_tanh(O, Rx, modcod, ebn0, n_ite, 
     F = 2
     _, llr, cw = make_llrs(O, modcod, F, ebn0, seed=23)
     llr = (llr * scale).astype(np.float32)
-    rx = Rx(modcod, max_frames=F, n_ite=n_ite, early_stop=False, implem="SPA")
+    rx = Rx(modcod, max_frames=F, n_ite=n_ite, early_stop=False, implem="SPA_EXACT")
     V, CWD, post, _ = rx.decode_siho(llr, with_post=True)
     Vo, posto, cwdo, _ = ch.ldpc.decode(llr, n_ite=n_ite, implem=O.SPA, sched=O.QC, early_stop=False)
     assert not np.isnan(post).any() and np.isfinite(post).all()
     assert float(np.abs(posto).max()) > 400.0                                    # the regime the test is about
     assert np.all(np.abs(post - posto) <= 1e-4 * np.maximum(1.0, np.abs(posto))), float((np.abs(post - posto) / np.maximum(1.0, np.abs(posto))).max())
+    assert np.array_equal(V, Vo) and np.array_equal(CWD, cwdo) and CWD.all()
+    rx.close()
+
+
+@pytest.mark.parametrize("modcod,ebn0,n_ite,scale", [("QPSK-S_8/9", 9.0, 20, 4.0), ("QPSK-S_3/5", 6.0, 10, 1.0), ("QPSK-N_8/9", 9.0, 10, 3.0)])
+def test_ldpc_spa_default_clips_where_the_reference_saturates(O, Rx, modcod, ebn0, n_ite, scale):
+    """--dec-implem SPA in the same regime: every c->v message stops at 16.6355 = 2 atanh(1 - FLT_EPSILON), the cap of AFF3CT's fp32 tanh product (the oracle's ORC_SPA_CLIP:
+    exact boxplus, then the clip), so a posterior cannot leave |channel| + 16.6355 x column weight; same bar as the unclipped rule, 1e-4 max(1, |L|)."""
+    ch = chain(O, modcod)
+    F = 2
+    _, llr, cw = make_llrs(O, modcod, F, ebn0, seed=23)
+    llr = (llr * scale).astype(np.float32)
+    rx = Rx(modcod, max_frames=F, n_ite=n_ite, early_stop=False, implem="SPA")
+    V, CWD, post, _ = rx.decode_siho(llr, with_post=True)
+    Vo, posto, cwdo, _ = ch.ldpc.decode(llr, n_ite=n_ite, implem=O.SPA_CLIP, sched=O.QC, early_stop=False)
+    assert np.isfinite(post).all()
+    assert np.all(np.abs(post - posto) <= 1e-4 * np.maximum(1.0, np.abs(posto))), float((np.abs(post - posto) / np.maximum(1.0, np.abs(posto))).max())
+    assert np.all(np.abs(post) <= np.abs(llr) + 16.6356 * 13 + 1e-2) and float(np.abs(post - llr).max()) > 3 * 16.0      # (column weights: at most 13 on these codes)
     assert np.array_equal(V, Vo) and np.array_equal(CWD, cwdo) and CWD.all()
     rx.close()
 
@@ -371,7 +393,7 @@ def test_ldpc_baseline_batch_of_exactly_4096_frames_matches_oracle(O, Rx):
     rx.close()
 
 
-@pytest.mark.parametrize("implem", ["NMS", "SPA"])
+@pytest.mark.parametrize("implem", ["NMS", "SPA", "SPA_EXACT"])
 @pytest.mark.parametrize("mode,kernel_mode", [("", None), ("cu1", 6), ("park", 5), ("park4", 4), ("static", 3), ("global", 1)])
 def test_ldpc_normal_frame_image_modes_agree_with_the_oracle(O, Rx, monkeypatch, mode, kernel_mode, implem):
     """Where the posteriors of a normal frame live -- static hybrid with 39 / 32 bit-group rows parked in the idle waves' registers (modes 5 / 4, the
@@ -384,17 +406,18 @@ def test_ldpc_normal_frame_image_modes_agree_with_the_oracle(O, Rx, monkeypatch,
     ch, sent, llr = _big_batch(O, modcod, F, (3.0, 4.2), seed=4242, n_cw=4)
     rng = np.random.default_rng(8)
     pick = np.unique(np.concatenate([np.arange(F - 6, F), rng.choice(F - 6, 6, replace=False)]))
-    spa = implem == "SPA"
+    spa = implem != "NMS"
+    orule = {"NMS": O.NMS, "SPA": O.SPA_CLIP, "SPA_EXACT": O.SPA}[implem]
     for early in (False, True):
         n_ite = 3 if spa and not early else 10
         rx = Rx(modcod, max_frames=F, n_ite=n_ite, alpha=1.0, early_stop=early, implem=implem)
         want = kernel_mode if kernel_mode is not None else (DEFAULT_SPA_MODE if spa else DEFAULT_NMS_MODE)
         if spa and want == 5:
             want = 4                    # (the sum-product kernel has no registers for 39 parked rows)
-        name = ("ldpc_cu1_kernel<27,true>" if spa else "ldpc_cu1_kernel<27>") if want == 6 else "ldpc_wg8_kernel<27,%d%s>" % (want, ",true" if spa else "")
+        name = ("ldpc_cu1_kernel<27,true>" if spa else "ldpc_cu1_kernel<27>") if want == 6 else "ldpc_wg8_kernel<27,%d%s>" % (want, ",1" if spa else "")
         assert rx.ldpc_kernel_name() == name, rx.ldpc_kernel_name()
         V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
-        Vo, posto, cwdo, iteso = ch.ldpc.decode(llr[pick], n_ite=n_ite, alpha=1.0, implem=O.SPA if spa else O.NMS, sched=O.QC, early_stop=early)
+        Vo, posto, cwdo, iteso = ch.ldpc.decode(llr[pick], n_ite=n_ite, alpha=1.0, implem=orule, sched=O.QC, early_stop=early)
         if spa:
             assert np.all(np.abs(post[pick] - posto) <= 1e-4 * np.maximum(1.0, np.abs(posto))), float(np.abs(post[pick] - posto).max())
             assert (V[pick] != Vo).mean() < 1e-4
@@ -420,7 +443,7 @@ def test_ldpc_spa_at_size_matches_oracle(O, Rx, modcod, F, dbs):
     pick = np.unique(np.concatenate([np.arange(F - 6, F), rng.choice(F - 6, 6, replace=False)]))
     rx = Rx(modcod, max_frames=F, n_ite=2, early_stop=False, implem="SPA")
     V, CWD, post, _ = rx.decode_siho(llr, with_post=True)
-    Vo, posto, cwdo, _ = ch.ldpc.decode(llr[pick], n_ite=2, implem=O.SPA, sched=O.QC, early_stop=False)
+    Vo, posto, cwdo, _ = ch.ldpc.decode(llr[pick], n_ite=2, implem=O.SPA_CLIP, sched=O.QC, early_stop=False)
     assert np.all(np.abs(post[pick] - posto) <= 1e-4 * np.maximum(1.0, np.abs(posto))), float(np.abs(post[pick] - posto).max())
     assert (V[pick] != Vo).mean() < 1e-4
     rx.close()

@@ -2,7 +2,7 @@
 Why it matters (tools/probe_issue2.hip, profiles/r04_probe_issue.txt): a SIMD issues a VOP3-encoded instruction every ~4.1 cycles and a VOP1 / VOP2 / VOPC one every
 ~2.07, whatever the number of waves -- and so does a VOP2 instruction that reads an SGPR; the transcendentals take 8 -- so the vector-issue time of a kernel is the sum of
 its instructions' prices per SIMD, not N x 2 (round 3) and not N x 4 (round 2).
-usage: python tools/kernel_mix.py [translation unit] [substring of the demangled kernel name]      e.g.  k_ldpc_wg8 "ldpc_wg8_kernel<27, 5, false>" """
+usage: python tools/kernel_mix.py [translation unit] [substring of the demangled kernel name]      e.g.  k_ldpc_wg8 "ldpc_wg8_kernel<27, 5, 0>" """
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
@@ -110,7 +110,7 @@ def price_kernel(kernel_name):
             except Exception:
                 _CACHE[tu] = {}
         for n, (ins, dem) in _CACHE[tu].items():
-            if dem == base_n or dem.replace(",false>", ">") == base_n:
+            if dem == base_n or dem.replace(",false>", ">") == base_n or dem.replace(",0>", ">") == base_n:
                 loop = layer_loop(ins)
                 sel = [i for i in ins if loop and loop[0] <= i[0] <= loop[1]] if loop else ins
                 c = {k: 0 for k in list(CYC) + ["other"]}
@@ -124,7 +124,7 @@ def price_kernel(kernel_name):
 
 if __name__ == "__main__":
     tu = sys.argv[1] if len(sys.argv) > 1 else "k_ldpc_wg8"
-    pat = sys.argv[2] if len(sys.argv) > 2 else "ldpc_wg8_kernel<27, 5, false>"
+    pat = sys.argv[2] if len(sys.argv) > 2 else "ldpc_wg8_kernel<27, 5, 0>"
     for r in mix(tu, pat):
         print("%-50s layer loop %s bytes: %d vector instructions %s -> %.2f SIMD cycles per vector instruction; %d scalar / memory / other"
               % (r["kernel"], r["loop_bytes"], r["valu"], r["mix"], r["cycles_per_valu"], r["other"]))

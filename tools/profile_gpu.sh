@@ -6,7 +6,7 @@ REPO="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$REPO/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="$REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --self-check-steps 0"
+ARGS="$REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --self-check-steps 0 --self-check-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- python3 $ARGS > "$OUT/prof_stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_fetch" -- python3 $ARGS > "$OUT/prof_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_write" -- python3 $ARGS > "$OUT/prof_write.log" 2>&1

@@ -108,7 +108,7 @@ if pmc:
     json.dump({"hbm_bytes_per_launch": cf * fetch_b + cw * write_b, "fetch_bytes_raw": fetch_b, "write_bytes_raw": write_b,
                "fetch_correction": cf, "write_correction": cw, "source": "profiles/%s_ldpc_rocprof.md" % tag,
                "kernel_sha": _bench.kernel_sha(), "kernel_sources": list(_bench.KERNEL_SOURCES), "git_head": head,
-               "kernel": meta[0].replace("void ", "").split("(")[0].replace("dvbs2::", "").replace(", false>", ">").replace(", ", ","),
+               "kernel": meta[0].replace("void ", "").split("(")[0].replace("dvbs2::", "").replace(", false>", ">").replace(", 0>", ">").replace(", ", ","),
                "frames": _bench.FRAMES_PER_GPU, "n_ite": _bench.N_ITE,
                "valu_occupancy": valu_frac, "valu_cycles_per_inst": cyc_per_valu, "vop3_share": vop3_share, "wave_issue_occupancy": wave_issue, "valu_insts_per_launch": pmc.get("SQ_INSTS_VALU"), "busy_cycles_per_launch": (pmc.get("SQ_BUSY_CYCLES") or 0) / 32.0,
                "l2_hit_rate": (pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])) if "TCC_HIT_sum" in pmc else None,
