@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -41,6 +43,10 @@ struct dvbs2hip_handle {
     // device state
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool capturing = false;
+    bool comm_dead = false;       // dvbs2hip_monitor_reduce timed out: the communicator was aborted
+    int red_timeout_ms = 0;
+    std::vector<hipGraphExec_t> graphs;      // dvbs2hip_graph_end: captured call sequences (a freed slot is nullptr)
     int n_cus = 256;
     LdpcPlan ldpc;
     BchPlan bch;
@@ -133,7 +139,7 @@ int fail(dvbs2hip_t *h, int code, const std::string &msg)
     } while (0)
 
 enum BufId { B_IN = 0, B_OUT, B_AUX0, B_AUX1, B_AUX2, B_AUX3, B_LLR, B_PACKED, B_EST, B_CWD0, B_CWD1, B_INFO, B_SIG, B_TXBCH, B_TXLDPC,
-             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY, B_SFM_DTAB, B_SFF_TMP, B_SFF_OUT, B_FLT2, B_MON_BE, B_MON_OUT, B_BCHFLAG, B_LR_TMP0, B_LR_TMP1, B_LR_TMP2, B_LR_TMP3, B_SFM_SCR, B_SFM_NEED };
+             B_SFM_CORR, B_SFM_MET, B_SFM_SOF, B_SFM_PLSC, B_SFM_DLY, B_SFM_DTAB, B_SFF_TMP, B_SFF_OUT, B_FLT2, B_MON_BE, B_MON_OUT, B_BCHFLAG, B_ORDER, B_LR_TMP0, B_LR_TMP1, B_LR_TMP2, B_LR_TMP3, B_SFM_SCR, B_SFM_NEED };
 
 int ensure(dvbs2hip_t *h, int id, size_t bytes, void **out)
 {
@@ -592,8 +598,9 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream && !h->comm_dead) (void)hipStreamSynchronize(h->stream);      // (a stream behind an aborted all-reduce may never drain)
     (void)dvbs2hip_monitor_reduce_finalize(h);
+    for (hipGraphExec_t g : h->graphs) if (g) (void)hipGraphExecDestroy(g);
     for (auto &kv : h->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (int k = 0; k < DVBS2HIP_K_COUNT; k++)
         for (auto &p : h->ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -618,8 +625,8 @@ int dvbs2hip_set_ldpc_schedule(dvbs2hip_t *h, int32_t schedule)
 {
     if (!h) return DVBS2HIP_EINVAL;
     if (schedule != DVBS2HIP_SCHED_QC && schedule != DVBS2HIP_SCHED_NATURAL) return fail(h, DVBS2HIP_EINVAL, "unknown LDPC schedule");
-    if (schedule == DVBS2HIP_SCHED_NATURAL && (!h->ldpc.fast || h->ldpc.spa))
-        return fail(h, DVBS2HIP_EUNSUPPORTED, "the natural-order schedule is implemented for NMS / MS on codes with check degree <= 27");
+    if (schedule == DVBS2HIP_SCHED_NATURAL && !h->ldpc.fast)
+        return fail(h, DVBS2HIP_EUNSUPPORTED, "the natural-order schedule is implemented for codes with check degree <= 27");
     h->ldpc_sched = schedule;
     return 0;
 }
@@ -638,6 +645,7 @@ const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
     if (!h) return "";
     if (h->ldpc_sched == DVBS2HIP_SCHED_NATURAL) {      // one lane per frame from 32768 frames on, a check's edges over 4 / 8 lanes below (k_ldpc_nat.hip: ldpc_nat_launch)
         const std::string d = std::to_string(h->ldpc.fast_deg);
+        if (h->ldpc.spa) { const_cast<dvbs2hip_t *>(h)->ldpc_name = "ldpc_nat_spa_kernel<" + d + "," + (h->ldpc.spa_rule == 2 ? "2" : "1") + ">"; return h->ldpc_name.c_str(); }
         const_cast<dvbs2hip_t *>(h)->ldpc_name = "ldpc_nat_kernel<" + d + "> / ldpc_nat_part_kernel<" + d + ",4|8> / ldpc_nat_ck_kernel<" + d + ",8|4,1|2|4> by batch size";
         return h->ldpc_name.c_str();
     }
@@ -712,6 +720,52 @@ int dvbs2hip_synchronize(dvbs2hip_t *h)
     return lr_check_all(h);      // (device-form L&R calls: their error words are looked at here)
 }
 
+// ------------------------------------------------------------------ call sequences as hipGraphs (small batches: the sequence filter -> extract -> rx_bb is six launches
+// and a fill for one workgroup's worth of work; captured once per (F, buffers) and replayed it is ONE submission)
+int dvbs2hip_graph_begin(dvbs2hip_t *h)
+{
+    int r0 = enter(h); if (r0) return r0;
+    if (h->capturing) return fail(h, DVBS2HIP_EINVAL, "a capture is already open on this handle");
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    h->capturing = true;
+    return 0;
+}
+
+int dvbs2hip_graph_end(dvbs2hip_t *h, int32_t *graph)
+{
+    if (!h || !graph) return DVBS2HIP_EINVAL;
+    if (!h->capturing) return fail(h, DVBS2HIP_EINVAL, "no capture is open on this handle");
+    h->capturing = false;
+    hipGraph_t g = nullptr;
+    HIPCHK(h, hipStreamEndCapture(h->stream, &g));
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIPCHK(h, e);
+    size_t k = 0;
+    while (k < h->graphs.size() && h->graphs[k]) k++;
+    if (k == h->graphs.size()) h->graphs.push_back(ex); else h->graphs[k] = ex;
+    *graph = (int32_t)k;
+    return 0;
+}
+
+int dvbs2hip_graph_launch(dvbs2hip_t *h, int32_t graph)
+{
+    int r0 = enter(h); if (r0) return r0;
+    if (graph < 0 || (size_t)graph >= h->graphs.size() || !h->graphs[(size_t)graph]) return fail(h, DVBS2HIP_EINVAL, "unknown graph");
+    HIPCHK(h, hipGraphLaunch(h->graphs[(size_t)graph], h->stream));
+    return 0;
+}
+
+int dvbs2hip_graph_destroy(dvbs2hip_t *h, int32_t graph)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    if (graph < 0 || (size_t)graph >= h->graphs.size() || !h->graphs[(size_t)graph]) return fail(h, DVBS2HIP_EINVAL, "unknown graph");
+    (void)hipGraphExecDestroy(h->graphs[(size_t)graph]);
+    h->graphs[(size_t)graph] = nullptr;
+    return 0;
+}
+
 int dvbs2hip_get_sizes(const dvbs2hip_t *h, dvbs2hip_sizes *o)
 {
     if (!h || !o) return DVBS2HIP_EINVAL;
@@ -721,6 +775,7 @@ int dvbs2hip_get_sizes(const dvbs2hip_t *h, dvbs2hip_sizes *o)
 }
 
 // ------------------------------------------------------------------ a1
+static bool env_is(const char *name, char c) { const char *e = getenv(name); return e && e[0] == c; }
 // the LDPC kernel can write the chain's output socket itself (descrambled info bits of a frame the BCH stage leaves alone)
 static bool ldpc_writes_info(const dvbs2hip_t *h) { return h->ldpc.fast_wg8 && h->ldpc_sched == DVBS2HIP_SCHED_QC && !getenv("DVBS2HIP_CHAIN_UNFUSED"); }
 
@@ -754,6 +809,17 @@ static int ldpc_dev(dvbs2hip_t *h, const float *Y, int8_t *CWD, int32_t *V, uint
         return 0;
     }
     Timer tm(h, DVBS2HIP_K_LDPC);
+    // (round 6, measured NEGATIVE and therefore opt-in: DVBS2HIP_LDPC_ORDER=1) with the stopping rule the work queue can hand out the noisiest frames first
+    // (frame_order_launch).  Same-box A/B of the reference's configuration, 2 M frames per point: 8.30 / 13.33 / 18.05 Gb/s at 3.6 / 3.7 / 3.8 dB in index order against
+    // 8.16 / 13.09 / 17.98 ordered (three clones: 22.5 -> 21.3 at 3.8 dB; QPSK-N: -4 %): the queue already balances the workgroups, the frames that run to the cap are not
+    // what a launch waits for -- the two small kernels and the lost locality cost more than the order gives (docs/negative_results.md, round 6).
+    if (h->early_stop && h->ldpc.fast_wg8 && F >= (h->ldpc.fast_cu1 ? 2 : 4) * h->n_cus && env_is("DVBS2HIP_LDPC_ORDER", '1')) {
+        void *dord;
+        int r = ensure(h, B_ORDER, (size_t)F * 8, &dord);
+        if (r) return r;
+        HIPCHK(h, frame_order_launch(Y, (float *)dord + F, (uint32_t *)dord, F, h->N_ldpc, h->stream));
+        p.order = (const uint32_t *)dord;
+    }
     HIPCHK(h, ldpc_launch(h->ldpc, p, h->stream));
     return 0;
 }
@@ -1510,6 +1576,7 @@ struct RcclApi {
     int (*CommInitRank)(void **, int, dvbs2hip_nccl_id, int) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;      // optional
     const char *(*GetErrorString)(int) = nullptr;
 };
 RcclApi g_rccl;
@@ -1527,6 +1594,7 @@ const char *rccl_load()
     g_rccl.CommInitRank = (int (*)(void **, int, dvbs2hip_nccl_id, int))dlsym(l, "ncclCommInitRank");
     g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(l, "ncclAllReduce");
     g_rccl.CommDestroy = (int (*)(void *))dlsym(l, "ncclCommDestroy");
+    g_rccl.CommAbort = (int (*)(void *))dlsym(l, "ncclCommAbort");
     g_rccl.GetErrorString = (const char *(*)(int))dlsym(l, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) return "librccl.so lacks the nccl* entry points";
     g_rccl.lib = l;
@@ -1648,7 +1716,7 @@ int dvbs2hip_monitor_reduce_init(dvbs2hip_t *h, int32_t rank, int32_t world, con
     int e = g_rccl.CommInitRank(&comm, world, id, rank);
     if (e) return fail(h, DVBS2HIP_EHIP, "ncclCommInitRank: " + rccl_err(e));
     if (!h->d_red && hipMalloc((void **)&h->d_red, 3 * sizeof(unsigned long long)) != hipSuccess) { (void)g_rccl.CommDestroy(comm); return fail(h, DVBS2HIP_ENOMEM, "hipMalloc failed"); }
-    h->nccl_comm = comm; h->red_rank = rank; h->red_world = world;
+    h->nccl_comm = comm; h->red_rank = rank; h->red_world = world; h->red_timeout_ms = timeout_ms > 0 ? timeout_ms : 0;
     return 0;
 }
 
@@ -1661,7 +1729,23 @@ int dvbs2hip_monitor_reduce(dvbs2hip_t *h, uint64_t out[3])
     if (e) return fail(h, DVBS2HIP_EHIP, "ncclAllReduce: " + rccl_err(e));
     unsigned long long tmp[3];
     HIPCHK(h, hipMemcpyAsync(tmp, h->d_red, sizeof tmp, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // A peer that died leaves this rank's all-reduce waiting on the device for ever: wait with the timeout given at _reduce_init instead of a blocking
+    // synchronize -- a launcher-less `dvbs2_tx_rx_bb --world N` then ends with a non-zero exit code of its own instead of hanging until somebody kills it.
+    if (h->red_timeout_ms > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) HIPCHK(h, q);
+            if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > h->red_timeout_ms) {
+                if (g_rccl.CommAbort) (void)g_rccl.CommAbort(h->nccl_comm);
+                h->nccl_comm = nullptr; h->comm_dead = true;
+                return fail(h, DVBS2HIP_ETIMEOUT, "monitor reduction: a peer rank did not arrive within " + std::to_string(h->red_timeout_ms) + " ms (rank " + std::to_string(h->red_rank) + " of " + std::to_string(h->red_world) + ")");
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    } else
+        HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < 3; i++) out[i] = tmp[i];
     return 0;
 }

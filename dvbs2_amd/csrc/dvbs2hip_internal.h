@@ -73,6 +73,7 @@ struct LdpcKParams {
     int32_t gwork_words;     // global words per frame in total (posteriors + c2v state)
     int32_t n_frames, n_ite, early_stop;
     float alpha;
+    const uint32_t *order;        // queue position -> frame index (n_frames entries), or null: frames in index order (k_ldpc_wg8.hip; built by frame_order_launch)
     float spa_cap;                // sum-product, exact check node: |c->v| is clipped to this (LDPC_SPA_CAP: the reference's results; +inf: no clip)
     int32_t inf_row;           // fast path: byte offset of the +inf row (padded layers) or -1
     uint32_t *cu_ctr;          // 8-wave workgroups: per-CU arrival counter (zeroed before the launch) or null
@@ -232,6 +233,7 @@ struct FrontKParams {
     int32_t sep, sep_ax[2];
     float sep_g[2], sep_h[2];
 };
+hipError_t frame_order_launch(const float *llr, float *metric, uint32_t *order, int F, int N, hipStream_t s);      // k_ldpc.hip: the work queue's order for launches with the stopping rule (noisiest frames first)
 hipError_t front_rx_launch(FrontKParams p, hipStream_t s);                     // a7+a6+a3+a4 fused, in = pl frames
 hipError_t demod_launch(FrontKParams p, bool deinterleave, hipStream_t s);     // a3 (+a4), in = xfec frames, sigma_in required
 hipError_t deinterleave_launch(const float *itl, float *nat, int N, int cols, int order, int F, hipStream_t s);

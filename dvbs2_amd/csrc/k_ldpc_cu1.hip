@@ -153,7 +153,8 @@ __device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const 
         C1_MARK(1);
     };
     const bool es = p.early_stop != 0;
-    for (int f = blockIdx.x; f < p.n_frames; ) {
+    for (int qp = blockIdx.x; qp < p.n_frames; ) {
+        const int f = p.order ? (int)p.order[qp] : qp;      // (queue position -> frame: LdpcKParams::order, k_ldpc_wg8.hip)
         const float *Y = p.llr + (size_t)f * p.N;
         const int elc = on ? el : 0;
 #pragma unroll
@@ -197,7 +198,7 @@ __device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const 
         for (int k = 0; k < NRG; k++) if (on) { const uint32_t b = a0 + (uint32_t)k * (uint32_t)C1_ROW; lst(b, R[k][0]); lst(b + A1, R[k][1]); lst(b + A2, R[k][2]); }
         __syncthreads();
         __syncthreads();                            // the image is reused by the next frame
-        f = s_misc[19];
+        qp = s_misc[19];
         C1_MARK(7);
 #ifdef LDPC_PHASE_PROF
         prof[9]++;
@@ -238,7 +239,8 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
 
-    for (int f = blockIdx.x; f < p.n_frames; ) {
+    for (int qp = blockIdx.x; qp < p.n_frames; ) {
+        const int f = p.order ? (int)p.order[qp] : qp;
         // ---- channel LLRs -> the LDS positions that hold a row at the start of an iteration (the row-keeping waves load theirs themselves); the two halves take
         //      alternate batches of rows
         const float *Y = p.llr + (size_t)f * p.N;
@@ -706,9 +708,9 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
                 for (int k = 0; k < C1_IO; k++) if (l0 + k < NRT && srow[l0 + k] != 0xFFFFFFFFu) emit((int)srow[l0 + k], v[k]);
             }
         }
-        if (first_wave && lane == 0) s_misc[19] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[LDPC_FRAME_CTR], 1u) + gridDim.x) : f + (int)gridDim.x;
+        if (first_wave && lane == 0) s_misc[19] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[LDPC_FRAME_CTR], 1u) + gridDim.x) : qp + (int)gridDim.x;
         __syncthreads();     // the posterior image is reused by the next frame of this workgroup
-        f = s_misc[19];
+        qp = s_misc[19];
         C1_MARK(7);
 #ifdef LDPC_PHASE_PROF
         prof[9]++;

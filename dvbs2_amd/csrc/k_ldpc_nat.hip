@@ -16,6 +16,7 @@
 // path (17 MB of state traffic per frame and decode, no reuse on chip) is HBM-bound and a 4096-frame batch
 // fills only 64 of the chip's 1024 SIMDs.  The QC-layer kernels are the throughput path.
 #include "dvbs2hip_internal.h"
+#include "ldpc_det.h"
 
 namespace dvbs2 {
 
@@ -36,7 +37,7 @@ struct NatParams {
     const uint32_t *haz;       // [ceil(M/32)] bit c: check c shares a bit other than p_{c-1} with the check before it
     int32_t *bits; uint32_t *packed; int8_t *cwd; float *post; int32_t *ites;
     int32_t N, K, M, q, F, n_ite, early_stop;
-    float alpha;
+    float alpha, spa_cap;
     uint32_t grp_words;        // words per group of 64 frames in `work`
 };
 
@@ -159,6 +160,121 @@ ldpc_nat_kernel(const NatParams p)
 #pragma unroll
                 for (int j = 0; j < DEG; j++) x ^= __float_as_uint(Lv[j]);
                 bad |= x >> 31;
+                if (++r2 == q) { r2 = 0; t2++; }
+            }
+            if (live) { ok = bad == 0u; if (ok) live = false; }
+            if (!__any(live)) break;
+        }
+    }
+    if (f < p.F) {
+        if (p.cwd) p.cwd[f] = ok ? 1 : 0;
+        if (p.ites) p.ites[f] = my_ite;
+    }
+}
+
+// ---- the sum-product decoders in the reference's sweep order (round 6): one lane per frame like ldpc_nat_kernel, the c->v messages kept per edge (fp32 rows behind the
+// posterior rows: [check][slot][64 frames]; the first iteration reads none).  RULE 2: AFF3CT's tanh-product check node (ldpc_det.h) -- with the slots in address-table
+// order (k_ldpc.hip: info edges, p_c, p_{c-1}) every operation is the oracle's decoder (ORC_SPA_TANH under ORC_SCHED_NATURAL) in the oracle's order: BIT-EXACT, and as close
+// to what the reference's `Decoder_LDPC_BP_horizontal_layered<.., Update_rule_SPA>` does as this library can get.  RULE 1: exact boxplus (forward / backward recursions on
+// the hardware exp2 / log2 units), every message clipped to p.spa_cap (`--dec-implem SPA`: AFF3CT's cap; SPA_EXACT: +inf): within 1e-4 max(1, |L|) of the oracle.
+// A validation mode: a frame's checks are a serial chain of memory round trips (~1 us each), so a launch wants tens of thousands of frames.
+__device__ __forceinline__ float nat_boxplus(float a, float b)
+{
+    const float e1 = __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(a + b)), e2 = __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(a - b));
+    const float l = (__builtin_amdgcn_logf(1.0f + e1) - __builtin_amdgcn_logf(1.0f + e2)) * 0.693147180559945309f;
+    const float mn = fminf(fabsf(a), fabsf(b));
+    const float sg = __uint_as_float((__float_as_uint(mn) & 0x7FFFFFFFu) | ((__float_as_uint(a) ^ __float_as_uint(b)) & 0x80000000u));
+    return a == INFINITY ? b : (b == INFINITY ? a : sg + l);
+}
+
+template <int DEG, int RULE>
+__global__ void __launch_bounds__(64)
+ldpc_nat_spa_kernel(const NatParams p)
+{
+    const int g = blockIdx.x, lane = threadIdx.x, f = g * 64 + lane;
+    float *W = p.work + (size_t)g * p.grp_words;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(W, 0, p.grp_words * 4, 0x00020000);
+    const uint32_t vo = (uint32_t)lane * 4u;
+    const const_u32 tab = (const_u32)p.tab, haz = (const_u32)p.haz;
+    const int q = p.q, M = p.M;
+    const uint32_t inf_row = (uint32_t)p.N * NAT_ROW, junk_row = inf_row + NAT_ROW, st0 = junk_row + NAT_ROW;
+    auto gld = [&](uint32_t soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, soff, 0)); };
+    auto gst = [&](uint32_t soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rs, vo, soff, 0); };
+    auto row_of = [&](const_u32 T, int j, int t, bool absent) -> uint32_t {
+        const uint32_t e = T[2 * j], A = T[2 * j + 1];
+        int elem = t - (int)(e & 0xFFFFu);
+        elem = elem < 0 ? elem + LDPC_Z : elem;
+        const uint32_t bit = A + (uint32_t)elem * ((e >> 16) & 1u ? (uint32_t)q : 1u);
+        return (((e >> 17) & 1u) || absent) ? inf_row : bit * NAT_ROW;
+    };
+    bool live = f < p.F, ok = false;
+    int it = 0, my_ite = 0;
+    while (it < p.n_ite) {
+        int r = 0, t = 0;
+        float fwd = INFINITY;
+        for (int c = 0; c < M; c++) {
+            const const_u32 T = tab + (size_t)r * DEG * 2;
+            if ((haz[c >> 5] >> (c & 31)) & 1u) __builtin_amdgcn_s_waitcnt(0);
+            uint32_t row[DEG];
+            float x[DEG], old[DEG];
+            const uint32_t mrow = st0 + (uint32_t)(c * DEG) * NAT_ROW;
+#pragma unroll
+            for (int j = 0; j < DEG; j++) row[j] = row_of(T, j, t, j == DEG - 1 && c == 0);
+#pragma unroll
+            for (int j = 0; j < DEG - 1; j++) x[j] = gld(row[j]);
+            x[DEG - 1] = c == 0 ? INFINITY : fwd;
+#pragma unroll
+            for (int j = 0; j < DEG; j++) old[j] = it > 0 ? gld(mrow + (uint32_t)j * NAT_ROW) : 0.f;
+#pragma unroll
+            for (int j = 0; j < DEG; j++) x[j] = x[j] - old[j];          // (+inf - 0 for an absent slot)
+            float nw[DEG];
+            if constexpr (RULE == 2) {
+                float tv[DEG], P = 1.0f;
+                uint32_t sx = 0u;
+#pragma unroll
+                for (int j = 0; j < DEG; j++) { tv[j] = w8_det_tanh_half(fabsf(x[j])); sx ^= __float_as_uint(x[j]); P = P * tv[j]; }
+#pragma unroll
+                for (int j = 0; j < DEG; j++) {
+                    float val = P / tv[j];
+                    val = (val < 1.0f) ? val : __uint_as_float(0x3F7FFFFEu);
+                    const float o = w8_det_log1p((val + val) / (1.0f - val));
+                    nw[j] = __uint_as_float((__float_as_uint(o) & 0x7FFFFFFFu) | ((sx ^ __float_as_uint(x[j])) & 0x80000000u));
+                }
+            } else {
+                float fw[DEG], bw;
+                fw[0] = INFINITY;
+#pragma unroll
+                for (int j = 1; j < DEG; j++) fw[j] = nat_boxplus(fw[j - 1], x[j - 1]);
+                bw = INFINITY;
+#pragma unroll
+                for (int j = DEG - 1; j >= 0; j--) {
+                    const float o = nat_boxplus(fw[j], bw);
+                    nw[j] = __uint_as_float((__float_as_uint(fminf(fabsf(o), p.spa_cap)) & 0x7FFFFFFFu) | (__float_as_uint(o) & 0x80000000u));
+                    bw = nat_boxplus(bw, x[j]);
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < DEG; j++) {
+                    gst(row[j] == inf_row ? junk_row : row[j], x[j] + nw[j]);
+                    gst(mrow + (uint32_t)j * NAT_ROW, row[j] == inf_row ? 0.f : nw[j]);
+                }
+            }
+            fwd = x[DEG - 2] + nw[DEG - 2];              // slot DEG-2 is p_c: the next check's p_{c-1}
+            if (++r == q) { r = 0; t++; }
+        }
+        it++;
+        if (live) my_ite = it;
+        if (p.early_stop || it == p.n_ite) {
+            __builtin_amdgcn_s_waitcnt(0);
+            uint32_t bad = 0u;
+            int r2 = 0, t2 = 0;
+            for (int c = 0; c < M; c++) {
+                const const_u32 T = tab + (size_t)r2 * DEG * 2;
+                uint32_t xs = 0u;
+#pragma unroll
+                for (int j = 0; j < DEG; j++) xs ^= __float_as_uint(gld(row_of(T, j, t2, j == DEG - 1 && c == 0)));
+                bad |= xs >> 31;
                 if (++r2 == q) { r2 = 0; t2++; }
             }
             if (live) { ok = bad == 0u; if (ok) live = false; }
@@ -678,6 +794,18 @@ hipError_t ldpc_nat_launch(const LdpcPlan &pl, const LdpcKParams &kp, float *wor
     p.llr = kp.llr; p.work = work; p.tab = pl.d_nat_tab; p.haz = pl.d_nat_haz;
     p.bits = kp.bits; p.packed = kp.packed; p.cwd = kp.cwd; p.post = kp.post; p.ites = kp.ites;
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.F = kp.n_frames; p.n_ite = kp.n_ite; p.early_stop = kp.early_stop; p.alpha = kp.alpha;
+    if (pl.spa) {      // sum-product in the reference's sweep order: one lane per frame (ldpc_nat_spa_kernel)
+        p.spa_cap = pl.spa_rule == 3 ? LDPC_SPA_CAP : INFINITY;
+        p.grp_words = (uint32_t)ldpc_nat_group_words(pl);
+        const int groups = (kp.n_frames + 63) / 64, tiles = (pl.N + 63) / 64;
+        hipLaunchKernelGGL(nat_load_kernel, dim3(tiles, groups), dim3(256), 0, s, p);
+#define NAT_SPA_CASE(D) \
+        if (pl.fast_deg == D) { if (pl.spa_rule == 2) hipLaunchKernelGGL((ldpc_nat_spa_kernel<D, 2>), dim3(groups), dim3(64), 0, s, p); else hipLaunchKernelGGL((ldpc_nat_spa_kernel<D, 1>), dim3(groups), dim3(64), 0, s, p); }
+        NAT_SPA_CASE(27) NAT_SPA_CASE(13) NAT_SPA_CASE(11)
+#undef NAT_SPA_CASE
+        hipLaunchKernelGGL(nat_store_kernel, dim3(tiles, groups), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
     // Form by the size of the batch.  Codes whose second hazard plane is empty and whose check count divides by eight (every DVB-S2 code of the library) run CONSECUTIVE CHECKS
     // side by side (ldpc_nat_ck_kernel).  (round 5) While the batch gives every CU at most ONE workgroup of 16 frames (4096 frames on 256 CUs: the BASELINE batch): 8 checks x 8
     // frames per wave, TWO waves per workgroup -- the sweep's step time follows the number of cache lines the waves of a CU touch per group of checks (every slot of every check
@@ -714,6 +842,6 @@ hipError_t ldpc_nat_launch(const LdpcPlan &pl, const LdpcKParams &kp, float *wor
     return hipGetLastError();
 }
 
-size_t ldpc_nat_group_words(const LdpcPlan &pl) { return (size_t)(pl.N + 2 + 3 * pl.M) * 64; }
+size_t ldpc_nat_group_words(const LdpcPlan &pl) { return (size_t)(pl.N + 2 + (pl.spa ? pl.fast_deg : 3) * pl.M) * 64; }      // (sum-product: one fp32 message per edge slot)
 
 }  // namespace dvbs2

@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "ldpc_det.h"      // w8_det_tanh_half / w8_det_log1p: the tanh-product rule's two functions, correctly rounded operations only (bit for bit the oracle's)
 namespace dvbs2 {
 
 typedef __attribute__((address_space(3))) float lds_float;
@@ -192,59 +193,6 @@ __device__ __forceinline__ float w8_boxplus(float a, float b)
     return a == INFINITY ? b : (b == INFINITY ? a : r);
 }
 
-// `--dec-implem SPA_TANH`: the check node in the form AFF3CT's Update_rule_SPA evaluates [UPSTREAM-RECALL, oracle/dvbs2_oracle.c chk_update_spa_tanh]:
-//     t_j = tanh(|v_j| / 2) in fp32 (1.0f beyond 18.02),  P = prod t_j in the oracle's edge order,  val = P / t_j clamped to 1 - 2^-23,  |out_j| = 2 atanh(val).
-// Near the cap the quotient moves in steps of 2^-24 = the message in steps of 0.1 .. 0.7: a twin of the oracle has to agree bit for bit.  tanh, the quotients and
-// log1p are therefore made of operations whose IEEE-754 result is correctly rounded (add, multiply, fma, divide, v_rndne) in exactly the oracle's order -- no
-// v_exp / v_log / v_rcp here (the build has no fast-math flag and -ffp-contract=off: `/` is the correctly rounded division sequence).
-__device__ __forceinline__ float w8_det_expm1(float y)            // e^y - 1, -2.1 <= y <= 45
-{
-    const float n = __builtin_rintf(y * 1.44269502f);
-    float r = __builtin_fmaf(-n, 0.693145751953125f, y);
-    r = __builtin_fmaf(-n, 1.42860677e-6f, r);
-    float q = 1.98412701e-4f;
-    q = __builtin_fmaf(q, r, 1.38888892e-3f);
-    q = __builtin_fmaf(q, r, 8.33333377e-3f);
-    q = __builtin_fmaf(q, r, 4.16666679e-2f);
-    q = __builtin_fmaf(q, r, 1.66666672e-1f);
-    q = __builtin_fmaf(q, r, 0.5f);
-    const float pm1 = __builtin_fmaf(q * r, r, r);
-    const float sc = __uint_as_float((uint32_t)((int)n + 127) << 23);
-    return __builtin_fmaf(sc, pm1, sc - 1.0f);
-}
-__device__ __forceinline__ float w8_det_tanh_half(float a)        // tanh(a / 2), a >= 0 (+inf: absent / NULL slots -> exactly 1); one expm1 and one division on either branch of the oracle's
-{
-    const bool big = a >= 2.0f;
-    const float ac = fminf(a, 44.0f);
-    const float t = w8_det_expm1(big ? ac : -ac);
-    const float d = (big ? 2.0f : -t) / (t + 2.0f);
-    const float r = big ? 1.0f - d : d;
-    return (a < 44.0f) ? r : 1.0f;
-}
-__device__ __forceinline__ float w8_det_log1p(float w)            // log(1 + w), 0 <= w < 2^26
-{
-    const float u = 1.0f + w;
-    const float c = w - (u - 1.0f);
-    const uint32_t iu = __float_as_uint(u);
-    int e = (int)(iu >> 23) - 127;
-    uint32_t im = (iu & 0x007FFFFFu) | 0x3F800000u;
-    const bool up = im >= 0x3FB504F3u;
-    im = up ? im - 0x00800000u : im;
-    e = up ? e + 1 : e;
-    const float f = __builtin_fmaf(c, __uint_as_float((uint32_t)(127 - e) << 23), __uint_as_float(im) - 1.0f);
-    const float s = f / (2.0f + f);
-    const float z = s * s;
-    float q = 0.111111112f;
-    q = __builtin_fmaf(q, z, 0.142857149f);
-    q = __builtin_fmaf(q, z, 0.2f);
-    q = __builtin_fmaf(q, z, 0.333333343f);
-    const float s2 = s + s;
-    const float lm = __builtin_fmaf(s2 * z, q, s2);
-    const float fe = (float)e;
-    float r = __builtin_fmaf(fe, 0.693145751953125f, lm);
-    r = __builtin_fmaf(fe, 1.42860677e-6f, r);
-    return r;
-}
 typedef float w8_f32x32 __attribute__((ext_vector_type(32)));
 
 // MODE 4 / 5: what the two waves of a workgroup that hold no check do instead of idling -- they keep NR = 32 / 39 bit-group rows of the frame in
@@ -315,7 +263,8 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_int *co
     };
     const bool es = p.early_stop != 0;
     // (wave priority 1 / 2 / 3 for these two waves: no difference, 6.00-6.04 ms for every setting, same box)
-    for (int f = blockIdx.x; f < p.n_frames; ) {
+    for (int qp = blockIdx.x; qp < p.n_frames; ) {
+        const int f = p.order ? (int)p.order[qp] : qp;      // (queue position -> frame: LdpcKParams::order)
         const float *Y = p.llr + (size_t)f * p.N;
         const int eln = sidx * 64 + w8_lane_now();  // (re-formed per frame: as a loop invariant the compiler keeps it, widened to 64 bits, across the layer loop -- in registers these waves do not have)
         const int elc = eln < LDPC_Z / 3 ? eln : 0; // (the eight lanes without elements load something harmless)
@@ -353,7 +302,7 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_int *co
         for (int k = 0; k < NR; k++) if (on) { const uint32_t b = (uint32_t)k * (uint32_t)W8_ROW; lst(b + a0, R[k][0]); lst(b + a0 + A1, R[k][1]); lst(b + a0 + A2, R[k][2]); }
         __syncthreads();
         __syncthreads();                            // the image is reused by the next frame
-        f = s_misc[9];
+        qp = s_misc[9];
     }
 }
 
@@ -481,7 +430,9 @@ ldpc_wg8_kernel(const LdpcKParams p)
     // Frames are handed out through a counter (the first one of every workgroup is its block index): with the syndrome early
     // stop frames take 1 .. n_ite iterations, and a fixed round-robin assignment left the workgroups with the slow frames running
     // alone at the end of the launch.
-    for (int f = blockIdx.x; f < p.n_frames; ) {
+    // (round 6) The queue can hand the frames out in an order of its own (LdpcKParams::order: the noisiest first, frame_order_launch in k_ldpc.hip) -- opt-in, measured a loss.
+    for (int qp = blockIdx.x; qp < p.n_frames; ) {
+        const int f = p.order ? (int)__builtin_amdgcn_readfirstlane((int)p.order[qp]) : qp;
         // ---- channel LLRs -> posterior image, W8_IO independent loads per lane in flight; packed state := 0
         const float *Y = p.llr + (size_t)f * p.N;
         // the frame I/O addresses are formed per frame from an opaque copy of the lane's index: hoisted out of the frame loop they are
@@ -1448,7 +1399,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
 #endif
         if (!fast_out) run_out(emit);
         PROF_MARK_O(4);
-        if (first) s_misc[9] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[LDPC_FRAME_CTR], 1u) + gridDim.x) : f + (int)gridDim.x;
+        if (first) s_misc[9] = p.cu_ctr ? (int)(atomicAdd(&p.cu_ctr[LDPC_FRAME_CTR], 1u) + gridDim.x) : qp + (int)gridDim.x;
         // the posterior image is reused by the next frame of this workgroup: every load of this phase has been consumed, the stores in flight touch the sockets only
         if (fast_out) out_bar(); else __syncthreads();
         PROF_MARK_O(5);
@@ -1459,7 +1410,7 @@ ldpc_wg8_kernel(const LdpcKParams p)
             p.bch_flag[fu] = nz ? 1 : 0;
             if (p.cwd_bch && !nz) p.cwd_bch[fu] = 1;
         }
-        f = SPA ? __builtin_amdgcn_readfirstlane(s_misc[9]) : s_misc[9];      // (uniform: the frame's base addresses stay on the scalar unit)
+        qp = SPA ? __builtin_amdgcn_readfirstlane(s_misc[9]) : s_misc[9];      // (uniform: the frame's base addresses stay on the scalar unit)
         PROF_MARK(7);
 #ifdef LDPC_PHASE_PROF
         prof[9]++;                                            // frames this workgroup decoded

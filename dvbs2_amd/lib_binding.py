@@ -78,6 +78,10 @@ ABI = {
     "dvbs2hip_set_ldpc_params": (C.c_int, [_vp, _i, _f, _i]),
     "dvbs2hip_get_stream": (_vp, [_vp]),
     "dvbs2hip_synchronize": (C.c_int, [_vp]),
+    "dvbs2hip_graph_begin": (C.c_int, [_vp]),
+    "dvbs2hip_graph_end": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    "dvbs2hip_graph_launch": (C.c_int, [_vp, _i]),
+    "dvbs2hip_graph_destroy": (C.c_int, [_vp, _i]),
     "dvbs2hip_get_sizes": (C.c_int, [_vp, C.POINTER(Sizes)]),
     "dvbs2hip_ldpc_decode_siho": (C.c_int, [_vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_ldpc_decode_siho_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i]),

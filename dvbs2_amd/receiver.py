@@ -323,6 +323,23 @@ class Dvbs2Hip:
     def add_noise_dev(self, sigma, X, Y, seed, n_elmts, n_frames):
         self._chk(self.L.dvbs2hip_add_noise_dev(self.h, _ptr(sigma), _ptr(X), _ptr(Y), int(seed), n_elmts, n_frames))
 
+    def graph_capture(self, fn):
+        """records the _dev calls `fn` makes on this handle as one hipGraph -> graph id (dvbs2hip_graph_begin / _end); run the sequence once before recording it"""
+        self._chk(self.L.dvbs2hip_graph_begin(self.h))
+        try:
+            fn()
+        finally:
+            g = C.c_int32(-1)
+            rc = self.L.dvbs2hip_graph_end(self.h, C.byref(g))
+        self._chk(rc)
+        return g.value
+
+    def graph_launch(self, graph):
+        self._chk(self.L.dvbs2hip_graph_launch(self.h, int(graph)))
+
+    def graph_destroy(self, graph):
+        self._chk(self.L.dvbs2hip_graph_destroy(self.h, int(graph)))
+
     def extract_dev(self, X, Y, n_cplx_out, osf, offset, n_frames):
         self._chk(self.L.dvbs2hip_extract_dev(self.h, _ptr(X), _ptr(Y), n_cplx_out, osf, int(offset), n_frames))
 

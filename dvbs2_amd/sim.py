@@ -30,12 +30,13 @@ def build_parser():
     ap.add_argument("-F", "--sim-inter-fra", type=int, default=512, help="frames per batch per GPU (grid width)")
     ap.add_argument("--dec-ite", type=int, default=50)
     ap.add_argument("--dec-implem", default="SPA", choices=["NMS", "MS", "SPA", "SPA_TANH", "SPA_EXACT"])    # the reference's defaults: SPA, 50 ite (DVBS2.cpp:135-138)
+    ap.add_argument("--dec-sched", default="QC", choices=["QC", "NATURAL"], help="NATURAL: the reference's sweep order over the rows of H (k_ldpc_nat.hip; a validation mode that wants -F 32768)")
     ap.add_argument("--dec-alpha", type=float, default=1.0)
     ap.add_argument("--no-early-stop", action="store_true")
     ap.add_argument("--est-type", default="DVBS2", choices=["DVBS2", "PERFECT"])
     ap.add_argument("--max-frames", type=int, default=10_000_000, help="cap on frames per noise point (all ranks)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--clones", type=int, default=1,
+    ap.add_argument("--clones", type=int, default=3,
                     help="clones of the chain per process, each with its own handle, stream and -F frames in flight (the reference's Sequence runs n_threads of them, "
                          "TX_RX_BB/main.cpp:19,96; host/dvbs2_tx_rx_bb --clones): batches are dealt to them in turn and a clone's counters are read when its turn comes again, "
                          "so the next clone's kernels fill the CUs that a batch's last frames leave idle under the early stop.  1 = one batch at a time (the loop every committed sweep used)")
@@ -75,6 +76,9 @@ def run(args, out=sys.stdout):
     class Clone:
         def __init__(self):
             self.rx = Dvbs2Hip(mc.name, max_frames=F, n_ite=args.dec_ite, alpha=alpha, early_stop=not args.no_early_stop, device=local_rank, implem=args.dec_implem)
+            if args.dec_sched == "NATURAL":
+                from dvbs2_amd import lib_binding as B
+                self.rx.set_ldpc_schedule(B.SCHED_NATURAL)
             self.pl = torch.empty((F, 2 * self.rx.pl_frame), dtype=torch.float32, device=dev)
             self.sent = torch.empty((F, self.rx.K_bch), dtype=torch.int32, device=dev)
             self.got = torch.empty((F, self.rx.K_bch), dtype=torch.int32, device=dev)
@@ -106,7 +110,7 @@ def run(args, out=sys.stdout):
     if rank == 0:
         print("# * DVB-S2 (HIP, %d GPU(s)) ---------------------------" % world, file=out)
         print("#    ** Modulation and coding = %s" % mc.name, file=out)
-        print("#    ** LDPC implem           = %s (alpha %.3f, QC-layer schedule)" % (args.dec_implem, alpha), file=out)
+        print("#    ** LDPC implem           = %s (alpha %.3f, %s schedule)" % (args.dec_implem, alpha, "QC-layer" if args.dec_sched == "QC" else "natural row order"), file=out)
         print("#    ** LDPC n iterations     = %d" % args.dec_ite, file=out)
         print("#    ** Estimator             = %s" % args.est_type, file=out)
         print("#    ** Frames per batch      = %d x %d" % (F, world), file=out)

@@ -29,14 +29,16 @@
 #include <vector>
 #include "../include/dvbs2hip.h"
 
-#define CHK(call) do { int rc__ = (call); if (rc__) { std::fprintf(stderr, "%s: %s\n", #call, dvbs2hip_last_error(h)); return 3; } } while (0)
+// (a reduction that timed out leaves GPU work that will never finish behind it: leave at once, without the runtime's teardown -- a fresh exit, never a re-exec)
+#define CHK(call) do { int rc__ = (call); if (rc__) { std::fprintf(stderr, "%s: %s\n", #call, dvbs2hip_last_error(h)); std::fflush(stdout); std::fflush(stderr); if (rc__ == DVBS2HIP_ETIMEOUT) std::_Exit(4); return 3; } } while (0)
 
 int main(int argc, char **argv)
 {
-    std::string modcod = "QPSK-S_8/9", implem = "SPA", est = "DVBS2";
+    std::string modcod = "QPSK-S_8/9", implem = "SPA", est = "DVBS2", sched = "QC";      // --dec-sched NATURAL: the reference's sweep order (k_ldpc_nat.hip; wants -F 32768)
     double ebn0_min = 3.2, ebn0_max = 6.0, step = 0.1;     // DVBS2.cpp:121-123
     int F = 512, n_ite = 50, max_fe = 100, n_clones = 3;   // DVBS2.cpp:135-142 (implem SPA, 50 ite, 100 frame errors)
     long long max_frames = 10000000;
+    int reduce_timeout_ms = 120000;      // rendezvous and every later reduction: a rank whose peers do not arrive leaves with exit code 4
     float alpha = 1.0f;
     auto env_int = [](const char *n, int d) { const char *v = std::getenv(n); return v && *v ? std::atoi(v) : d; };
     int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0), local_rank = env_int("LOCAL_RANK", -1);
@@ -53,6 +55,7 @@ int main(int argc, char **argv)
         else if (a == "--dec-ite") n_ite = std::atoi(next());
         else if (a == "--dec-implem") implem = next();
         else if (a == "--dec-alpha") alpha = (float)std::atof(next());
+        else if (a == "--dec-sched") sched = next();
         else if (a == "--est-type") est = next();
         else if (a == "--max-frames") max_frames = std::atoll(next());
         else if (a == "--clones") n_clones = std::atoi(next());
@@ -60,6 +63,7 @@ int main(int argc, char **argv)
         else if (a == "--rank") rank = std::atoi(next());
         else if (a == "--local-rank") local_rank = std::atoi(next());
         else if (a == "--rendezvous") rendezvous = next();
+        else if (a == "--reduce-timeout-ms") reduce_timeout_ms = std::atoi(next());
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     dvbs2hip_t *h = nullptr;
@@ -79,9 +83,11 @@ int main(int argc, char **argv)
     for (int k = 0; k < n_clones; k++) {
         if (dvbs2hip_create(&cfg, &cl[k].h)) { std::fprintf(stderr, "%s\n", dvbs2hip_last_error(nullptr)); return 3; }
         h = cl[k].h;
+        if (sched == "NATURAL") CHK(dvbs2hip_set_ldpc_schedule(h, DVBS2HIP_SCHED_NATURAL));
+        else if (sched != "QC") { std::fprintf(stderr, "--dec-sched has to be QC or NATURAL\n"); return 2; }
         CHK(dvbs2hip_get_sizes(h, &sz));
         // one communicator per clone (its all-reduce runs on the clone's stream); every rank calls them in the same order
-        if (reduce) CHK(dvbs2hip_monitor_reduce_init(h, rank, world, (rendezvous + (k ? ".c" + std::to_string(k) : "")).c_str(), 120000));
+        if (reduce) CHK(dvbs2hip_monitor_reduce_init(h, rank, world, (rendezvous + (k ? ".c" + std::to_string(k) : "")).c_str(), reduce_timeout_ms));
         CHK(dvbs2hip_malloc(h, &cl[k].d_pl, (size_t)F * 2 * sz.pl_frame_sym * sizeof(float)));
         CHK(dvbs2hip_malloc(h, &cl[k].d_sent, (size_t)F * sz.K_bch * sizeof(int32_t)));
         CHK(dvbs2hip_malloc(h, &cl[k].d_got, (size_t)F * sz.K_bch * sizeof(int32_t)));

@@ -37,7 +37,9 @@ typedef enum {
     DVBS2HIP_ENOMEM       = -2,  /* spu::tools::cannot_allocate                        */
     DVBS2HIP_EHIP         = -3,  /* spu::tools::runtime_error (HIP runtime failure)    */
     DVBS2HIP_EUNSUPPORTED = -4,  /* spu::tools::unimplemented_error                    */
-    DVBS2HIP_ENODEVICE    = -5   /* no HIP device: the product never falls back to CPU */
+    DVBS2HIP_ENODEVICE    = -5,  /* no HIP device: the product never falls back to CPU */
+    DVBS2HIP_ETIMEOUT     = -6   /* dvbs2hip_monitor_reduce: a peer rank did not arrive within the timeout given at _reduce_init (it died): the communicator is
+                                    aborted, the handle's stream is no longer usable -- the caller should leave with a non-zero exit code (a fresh exit, no re-exec) */
 } dvbs2hip_status;
 
 typedef struct dvbs2hip_handle dvbs2hip_t;
@@ -137,6 +139,14 @@ int dvbs2hip_reset(dvbs2hip_t *h);
 int dvbs2hip_set_ldpc_params(dvbs2hip_t *h, int32_t n_ite, float alpha, int32_t early_stop);
 void *dvbs2hip_get_stream(dvbs2hip_t *h);      /* hipStream_t */
 int dvbs2hip_synchronize(dvbs2hip_t *h);
+/* A sequence of _dev calls as ONE submission (hipGraph; BASELINE configs[4], small-frame latency: at -F 1 the sequence filter -> extract -> rx_bb is six launches and a fill
+ * around one workgroup's ten iterations).  Between _begin and _end the _dev calls of this handle are RECORDED, not run (same pointers, same n_frames on every replay; no host-
+ * socket form, no dvbs2hip_synchronize, no timing in between; run the sequence once before recording it: first calls allocate).  The reference's counterpart is the task
+ * sequence itself (RX/main_sched.cpp:199-223: a spu::runtime::Sequence runs its bound tasks back to back). */
+int dvbs2hip_graph_begin(dvbs2hip_t *h);
+int dvbs2hip_graph_end(dvbs2hip_t *h, int32_t *graph);
+int dvbs2hip_graph_launch(dvbs2hip_t *h, int32_t graph);
+int dvbs2hip_graph_destroy(dvbs2hip_t *h, int32_t graph);
 /* derived sizes (per frame), as DVBS2.cpp:351-355 */
 typedef struct dvbs2hip_sizes {
     int32_t N_ldpc, K_ldpc, K_bch, bps, N_xfec_sym, pl_frame_sym, ldpc_edges, ldpc_q;
@@ -269,7 +279,8 @@ int dvbs2hip_monitor_check_errors2_dev(dvbs2hip_t *h, const int32_t *U, const in
  *   init    : rank 0 creates the communicator id and hands it to the other ranks through files named after `rendezvous_path`
  *             (dvbs2hip_rendezvous below); each side waits for at most timeout_ms (< 0: for ever).  world_size 1 needs no file.
  *             ncclCommInitRank itself has no timeout: a launcher has to end the whole job when one rank dies.
- *   reduce  : the reduced counters; on a handle without _init it is dvbs2hip_monitor_get (a single process).
+ *   reduce  : the reduced counters; on a handle without _init it is dvbs2hip_monitor_get (a single process).  With timeout_ms > 0 at _init a reduction whose peers do
+ *             not arrive within timeout_ms returns DVBS2HIP_ETIMEOUT (the communicator is aborted; leave with a non-zero exit code) instead of waiting for ever.
  *   finalize: destroys the communicator (also done by dvbs2hip_destroy).                                              */
 int dvbs2hip_monitor_reduce_init(dvbs2hip_t *h, int32_t rank, int32_t world_size, const char *rendezvous_path, int32_t timeout_ms);
 /* the out-of-band step of _reduce_init on its own (no GPU needed): rank 0 hands `bytes` bytes of `blob` to every other rank, which

@@ -291,6 +291,42 @@ def test_ldpc_natural_order_matches_oracle(O, Rx, monkeypatch, modcod, ebn0, F, 
     rx.close()
 
 
+@pytest.mark.parametrize("modcod,ebn0,F", [("QPSK-S_8/9", 3.9, 5), ("QPSK-S_8/9", 3.2, 70), ("QPSK-S_3/5", 1.5, 3), ("8PSK-S_3/5", 3.0, 3), ("32APSK-S_3/4", 3.2, 3), ("QPSK-N_8/9", 3.9, 2)])
+def test_ldpc_sum_product_in_the_references_sweep_order(O, Rx, modcod, ebn0, F):
+    """The reference's decoder as recalled -- Decoder_LDPC_BP_horizontal_layered<.., Update_rule_SPA>: the tanh-product check node, the checks in the row order of H -- is the
+    oracle's orc_ldpc_decode(ORC_SPA_TANH, ORC_SCHED_NATURAL); on the device: --dec-implem SPA_TANH with dvbs2hip_set_ldpc_schedule(NATURAL) (ldpc_nat_spa_kernel<.., 2>: one
+    lane per frame, every operation correctly rounded and in the oracle's order), BIT FOR BIT after 1, 2 and 50 iterations and with the stopping rule.  `SPA` (exact check
+    node + AFF3CT's cap) and SPA_EXACT in the same sweep order: within 1e-4 max(1, |L|) of the oracle after 1 and 2 iterations, converged frames = the sent word."""
+    from dvbs2_amd import lib_binding as B
+    ch = chain(O, modcod)
+    _, llr, cw = make_llrs(O, modcod, F, ebn0, seed=37)
+    for n_ite, early in ((1, False), (2, False), (50, False), (50, True)):
+        rx = Rx(modcod, max_frames=F, n_ite=n_ite, early_stop=early, implem="SPA_TANH")
+        rx.set_ldpc_schedule(B.SCHED_NATURAL)
+        assert rx.ldpc_kernel_name() == "ldpc_nat_spa_kernel<%d,2>" % (27 if "8/9" in modcod else 11 if "3/5" in modcod else 13)
+        V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+        Vo, posto, cwdo, iteso = ch.ldpc.decode(llr, n_ite=n_ite, implem=O.SPA_TANH, sched=O.NATURAL, early_stop=early)
+        assert np.array_equal(post.view(np.uint32), posto.view(np.uint32)), "%d posteriors differ after %d iterations" % (int((post.view(np.uint32) != posto.view(np.uint32)).sum()), n_ite)
+        assert np.array_equal(V, Vo) and np.array_equal(CWD, cwdo) and np.array_equal(ites, iteso)
+        rx.close()
+    for implem, orule in SPA_RULES:
+        for n_ite in (1, 2):
+            rx = Rx(modcod, max_frames=F, n_ite=n_ite, early_stop=False, implem=implem)
+            rx.set_ldpc_schedule(B.SCHED_NATURAL)
+            V, CWD, post, _ = rx.decode_siho(llr, with_post=True)
+            Vo, posto, cwdo, _ = ch.ldpc.decode(llr, n_ite=n_ite, implem=getattr(O, orule), sched=O.NATURAL, early_stop=False)
+            assert np.all(np.abs(post - posto) <= 1e-4 * np.maximum(1.0, np.abs(posto))), float(np.abs(post - posto).max())
+            assert (V != Vo).mean() < 1e-4
+            rx.close()
+        rx = Rx(modcod, max_frames=F, n_ite=50, early_stop=True, implem=implem)
+        rx.set_ldpc_schedule(B.SCHED_NATURAL)
+        V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+        Vo, posto, cwdo, iteso = ch.ldpc.decode(llr, n_ite=50, implem=getattr(O, orule), sched=O.NATURAL, early_stop=True)
+        conv = (CWD == 1) & (cwdo == 1)
+        assert conv.sum() >= cwdo.sum() - 1 and np.array_equal(V[conv], cw[conv][:, :ch.mc.K_ldpc]) and np.all(np.abs(ites[conv] - iteso[conv]) <= 1)      # (3.2 dB: no frame converges on either side)
+        rx.close()
+
+
 def test_natural_order_in_the_fused_chain(O, Rx):
     from dvbs2_amd import lib_binding as B
     from helpers import make_pl_frames
@@ -450,6 +486,31 @@ def test_ldpc_spa_at_size_matches_oracle(O, Rx, modcod, F, dbs):
     rx = Rx(modcod, max_frames=F, n_ite=30, early_stop=True, implem="SPA")
     V, CWD = rx.decode_siho(llr)
     assert CWD[1::2].mean() > 0.99 and np.array_equal(V[CWD == 1], sent[CWD == 1])
+    rx.close()
+
+
+@pytest.mark.parametrize("modcod,implem,n_ite", [("QPSK-S_8/9", "NMS", 10), ("QPSK-S_8/9", "SPA", 30), ("QPSK-S_3/5", "SPA", 30), ("QPSK-N_8/9", "NMS", 10)])
+def test_ldpc_work_queue_order_changes_no_result(O, Rx, monkeypatch, modcod, implem, n_ite):
+    """(round 6) With DVBS2HIP_LDPC_ORDER=1 and the stopping rule the persistent grid's work queue hands out the noisiest frames first (frame_order_launch: sum |LLR| per
+    frame, a counting sort; written so that the frames that run to the iteration cap start early -- measured a 0.4 - 5 % loss and therefore opt-in).  Scheduling only: every frame is decoded
+    exactly once into its own sockets -- hard decisions, CWD, iteration counts and posteriors of the whole batch are those of the index-order queue (DVBS2HIP_LDPC_ORDER=0),
+    bit for bit, on a batch of converging and non-converging frames several times the grid's size; and the order really is by difficulty: the frames that do not converge
+    sit in the first part of the queue."""
+    F = 2600 if "-S_" in modcod else 1300
+    ch, sent, llr = _big_batch(O, modcod, F, (3.4, 4.4) if "8/9" in modcod else (1.0, 2.8), seed=91, n_cw=4)
+    rx = Rx(modcod, max_frames=F, n_ite=n_ite, alpha=1.0, early_stop=True, implem=implem)
+    monkeypatch.setenv("DVBS2HIP_LDPC_ORDER", "1")
+    a = rx.decode_siho(llr, with_post=True)
+    monkeypatch.delenv("DVBS2HIP_LDPC_ORDER")
+    b = rx.decode_siho(llr, with_post=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+    V, CWD, post, ites = a
+    assert 0.2 < CWD.mean() < 0.8 and np.array_equal(V[CWD == 1], sent[CWD == 1])
+    # the predictor: mean |LLR| separates the two halves of this batch (the test's frames alternate between the two Eb/N0)
+    m = np.abs(llr).mean(axis=1)
+    hard = np.argsort(m)[:F // 2]
+    assert (CWD[hard] == 0).mean() > 0.9
     rx.close()
 
 

@@ -88,7 +88,7 @@ def test_gpu_sim_with_clones_counts_what_one_clone_counts(clones):
     # with C clones the loop stops when the collected total reaches the cap: batches issued = 6 + (C - 1) in flight at that moment, all counted
     assert one["fra"] == 6 * 1024 and many["fra"] == (6 + clones - 1) * 1024
     assert many["fe"] >= one["fe"] > 0 and many["be"] >= one["be"]
-    capped = ["--mod-cod", "QPSK-S_8/9", "-m", "3.90", "-M", "3.91", "--dec-implem", "NMS", "--dec-ite", "10", "-F", "1024", "--max-frames", str((6 + clones - 1) * 1024), "-e", "1000000"]
+    capped = ["--mod-cod", "QPSK-S_8/9", "-m", "3.90", "-M", "3.91", "--dec-implem", "NMS", "--dec-ite", "10", "-F", "1024", "--max-frames", str((6 + clones - 1) * 1024), "-e", "1000000", "--clones", "1"]
     same = sim.run(sim.build_parser().parse_args(capped), out=io.StringIO())[0]
     assert (same["fra"], same["be"], same["fe"]) == (many["fra"], many["be"], many["fe"])      # the same batches, seed for seed
 
