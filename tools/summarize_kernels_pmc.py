@@ -69,6 +69,10 @@ for key in sorted(dur, key=lambda k: -sum(dur[k])):
     cpi, how = KM.price_kernel(key[0])
     tr = c.get("SQ_INSTS_VALU_TRANS_F32", 0)
     issue = ((c.get("SQ_INSTS_VALU", 0) - tr) * (cpi or 3.0) + tr * 8.06) / (1024.0 * busy) if busy else None
+    if not c:      # the counter passes attributed no row to this (kernel, grid) -- e.g. a launch whose grid differs between the passes: say so instead of printing zeros
+        rows_json.append(dict(kernel=key[0], grid=key[1], launches=len(dur[key]), avg_us=us, fabric_bytes=None, valu_issue=None, cycles_per_valu=cpi, valu_mix=how, counters=None))
+        lines.append("| `%s` | %s | %d | %.1f | n/a: the counter passes attributed nothing to this launch | | | | | | | | | | |" % (key[0], key[1], len(dur[key]), us))
+        continue
     rows_json.append(dict(kernel=key[0], grid=key[1], launches=len(dur[key]), avg_us=us, fabric_bytes=fab, valu_issue=issue, cycles_per_valu=cpi, valu_mix=how, counters=c))
     lines.append("| `%s` | %s | %d | %.1f | %.3f | %.2f | %.3g | %.3g | %s | %.3g | %.3g / %.3g | %s | %s | %s | %s |" % (
         key[0], key[1], len(dur[key]), us, fab / 1e9, fab / (us * 1e-6) / 1e12 if us else 0, c.get("SQ_INSTS_VALU", 0), c.get("SQ_INSTS_VALU_TRANS_F32", 0),
