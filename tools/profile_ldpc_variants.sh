@@ -24,6 +24,7 @@ QPSK-N_8/9 NMS 4096
 QPSK-N_8/9 SPA 4096
 QPSK-S_8/9 NMS 8192
 QPSK-S_8/9 SPA 8192
+QPSK-S_8/9 SPA_TANH 8192
 QPSK-S_3/5 NMS 8192
 QPSK-S_3/5 SPA 8192
 32APSK-S_3/4 NMS 8192
