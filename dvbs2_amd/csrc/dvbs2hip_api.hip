@@ -1742,7 +1742,7 @@ int dvbs2hip_monitor_reduce(dvbs2hip_t *h, uint64_t out[3])
                 h->nccl_comm = nullptr; h->comm_dead = true;
                 return fail(h, DVBS2HIP_ETIMEOUT, "monitor reduction: a peer rank did not arrive within " + std::to_string(h->red_timeout_ms) + " ms (rank " + std::to_string(h->red_rank) + " of " + std::to_string(h->red_world) + ")");
             }
-            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= 5) std::this_thread::sleep_for(std::chrono::microseconds(50));      // (spin for the first 5 ms: a reduction that arrives is microseconds away)
         }
     } else
         HIPCHK(h, hipStreamSynchronize(h->stream));
