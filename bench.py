@@ -200,7 +200,7 @@ def main(argv=None, runtime=None):
     # ---- untimed extras, separate from `value`.  Every rank runs the ones that exercise its own GPU (so that the ranks stay in step and rank 0's figures are taken on a node
     # whose other GPUs are busy too); the two that time the HOST side -- PCIe-inclusive sockets (2 GB of pinned host memory per rank) and the one-frame call latency -- belong to
     # the N = 1 line: at N > 1 every rank would be timing the host's PCIe complex and call path against N - 1 others, so they are skipped there and the line says so
-    hard, es, copy_gbps, chain, quad, configs, host_form, natural, spa, ref_cfg, sync_loc = None, {}, None, None, None, None, None, None, None, None, None
+    hard, es, copy_gbps, chain, quad, configs, host_form, natural, spa, ref_cfg, sync_loc, nfl = None, {}, None, None, None, None, None, None, None, None, None, None
     skipped = {}
     if not args.no_extras:
         quad = _four_way(rx, torch, B, llr, llr_hard, cwd, bits, F, info, sel, dev, args.quad_launches)
@@ -220,6 +220,7 @@ def main(argv=None, runtime=None):
             configs["4"] = _fir_config(Dvbs2Hip, torch, B, dev, local_rank, rank)
             host_form = _host_socket_form(rx, torch, llr, F)
             if not rt.is_stub:
+                nfl = _normal_frame_latency(Dvbs2Hip, torch, B, llr, dev, local_rank)
                 ref_cfg = _ref_config(args.ref_config_frames)
                 sync_loc = _sync_located(Dvbs2Hip, torch, B, dev, local_rank)
         else:
@@ -338,7 +339,7 @@ def main(argv=None, runtime=None):
                   "hard_batch_fixed_10_ite": hard, "fused_rx_chain": chain, "configs": configs,
                   "natural_order_fps": natural["fec_frames_per_s"] if natural else None, "natural_order": natural,
                   "host_socket_form": host_form, "skipped_at_this_n": skipped,
-                  "spa": spa, "ref_config": ref_cfg, "sync_located": sync_loc,
+                  "spa": spa, "ref_config": ref_cfg, "sync_located": sync_loc, "normal_frame_latency": nfl,
                   "early_stop_fps": {k: v["fec_frames_per_s"] for k, v in es.items()}, "early_stop": es,
                   "early_stop_note": "the reference's default rule (syndrome check after every iteration, enable_syndrome); untimed for `value`"},
     }
@@ -490,6 +491,30 @@ def _spa_rates(Dvbs2Hip, torch, B, llr, cwd, bits, F, dev, local_rank, rank):
     run("QPSK-S_8/9 SPA_TANH", "QPSK-S_8/9", "SPA_TANH", xs, n, reps=3)
     out["what"] = "hipEvent ms per LDPC launch, 10 fixed iterations, early stop off; SPA = the reference's default rule (DVBS2.cpp:135,138)"
     return out
+
+
+def _normal_frame_latency(Dvbs2Hip, torch, B, llr, dev, local_rank):
+    """per-call wall latency (one dvbs2hip_ldpc_decode_siho_dev + synchronize) of the BASELINE code at small batches -- a handle created for at most one
+    frame per CU takes the one-frame-per-CU image (k_ldpc_cu1.hip, two lanes per check); NMS, 10 fixed iterations and the reference's stopping rule; the first F timed LLR frames."""
+    rows = []
+    for F in (1, 64):
+        rx = Dvbs2Hip(MODCOD, max_frames=F, n_ite=N_ITE, alpha=1.0, early_stop=False, device=local_rank)
+        c, b = torch.empty((F,), dtype=torch.int8, device=dev), torch.empty((F, rx.K_ldpc), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        row = {"frames": F, "kernel": rx.ldpc_kernel_name()}
+        for name, stop in (("latency_ms_fixed_10", False), ("latency_ms_early_stop", True)):
+            rx.set_ldpc_params(N_ITE, 1.0, stop)
+            for _ in range(3):
+                rx.decode_siho_dev(llr.data_ptr(), c.data_ptr(), b.data_ptr(), F)
+            rx.synchronize()
+            lat = []
+            for _ in range(20):
+                t = time.perf_counter(); rx.decode_siho_dev(llr.data_ptr(), c.data_ptr(), b.data_ptr(), F); rx.synchronize(); lat.append(time.perf_counter() - t)
+            row[name] = 1e3 * sorted(lat)[10]
+        row["cwd"] = int(c.sum().item())
+        rows.append(row)
+        rx.close()
+    return {"what": "QPSK-N_8/9 NMS, one decode_siho_dev call + synchronize, handle with max_frames = frames", "per_F": rows}
 
 
 def _ref_config(max_frames):

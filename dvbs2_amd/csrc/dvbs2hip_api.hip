@@ -353,7 +353,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
     if (lds_limit < 32 * 1024) lds_limit = 32 * 1024;
     lds_limit -= 512;                                    // static LDS of the kernel + slack
     std::string e = ldpc_build_plan(h->ldpc, cfg->N_ldpc, cfg->K_ldpc, cfg->ldpc_n_rows, cfg->ldpc_row_ptr, cfg->ldpc_addr,
-                                    cfg->ldpc_lds_groups, lds_limit, cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA ? 3 : cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA_TANH ? 2 : cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA_EXACT ? 1 : 0);
+                                    cfg->ldpc_lds_groups, lds_limit, cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA ? 3 : cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA_TANH ? 2 : cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA_EXACT ? 1 : 0, cfg->max_frames <= h->n_cus);
     if (!e.empty()) CREATE_FAIL(DVBS2HIP_EINVAL, e);
     LdpcPlan &lp = h->ldpc;
     if (upload(h, &lp.d_entries, lp.entries.data(), lp.entries.size()) ||

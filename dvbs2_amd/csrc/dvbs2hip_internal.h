@@ -184,7 +184,7 @@ int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl);
 
 // builds the layer tables; returns empty string on success, else the error text
 std::string ldpc_build_plan(LdpcPlan &pl, int N, int K, int n_rows, const int32_t *row_ptr,
-                            const int32_t *addr, int lds_groups_req, size_t lds_limit_bytes, int spa_rule = 0);      // spa_rule: LdpcPlan::spa_rule
+                            const int32_t *addr, int lds_groups_req, size_t lds_limit_bytes, int spa_rule = 0, bool small_batch = false);      // small_batch: the handle never sees more frames than CUs      // spa_rule: LdpcPlan::spa_rule
 hipError_t ldpc_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
 int ldpc_blocks_per_cu(const LdpcPlan &pl);
 

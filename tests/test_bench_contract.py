@@ -124,6 +124,8 @@ def test_bench_line_on_the_gpu():
         assert rc[k]["fra"] >= 400000 and 1.0 / 2.5 < rc[k]["fer_over_ref"] < 2.5 and rc[k]["info_Gbps"] > 5.0, rc[k]
     sl = ex["sync_located"]
     assert sl["32APSK-S_3/4"]["frames"] == 4096 and sl["QPSK-N_8/9"]["frames"] == 1024 and all(0.0 < v["ms_per_call"] < 1.0 and v["flag"] == 1 for v in sl.values())
+    nl = ex["normal_frame_latency"]["per_F"]
+    assert [r["frames"] for r in nl] == [1, 64] and all(r["kernel"] == "ldpc_cu1_kernel<27>" and 0.05 < r["latency_ms_early_stop"] <= r["latency_ms_fixed_10"] < 0.6 for r in nl), nl
     for k in ("2", "3"):
         assert cf[k]["floor_ms"] > cf[k]["ldpc_kernel_ms"] > 0 and 1.0 <= cf[k]["tail_over_floor"] < 1.25, cf[k]
 

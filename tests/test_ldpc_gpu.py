@@ -398,6 +398,25 @@ def test_ldpc_headline_config_at_size_matches_oracle(O, Rx, n_ite, F, ebn0s):
     assert (CWD[0::2] if len(ebn0s) == 2 else CWD).mean() < 0.5      # 3.0 dB: most frames fail, which is the point
 
 
+def test_small_batch_handles_take_the_one_frame_per_cu_image(O, Rx):
+    """(round 6) A handle created for at most one frame per CU (max_frames <= the CU count) decodes normal frames with the one-frame-per-CU image
+    (k_ldpc_cu1.hip: two lanes per check -- a call is one frame's ten iterations on one CU, 0.42 ms instead of 0.54); a larger handle keeps the two-frames-per-CU kernel.
+    Same decoder either way: hard decisions, CWD, iteration counts and posteriors bit for bit, against each other and against the oracle, with and without the stopping rule."""
+    modcod, F = "QPSK-N_8/9", 6
+    ch = chain(O, modcod)
+    _, llr, cw = make_llrs(O, modcod, F, 3.9, seed=61)
+    for early in (False, True):
+        small = Rx(modcod, max_frames=F, n_ite=10, alpha=1.0, early_stop=early)
+        big = Rx(modcod, max_frames=1024, n_ite=10, alpha=1.0, early_stop=early)
+        assert small.ldpc_kernel_name() == "ldpc_cu1_kernel<27>" and big.ldpc_kernel_name() == "ldpc_wg8_kernel<27,%d>" % DEFAULT_NMS_MODE
+        a, b = small.decode_siho(llr, with_post=True), big.decode_siho(llr, with_post=True)
+        Vo, posto, cwdo, iteso = ch.ldpc.decode(llr, n_ite=10, alpha=1.0, sched=O.QC, early_stop=early)
+        for x, y, z in zip(a, b, (Vo, cwdo, posto, iteso)):
+            v = (lambda t: t.view(np.uint32) if t.dtype == np.float32 else t)
+            assert np.array_equal(v(x), v(y)) and np.array_equal(v(x), v(z))
+        small.close(); big.close()
+
+
 def test_ldpc_baseline_batch_of_exactly_4096_frames_matches_oracle(O, Rx):
     """BASELINE configs[1] AT ITS STATED SIZE: 4096 QPSK-N 8/9 frames in ONE call, 10 fixed iterations -- the batch bench.py times -- at 3.0 dB (nothing
     converges) and 4.2 dB interleaved: 16 random frames + the last 8 against the oracle by posterior BIT PATTERN, hard decisions and CWD; then the same batch in the
