@@ -1194,7 +1194,7 @@ static int sfm_ready(dvbs2hip_t *h)
     }
     HIPCHK(h, hipMalloc((void **)&S.cv, sizeof(float) * (size_t)n));
     for (int i = 0; i < 2; i++) HIPCHK(h, hipMalloc((void **)&S.yprev[i], sizeof(float) * 2 * (size_t)n));
-    HIPCHK(h, hipMalloc((void **)&S.keys, sizeof(unsigned long long) * (size_t)h->max_frames * (size_t)((n + 63) / 64)));
+    HIPCHK(h, hipMalloc((void **)&S.keys, sizeof(unsigned long long) * (size_t)h->max_frames * (size_t)((n + 63) / 64) + sizeof(float) * 2 * (size_t)((h->max_frames + SYNC_SUB - 1) / SYNC_SUB) * (size_t)n));      // (+ the segments' {A, B} of the average over frames: k_sync.hip)
     HIPCHK(h, hipMalloc((void **)&S.metric, sizeof(float)));
     const std::vector<uint16_t> fr = sync_frag_default();
     HIPCHK(h, hipMalloc((void **)&S.frag, fr.size() * sizeof(uint16_t)));
@@ -1249,7 +1249,7 @@ static int sfm_sync2(dvbs2hip_t *h, const float *X_N1, const float *cor_SOF, con
         (r = ensure(h, B_SFM_DTAB, sizeof(int32_t) * (size_t)F, &dtab))) return r;
     Timer tm(h, DVBS2HIP_K_MISC);
     if (TRI) met = TRI;
-    const SyncTail tail{S.keys, delay, (float *)met, FLG, S.trigger, (int32_t *)dtab, S.metric};
+    const SyncTail tail{S.keys, delay, (float *)met, FLG, S.trigger, (int32_t *)dtab, S.metric, reinterpret_cast<float *>(S.keys + (size_t)h->max_frames * (size_t)((n + 63) / 64))};
     if (fused) {
         HIPCHK(h, sync_corr_metric_launch(X_N1, S.xh[S.xh_cur], S.xh[S.xh_cur ^ 1], sfm_frag(h), S.sofh[S.sofh_cur], S.sofh[S.sofh_cur ^ 1], S.cv, (float *)corr, tail,
                                           n, F, S.alpha, S.vec_width, h->stream));

@@ -291,7 +291,9 @@ struct SyncTail {
     unsigned long long *keys;        // F x ceil(n / 64) words of device scratch
     int32_t *delay; float *metric; int32_t *flag; float trigger;
     int32_t *Dtab; float *last_metric;
+    float *seg;                      // 2 x ceil(max_frames / SYNC_SUB) x n floats of device scratch: per sub-segment of the call's frames {alpha^len, its own average from 0} (k_sync.hip)
 };
+constexpr int SYNC_MAX_SEG = 8, SYNC_SUB = 64;
 hipError_t sync_corr_launch(const float *x, const float *xh_in, float *xh_out, const uint16_t *frag, float *cor_sof, float *cor_plsc, long long n_total, hipStream_t s);
 std::vector<uint16_t> sync_mfma_frag(const float *sof25, const float *plsc64);       // k_sync_mfma.hip: band fragments of the two correlators
 bool sync_mfma_usable(const float *x, const void *frag);

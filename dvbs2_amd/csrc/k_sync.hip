@@ -326,10 +326,48 @@ sync_metric_argmax4_kernel(float *__restrict__ cv, const float *__restrict__ cor
 #else
 #define SYB() sy_lds_barrier()
 #endif
+// (round 6) THE FRAMES OF A CALL IN SEGMENTS.  The average over frames is a first-order recurrence c_f = al c_(f-1) + om m_f per position: a serial chain over the call's
+// frames that one wave per 64 positions walks while most of the chip idles (32APSK-S: 54 workgroups).  A recurrence of this form composes: over a segment of frames,
+// c_end = A c_start + B with A = al^len and B = the segment's own result from c_start = 0.  So: a first kernel (sync_seg_partial_kernel) forms {A, B} of every segment but the
+// last, all segments side by side; then every segment runs THIS kernel on its own workgroups (grid y), its start value folded from the carried average and the {A, B} of the
+// segments before it.  Same recurrence, same operations inside a segment; across a seam the start value is rounded differently from the one-wave walk (al^len c + B instead of
+// len steps): ~1e-7 relative, far inside the metric's 2e-4 bar.  DVBS2HIP_SYNC_SEGMENTS=1 keeps the single walk.
+// {A, B} per SUB-SEGMENT of SYNC_SUB frames (a segment = seg_F / SYNC_SUB of them): one lane per position walks 64 frames with all of their loads in flight -- thousands of
+// short walks side by side instead of a few long ones (the first form, one walk of 1024 frames per segment with 8 loads in flight, cost 49 us more than it saved)
+__global__ void __launch_bounds__(64)
+sync_seg_partial_kernel(const float *__restrict__ corr, float *__restrict__ seg, int n, int F, float alpha, int end_vec)
+{
+    const int i = blockIdx.x * 64 + (int)threadIdx.x, k = blockIdx.y;
+    if (i >= n) return;
+    const int f0 = k * SYNC_SUB, cnt = f0 + SYNC_SUB <= F ? SYNC_SUB : F - f0;
+    const float al = i < end_vec ? alpha : 0.f, om = i < end_vec ? 1.0f - alpha : 1.f;
+    const float *p = corr + (size_t)f0 * n + i;
+    float a = 1.f, b = 0.f;
+    if (cnt == SYNC_SUB) {
+#pragma unroll
+        for (int h = 0; h < SYNC_SUB; h += 32) {
+            float m[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) m[u] = __builtin_nontemporal_load(p + (size_t)(h + u) * n);
+#pragma unroll
+            for (int u = 0; u < 32; u++) { const float x = om * m[u]; b = al * b + x; a = a * al; }
+        }
+    } else
+        for (int f = 0; f < cnt; f++) { const float x = om * __builtin_nontemporal_load(p + (size_t)f * n); b = al * b + x; a = a * al; }
+    seg[(size_t)(2 * k) * n + i] = a;
+    seg[(size_t)(2 * k + 1) * n + i] = b;
+}
+
 template <int UF>
 __global__ void __launch_bounds__(64 * (SYM_NC + UF / 8))
-sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr, unsigned long long *__restrict__ keys, int n, int F, float alpha, int end_vec)
+sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr, unsigned long long *__restrict__ keys, int n, int F, float alpha, int end_vec,
+                          const float *__restrict__ seg, int seg_F)
 {
+    // this workgroup's segment of the call's frames (grid y; one segment = the whole call when seg is null)
+    const int seg_id = (int)blockIdx.y, n_seg = (int)gridDim.y, f_base = seg_id * seg_F;
+    corr += (size_t)f_base * n;
+    keys += (size_t)f_base * gridDim.x;
+    F = F - f_base < seg_F ? F - f_base : seg_F;
     constexpr int ST = UF + 4;           // LDS row of a lane: UF frames + 4 words (16-byte pieces of the 64 lanes on all banks: ST / 4 is odd)
     constexpr int NL = UF / 16, NC = SYM_NC;
     static_assert(UF == 96 && ((ST / 4) & 1) == 1, "role placement below is written for 13 waves");
@@ -359,6 +397,7 @@ sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr
         const bool mine = lane < 64 / NC, actc = ic < n;
         const int ilc = actc ? ic : n - 1;
         float c = mine && actc ? cv[ilc] : 0.f;
+        for (int j = 0; j < seg_id * (seg_F / SYNC_SUB); j++) c = mine && actc ? seg[(size_t)(2 * j) * n + ilc] * c + seg[(size_t)(2 * j + 1) * n + ilc] : 0.f;      // the sub-segments before this segment, folded
         const float al = ilc < end_vec ? alpha : 0.f;         // positions past the last full vector are not averaged (:284-285): 0 c + 1 m = m exactly
         SYB();                                                // chunk 0 is in pm[0]
         for (int t = 0; t <= nq; t++) {
@@ -415,7 +454,7 @@ sync_metric_argmax_kernel(float *__restrict__ cv, const float *__restrict__ corr
             }
             SYB();
         }
-        if (mine && actc) cv[ic] = c;
+        if (mine && actc && seg_id == n_seg - 1) cv[ic] = c;
     } else if (wv < NC + NL) {
         // ---- loaders: frames 16 L .. 16 L + 15 of every chunk; the loads of chunk t + 3 leave in tick t and are taken up in tick t + 2
         const int L = wv - NC;
@@ -1045,7 +1084,16 @@ static void sync_average_argmax(float *cv, float *corr, int n, int F, float alph
     // few positions (short frames): the thirteen-wave form, one workgroup per CU at most; long frames: round 3's four-wave form (the stage is bound by its 4 bytes per
     // sample there: QPSK-N 1024 frames 42-45 us in the four-wave form, 65 us in this one)
     static const bool four = getenv("DVBS2HIP_SYNC_ARGMAX4") != nullptr;      // development: round 3's kernel for every frame length
-    if (SYNC_ARGMAX10 && !four && nwg <= SYNC_UF96_MAX_WG) hipLaunchKernelGGL(sync_metric_argmax_kernel<96>, dim3(nwg), dim3(64 * (SYM_NC + 12)), 0, s, cv, corr, t.keys, n, F, alpha, end_vec);
+    if (SYNC_ARGMAX10 && !four && nwg <= SYNC_UF96_MAX_WG) {
+        // segments of the call's frames side by side while they fit the chip (one workgroup per CU) and stay long enough to be worth a seam (>= 768 frames each)
+        static const int cap = getenv("DVBS2HIP_SYNC_SEGMENTS") ? atoi(getenv("DVBS2HIP_SYNC_SEGMENTS")) : SYNC_MAX_SEG;      // (development: 1 = the single walk)
+        int S = cap <= 1 || !t.seg ? 1 : std::min(std::min(std::min(cap, SYNC_MAX_SEG), SYNC_UF96_MAX_WG / nwg), F / 768);
+        int seg_F = F;
+        if (S > 1) { seg_F = ((F + S - 1) / S + 191) / 192 * 192; S = (F + seg_F - 1) / seg_F; }      // (a multiple of the chunk's 96 frames and of SYNC_SUB)
+        if (S > 1) hipLaunchKernelGGL(sync_seg_partial_kernel, dim3(nwg, (S - 1) * (seg_F / SYNC_SUB)), dim3(64), 0, s, (const float *)corr, t.seg, n, F, alpha, end_vec);
+        else { S = 1; seg_F = F; }
+        hipLaunchKernelGGL(sync_metric_argmax_kernel<96>, dim3(nwg, S), dim3(64 * (SYM_NC + 12)), 0, s, cv, corr, t.keys, n, F, alpha, end_vec, (const float *)t.seg, seg_F);
+    }
     else hipLaunchKernelGGL(sync_metric_argmax4_kernel, dim3(nwg), dim3(256), 0, s, cv, corr, t.keys, n, F, alpha, end_vec);
     hipLaunchKernelGGL(sync_finalize_kernel, dim3(F), dim3(64), 0, s, t.keys, nwg, t.delay, t.metric, t.flag, t.trigger, t.Dtab, t.last_metric, n, 25, 64, F);
 }
