@@ -28,7 +28,10 @@ if kt:
     for r in csv.DictReader(open(kt)):
         k = short(r["Kernel_Name"])
         if any(w in k for w in want):
-            dur[(k, r["Grid_Size"] if "Grid_Size" in r else r.get("Grid_Size_X", "?"))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            # the counter files carry the TOTAL grid size, the kernel trace its three dimensions: the key is the product (a 2-D launch otherwise finds no counter row:
+            # the all-zero sync_vdelay_batch_kernel rows of rounds 4-5)
+            grid = r["Grid_Size"] if "Grid_Size" in r else str(int(r.get("Grid_Size_X", 1)) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1)))
+            dur[(k, grid)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pk_fetch", "pk_write", "pk_sq1", "pk_sq2", "pk_sq3"):
     f = first(d + "/*/*_counter_collection.csv")
