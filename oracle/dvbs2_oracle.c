@@ -293,8 +293,11 @@ static int ldpc_decode_ws(const orc_ldpc *c, const float *llr, int implem, int s
     int max_lvl = 0;
     for (int i = 0; i < c->E; i++) if (c->chk_lvl[i] > max_lvl) max_lvl = c->chk_lvl[i];
     for (; ite < n_ite; ) {
-        if (sched == ORC_SCHED_NATURAL) {
-            for (int k = 0; k < M; k++) {
+        if (sched == ORC_SCHED_NATURAL || sched == ORC_SCHED_QC_SEQ) {
+            /* ORC_SCHED_QC_SEQ (an analysis aid, round 6): the checks in the ORDER of the QC layers (layer r = checks q t + r, t = 0 .. 359) but one after the other, every
+             * check reading what the one before it wrote -- separates what the QC schedule's ORDER costs against the row order from what its 360-check SNAPSHOT costs */
+            for (int kk = 0; kk < M; kk++) {
+                const int k = sched == ORC_SCHED_NATURAL ? kk : q * (kk % 360) + kk / 360;
                 int b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
                 for (int j = 0; j < d; j++) v2c[j] = L[c->chk_var[b + j]] - msg[b + j];
                 chk_update(implem, alpha, v2c, d, nw);
