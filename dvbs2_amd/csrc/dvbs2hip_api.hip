@@ -653,8 +653,9 @@ const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
         const LdpcPlan &pl = h->ldpc;
         char buf[96];
         if (!pl.fast) snprintf(buf, sizeof buf, "ldpc_layered_nms_kernel<%d,%s,%s>", pl.ent_stride, pl.hybrid ? "true" : "false", pl.c2v_lds ? "true" : "false");
-        else if (pl.fast_cu1) snprintf(buf, sizeof buf, pl.spa ? "ldpc_cu1_kernel<%d,true>" : "ldpc_cu1_kernel<%d>", pl.fast_deg);
-        else if (pl.spa) snprintf(buf, sizeof buf, "ldpc_wg8_kernel<%d,%d,%d>", pl.fast_deg, pl.fast_mode, pl.spa_rule == 2 ? 2 : 1);
+        else if (pl.fast_cu1 && pl.spa) snprintf(buf, sizeof buf, "ldpc_cu1_kernel<%d,%d>", pl.fast_deg, pl.spa_rule == 3 ? 3 : 1);
+        else if (pl.fast_cu1) snprintf(buf, sizeof buf, "ldpc_cu1_kernel<%d>", pl.fast_deg);
+        else if (pl.spa) snprintf(buf, sizeof buf, "ldpc_wg8_kernel<%d,%d,%d>", pl.fast_deg, pl.fast_mode, pl.spa_rule);
         else snprintf(buf, sizeof buf, "ldpc_wg8_kernel<%d,%d>", pl.fast_deg, pl.fast_mode);
         const_cast<dvbs2hip_t *>(h)->ldpc_name = buf;
     }

@@ -80,7 +80,7 @@ __device__ __forceinline__ float c1_unpack(float c1, float c2, uint32_t pk, uint
 // ---- the row-keeping waves: group `grp` (two waves, 120 of their 128 lanes hold elements e, e + 120, e + 240 of NRG rows) follows the working waves barrier for
 // barrier and swaps rows with LDS positions by the plan's table (w8_park_server of k_ldpc_wg8.hip, for a workgroup with two such groups and the barrier
 // sequence of this kernel's layer: one barrier always, then the duplicate-edge barriers, then the end barrier)
-template <int NRG, bool SPA>
+template <int NRG, int SPA>      // SPA: 0 min-sum, 1 sum-product (exact, per-check scale: two exchanges per layer), 3 sum-product with AFF3CT's cap (no scale: one exchange)
 __device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const s_misc, const int grp, const int sidx, const int lane, const bool vote_writer
 #ifdef LDPC_PHASE_PROF
                                            , uint32_t *prof, unsigned long long &pt_
@@ -136,7 +136,7 @@ __device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const 
         const uint32_t cinfo = T[28];
         const int ncf = (int)(cinfo & 0xFFu);
         bar_nowait();                               // the halves' partial minima are in the exchange area; every read of the layer precedes its writes
-        if (SPA) bar_nowait();                      // sum-product layer: the halves' products are in the exchange area
+        if (SPA == 1) bar_nowait();                 // sum-product layer with the per-check scale: the halves' products are in the exchange area (the capped rule needs one exchange)
 #if C1_KEEP_LATE
         moves(r);
 #endif
@@ -207,7 +207,7 @@ __device__ __forceinline__ void cu1_keeper(const LdpcKParams &p, lds_int *const 
 }
 
 // ---- one half-check's lanes.  HALF 0: slots 0 .. 13 (duplicate edges among the first ones, replayed by these lanes); HALF 1: slots 14 .. 26 (25 = p_c, 26 = p_{c-1})
-template <int DEG, int HALF, bool SPA, int HA>
+template <int DEG, int HALF, int SPA, int HA>
 __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_misc, const int cb, const int lane, const int wave, const bool vote_writer, const bool first_wave
 #ifdef LDPC_PHASE_PROF
                                          , uint32_t *prof, unsigned long long &pt_
@@ -363,6 +363,20 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
 #pragma unroll
                         for (int j = 0; j < NS; j++) x[j] = x[j] - onx[j];      // zeros in the first iteration
                         if (HALF == 1 && mask0) x[NS - 1] = INFINITY;
+                        if constexpr (SPA == 3) {
+                            // (round 6) `--dec-implem SPA`: the clip at 16.64 on the way out makes the per-check scale, the minima it is chosen from and the overflow rule
+                            // unnecessary (k_ldpc_wg8.hip, SPA = 3) -- and with them the halves' FIRST exchange: this half's product and sign parity go out together
+#pragma unroll
+                            for (int j = 0; j < NS; j++) {
+                                sx ^= __float_as_uint(x[j]);
+                                u[j] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(__builtin_fmaf(fabsf(x[j]), 1.44269504088896341f, -1.f)) + 0.5f);
+                            }
+                            float b = 0.f;
+#pragma unroll
+                            for (int j = NS - 1; j >= 0; j--) { if (j % BS == BS - 1 || j == NS - 1) Bs[j / BS] = b; b = __builtin_fmaf(u[j], 1.f - b, b); }
+                            Qown = b;
+                            *c1_lds(xmine) = __uint_as_float(__float_as_uint(Qown) | (sx & 0x80000000u));      // (0 <= Qown <= 1: bit 31 is free for the sign parity)
+                        } else {
 #pragma unroll
                         for (int j = 0; j < NS; j++) {
                             const float a = fabsf(x[j]);
@@ -373,11 +387,16 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
                         f32x2 mine;
                         mine.x = __uint_as_float(__float_as_uint(mn1) | (sx & 0x80000000u)); mine.y = mn2;      // (+inf | sign bit: the magnitude bits stay those of +inf)
                         *(lds_f32x2 *)(size_t)xmine = mine;
+                        }
                     }
                     C1_MARK(1);
-                    __syncthreads();         // the halves' minima are in place; every read of the layer precedes its writes
+                    __syncthreads();         // the halves' minima (SPA = 3: products) are in place; every read of the layer precedes its writes
                     C1_MARK(2);
                     uint32_t SXT = 0u;
+                    float Aoth = 0.f;
+                    if constexpr (SPA == 3) {
+                        if (act) { const float o = *c1_lds(xother); SXT = (sx ^ __float_as_uint(o)) & 0x80000000u; Aoth = fabsf(o); }
+                    } else {
                     if (act) {
                         const f32x2 oth = *(lds_f32x2 *)(size_t)xother;
                         const float o1 = fabsf(oth.x), o2 = oth.y;
@@ -402,10 +421,11 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
                         *c1_lds(xother) = Qown;      // into the other half's slot (its content has been consumed above); that half reads its own slot behind the barrier
                     }
                     __syncthreads();         // the halves' totals are in place
+                    }
                     if (act) {
                         // the prefix recursion STARTS from the other half's total: A_j then holds "the other half and this half's slots before j", and Q_j = comb(A_j, B_j)
                         // needs no third operand (two fused multiply-adds per slot less than comb(comb(A_j, B_j), Q_other))
-                        float A = *c1_lds(xmine);
+                        float A = SPA == 3 ? Aoth : *c1_lds(xmine);
                         const bool anykey = __ballot(key == key) != 0ull;      // some check of this wave is in the overflow case (min2 - min1 > 60): rare, and wave-uniform
                         float mq[4] = {0.f, 0.f, 0.f, 0.f};
                         const uint32_t mrow = (uint32_t)r * LB;
@@ -425,8 +445,8 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
                             }
                             const float Q = __builtin_fmaf(Bj, wA, A);                    // every slot of the check but j
                             const float lg = __builtin_amdgcn_logf(__builtin_fmaf(2.f, __builtin_amdgcn_rcpf(Q), -kap));
-                            float o = __builtin_fmaf(lg, 0.693147180559945309f, cln);
-                            if (anykey) { asm volatile("" ::: "memory"); o = __builtin_islessgreater(fabsf(x[j]), key) ? mn1 : o; }      // (the empty asm keeps the compiler from turning the wave-uniform branch back into two selects per slot)      // (ordered "not equal": false against the NaN that stands for "no overflow")
+                            float o = SPA == 3 ? lg * 0.693147180559945309f : __builtin_fmaf(lg, 0.693147180559945309f, cln);
+                            if (SPA != 3 && anykey) { asm volatile("" ::: "memory"); o = __builtin_islessgreater(fabsf(x[j]), key) ? mn1 : o; }      // (the empty asm keeps the compiler from turning the wave-uniform branch back into two selects per slot)      // (ordered "not equal": false against the NaN that stands for "no overflow")
                             o = fminf(o, p.spa_cap);      // (`--dec-implem SPA`: the cap of AFF3CT's tanh-product rule; SPA_EXACT: +inf)
                             float nw;
                             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(nw) : "s"(MAGM), "v"(o), "v"(SXT ^ __float_as_uint(x[j])));
@@ -718,7 +738,7 @@ __device__ __forceinline__ void cu1_work(const LdpcKParams &p, lds_int *const s_
     }
 }
 
-template <int DEG, bool SPA>
+template <int DEG, int SPA>
 __global__ void __launch_bounds__(C1_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 ldpc_cu1_kernel(const LdpcKParams p)
 {
@@ -789,11 +809,11 @@ hipError_t ldpc_cu1_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s)
     p.N = pl.N; p.K = pl.K; p.M = pl.M; p.q = pl.q; p.n_info = pl.n_info; p.n_groups = pl.n_groups;
     p.gwork_words = pl.w8_gwork_words;
     if (pl.fast_deg != 27 || pl.cu1_pairs != 2 * ldpc_cu1_nrg()) return hipErrorInvalidValue;
-    auto kern = pl.spa ? ldpc_cu1_kernel<27, true> : ldpc_cu1_kernel<27, false>;
-    static size_t configured_dev[2][64] = {{0}, {0}};
+    auto kern = pl.spa_rule == 3 ? ldpc_cu1_kernel<27, 3> : pl.spa ? ldpc_cu1_kernel<27, 1> : ldpc_cu1_kernel<27, 0>;
+    static size_t configured_dev[3][64] = {{0}, {0}, {0}};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    size_t &configured = configured_dev[pl.spa ? 1 : 0][dev & 63];
+    size_t &configured = configured_dev[pl.spa_rule == 3 ? 2 : pl.spa ? 1 : 0][dev & 63];
     const size_t lds = (size_t)pl.w8_lds_bytes;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -308,7 +308,8 @@ __device__ __forceinline__ void w8_park_server(const LdpcKParams &p, lds_int *co
 
 // SPA = 0: normalised min-sum with the packed per-check state.  SPA = 1: sum-product check node (exact, complement-product domain), the c->v
 // messages kept per edge (fp32, [layer][slot][360] after the image in the workgroup's global slot).  SPA = 2: the same layer with the check node as
-// AFF3CT's Update_rule_SPA evaluates it (tanh product in fp32, saturating), bit for bit the oracle's ORC_SPA_TANH (w8_det_*).
+// AFF3CT's Update_rule_SPA evaluates it (tanh product in fp32, saturating), bit for bit the oracle's ORC_SPA_TANH (w8_det_*).  SPA = 3: `--dec-implem SPA`, the exact node with
+// every message clipped at AFF3CT's cap -- which makes the scale, the running minima and the overflow rule of SPA = 1 unnecessary.
 template <int DEG, int MODE, int SPA = 0>      // MODE 0: image in LDS, 1: in the workgroup's global slot, 3: static hybrid
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((SPA == 2 && DEG > 13) ? 2 : 4, 4)))      // (the tanh-product rule on 27 slots: one workgroup per CU, 256 registers -- a parity mode, not a throughput one)
 ldpc_wg8_kernel(const LdpcKParams p)
@@ -669,6 +670,22 @@ ldpc_wg8_kernel(const LdpcKParams p)
                             for (int j = 0; j < DEG; j++) { sx ^= __float_as_uint(x[j]); tv[j] = w8_det_tanh_half(fabsf(x[j])); }
 #pragma unroll
                             for (int c = 0; c < DEG; c++) tprod = tprod * tv[(pw[c / 6] >> (5 * (c % 6))) & 31u];
+                        } else if constexpr (SPA == 3) {
+                            // (round 6) `--dec-implem SPA`: every message is clipped at 16.64 on the way out, i.e. wherever Q = 1 - prod (1 - u_i) falls below 1.2e-7 the clip
+                            // decides -- Q needs no more range than plain fp32 gives (u_i = 2 / (e^a_i + 1) may underflow to 0: a sum of zeros is below 1.2e-7 too, 2 / 0 = +inf,
+                            // log = +inf, the clip takes it), so the per-check scale 2^s2 of the unclipped rule, the two running minima it is chosen from and the
+                            // weakest-edge overflow rule all go: ~6 of the layer's 36 vector instructions per edge
+#pragma unroll
+                            for (int j = 0; j < DEG; j++) {
+                                sx ^= __float_as_uint(x[j]);
+                                u[j] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(__builtin_fmaf(fabsf(x[j]), 1.44269504088896341f, -1.f)) + 0.5f);
+                            }
+                            float b = 0.f;
+#pragma unroll
+                            for (int j = DEG - 1; j >= 0; j--) {
+                                if (j % BS == BS - 1 || j == DEG - 1) B[j / BS] = b;
+                                b = __builtin_fmaf(u[j], 1.f - b, b);
+                            }
                         } else {
                         float mn2 = INFINITY;
 #pragma unroll
@@ -718,6 +735,20 @@ ldpc_wg8_kernel(const LdpcKParams p)
                                 val = (val < 1.0f) ? val : __uint_as_float(0x3F7FFFFEu);      // 1 - FLT_EPSILON
                                 const float o = w8_det_log1p((val + val) / (1.0f - val));
                                 asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(nw) : "s"(MAGM), "v"(o), "v"(sx ^ __float_as_uint(x[j])));
+                            } else if constexpr (SPA == 3) {
+                                const float wA = 1.f - A;
+                                float Bj;
+                                {
+                                    const int js = (j / BS) * BS + BS - 1 < DEG - 1 ? (j / BS) * BS + BS - 1 : DEG - 1;
+                                    Bj = B[j / BS];
+#pragma unroll
+                                    for (int i = js; i > j; i--) Bj = __builtin_fmaf(u[i], 1.f - Bj, Bj);
+                                }
+                                const float Q = __builtin_fmaf(Bj, wA, A);
+                                float o = __builtin_amdgcn_logf(__builtin_fmaf(2.f, __builtin_amdgcn_rcpf(Q), -1.f)) * 0.693147180559945309f;
+                                o = fminf(o, p.spa_cap);
+                                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(nw) : "s"(MAGM), "v"(o), "v"(sx ^ __float_as_uint(x[j])));
+                                A = __builtin_fmaf(u[j], wA, A);
                             } else {
                             const float wA = __builtin_fmaf(-kap, A, 1.f);
                             float Bj;
@@ -1490,7 +1521,7 @@ static int wg8_occ(const LdpcPlan &pl)
      : pl.fast_deg == 13 ? (pl.fast_mode == 0 ? FN<13, 0, RULE>(__VA_ARGS__) : FN<13, 1, RULE>(__VA_ARGS__))                                                 \
                          : (pl.fast_mode == 0 ? FN<11, 0, RULE>(__VA_ARGS__) : FN<11, 1, RULE>(__VA_ARGS__)))
 #define WG8_ANY_DISPATCH(FN, ...)                                                                                  \
-    (pl.spa_rule == 2 ? WG8_RULE_DISPATCH(2, FN, __VA_ARGS__)                                                     \
+    (pl.spa_rule == 2 ? WG8_RULE_DISPATCH(2, FN, __VA_ARGS__) : pl.spa_rule == 3 ? WG8_RULE_DISPATCH(3, FN, __VA_ARGS__) \
      : pl.spa ? WG8_RULE_DISPATCH(1, FN, __VA_ARGS__) : WG8_DISPATCH(FN, __VA_ARGS__))
 
 int ldpc_wg8_blocks_per_cu(const LdpcPlan &pl) { return WG8_ANY_DISPATCH(wg8_occ, pl); }

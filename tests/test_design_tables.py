@@ -14,4 +14,4 @@ def test_design_tables_are_the_generators_output():
     assert blk is not None, "DESIGN.md lost its GENERATED markers"
     tag = re.search(r"make_design_tables\.py (r\d+)`", blk).group(1)
     assert blk == M.render(tag), "DESIGN.md's generated block is stale or hand-edited: python tools/make_design_tables.py %s --write" % tag
-    assert "Headline (bench.py" in blk and "fir_mfma_kernel<2>" in blk and "ldpc_cu1_kernel<27, true>" in blk and "ldpc_wg8_kernel<27, 5, 0>" in blk
+    assert "Headline (bench.py" in blk and "fir_mfma_kernel<2>" in blk and "ldpc_cu1_kernel<27, 3>" in blk and "ldpc_wg8_kernel<27, 5, 0>" in blk

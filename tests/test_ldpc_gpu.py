@@ -469,7 +469,7 @@ def test_ldpc_normal_frame_image_modes_agree_with_the_oracle(O, Rx, monkeypatch,
         want = kernel_mode if kernel_mode is not None else (DEFAULT_SPA_MODE if spa else DEFAULT_NMS_MODE)
         if spa and want == 5:
             want = 4                    # (the sum-product kernel has no registers for 39 parked rows)
-        name = ("ldpc_cu1_kernel<27,true>" if spa else "ldpc_cu1_kernel<27>") if want == 6 else "ldpc_wg8_kernel<27,%d%s>" % (want, ",1" if spa else "")
+        name = {"NMS": "ldpc_cu1_kernel<27>", "SPA": "ldpc_cu1_kernel<27,3>", "SPA_EXACT": "ldpc_cu1_kernel<27,1>"}[implem] if want == 6 else "ldpc_wg8_kernel<27,%d%s>" % (want, {"NMS": "", "SPA": ",3", "SPA_EXACT": ",1"}[implem])
         assert rx.ldpc_kernel_name() == name, rx.ldpc_kernel_name()
         V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
         Vo, posto, cwdo, iteso = ch.ldpc.decode(llr[pick], n_ite=n_ite, alpha=1.0, implem=orule, sched=O.QC, early_stop=early)
