@@ -2,7 +2,7 @@
 # BER/FER sweeps on one MI355X (BASELINE configs 1, 3, 4-at-1-GPU, 5-modcod); tables -> gpurun_out/ber_*.txt
 set -u
 OUT=gpurun_out; mkdir -p $OUT
-run() { name=$1; shift; python -m dvbs2_amd.sim "$@" --json $OUT/ber_$name.json 2>&1 | grep -v amdgpu.ids > $OUT/ber_$name.txt; tail -4 $OUT/ber_$name.txt; }
+run() { name=$1; shift; python -m dvbs2_amd.sim "$@" --clones 1 --json $OUT/ber_$name.json 2>&1 | grep -v amdgpu.ids > $OUT/ber_$name.txt; tail -4 $OUT/ber_$name.txt; }
 run qpsk_s_8_9_nms10      --mod-cod QPSK-S_8/9   -m 3.6 -M 4.41 -s 0.1 --dec-implem NMS --dec-ite 10 -F 2048 --max-frames 4000000
 run qpsk_s_8_9_nms50_a875 --mod-cod QPSK-S_8/9   -m 3.6 -M 4.21 -s 0.1 --dec-implem NMS --dec-ite 50 --dec-alpha 0.875 -F 2048 --max-frames 4000000
 run qpsk_s_3_5_nms10      --mod-cod QPSK-S_3/5   -m 1.4 -M 2.41 -s 0.2 --dec-implem NMS --dec-ite 10 -F 2048 --max-frames 1000000

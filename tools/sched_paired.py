@@ -8,7 +8,7 @@ import numpy as np
 
 
 def work(job):
-    modcod, ebn0, seed, n, ite, implem = job
+    modcod, ebn0, seed, n, ite, implem, stop = job
     from oracle import oracle as O
     from helpers import chain
     ch = chain(O, modcod)
@@ -21,7 +21,7 @@ def work(job):
     llr = (2.0 * ((1.0 - 2.0 * cw) + sigma * rng.standard_normal(cw.shape)) / sigma ** 2).astype(np.float32)
     bad = {}
     for name, sc in (("natural", O.NATURAL), ("qc", O.QC), ("qc_seq", O.QC_SEQ)):
-        V, _, _, _ = ch.ldpc.decode(llr, n_ite=ite, alpha=1.0, implem=getattr(O, implem), sched=sc, early_stop=False)
+        V, _, _, _ = ch.ldpc.decode(llr, n_ite=ite, alpha=1.0, implem=getattr(O, implem), sched=sc, early_stop=stop)
         bad[name] = (V != cw[:, :mc.K_ldpc]).any(axis=1)
     return {k: int(v.sum()) for k, v in bad.items()}, int((bad["qc"] & ~bad["natural"]).sum()), int((bad["natural"] & ~bad["qc"]).sum()), int((bad["qc_seq"] & ~bad["natural"]).sum()), int((bad["natural"] & ~bad["qc_seq"]).sum()), n
 
@@ -29,10 +29,10 @@ def work(job):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--mod-cod", default="QPSK-S_8/9"); ap.add_argument("--ebn0", type=float, default=4.0); ap.add_argument("--frames", type=int, default=12000)
-    ap.add_argument("--ite", type=int, default=10); ap.add_argument("--implem", default="NMS"); ap.add_argument("--workers", type=int, default=6); ap.add_argument("--out", default="")
+    ap.add_argument("--ite", type=int, default=10); ap.add_argument("--implem", default="NMS"); ap.add_argument("--workers", type=int, default=6); ap.add_argument("--out", default=""); ap.add_argument("--early-stop", action="store_true")
     a = ap.parse_args()
     per = 100
-    jobs = [(a.mod_cod, a.ebn0, 500 + j, per, a.ite, a.implem) for j in range((a.frames + per - 1) // per)]
+    jobs = [(a.mod_cod, a.ebn0, 500 + j, per, a.ite, a.implem, a.early_stop) for j in range((a.frames + per - 1) // per)]
     tot = {"natural": 0, "qc": 0, "qc_seq": 0}
     d = [0, 0, 0, 0]; N = 0
     t0 = time.time()
