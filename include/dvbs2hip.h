@@ -52,7 +52,7 @@ enum { DVBS2HIP_IMPLEM_NMS = 0, DVBS2HIP_IMPLEM_MS = 1,
        DVBS2HIP_IMPLEM_SPA_TANH = 3,   /* sum-product as AFF3CT's Update_rule_SPA evaluates it [UPSTREAM-RECALL]: tanh product in fp32, messages capped at
                                             2 atanh(1 - FLT_EPSILON) = 16.64; BIT-EXACT against the oracle's ORC_SPA_TANH (every operation correctly rounded) */
        DVBS2HIP_IMPLEM_SPA_EXACT = 4 };  /* the exact check node without the clip (rounds 1-5's SPA): within 1e-4 max(1, |L|) of the oracle's ORC_SPA; loses 20-50 % more frames than the
-                                            reference at the low-FER end of the rate-3/5 traces */
+                                            reference at the low-FER end of the rate-3/5 traces and has an error floor below them (results/r06/spa_rules.md) */
 /* Order in which the layered decoder visits the checks of a frame (dvbs2hip_set_ldpc_schedule) */
 enum { DVBS2HIP_SCHED_QC = 0,        /* quasi-cyclic layers of 360 independent checks: the throughput path */
        DVBS2HIP_SCHED_NATURAL = 1 }; /* natural row order of H, what AFF3CT's BP_HORIZONTAL_LAYERED runs: one lane per frame */
