@@ -75,6 +75,19 @@ def test_gpu_spa50_pooled_over_the_19_rows_and_the_three_rules():
         assert got["SPA_EXACT"][1] > 1.10 * got["SPA_TANH"][1], got
 
 
+def test_uncapped_sum_product_has_an_error_floor_the_default_does_not():
+    """(round 6) Two million QPSK-S 3/5 frames at 1.8 dB, 0.3 dB above the last row of the reference's trace: the default `SPA` (AFF3CT's message cap) loses a handful of frames
+    or none (6 in 20 M, results/r06/spa_rules.md), rounds 1-5's uncapped rule hundreds (5899 in 20 M: FER 3e-4, a floor) -- same seeds, same frames."""
+    import io
+    from dvbs2_amd import sim
+    def run(implem):
+        argv = ["--mod-cod", "QPSK-S_3/5", "-m", "1.80", "-M", "1.81", "--dec-implem", implem, "--dec-ite", "50", "-F", "8192", "--max-frames", "2000000", "-e", "100000000", "--clones", "1"]
+        return sim.run(sim.build_parser().parse_args(argv), out=io.StringIO())[0]
+    cap, exact = run("SPA"), run("SPA_EXACT")
+    assert cap["fra"] == exact["fra"] >= 2000000
+    assert cap["fe"] <= 8 and exact["fe"] >= 200, (cap["fe"], exact["fe"])
+
+
 @pytest.mark.parametrize("clones", [2, 3])
 def test_gpu_sim_with_clones_counts_what_one_clone_counts(clones):
     """--clones C (the reference's Sequence with n_threads clones, TX_RX_BB/main.cpp:19,96): the batches are the same batches -- dealt to C handles in turn -- so the counters after
