@@ -10,6 +10,28 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 BEGIN, END = "<!-- BEGIN GENERATED HEADLINE TABLE (tools/make_readme_table.py) -->", "<!-- END GENERATED HEADLINE TABLE -->"
 
 
+def floor_row(rd):
+    """the error floor of the uncapped rule, from results/<tag>/floor_spa.txt (tools/r06_floor_spa.sh)"""
+    import re
+    p = os.path.join(rd, "floor_spa.txt")
+    if not os.path.exists(p):
+        return "| error floor | (results missing) | | |"
+    cur, t = None, {}
+    for l in open(p):
+        m = re.match(r"^== --mod-cod (\S+) .*--dec-implem (\S+) ", l)
+        if m:
+            cur = (m.group(1), m.group(2)); continue
+        m = re.match(r"^ +(-?[0-9.]+) \| +([0-9.]+) \|\| +(\d+) \| +(\d+) \| +(\d+) \|", l)
+        if m and cur:
+            t.setdefault((cur[0], float(m.group(2))), {})[cur[1]] = (int(m.group(3)), int(m.group(5)))
+    k = ("QPSK-S_3/5", 1.7)
+    a, b = t[k]["SPA"], t[k]["SPA_EXACT"]
+    k2 = ("QPSK-S_8/9", 4.2)
+    c, d = t[k2]["SPA"], t[k2]["SPA_EXACT"]
+    return ("| no error floor: `SPA` (AFF3CT's message cap) against rounds 1-5's uncapped rule, same %.0f M frames | QPSK-S 3/5 at 1.7 dB: **%d** frame errors against %d; QPSK-S 8/9 at 4.2 dB: %d against %d "
+            "| FER %.1e against %.1e | `test_uncapped_sum_product_has_an_error_floor_the_default_does_not` |" % (a[0] / 1e6, a[1], b[1], c[1], d[1], a[1] / a[0], b[1] / b[0]))
+
+
 def render(tag, bench_path=None):
     import refs_pooled
     p = bench_path or os.path.join(ROOT, "profiles", "%s_bench.json" % tag)
@@ -37,6 +59,7 @@ def render(tag, bench_path=None):
          "| **parity with the reference** (pooled FER over its 19 regression rows, run / reference) | `SPA` %.3f +- %.3f; the reference's decoder as recalled (`SPA_TANH`, natural order) **%.3f +- %.3f**; rounds 1-5's rule %.3f +- %.3f | chi^2 on 19 dof: %.1f / %.1f / %.1f | `test_gpu_spa50_pooled_over_the_19_rows_and_the_three_rules` |" % (
              pq["pooled_ratio"], pq["pooled_ratio"] * pq["pooled_sigma"], pn["pooled_ratio"], pn["pooled_ratio"] * pn["pooled_sigma"], pe["pooled_ratio"], pe["pooled_ratio"] * pe["pooled_sigma"],
              pq["chi2"], pn["chi2"], pe["chi2"]) if pq and pn and pe else "| parity with the reference | (results missing) | | |",
+         floor_row(rd),
          "| natural row order (the reference's sweep), NMS 10 ite, 4096 normal frames | %.0f k frames/s | bit-exact with the oracle's ORC_SCHED_NATURAL | `test_ldpc_natural_order_matches_oracle` |" % ((ex.get("natural_order_fps") or 0) / 1e3),
          "| frame synchronizer, located form | %.3f ms per 4096 32APSK-S frames, %.3f ms per 1024 QPSK-N frames | %.2f / %.2f of 8 TB/s (16 B per sample) | `tests/test_sync_gpu.py` |" % (
              sl["32APSK-S_3/4"]["ms_per_call"], sl["QPSK-N_8/9"]["ms_per_call"], sl["32APSK-S_3/4"]["frac_of_8TBps"], sl["QPSK-N_8/9"]["frac_of_8TBps"]),
