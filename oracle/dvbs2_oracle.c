@@ -309,11 +309,30 @@ static int ldpc_decode_ws(const orc_ldpc *c, const float *llr, int implem, int s
              * edges write v2c + new (phase 2); level-k duplicate edges then add
              * (new - old) in level order (phase 3). */
             const int D = c->max_deg;
+            float *acc = sched == ORC_SCHED_QC_FIX ? (float *)calloc((size_t)N, sizeof(float)) : NULL;
             for (int r = 0; r < q; r++) {
                 for (int t = 0; t < 360; t++) {
                     int k = q * t + r, b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
                     for (int j = 0; j < d; j++) v2c[t * D + j] = L[c->chk_var[b + j]] - msg[b + j];
                     chk_update(implem, alpha, v2c + t * D, d, nw + t * D);
+                }
+                if (sched == ORC_SCHED_QC_FIX) {
+                    /* ORC_SCHED_QC_FIX (an analysis aid, round 6): one Jacobi correction inside the layer -- a check whose bit is shared with another check of the layer
+                     * recomputes with that bit's value moved by the other check's first-pass delta (what a second, parallel pass over the layer's checks would cost) */
+                    for (int t = 0; t < 360; t++) {
+                        int k = q * t + r, b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
+                        for (int j = 0; j < d; j++) acc[c->chk_var[b + j]] += nw[t * D + j] - msg[b + j];
+                    }
+                    for (int t = 0; t < 360; t++) {
+                        int k = q * t + r, b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
+                        for (int j = 0; j < d; j++) v2c[t * D + j] += acc[c->chk_var[b + j]] - (nw[t * D + j] - msg[b + j]);      /* the OTHER checks' deltas on this bit */
+                    }
+                    for (int t = 0; t < 360; t++) {
+                        int k = q * t + r, b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
+                        float tmp[64];
+                        chk_update(implem, alpha, v2c + t * D, d, tmp);
+                        for (int j = 0; j < d; j++) { acc[c->chk_var[b + j]] = 0.f; v2c[t * D + j] = L[c->chk_var[b + j]] - msg[b + j]; nw[t * D + j] = tmp[j]; }
+                    }
                 }
                 for (int t = 0; t < 360; t++) {
                     int k = q * t + r, b = c->chk_ptr[k], d = c->chk_ptr[k + 1] - b;
@@ -334,6 +353,7 @@ static int ldpc_decode_ws(const orc_ldpc *c, const float *llr, int implem, int s
                     for (int j = 0; j < d; j++) msg[b + j] = nw[t * D + j];
                 }
             }
+            free(acc);
         }
         ite++;
         if (early_stop && soft_syndrome_ok(c, L)) break;

@@ -41,7 +41,7 @@ int       orc_ldpc_syndrome_weight(const orc_ldpc *c, const int32_t *cw);
 /* ORC_SPA: exact boxplus (no saturation).  ORC_SPA_TANH: the tanh-product form with fp32 saturation as AFF3CT's Update_rule_SPA evaluates it
  * [UPSTREAM-RECALL], written with correctly rounded IEEE operations only so that the HIP kernels match it bit for bit (dvbs2_oracle.c). */
 enum { ORC_NMS = 0, ORC_SPA = 1, ORC_SPA_TANH = 2, ORC_SPA_CLIP = 3 };      /* ORC_SPA_CLIP: ORC_SPA with |c->v| clipped to 2 atanh(1 - FLT_EPSILON) = 16.6355 */
-enum { ORC_SCHED_NATURAL = 0, ORC_SCHED_QC = 1, ORC_SCHED_QC_SEQ = 2 };      /* QC_SEQ: the QC layers' order of checks, processed one after the other (analysis aid) */
+enum { ORC_SCHED_NATURAL = 0, ORC_SCHED_QC = 1, ORC_SCHED_QC_SEQ = 2, ORC_SCHED_QC_FIX = 3 };      /* QC_SEQ: the QC layers' order of checks, processed one after the other (analysis aid) */
 /*
  * Horizontal-layered BP (dec type "BP_HORIZONTAL_LAYERED", DVBS2.cpp:428), implem
  * NMS (alpha; alpha = 1 gives plain MS), SPA (exact) or SPA_TANH (AFF3CT's saturating form).

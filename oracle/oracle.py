@@ -201,7 +201,7 @@ def _i32(a):
 
 
 NMS, SPA, SPA_TANH, SPA_CLIP = 0, 1, 2, 3      # SPA: exact boxplus; SPA_TANH: the saturating tanh-product form of AFF3CT's Update_rule_SPA (dvbs2_oracle.c)
-NATURAL, QC, QC_SEQ = 0, 1, 2
+NATURAL, QC, QC_SEQ, QC_FIX = 0, 1, 2, 3
 
 
 def det_tanh_half(a):

@@ -20,7 +20,7 @@ def work(job):
     cw = ch.ldpc.encode(ch.bch.encode(info))
     llr = (2.0 * ((1.0 - 2.0 * cw) + sigma * rng.standard_normal(cw.shape)) / sigma ** 2).astype(np.float32)
     bad = {}
-    for name, sc in (("natural", O.NATURAL), ("qc", O.QC), ("qc_seq", O.QC_SEQ)):
+    for name, sc in (("natural", O.NATURAL), ("qc", O.QC), ("qc_seq", O.QC_SEQ), ("qc_fix", O.QC_FIX)):
         V, _, _, _ = ch.ldpc.decode(llr, n_ite=ite, alpha=1.0, implem=getattr(O, implem), sched=sc, early_stop=stop)
         bad[name] = (V != cw[:, :mc.K_ldpc]).any(axis=1)
     return {k: int(v.sum()) for k, v in bad.items()}, int((bad["qc"] & ~bad["natural"]).sum()), int((bad["natural"] & ~bad["qc"]).sum()), int((bad["qc_seq"] & ~bad["natural"]).sum()), int((bad["natural"] & ~bad["qc_seq"]).sum()), n
@@ -33,7 +33,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     per = 100
     jobs = [(a.mod_cod, a.ebn0, 500 + j, per, a.ite, a.implem, a.early_stop) for j in range((a.frames + per - 1) // per)]
-    tot = {"natural": 0, "qc": 0, "qc_seq": 0}
+    tot = {"natural": 0, "qc": 0, "qc_seq": 0, "qc_fix": 0}
     d = [0, 0, 0, 0]; N = 0
     t0 = time.time()
     with mp.Pool(a.workers) as pool:
@@ -41,7 +41,7 @@ if __name__ == "__main__":
             for k in tot: tot[k] += fe[k]
             d[0] += a1; d[1] += a2; d[2] += a3; d[3] += a4; N += n
     res = dict(modcod=a.mod_cod, ebn0=a.ebn0, ite=a.ite, implem=a.implem, frames=N, frame_errors=tot, qc_only=d[0], natural_only_vs_qc=d[1], qc_seq_only=d[2], natural_only_vs_qc_seq=d[3],
-               qc_over_natural=tot["qc"] / max(1, tot["natural"]), qc_seq_over_natural=tot["qc_seq"] / max(1, tot["natural"]), seconds=time.time() - t0)
+               qc_over_natural=tot["qc"] / max(1, tot["natural"]), qc_seq_over_natural=tot["qc_seq"] / max(1, tot["natural"]), qc_fix_over_natural=tot["qc_fix"] / max(1, tot["natural"]), seconds=time.time() - t0)
     print(json.dumps(res))
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
