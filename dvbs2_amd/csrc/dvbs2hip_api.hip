@@ -44,6 +44,7 @@ struct dvbs2hip_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool capturing = false;
+    bool lat_lds_ok = false;      // the device's LDS holds k_ldpc_lat.hip's image + state (gfx950: 160 KB)
     bool comm_dead = false;       // dvbs2hip_monitor_reduce timed out: the communicator was aborted
     int red_timeout_ms = 0;
     std::vector<hipGraphExec_t> graphs;      // dvbs2hip_graph_end: captured call sequences (a freed slot is nullptr)
@@ -351,6 +352,7 @@ int dvbs2hip_create(const dvbs2hip_cfg *cfg, dvbs2hip_t **out)
     size_t lds_limit = strstr(prop.gcnArchName, "gfx950") ? 160 * 1024 : prop.sharedMemPerBlock;
     if (const char *ev = getenv("DVBS2HIP_LDS_LIMIT")) lds_limit = (size_t)atol(ev);
     if (lds_limit < 32 * 1024) lds_limit = 32 * 1024;
+    h->lat_lds_ok = lds_limit >= 160 * 1024;
     lds_limit -= 512;                                    // static LDS of the kernel + slack
     std::string e = ldpc_build_plan(h->ldpc, cfg->N_ldpc, cfg->K_ldpc, cfg->ldpc_n_rows, cfg->ldpc_row_ptr, cfg->ldpc_addr,
                                     cfg->ldpc_lds_groups, lds_limit, cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA ? 3 : cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA_TANH ? 2 : cfg->ldpc_implem == DVBS2HIP_IMPLEM_SPA_EXACT ? 1 : 0, cfg->max_frames <= h->n_cus);
@@ -640,6 +642,7 @@ int dvbs2hip_set_filter_kernel(dvbs2hip_t *h, int32_t kernel)
     return 0;
 }
 
+static bool ldpc_lat_ok(const dvbs2hip_t *h, int F);
 const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
 {
     if (!h) return "";
@@ -652,6 +655,7 @@ const char *dvbs2hip_ldpc_kernel_name(const dvbs2hip_t *h)
     {
         const LdpcPlan &pl = h->ldpc;
         char buf[96];
+        if (ldpc_lat_ok(h, h->max_frames)) { snprintf(buf, sizeof buf, "ldpc_lat_kernel<%d>", pl.fast_deg); const_cast<dvbs2hip_t *>(h)->ldpc_name = buf; return h->ldpc_name.c_str(); }      // (every call of this handle is a small batch)
         if (!pl.fast) snprintf(buf, sizeof buf, "ldpc_layered_nms_kernel<%d,%s,%s>", pl.ent_stride, pl.hybrid ? "true" : "false", pl.c2v_lds ? "true" : "false");
         else if (pl.fast_cu1 && pl.spa) snprintf(buf, sizeof buf, "ldpc_cu1_kernel<%d,%d>", pl.fast_deg, pl.spa_rule == 3 ? 3 : 1);
         else if (pl.fast_cu1) snprintf(buf, sizeof buf, "ldpc_cu1_kernel<%d>", pl.fast_deg);
@@ -778,6 +782,16 @@ int dvbs2hip_get_sizes(const dvbs2hip_t *h, dvbs2hip_sizes *o)
 // ------------------------------------------------------------------ a1
 static bool env_is(const char *name, char c) { const char *e = getenv(name); return e && e[0] == c; }
 // the LDPC kernel can write the chain's output socket itself (descrambled info bits of a frame the BCH stage leaves alone)
+// (round 6) a call of at most one frame per CU on a code whose image and packed state fit the LDS can run on the two-lanes-per-check kernel (k_ldpc_lat.hip) -- OPT-IN,
+// DVBS2HIP_LDPC_LAT=1: bit-exact, and measured SLOWER than the lone workgroup of k_ldpc_wg8.hip (one 32APSK-S 3/4 frame: 210 against 177 us; QPSK-S 8/9: 178 against 141):
+// splitting a check over two lanes halves a wave's work per layer but not the SIMDs' -- the same vector instructions issue from twice the waves (docs/negative_results.md)
+static bool ldpc_lat_ok(const dvbs2hip_t *h, int F)
+{
+    const char *e = getenv("DVBS2HIP_LDPC_LAT");
+    const size_t lds = ldpc_lat_lds_bytes(h->ldpc);
+    return e && e[0] == '1' && h->ldpc_sched == DVBS2HIP_SCHED_QC && F <= h->n_cus && lds > 0 && lds <= 160 * 1024 - 512 && h->lat_lds_ok;
+}
+
 static bool ldpc_writes_info(const dvbs2hip_t *h) { return h->ldpc.fast_wg8 && h->ldpc_sched == DVBS2HIP_SCHED_QC && !getenv("DVBS2HIP_CHAIN_UNFUSED"); }
 
 // (round 5) ... and check the BCH remainder of what it outputs: the BCH stage then decodes the flagged frames only (DVBS2HIP_CHAIN_SYN=0: round 4's form, the BCH stage
@@ -807,6 +821,11 @@ static int ldpc_dev(dvbs2hip_t *h, const float *Y, int8_t *CWD, int32_t *V, uint
         }
         Timer tm(h, DVBS2HIP_K_LDPC);
         HIPCHK(h, ldpc_nat_launch(pl, p, h->d_nat_work, h->stream));
+        return 0;
+    }
+    if (ldpc_lat_ok(h, F) && !info_out) {
+        Timer tm(h, DVBS2HIP_K_LDPC);
+        HIPCHK(h, ldpc_lat_launch(h->ldpc, p, h->stream));
         return 0;
     }
     Timer tm(h, DVBS2HIP_K_LDPC);
@@ -1799,7 +1818,7 @@ static int rx_bb_any_dev(dvbs2hip_t *h, const float *pl, const float *const *src
     // the LDPC kernel writes the descrambled info bits of every frame straight into the output socket (what the BCH stage outputs for a
     // frame it does not correct: nearly all of them behind a converged LDPC decoder); the BCH stage then only checks the syndromes of the
     // packed hard decisions and flips the bits it corrects -- its 4 K_bch output bytes per frame were 90 % of its time
-    const bool fused_out = ldpc_writes_info(h);
+    const bool fused_out = ldpc_writes_info(h) && !ldpc_lat_ok(h, F);      // (the latency kernel of small batches writes the packed hard decisions only: the BCH stage does the rest)
     // (round 5) ... and forms the frame's BCH remainder r(x) mod g(x) from the hard decisions it outputs: a frame whose remainder is zero is finished (information bits and
     // both CWD flags written by the LDPC kernel); the BCH stage rebuilds and decodes the flagged frames only
     void *dflag = nullptr;

@@ -233,6 +233,8 @@ struct FrontKParams {
     int32_t sep, sep_ax[2];
     float sep_g[2], sep_h[2];
 };
+size_t ldpc_lat_lds_bytes(const LdpcPlan &pl);                                    // k_ldpc_lat.hip: small batches of short frames, two lanes per check (0: not applicable)
+hipError_t ldpc_lat_launch(const LdpcPlan &pl, LdpcKParams p, hipStream_t s);
 hipError_t frame_order_launch(const float *llr, float *metric, uint32_t *order, int F, int N, hipStream_t s);      // k_ldpc.hip: the work queue's order for launches with the stopping rule (noisiest frames first)
 hipError_t front_rx_launch(FrontKParams p, hipStream_t s);                     // a7+a6+a3+a4 fused, in = pl frames
 hipError_t demod_launch(FrontKParams p, bool deinterleave, hipStream_t s);     // a3 (+a4), in = xfec frames, sigma_in required

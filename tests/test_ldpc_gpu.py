@@ -398,6 +398,24 @@ def test_ldpc_headline_config_at_size_matches_oracle(O, Rx, n_ite, F, ebn0s):
     assert (CWD[0::2] if len(ebn0s) == 2 else CWD).mean() < 0.5      # 3.0 dB: most frames fail, which is the point
 
 
+@pytest.mark.parametrize("modcod,ebn0", [("QPSK-S_8/9", 4.2), ("QPSK-S_3/5", 2.0), ("32APSK-S_3/4", 3.4)])
+def test_two_lanes_per_check_kernel_is_bit_exact(O, Rx, monkeypatch, modcod, ebn0):
+    """k_ldpc_lat.hip (opt-in, DVBS2HIP_LDPC_LAT=1: written for the one-frame call's latency, measured slower than the lone workgroup it was meant to beat): one frame per CU, a
+    check's slots over two adjacent lanes, image and packed state in LDS -- posteriors, hard decisions, CWD and iteration counts bit for bit the oracle's QC schedule, the
+    27-, 11- and padded 13-slot layers, with and without the stopping rule."""
+    monkeypatch.setenv("DVBS2HIP_LDPC_LAT", "1")
+    ch = chain(O, modcod)
+    F = 5
+    _, llr, cw = make_llrs(O, modcod, F, ebn0, seed=71)
+    for early, alpha in ((False, 1.0), (True, 0.875)):
+        rx = Rx(modcod, max_frames=F, n_ite=10, alpha=alpha, early_stop=early)
+        assert rx.ldpc_kernel_name().startswith("ldpc_lat_kernel<")
+        V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+        Vo, posto, cwdo, iteso = ch.ldpc.decode(llr, n_ite=10, alpha=alpha, sched=O.QC, early_stop=early)
+        assert np.array_equal(post.view(np.uint32), posto.view(np.uint32)) and np.array_equal(V, Vo) and np.array_equal(CWD, cwdo) and np.array_equal(ites, iteso)
+        rx.close()
+
+
 def test_small_batch_handles_take_the_one_frame_per_cu_image(O, Rx):
     """(round 6) A handle created for at most one frame per CU (max_frames <= the CU count) decodes normal frames with the one-frame-per-CU image
     (k_ldpc_cu1.hip: two lanes per check -- a call is one frame's ten iterations on one CU, 0.42 ms instead of 0.54); a larger handle keeps the two-frames-per-CU kernel.
