@@ -46,7 +46,8 @@ def pooled(directory, prefix):
             lr = math.log(fer_run / fer_ref)
             sg = math.sqrt(1.0 / r["fe"] + 1.0 / g["fe"])
             row = dict(ref=ref_file, modcod=modcod, ebn0=eb, fer_ref=fer_ref, fe_ref=r["fe"], fer_run=fer_run, fe_run=g["fe"], fra_run=g["fra"], ratio=math.exp(lr), log_ratio=lr, sigma=sg,
-                       z=lr / sg, x=-math.log10(fer_ref))
+                       z=lr / sg, x=-math.log10(fer_ref),
+                       ber_log_ratio=math.log((g["be"] / g["fra"]) / (r["be"] / r["fra"])) if g["be"] and r["be"] else 0.0)
             rows.append(row)
             traces.setdefault(ref_file, []).append(row)
     if not rows:
@@ -55,6 +56,7 @@ def pooled(directory, prefix):
     m = sum(r["log_ratio"] / r["sigma"] ** 2 for r in rows) / W
     s = 1 / math.sqrt(W)
     chi2 = sum((r["log_ratio"] / r["sigma"]) ** 2 for r in rows)
+    mb = sum(r["ber_log_ratio"] / r["sigma"] ** 2 for r in rows) / W      # bit-error-rate ratio, pooled with the same weights (bit errors come in bursts of one frame: the frames' sigma is the honest one)
     slopes = {}
     for t, rr in traces.items():
         if len(rr) < 3:
@@ -75,16 +77,16 @@ def pooled(directory, prefix):
         yb = sum(wi * r["log_ratio"] for wi, r in zip(w, rr)) / sw
         num += sum(wi * (r["x"] - xb) * (r["log_ratio"] - yb) for wi, r in zip(w, rr))
         den += sum(wi * (r["x"] - xb) ** 2 for wi, r in zip(w, rr))
-    return dict(rows=rows, n=len(rows), pooled_log_ratio=m, pooled_sigma=s, pooled_ratio=math.exp(m), z=m / s, chi2=chi2, dof=len(rows), slopes=slopes,
+    return dict(rows=rows, n=len(rows), pooled_ber_ratio=math.exp(mb), pooled_log_ratio=m, pooled_sigma=s, pooled_ratio=math.exp(m), z=m / s, chi2=chi2, dof=len(rows), slopes=slopes,
                 common_slope=num / den if den else None, common_slope_sigma=1 / math.sqrt(den) if den else None, rows_above_1=sum(r["ratio"] > 1 for r in rows))
 
 
 def render(res, title):
     out = ["### %s" % title, "",
            "pooled FER ratio run / reference: **%.3f +- %.3f** (log-ratio %.4f +- %.4f = %.1f sigma; %d rows, %d above 1); chi^2 against ratio 1: %.1f on %d dof; "
-           "common slope of log-ratio per decade of reference FER: %+.3f +- %.3f"
+           "common slope of log-ratio per decade of reference FER: %+.3f +- %.3f; pooled BER ratio (same weights) %.3f"
            % (res["pooled_ratio"], res["pooled_ratio"] * res["pooled_sigma"], res["pooled_log_ratio"], res["pooled_sigma"], res["z"], res["n"], res["rows_above_1"], res["chi2"], res["dof"],
-              res["common_slope"] or 0.0, res["common_slope_sigma"] or 0.0), "",
+              res["common_slope"] or 0.0, res["common_slope_sigma"] or 0.0, res["pooled_ber_ratio"]), "",
            "| ref file | MODCOD | Eb/N0 | ref FER (FE) | run FER (FE) | run / ref | sigma | z |", "|---|---|---|---|---|---|---|---|"]
     for r in res["rows"]:
         out.append("| %s | %s | %.2f | %.2e (%d) | %.2e (%d) | %.3f | %.3f | %+.1f |" % (r["ref"], r["modcod"], r["ebn0"], r["fer_ref"], r["fe_ref"], r["fer_run"], r["fe_run"], r["ratio"], r["sigma"], r["z"]))
