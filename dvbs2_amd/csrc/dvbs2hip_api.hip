@@ -116,6 +116,7 @@ struct dvbs2hip_handle {
     // monitor reduction over RCCL (one process per GPU): communicator + the 3 x uint64 receive buffer
     void *nccl_comm = nullptr;
     unsigned long long *d_red = nullptr;
+    unsigned long long *h_red = nullptr;      // pinned: the reduced counters' way back (a copy into pageable memory would wait for the stream itself -- and for a dead peer for ever)
     int red_rank = 0, red_world = 1;
     // timing
     bool timing = false;
@@ -614,6 +615,7 @@ void dvbs2hip_destroy(dvbs2hip_t *h)
                         h->sfm.yprev[0], h->sfm.yprev[1], h->sfm.keys, h->sfm.metric, h->sfm.frag, h->d_lr_R, h->d_nat_work, h->ldpc.d_nat_tab, h->ldpc.d_nat_haz, h->d_fir_afrag, h->d_upfir_afrag, h->d_bch_shift, h->d_hist_zero, h->d_hist_junk, h->d_red, h->bch.d_prbs_rw};
     for (void *p : sfm_ptrs) if (p) (void)hipFree(p);
     if (h->lr_err_host) (void)hipHostFree(h->lr_err_host);
+    if (h->h_red) (void)hipHostFree(h->h_red);
     void *ptrs[] = {h->ldpc.d_cu_ctr, h->ldpc.d_w8_tab, h->ldpc.d_w8_atab, h->ldpc.d_w8_rows, h->ldpc.d_entries, h->ldpc.d_layer_deg, h->ldpc.d_layer_lvl, h->ldpc.d_groups, h->bch.d_syn_tab, h->bch.d_exp, h->bch.d_log,
                     h->bch.d_prbs, h->d_cstl, h->d_pl_seq, h->d_taps_rev, h->d_hist_all, h->d_ctr, h->d_gwork, h->d_enc_tab, h->d_enc_deg, h->d_plh, h->d_bch_tab, h->d_syn_pos, h->d_prbs_s, h->d_taps};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1736,6 +1738,7 @@ int dvbs2hip_monitor_reduce_init(dvbs2hip_t *h, int32_t rank, int32_t world, con
     int e = g_rccl.CommInitRank(&comm, world, id, rank);
     if (e) return fail(h, DVBS2HIP_EHIP, "ncclCommInitRank: " + rccl_err(e));
     if (!h->d_red && hipMalloc((void **)&h->d_red, 3 * sizeof(unsigned long long)) != hipSuccess) { (void)g_rccl.CommDestroy(comm); return fail(h, DVBS2HIP_ENOMEM, "hipMalloc failed"); }
+    if (!h->h_red && hipHostMalloc((void **)&h->h_red, 3 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { h->h_red = nullptr; (void)g_rccl.CommDestroy(comm); return fail(h, DVBS2HIP_ENOMEM, "hipHostMalloc failed"); }
     h->nccl_comm = comm; h->red_rank = rank; h->red_world = world; h->red_timeout_ms = timeout_ms > 0 ? timeout_ms : 0;
     return 0;
 }
@@ -1747,8 +1750,8 @@ int dvbs2hip_monitor_reduce(dvbs2hip_t *h, uint64_t out[3])
     int r0 = enter(h); if (r0) return r0;
     const int e = g_rccl.AllReduce(h->d_ctr, h->d_red, 3, 5 /* ncclUint64 */, 0 /* ncclSum */, h->nccl_comm, h->stream);
     if (e) return fail(h, DVBS2HIP_EHIP, "ncclAllReduce: " + rccl_err(e));
-    unsigned long long tmp[3];
-    HIPCHK(h, hipMemcpyAsync(tmp, h->d_red, sizeof tmp, hipMemcpyDeviceToHost, h->stream));
+    unsigned long long *tmp = h->h_red;
+    HIPCHK(h, hipMemcpyAsync(tmp, h->d_red, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     // A peer that died leaves this rank's all-reduce waiting on the device for ever: wait with the timeout given at _reduce_init instead of a blocking
     // synchronize -- a launcher-less `dvbs2_tx_rx_bb --world N` then ends with a non-zero exit code of its own instead of hanging until somebody kills it.
     if (h->red_timeout_ms > 0) {

@@ -50,6 +50,24 @@ int ncclCommInitRank(void **comm, int world, nccl_id id, int rank)
     return 0;
 }
 
+/* STUB_RCCL_ASYNC=1: like the real library, ncclAllReduce RETURNS once its work is enqueued and the wait for the peers happens ON THE STREAM (a host function that spins in the
+ * runtime's callback thread, the result copied to the device behind it) -- so that a peer that dies leaves this rank's stream busy for ever, which is the case
+ * dvbs2hip_monitor_reduce's timeout exists for (tests/test_host_cpp.py::test_cpp_tx_rx_bb_leaves_when_its_peer_dies). */
+extern int hipLaunchHostFunc(hipStream_t s, void (*fn)(void *), void *user);
+extern int hipHostMalloc(void **p, size_t n, unsigned flags);
+typedef struct { comm_t *c; int p; size_t count; uint64_t *stage; } wait_t;
+static void wait_for_peers(void *u)
+{
+    wait_t *w = (wait_t *)u;
+    shm_t *m = w->c->m;
+    for (long spins = 0; m->arrived[w->p] < (uint64_t)w->c->world && spins < 1200000; spins++) usleep(100);      /* at most 120 s */
+    uint64_t sum[4] = {0, 0, 0, 0};
+    for (int r = 0; r < w->c->world; r++) for (size_t i = 0; i < w->count; i++) sum[i] += m->val[w->p][r][i];
+    if (__sync_add_and_fetch(&m->left[w->p], 1) == (uint64_t)w->c->world) { m->left[w->p] = 0; __sync_synchronize(); m->arrived[w->p] = 0; }
+    for (size_t i = 0; i < w->count; i++) w->stage[i] = sum[i];
+    free(w);
+}
+
 int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t s)
 {
     comm_t *c = (comm_t *)comm;
@@ -58,6 +76,17 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op,
     if (hipMemcpyAsync(v, send, count * 8, 2 /* D2H */, s) || hipStreamSynchronize(s)) return 1;
     const int p = (int)(c->call++ & 1);
     shm_t *m = c->m;
+    if (getenv("STUB_RCCL_ASYNC")) {
+        static uint64_t *stage[2] = {NULL, NULL};
+        if (!stage[p] && hipHostMalloc((void **)&stage[p], 4 * sizeof(uint64_t), 0)) return 1;
+        for (size_t i = 0; i < count; i++) m->val[p][c->rank][i] = v[i];
+        __sync_synchronize();
+        __sync_fetch_and_add(&m->arrived[p], 1);
+        wait_t *w = (wait_t *)malloc(sizeof *w);
+        w->c = c; w->p = p; w->count = count; w->stage = stage[p];
+        if (hipLaunchHostFunc(s, wait_for_peers, w)) return 1;
+        return hipMemcpyAsync(recv, stage[p], count * 8, 1 /* H2D */, s) ? 1 : 0;
+    }
     for (size_t i = 0; i < count; i++) m->val[p][c->rank][i] = v[i];
     __sync_synchronize();
     __sync_fetch_and_add(&m->arrived[p], 1);

@@ -178,3 +178,32 @@ def test_cpp_tx_rx_bb_two_processes_reduce_and_stop_together(tmp_path, clones):
     fra, fe = int(f[2]), int(f[4])
     assert fe >= max_fe and fra % (2 * F) == 0          # every batch of the loop adds BOTH ranks' frames: the stop was decided on the sum, in the same iteration on both ranks
     assert sorted(os.listdir(tmp_path)) == []            # the rendezvous cleaned up after itself
+
+
+@pytest.mark.gpu
+def test_cpp_tx_rx_bb_leaves_when_its_peer_dies(tmp_path):
+    """a rank whose peer dies must not wait in the monitors' all-reduce for ever.  Two processes on this box's one GPU through the test-side RCCL stand-in in
+    its ASYNCHRONOUS mode (STUB_RCCL_ASYNC=1: like the real library the all-reduce returns once enqueued and the wait for the peers happens on the stream), a run that would
+    go on for minutes; rank 1 is killed after both have reduced a few batches: rank 0's next dvbs2hip_monitor_reduce returns DVBS2HIP_ETIMEOUT after --reduce-timeout-ms and
+    the simulator leaves with exit code 4 -- a fresh exit, no re-exec, no teardown behind a stream that will never drain."""
+    import signal
+    import time
+    build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "stub_rccl"), "-s"])
+    exe = os.path.join(ROOT, "host", "dvbs2_tx_rx_bb")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "tests", "stub_rccl") + ":" + os.environ.get("LD_LIBRARY_PATH", ""), STUB_RCCL_ASYNC="1")
+    cmd = [exe, "--mod-cod", "QPSK-S_8/9", "-m", "4.4", "-M", "4.41", "--dec-implem", "NMS", "--dec-ite", "10", "-F", "256", "--world", "2", "--local-rank", "0",
+           "--rendezvous", str(tmp_path / "rdv"), "--clones", "1", "-e", "100000000", "--max-frames", "2000000000", "--reduce-timeout-ms", "3000"]
+    procs = [subprocess.Popen(cmd + ["--rank", str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in (1, 0)]
+    time.sleep(8.0)                                   # both ranks are up and reducing (the first import of the runtime on a fresh box takes seconds)
+    assert procs[0].poll() is None and procs[1].poll() is None, [p.communicate() for p in procs if p.poll() is not None]
+    procs[0].send_signal(signal.SIGKILL)              # rank 1 dies
+    t0 = time.time()
+    try:
+        out0, err0 = procs[1].communicate(timeout=60)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert procs[1].returncode == 4, (procs[1].returncode, err0[-600:])
+    assert "did not arrive" in err0 and time.time() - t0 < 30.0
