@@ -733,6 +733,7 @@ int dvbs2hip_graph_begin(dvbs2hip_t *h)
 {
     int r0 = enter(h); if (r0) return r0;
     if (h->capturing) return fail(h, DVBS2HIP_EINVAL, "a capture is already open on this handle");
+    if (h->timing) return fail(h, DVBS2HIP_EINVAL, "the per-kernel timers are on: their events cannot be recorded into a graph (dvbs2hip_timing_enable(h, 0) first)");
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     h->capturing = true;
     return 0;
@@ -1913,7 +1914,13 @@ int dvbs2hip_tx_bb(dvbs2hip_t *h, const int32_t *info_in, uint64_t seed, const f
 }
 
 // ------------------------------------------------------------------ measurement + memory helpers
-int dvbs2hip_timing_enable(dvbs2hip_t *h, int32_t on) { if (!h) return DVBS2HIP_EINVAL; h->timing = on != 0; return 0; }
+int dvbs2hip_timing_enable(dvbs2hip_t *h, int32_t on)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    if (h->capturing) return fail(h, DVBS2HIP_EINVAL, "a capture is open on this handle");
+    h->timing = on != 0;
+    return 0;
+}
 int dvbs2hip_timing_reset(dvbs2hip_t *h)
 {
     if (!h) return DVBS2HIP_EINVAL;

@@ -84,6 +84,10 @@ def test_a_call_sequence_recorded_as_a_graph_replays_the_same_results(modcod, F)
 
     make_input(101)
     once(); rx.synchronize()                                  # first calls allocate: run the sequence once before recording it
+    rx.timing_enable(True)
+    with pytest.raises(Exception):
+        rx.graph_capture(once)                                 # the per-kernel timers' events cannot go into a graph: refused, nothing recorded
+    rx.timing_enable(False)
     gid = rx.graph_capture(once)
     with pytest.raises(Exception):
         rx.graph_launch(gid + 7)
