@@ -52,7 +52,7 @@ def render(tag, bench_path=None):
          "| configs[3]: 16APSK-N 8/9, NMS 20 ite, fused chain | %.3f ms per 4096 = %.2f Gb/s | %.3f x its floor | `tests/test_chain_gpu.py` |" % (c3["ms"], c3["info_bits_per_s"] / 1e9, c3["tail_over_floor"]),
          "| configs[4]: 32APSK-S 3/4 behind the 81-tap matched filter, one frame per call | %.3f ms (early stop: %.3f ms); 4096 frames: %.2f M frames/s | one workgroup's 120 layers of 1.4 us; FIR %.0f fp32-equivalent TFLOP/s at 4096 frames | `tests/test_rx_lite_gpu.py`, `tests/test_fir_gpu.py` |" % (
              f1["latency_ms_median"], f1.get("latency_ms_early_stop") or 0, big["frames_per_s"] / 1e6, (big["fir_GFLOPs_fp32_equiv"] or 0) / 1e3),
-         "| the reference's default decoder, `--dec-implem SPA`, 10 ite fixed | N = 64800: %.0f k frames/s; N = 16200: %.2f M frames/s | vector issue bound (transcendentals) | `test_ldpc_spa_matches_oracle` (1e-4 max(1, abs(L))) |" % (
+         "| the reference's default decoder, `--dec-implem SPA`, 10 ite fixed | N = 64800: %.0f k frames/s; N = 16200: %.2f M frames/s | N = 16200: vector issue 0.97 busy (a quarter of it transcendentals) with the fp32 messages streaming at 0.76 of the fabric's rate; N = 64800: 0.78 / 0.73 (`profiles/r06_ldpc_variants.md`) | `test_ldpc_spa_matches_oracle` (1e-4 max(1, abs(L))) |" % (
              sp["QPSK-N_8/9"]["fec_frames_per_s"] / 1e3, sp["QPSK-S_8/9"]["fec_frames_per_s"] / 1e6),
          "| the reference's own configuration: QPSK-S 8/9, SPA 50 ite, early stop, 3.8 dB, TX + AWGN + RX + monitor on the GPU, -F 8192 | %.1f Gb/s (1 clone), **%.1f Gb/s** (3 clones) | the reference's trace: 24.5 Mb/s on an unstated CPU | `tests/test_refs_gpu.py` (19 rows + pooled) |" % (
              rc["clones_1"]["info_Gbps"], rc["clones_3"]["info_Gbps"]),
