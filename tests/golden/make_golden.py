@@ -7,6 +7,9 @@
                          packed 4 values per byte (DATA: expected output of the Gold generator)
   refs_tx_rx_bb.json     the result rows + size headers of refs/TX_RX_BB/*.txt (the reference's
                          only regression oracle: BER/FER traces, SPA 50 ite)
+  refs_tx_rx.json        the result rows of refs/TX_RX/*.txt: the reference's FULL chain (shaping filter, channel with delay / frequency shift, its sample-serial
+                         synchronizers, SPA 50 ite).  The synchronizers' loops are out of scope, so these rows bound the genie-timed filtered loop
+                         from above (`python make_golden.py refs_full` remakes only this one)
   src_K_14232.npy        conf/src/K_14232.src fixed payload (data file), packed bits
   kat_*.npz              known-answer vectors produced by the CPU oracle (seeded), small frames
                          (`python make_golden.py sync` remakes only kat_sync_frame_32apsk.npz)
@@ -51,6 +54,25 @@ def refs():
             hdr[key] = m.group(1) if m else None
         out[name] = dict(command=cmd, header=hdr, rows=rows)
     json.dump(out, open(os.path.join(HERE, "refs_tx_rx_bb.json"), "w"), indent=1)
+
+def refs_full():
+    out = {}
+    for name in sorted(os.listdir(os.path.join(REF, "refs/TX_RX"))):
+        txt = open(os.path.join(REF, "refs/TX_RX", name)).read()
+        cmd = re.search(r"command=(.*)", txt).group(1).strip()
+        rows = []
+        for line in txt.splitlines():
+            if line.startswith("#") or "|" not in line:          # (rows the reference's CI does not run are commented out in the trace)
+                continue
+            f = [x.strip() for x in line.replace("||", "|").split("|")]
+            rows.append(dict(esn0=float(f[0]), ebn0=float(f[1]), fra=int(f[2]), be=int(f[3]), fe=int(f[4]), ber=float(f[5]), fer=float(f[6]), thr_mbps=float(f[7])))
+        hdr = {}
+        for key, pat in (("modcod", r"Modulation and coding\s+= (\S+)"), ("max_delay", r"Maximum Channel Delay\s+= (\S+)"), ("implem", r"LDPC implem\s+= (\S+)"),
+                         ("n_ite", r"LDPC n iterations\s+= (\d+)"), ("perfect_sync", r"Perfect synchronization = (\S+)"), ("estimator", r"Estimator type\s+= (\S+)")):
+            m = re.search(pat, txt)
+            hdr[key] = m.group(1) if m else None
+        out[name] = dict(command=cmd, header=hdr, rows=rows)
+    json.dump(out, open(os.path.join(HERE, "refs_tx_rx.json"), "w"), indent=1)
 
 def src():
     t = open(os.path.join(REF, "conf/src/K_14232.src")).read().split()
@@ -144,7 +166,9 @@ if __name__ == "__main__":
         kat_sync()
     elif len(sys.argv) > 1 and sys.argv[1] == "normal":
         kats_normal()
+    elif len(sys.argv) > 1 and sys.argv[1] == "refs_full":
+        refs_full()
     else:
-        pl_seq(); refs(); src(); kats(); kat_sync(); kats_normal()
+        pl_seq(); refs(); refs_full(); src(); kats(); kat_sync(); kats_normal()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -106,6 +106,27 @@ def test_gpu_sim_with_clones_counts_what_one_clone_counts(clones):
     assert (same["fra"], same["be"], same["fe"]) == (many["fra"], many["be"], many["fe"])      # the same batches, seed for seed
 
 
+def test_filtered_loop_matches_the_baseband_loop_and_stays_below_the_full_chain_traces():
+    """The reference's second set of traces, refs/TX_RX/*.txt, is its FULL chain: shaping filter, channel, matched filter and its sample-serial synchronizers.  With genie timing
+    (`dvbs2_tx_rx --perfect-sync`, TX_RX/main.cpp:440; here `sim --filtered`) what is left of that loop is rows N2 + a5 around the baseband chain, and since both filters have
+    unit-energy taps and the channel's sigma is the symbol-rate one (TX_RX/main.cpp:408-409) the matched filter's output IS the baseband channel: the filtered loop's FER has to
+    equal the baseband loop's (here: within 4 sigma of the counting error at ~600 frame errors each), and every full-chain trace has to lie above it -- by the reference's own
+    synchronization loss, 0.07-0.09 dB = a factor 3-5 in FER at 3.7 dB (results/r06/filtered_loop.md)."""
+    import math
+    from dvbs2_amd import sim
+    full = json.load(open(os.path.join(GOLD, "refs_tx_rx.json")))
+    def run(filtered):
+        argv = ["--mod-cod", "QPSK-S_8/9", "-m", "3.70", "-M", "3.71", "--dec-implem", "SPA", "--dec-ite", "50", "-F", "2048", "-e", "600", "--max-frames", "200000", "--clones", "2"]
+        return sim.run(sim.build_parser().parse_args(argv + (["--filtered"] if filtered else [])), out=io.StringIO())[0]
+    f, b = run(True), run(False)
+    assert f["fe"] >= 600 and b["fe"] >= 600
+    assert f["fra"] % 2047 == 0 and b["fra"] % 2048 == 0                      # the filters' delay cuts the last frame of every batch
+    ratio = f["fer"] / b["fer"]
+    assert abs(math.log(ratio)) < 4.0 * math.sqrt(1.0 / f["fe"] + 1.0 / b["fe"]), (f, b)
+    at37 = [r["fer"] for t in full.values() for r in t["rows"] if round(r["ebn0"], 2) == 3.7]
+    assert len(at37) == 5 and min(at37) > 2.0 * f["fer"], (at37, f["fer"])
+
+
 @pytest.mark.parametrize("modcod,anchor_db", [("QPSK-N_8/9", 6.20), ("8PSK-N_8/9", 10.69), ("16APSK-N_8/9", 12.89)])
 def test_normal_frame_waterfall_sits_at_the_etsi_anchor(modcod, anchor_db):
     """The N = 64800 codes are an extension beyond the reference (their LDPC table is entered from ETSI EN 302 307 Annex B): the only

@@ -36,6 +36,22 @@ def test_sizes_match_refs_headers(P):
             assert abs(P.ebn0_to_esn0(row["ebn0"], mc.code_rate, mc.bps) - row["esn0"]) < 0.0051
 
 
+def test_full_chain_traces_are_the_same_noise_points_as_the_baseband_ones(P):
+    """refs/TX_RX/*.txt (the reference's full chain: its own synchronizers, not a genie): same MODCOD, same Es/N0 <-> Eb/N0 mapping (TX_RX/main.cpp:408) and the same stopping rule as
+    the baseband traces, so the two sets can be read side by side; at every common point the full chain loses at least as many frames as the baseband loop."""
+    full = json.load(open(os.path.join(GOLD, "refs_tx_rx.json")))
+    bb = {round(r["ebn0"], 2): r for r in json.load(open(os.path.join(GOLD, "refs_tx_rx_bb.json")))["QPSK_8_9.txt"]["rows"]}
+    assert len(full) == 5
+    for fname, d in full.items():
+        mc = P.get_modcod(d["header"]["modcod"])
+        assert mc.name == "QPSK-S_8/9" and d["header"]["perfect_sync"] == "NO" and d["header"]["implem"] == "SPA" and d["header"]["n_ite"] == "50"
+        for row in d["rows"]:
+            assert abs(P.ebn0_to_esn0(row["ebn0"], mc.code_rate, mc.bps) - row["esn0"]) < 0.0051 and 100 <= row["fe"] <= 101
+            b = bb.get(round(row["ebn0"], 2))
+            if b:
+                assert row["fer"] > 1.5 * b["fer"], (fname, row["ebn0"])
+
+
 @pytest.mark.parametrize("name,N,K,E,deg", [("N16200_8_9.txt", 16200, 14400, 48599, {4: 5, 3: 35}),
                                             ("N16200_3_5.txt", 16200, 9720, 71279, {12: 9, 3: 18}),
                                             ("N16200_3_4.txt", 16200, 11880, 47519, {12: 1, 3: 32}),
