@@ -10,7 +10,7 @@
   refs_tx_rx.json        the result rows of refs/TX_RX/*.txt: the reference's FULL chain (shaping filter, channel with delay / frequency shift, its sample-serial
                          synchronizers, SPA 50 ite).  The synchronizers' loops are out of scope, so these rows bound the genie-timed filtered loop
                          from above (`python make_golden.py refs_full` remakes only this one)
-  src_K_14232.npy        conf/src/K_14232.src fixed payload (data file), packed bits
+  src_K_14232.npy, src_K_9552.npy   conf/src/K_14232.src, K_9552.src fixed payloads (data files), packed bits (`python make_golden.py src`)
   kat_*.npz              known-answer vectors produced by the CPU oracle (seeded), small frames
                          (`python make_golden.py sync` remakes only kat_sync_frame_32apsk.npz)
   kat_ldpc_normal_8_9.npz, kat_chain_16apsk_normal_20ite.npz
@@ -75,10 +75,12 @@ def refs_full():
     json.dump(out, open(os.path.join(HERE, "refs_tx_rx.json"), "w"), indent=1)
 
 def src():
-    t = open(os.path.join(REF, "conf/src/K_14232.src")).read().split()
-    assert t[0] == "1" and t[1] == "14232"
-    bits = np.array([int(x) for x in t[2:2 + 14232]], dtype=np.uint8)
-    np.save(os.path.join(HERE, "src_K_14232.npy"), np.packbits(bits))
+    for K in (14232, 9552):          # the rate-8/9 and rate-3/5 payloads (DVBS2.cpp:336-349 names the file per code rate)
+        t = open(os.path.join(REF, "conf/src/K_%d.src" % K)).read().split()
+        assert t[0] == "1" and t[1] == str(K)
+        bits = np.array([int(x) for x in t[2:2 + K]], dtype=np.uint8)
+        assert bits.size == K and bits.max() <= 1
+        np.save(os.path.join(HERE, "src_K_%d.npy" % K), np.packbits(bits))
 
 def kats():
     from oracle import oracle as O
@@ -168,6 +170,8 @@ if __name__ == "__main__":
         kats_normal()
     elif len(sys.argv) > 1 and sys.argv[1] == "refs_full":
         refs_full()
+    elif len(sys.argv) > 1 and sys.argv[1] == "src":
+        src()
     else:
         pl_seq(); refs(); refs_full(); src(); kats(); kat_sync(); kats_normal()
     for f in sorted(os.listdir(HERE)):

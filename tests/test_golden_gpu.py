@@ -105,15 +105,16 @@ def test_sync_frame_golden(Rx):
     rx.close()
 
 
-def test_reference_fixed_payload_roundtrip(Rx, O):
-    """conf/src/K_14232.src (the reference's Source_user pattern) through oracle TX -> GPU RX."""
+@pytest.mark.parametrize("modcod,K,ebn0", [("QPSK-S_8/9", 14232, 4.5), ("8PSK-S_3/5", 9552, 4.5)])
+def test_reference_fixed_payload_roundtrip(Rx, O, modcod, K, ebn0):
+    """conf/src/K_14232.src and K_9552.src (the reference's Source_user patterns, one per code rate: DVBS2.cpp:336-349) through oracle TX -> GPU RX."""
     from helpers import chain, sigma_for
-    info = np.unpackbits(np.load(os.path.join(GOLD, "src_K_14232.npy")))[:14232].astype(np.int32)
-    ch = chain(O, "QPSK-S_8/9")
+    info = np.unpackbits(np.load(os.path.join(GOLD, "src_K_%d.npy" % K)))[:K].astype(np.int32)
+    ch = chain(O, modcod)
     plf, _ = ch.tx(info)
-    sigma = sigma_for(ch.mc, 4.5)
+    sigma = sigma_for(ch.mc, ebn0)
     noisy = plf + (sigma * np.random.default_rng(9).standard_normal(plf.size)).astype(np.float32)
-    rx = Rx("QPSK-S_8/9", max_frames=1, n_ite=10, alpha=1.0, early_stop=True)
+    rx = Rx(modcod, max_frames=1, n_ite=10, alpha=1.0, early_stop=True)
     out, c0, c1 = rx.rx_bb(noisy)
     assert np.array_equal(out[0], info) and c0[0] == 1 and c1[0] == 1
     rx.close()
