@@ -103,3 +103,23 @@ def test_a_call_sequence_recorded_as_a_graph_replays_the_same_results(modcod, F)
     with pytest.raises(Exception):
         rx.graph_launch(gid)
     rx.close()
+
+
+def test_in_scope_synchronizers_in_the_loop_at_the_operating_point():
+    """tools/sync_in_loop.py: one continuous noisy stream with an unknown frame start, a carrier phase and a residual frequency offset through the reference's RX task order with
+    the in-scope synchronizers doing the work (frame synchronizer, Luise-Reggiannini, pilot-aided phase; timing by genie), at 3.7 dB where the genie-timed loop loses 4.5 % of its
+    frames (results/r06/filtered_loop.md).  The frame synchronizer must hold its alignment and cost nothing; the fine synchronizers must cost what a phase estimate from 36 pilot
+    symbols costs (0.05-0.06 dB = about twice the frame errors here) and no more."""
+    import math, os, sys, types
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import sync_in_loop as S
+    from dvbs2_amd.receiver import Dvbs2Hip
+    from dvbs2_amd import params as P
+    mc = P.get_modcod("QPSK-S_8/9")
+    a = types.SimpleNamespace(F=256, off=1234, phase=0.7, freq=1e-4, seed=3, fe=250, max_frames=20000, skip=32)
+    fr = S.run_point(Dvbs2Hip, P, mc, 3.7, "frame", a)
+    fi = S.run_point(Dvbs2Hip, P, mc, 3.7, "fine", a)
+    assert fr["moved"] == 0 and fi["moved"] == 0 and fr["delay"] == fi["delay"] == 1234 + 40            # the two filters' 40 symbols are part of the frame start it finds
+    genie = 0.0455                                                                                      # 1490 / 32760 and 1492 / 32768: both loops of results/r06/filtered_loop.md
+    assert abs(math.log(fr["fer"] / genie)) < 4.0 * math.sqrt(1.0 / fr["fe"] + 1.0 / 1490), fr
+    assert 1.3 * genie < fi["fer"] < 3.5 * genie, fi

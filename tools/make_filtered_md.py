@@ -51,6 +51,29 @@ def build(tag):
         x = interp_db(gen, r38[0]["fer"])
         out.append("| `%s` (%s) | %.3g | %s | %s |" % (name, t["command"].split("-s 0.1 ")[1], r38[0]["fer"], "%.3f dB" % x if x else "--", "%.2f dB" % (3.8 - x) if x else "--"))
     out += ["", "0.07 dB with the integer delay, 0.08-0.09 dB with the half-sample one."]
+    # the in-scope synchronizers in the loop (tools/sync_in_loop.py)
+    import glob
+    runs = sorted(glob.glob(os.path.join(d, "sync_in_loop*.json")))
+    if runs:
+        out += ["", "## The in-scope synchronizers in the loop (SURVEY.md 8f N4), timing still by genie", "",
+                "`tools/sync_in_loop.py`: ONE continuous stream per point as a receiver sees it -- the fixed payload `conf/src/K_14232.src` in every frame, an unknown frame start (1234 symbols), "
+                "a carrier phase of 0.7 rad and a residual frequency offset -- through shaping filter, AWGN, matched filter, every second sample, then the tasks of the reference's RX graph in its "
+                "order, one C-ABI call per task: frame synchronizer -> PL descrambler -> Luise-Reggiannini -> pilot-aided phase synchronizer -> remove PLH -> estimate -> demodulate -> LDPC -> "
+                "BCH -> BB descrambler (`frame`: the frame synchronizer alone in front of the fused chain, nothing rotated).  Every frame after the first 16 (64) counts, locked or not.", "",
+                "| Eb/N0 | variant | frequency offset (cycles / symbol) | FER (FE / frames) | genie-timed loop at that Eb/N0 | the genie curve reaches this FER at | loss | synchronizer left its alignment |",
+                "|---|---|---|---|---|---|---|---|"]
+        gmap = {round(r["ebn0"], 2): r for r in gen}
+        for fn in runs:
+            j = json.load(open(fn))
+            for r in j["rows"]:
+                x = interp_db(gen, r["fer"])
+                out.append("| %.1f | %s | %s | %.3g (%d / %d) | %.3g | %s | %s | %d times |" % (r["ebn0"], r["variant"], "--" if r["variant"] == "frame" else "%g" % j["args"]["freq"], r["fer"], r["fe"], r["counted"],
+                           gmap[round(r["ebn0"], 2)]["fer"], "%.3f dB" % x if x else "--", "%.3f dB" % (r["ebn0"] - x) if x else "--", r["moved"]))
+        out += ["", "The frame synchronizer costs nothing (it holds its alignment through every run, and the FER is the genie loop's to within the counting error).  "
+                "The fine synchronizers cost 0.05-0.06 dB whatever the frequency offset up to 5e-4 cycles per symbol (Luise-Reggiannini removes it): that is the noise of a phase estimate from 36 pilot symbols -- "
+                "variance 1 / (2 . 36 . Es/N0) = 0.0033 rad^2 at 6.25 dB, i.e. crosstalk 25 dB below the signal, 0.06 dB on top of the channel's noise.  These kernels match "
+                "the oracle's restatement of the reference's `Synchronizer_Luise_Reggiannini_DVBS2_aib` / `Synchronizer_freq_phase_DVBS2_aib` to 1e-6 in their estimates (`tests/test_sync_gpu.py::test_fine_synchronizers_match_oracle`), so the "
+                "loss is the algorithm's; the reference's full chain shows 0.07-0.09 dB with its timing and coarse-frequency loops on top (table above)."]
     return "\n".join(out) + "\n"
 
 
