@@ -32,6 +32,22 @@ def floor_row(rd):
             "| FER %.1e against %.1e | `test_uncapped_sum_product_has_an_error_floor_the_default_does_not` |" % (a[0] / 1e6, a[1], b[1], c[1], d[1], a[1] / a[0], b[1] / b[0]))
 
 
+def loop_row(rd):
+    """the filtered loop and the synchronizers in it (results/<tag>/filtered_loop_*.json, sync_in_loop.json) against the reference's full-chain traces"""
+    try:
+        g = json.load(open(os.path.join(rd, "filtered_loop_genie.json")))["rows"]
+        b = json.load(open(os.path.join(rd, "filtered_loop_bb.json")))["rows"]
+        s = json.load(open(os.path.join(rd, "sync_in_loop.json")))["rows"]
+    except OSError:
+        return "| the filtered loop (shaping filter .. matched filter) against the reference's full-chain traces | (results missing) | | |"
+    rat = [x["fer"] / y["fer"] for x, y in zip(g, b)]
+    at = {(r["variant"], round(r["ebn0"], 2)): r for r in s}
+    return ("| the reference's other five traces, `refs/TX_RX/*.txt` (its full chain, sample-serial synchronizers included): the filtered loop with genie timing, and with the in-scope "
+            "synchronizers doing the work | filtered / baseband FER %.2f-%.2f over %d points; frame synchronizer in the loop: FER %.4f against the genie's %.4f at 3.8 dB; L&R + pilot-aided phase: %.4f "
+            "(0.06 dB) | the reference's traces: 0.0197-0.0355 at 3.8 dB (0.07-0.09 dB from the genie curve) | `results/r06/filtered_loop.md`; `test_filtered_loop_matches_the_baseband_loop_and_stays_below_the_full_chain_traces`, "
+            "`test_in_scope_synchronizers_in_the_loop_at_the_operating_point` |" % (min(rat), max(rat), len(rat), at[("frame", 3.8)]["fer"], [r for r in g if round(r["ebn0"], 2) == 3.8][0]["fer"], at[("fine", 3.8)]["fer"]))
+
+
 def render(tag, bench_path=None):
     import refs_pooled
     p = bench_path or os.path.join(ROOT, "profiles", "%s_bench.json" % tag)
@@ -60,6 +76,7 @@ def render(tag, bench_path=None):
              pq["pooled_ratio"], pq["pooled_ratio"] * pq["pooled_sigma"], pn["pooled_ratio"], pn["pooled_ratio"] * pn["pooled_sigma"], pe["pooled_ratio"], pe["pooled_ratio"] * pe["pooled_sigma"],
              pq["chi2"], pn["chi2"], pe["chi2"]) if pq and pn and pe else "| parity with the reference | (results missing) | | |",
          floor_row(rd),
+         loop_row(rd),
          "| natural row order (the reference's sweep), NMS 10 ite, 4096 normal frames | %.0f k frames/s | bit-exact with the oracle's ORC_SCHED_NATURAL | `test_ldpc_natural_order_matches_oracle` |" % ((ex.get("natural_order_fps") or 0) / 1e3),
          "| frame synchronizer, located form | %.3f ms per 4096 32APSK-S frames, %.3f ms per 1024 QPSK-N frames | %.2f / %.2f of 8 TB/s (16 B per sample) | `tests/test_sync_gpu.py` |" % (
              sl["32APSK-S_3/4"]["ms_per_call"], sl["QPSK-N_8/9"]["ms_per_call"], sl["32APSK-S_3/4"]["frac_of_8TBps"], sl["QPSK-N_8/9"]["frac_of_8TBps"]),
