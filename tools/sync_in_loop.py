@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 def run_point(Rx, P, mc, ebn0, variant, a):
     F, n, off = a.F, mc.pl_frame, a.off
     rx = Rx(mc.name, max_frames=F, n_ite=50, alpha=1.0, early_stop=True, implem="SPA")
-    pattern = np.unpackbits(np.load(os.path.join(ROOT, "tests", "golden", "src_K_14232.npy")))[:mc.K_bch].astype(np.int32)
+    pattern = np.unpackbits(np.load(os.path.join(ROOT, "tests", "golden", "src_K_%d.npy" % (14232 if mc.K_bch == 14232 else 9552))))[:mc.K_bch].astype(np.int32)      # DVBS2.cpp:336-349
     _, pl = rx.tx_bb(1, info=pattern[None, :])
     frame = pl.reshape(n, 2).astype(np.float64)
     frame = frame[:, 0] + 1j * frame[:, 1]
@@ -40,13 +40,13 @@ def run_point(Rx, P, mc, ebn0, variant, a):
         sym = np.ascontiguousarray(mf[0::2]).reshape(F, 2 * n)                         # the two filters delay the stream by 40 symbols: part of the unknown frame start
         delay, flags, tri, aligned = rx.sync_frame_synchronize(sym, with_flags=True)
         if variant == "frame":
-            bits, _, _ = rx.rx_bb(aligned)
+            bits, _, _ = rx.rx_bb(aligned, sigma=sigma if a.est_perfect else None)
         else:
             desc = rx.pl_descramble(aligned)
             _, _, desc = rx.sync_lr_synchronize(desc)
             _, _, fixed = rx.sync_freq_phase_synchronize(desc)
             xf = rx.remove_plh(fixed)
-            sg, _, _ = rx.estimate(xf)
+            sg = np.full(F, sigma, np.float32) if a.est_perfect else rx.estimate(xf)[0]
             vk, _ = rx.decode_siho(rx.demodulate(sg, xf, deinterleave=True))
             bits = rx.bb_descramble(rx.decode_hiho(vk)[0])
         err = (bits != pattern[None, :]).sum(axis=1)
@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--phase", type=float, default=0.7)
     ap.add_argument("--freq", type=float, default=2e-5)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--est-perfect", action="store_true", help="the channel's sigma instead of the M2M4 estimate (the reference's 16APSK trace: --est-type PERFECT)")
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
     from dvbs2_amd.receiver import Dvbs2Hip
