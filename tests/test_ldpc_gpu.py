@@ -4,7 +4,7 @@ schedule.  Bar (BASELINE.json north_star): hard decisions bit-exact, soft values
 import numpy as np
 import pytest
 
-from helpers import chain, make_llrs
+from helpers import chain, make_llrs, sigma_for
 
 pytestmark = pytest.mark.gpu
 
@@ -147,6 +147,36 @@ def test_ldpc_ties_zeros_and_extremes_match_oracle(O, Rx, modcod):
         assert np.array_equal(post.view(np.uint32), posto.view(np.uint32)), "bit patterns (incl. the sign of zero) must match"
         rx.close()
     assert np.array_equal(V[1], info[0])      # 1 % erasures are filled in
+
+
+@pytest.mark.parametrize("implem", ["NMS", "SPA", "SPA_TANH", "SPA_EXACT"])
+@pytest.mark.parametrize("modcod", ["QPSK-S_8/9", "QPSK-N_8/9"])
+def test_ldpc_non_finite_llrs_end_and_stay_in_their_frame(O, Rx, modcod, implem):
+    """+-inf and NaN on the LLR socket (a demapper fed sigma = 0, a saturated front end): the call has to come back (every loop of the kernels is bounded by n_ite), frames WITHOUT
+    such values have to come out bit for bit as they do when decoded alone (frames share a workgroup's queue, nothing else), and a frame whose infinities all carry the right sign is
+    decoded: certain bits can only help."""
+    ch = chain(O, modcod)
+    mc = ch.mc
+    rng = np.random.default_rng(77)
+    info = rng.integers(0, 2, (4, mc.K_ldpc)).astype(np.int32)
+    cw = ch.ldpc.encode(info)
+    sigma = sigma_for(mc, 4.6)
+    llr = ((1.0 - 2.0 * cw) + sigma * rng.standard_normal(cw.shape)).astype(np.float32) * np.float32(2.0 / sigma ** 2)
+    clean = llr.copy()
+    pos = rng.choice(mc.N_ldpc, mc.N_ldpc // 20, replace=False)
+    llr[1, pos] = np.where(cw[1, pos] == 0, np.inf, -np.inf).astype(np.float32)          # certain and right
+    llr[2, pos[:50]] = np.nan
+    llr[2, pos[50:100]] = np.where(cw[2, pos[50:100]] == 0, -np.inf, np.inf)             # certain and wrong
+    for early in (False, True):
+        rx = Rx(modcod, max_frames=4, n_ite=10, alpha=0.875, early_stop=early, implem=implem)
+        V, CWD, post, ites = rx.decode_siho(llr, with_post=True)
+        V0, CWD0, post0, ites0 = rx.decode_siho(clean[[0, 3]], with_post=True)
+        rx.close()
+        assert np.array_equal(V[[0, 3]], V0) and np.array_equal(CWD[[0, 3]], CWD0) and np.array_equal(ites[[0, 3]], ites0)
+        assert np.array_equal(post[[0, 3]].view(np.uint32), post0.view(np.uint32))
+        assert np.array_equal(V[1], info[1]) and CWD[1] == 1
+        assert np.array_equal(V[0], info[0]) and np.array_equal(V[3], info[3])
+        assert ites.min() >= 1 and ites.max() <= 10
 
 
 SPA_RULES = [("SPA", "SPA_CLIP"), ("SPA_EXACT", "SPA")]      # (--dec-implem, the oracle's rule): SPA = the exact check node with AFF3CT's message cap, SPA_EXACT = without
