@@ -16,7 +16,7 @@ import numpy as np
 
 from . import params as P
 from .iqfile import ProcessingAborted, RadioUserBinary
-from .srcfile import load_src
+from .srcfile import SinkUserBinary, load_src
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -35,7 +35,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--dec-alpha", type=float, default=1.0)
     ap.add_argument("--dec-simd", default="", help="accepted and ignored (the GPU batches frames with -F)")
     ap.add_argument("--no-wl-phases", action="store_true", help="accepted: there are no waiting / learning phases here")
-    ap.add_argument("--snk-path", default="", help="decoded information bits, one byte per bit")
+    ap.add_argument("--snk-path", default="", help="decoded payload of every frame, eight bits per byte (the reference's Sink_user_binary: a file sent with dvbs2_tx --src-type USER_BIN comes out as it went in)")
     ap.add_argument("--timing-offset", type=int, default=-1, help="sample index of the first symbol after the matched filter (default: two group delays)")
     ap.add_argument("--sync-fine", action="store_true", help="run the pilot-aided phase synchronizer before the chain")
     ap.add_argument("--device", type=int, default=0)
@@ -51,7 +51,7 @@ def run(args, out=sys.stdout) -> dict:
     pattern = load_src(args.src_path, mc.K_bch) if args.src_type == "USER" and args.src_path else None
     rx = Dvbs2Hip(mc.name, max_frames=F, n_ite=args.dec_ite, alpha=args.dec_alpha, early_stop=True, implem=args.dec_implem, device=args.device)
     rcv = RadioUserBinary(n * osf, input_filename=args.rad_rx_file_path, auto_reset=not args.rad_rx_no_loop, n_frames=F)
-    snk = open(args.snk_path, "wb") if args.snk_path else None
+    snk = SinkUserBinary(args.snk_path, mc.K_bch) if args.snk_path else None
     off = args.timing_offset if args.timing_offset >= 0 else 2 * 20 * osf          # two group delays of grp_delay * osf samples
     tail = np.zeros((0, 2), np.float32)                                            # matched-filter samples not yet turned into symbols
     skip = off
@@ -90,7 +90,7 @@ def run(args, out=sys.stdout) -> dict:
                     locked = stable >= 2                                           # the delay line has settled on this alignment
                     st["delay"] = int(delay[f])
                     if snk:
-                        snk.write(bits[f].astype(np.uint8).tobytes())
+                        snk.send(bits[f])
                     if pattern is not None and locked:
                         e = min(int((bits[f] != p).sum()) for p in pattern)
                         st["locked_frames"] += 1; st["be"] += e; st["fe"] += e > 0

@@ -19,7 +19,7 @@ def test_filtered_stream_with_unknown_frame_start_is_decoded(modcod, ebn0):
     sent, pl = rx.tx_bb(F, seed=11)                           # noiseless PL frames [F, 2 n]
     stream = np.concatenate([np.zeros(2 * off, np.float32), pl.reshape(-1)])[: F * 2 * n]
     up = rx.shape_filter(stream, n_frames=F, osf=2)           # 2 samples per symbol
-    sigma = P.esn0_to_sigma(P.ebn0_to_esn0(ebn0, mc.K_bch / mc.N_ldpc, mc.bps)) * np.sqrt(2.0)   # matched filter of gain 1: per-sample noise at osf 2
+    sigma = P.esn0_to_sigma(P.ebn0_to_esn0(ebn0, mc.K_bch / mc.N_ldpc, mc.bps)) * np.sqrt(2.0)   # (3 dB more noise than the label says: the unit-energy filters keep the symbol-rate sigma, results/r06/filtered_loop.md; these Eb/N0 are far above the waterfalls)
     noisy = rx.add_noise(np.float32(sigma), up, seed=5, n_frames=F)
     mf = rx.filter(noisy, n_frames=F).reshape(-1, 2)
     sym = np.zeros((F * n, 2), np.float32)
