@@ -34,6 +34,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--sim-seed", type=int, default=0, dest="seed")
     ap.add_argument("--max-frames", type=int, default=0, help="stop after this many frames (needed when the input loops)")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--sim-stats", action="store_true", help="per-kernel-group device time at the end (the reference's --sim-stats)")
     return ap
 
 
@@ -46,6 +47,8 @@ def run(args, out=sys.stdout) -> int:
     rcv = RadioUserBinary(N, input_filename=args.rad_rx_file_path, auto_reset=not args.rad_rx_no_loop, n_frames=args.n_frames)
     snd = RadioUserBinary(N, output_filename=args.rad_tx_file_path, n_frames=args.n_frames)
     rx = Dvbs2Hip(mc.name, max_frames=args.n_frames, device=args.device)
+    if args.sim_stats:
+        rx.timing_enable(True)
     print("Channel AWGN", file=out)
     frames, call = 0, 0
     try:
@@ -59,6 +62,9 @@ def run(args, out=sys.stdout) -> int:
             frames += args.n_frames
             call += 1
     finally:
+        if args.sim_stats:
+            from .sim import print_stats
+            print_stats([rx], out)
         rx.close(); rcv.close(); snd.close()
     mb = 2 * N * frames * 4 / (1024 * 1024)
     print("Samples size: %d MB" % mb, file=out)

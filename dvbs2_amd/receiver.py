@@ -434,6 +434,11 @@ class Dvbs2Hip:
         self._chk(self.L.dvbs2hip_device_copy_bandwidth(self.h, int(nbytes), int(reps), C.byref(g)))
         return g.value
 
+    def timing_stats(self):
+        """-> {group: (device ms, launches)} of the per-kernel timers, the groups of `--sim-stats` (include/dvbs2hip.h DVBS2HIP_K_*)"""
+        names = ("LDPC decoder", "BCH decoder", "demodulator", "filters", "front end (descramble + estimate + demodulate)", "other (TX mirror, synchronizers, monitor)")
+        return {n: self.timing_get(k) for k, n in enumerate(names)}
+
     def timing_get(self, k):
         ms, n = C.c_double(), C.c_int64()
         self._chk(self.L.dvbs2hip_timing_get(self.h, k, C.byref(ms), C.byref(n)))

@@ -39,6 +39,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--timing-offset", type=int, default=-1, help="sample index of the first symbol after the matched filter (default: two group delays)")
     ap.add_argument("--sync-fine", action="store_true", help="run the pilot-aided phase synchronizer before the chain")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--sim-stats", action="store_true", help="per-kernel-group device time at the end (the reference's --sim-stats)")
     return ap
 
 
@@ -50,6 +51,8 @@ def run(args, out=sys.stdout) -> dict:
         raise ValueError("a looping input needs --max-frames")
     pattern = load_src(args.src_path, mc.K_bch) if args.src_type == "USER" and args.src_path else None
     rx = Dvbs2Hip(mc.name, max_frames=F, n_ite=args.dec_ite, alpha=args.dec_alpha, early_stop=True, implem=args.dec_implem, device=args.device)
+    if args.sim_stats:
+        rx.timing_enable(True)
     rcv = RadioUserBinary(n * osf, input_filename=args.rad_rx_file_path, auto_reset=not args.rad_rx_no_loop, n_frames=F)
     snk = SinkUserBinary(args.snk_path, mc.K_bch) if args.snk_path else None
     off = args.timing_offset if args.timing_offset >= 0 else 2 * 20 * osf          # two group delays of grp_delay * osf samples
@@ -95,6 +98,9 @@ def run(args, out=sys.stdout) -> dict:
                         e = min(int((bits[f] != p).sum()) for p in pattern)
                         st["locked_frames"] += 1; st["be"] += e; st["fe"] += e > 0
     finally:
+        if args.sim_stats:
+            from .sim import print_stats
+            print_stats([rx], out)
         rx.close(); rcv.close()
         if snk:
             snk.close()

@@ -45,7 +45,24 @@ def build_parser():
                          "(the filtered loop of src/mains/TX_RX/main.cpp with --perfect-sync); the last frame of every batch "
                          "is cut by the filters' delay and not counted")
     ap.add_argument("--json", default=None, help="also write the rows as JSON")
+    ap.add_argument("--sim-stats", action="store_true", help="per-kernel-group device time at the end (the reference's --sim-stats, TX_RX_BB/main.cpp:110,170-178); the timers' events cost a few percent")
     return ap
+
+
+def print_stats(handles, out=sys.stdout):
+    """the table of --sim-stats: device time per kernel group, summed over the handles (clones) of this process"""
+    tot = {}
+    for h in handles:
+        for name, (ms, n) in h.timing_stats().items():
+            a = tot.setdefault(name, [0.0, 0])
+            a[0] += ms; a[1] += n
+    all_ms = sum(v[0] for v in tot.values()) or 1.0
+    print("# -------------------------------------------------||------------||------------||---------", file=out)
+    print("#                                     Kernel group ||   launches || device (ms) ||    share", file=out)
+    print("# -------------------------------------------------||------------||------------||---------", file=out)
+    for name, (ms, n) in tot.items():
+        if n:
+            print("# %48s || %10d || %10.2f || %6.1f %%" % (name, n, ms, 100.0 * ms / all_ms), file=out)
 
 
 def run(args, out=sys.stdout):
@@ -104,6 +121,9 @@ def run(args, out=sys.stdout):
 
     clones = [Clone() for _ in range(args.clones)]
     rx = clones[0].rx
+    if args.sim_stats:
+        for c in clones:
+            c.rx.timing_enable(True)
     torch.cuda.synchronize()
 
     rows = []
@@ -163,6 +183,8 @@ def run(args, out=sys.stdout):
         ebn0 += args.sim_noise_step
     if rank == 0:
         print("# End of the simulation", file=out)
+        if args.sim_stats:
+            print_stats([c.rx for c in clones], out)
         if args.json:
             with open(args.json, "w") as fh:
                 json.dump(dict(args=vars(args), n_gpus=world, rows=rows), fh, indent=1)

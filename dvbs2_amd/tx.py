@@ -28,6 +28,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--tx-time-limit", type=float, default=0.0, help="stop after this many milliseconds")
     ap.add_argument("--sim-seed", type=int, default=0, dest="seed")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--sim-stats", action="store_true", help="per-kernel-group device time at the end (the reference's --sim-stats)")
     return ap
 
 
@@ -44,6 +45,8 @@ def run(args, out=sys.stdout) -> int:
     src = (SourceUser(args.src_path, mc.K_bch) if args.src_type == "USER" else SourceUserBinary(args.src_path, mc.K_bch, auto_reset=not args.src_no_loop) if args.src_type == "USER_BIN"
            else SourceAZCW(mc.K_bch) if args.src_type == "AZCW" else None)
     rx = Dvbs2Hip(mc.name, max_frames=F, device=args.device)
+    if args.sim_stats:
+        rx.timing_enable(True)
     snd = RadioUserBinary(mc.pl_frame * args.osf, output_filename=args.rad_tx_file_path, n_frames=F)
     t0, frames, call = time.perf_counter(), 0, 0
     try:
@@ -57,6 +60,9 @@ def run(args, out=sys.stdout) -> int:
             frames += F
             call += 1
     finally:
+        if args.sim_stats:
+            from .sim import print_stats
+            print_stats([rx], out)
         rx.close(); snd.close()
     print("(II) %d frames of %d complex samples written in '%s'" % (frames, mc.pl_frame * args.osf, args.rad_tx_file_path), file=out)
     return frames

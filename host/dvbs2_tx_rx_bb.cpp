@@ -38,7 +38,8 @@ int main(int argc, char **argv)
     double ebn0_min = 3.2, ebn0_max = 6.0, step = 0.1;     // DVBS2.cpp:121-123
     int F = 512, n_ite = 50, max_fe = 100, n_clones = 3;   // DVBS2.cpp:135-142 (implem SPA, 50 ite, 100 frame errors)
     long long max_frames = 10000000;
-    int reduce_timeout_ms = 120000;      // rendezvous and every later reduction: a rank whose peers do not arrive leaves with exit code 4
+    int reduce_timeout_ms = 120000;
+    bool sim_stats = false;      // rendezvous and every later reduction: a rank whose peers do not arrive leaves with exit code 4
     float alpha = 1.0f;
     auto env_int = [](const char *n, int d) { const char *v = std::getenv(n); return v && *v ? std::atoi(v) : d; };
     int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0), local_rank = env_int("LOCAL_RANK", -1);
@@ -64,6 +65,7 @@ int main(int argc, char **argv)
         else if (a == "--local-rank") local_rank = std::atoi(next());
         else if (a == "--rendezvous") rendezvous = next();
         else if (a == "--reduce-timeout-ms") reduce_timeout_ms = std::atoi(next());
+        else if (a == "--sim-stats") sim_stats = true;                         // TX_RX_BB/main.cpp:110,170-178: per-task statistics at the end
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     dvbs2hip_t *h = nullptr;
@@ -86,6 +88,7 @@ int main(int argc, char **argv)
         if (sched == "NATURAL") CHK(dvbs2hip_set_ldpc_schedule(h, DVBS2HIP_SCHED_NATURAL));
         else if (sched != "QC") { std::fprintf(stderr, "--dec-sched has to be QC or NATURAL\n"); return 2; }
         CHK(dvbs2hip_get_sizes(h, &sz));
+        if (sim_stats) CHK(dvbs2hip_timing_enable(h, 1));
         // one communicator per clone (its all-reduce runs on the clone's stream); every rank calls them in the same order
         if (reduce) CHK(dvbs2hip_monitor_reduce_init(h, rank, world, (rendezvous + (k ? ".c" + std::to_string(k) : "")).c_str(), reduce_timeout_ms));
         CHK(dvbs2hip_malloc(h, &cl[k].d_pl, (size_t)F * 2 * sz.pl_frame_sym * sizeof(float)));
@@ -137,6 +140,15 @@ int main(int argc, char **argv)
         std::fflush(stdout);
     }
     if (chief) std::printf("# End of the simulation\n");
+    if (sim_stats && chief) {      // device time per kernel group, summed over the clones of this process (hipEvents around every launch: include/dvbs2hip.h, "measurement")
+        static const char *names[DVBS2HIP_K_COUNT] = {"LDPC decoder", "BCH decoder", "demodulator", "filters", "front end (descramble + estimate + demodulate)", "other (TX mirror, synchronizers, monitor)"};
+        double ms[DVBS2HIP_K_COUNT] = {0}, all = 0; long long n[DVBS2HIP_K_COUNT] = {0};
+        for (auto &k : cl)
+            for (int g = 0; g < DVBS2HIP_K_COUNT; g++) { double m1 = 0; int64_t n1 = 0; h = k.h; CHK(dvbs2hip_timing_get(h, g, &m1, &n1)); ms[g] += m1; n[g] += (long long)n1; all += m1; }
+        std::printf("# -------------------------------------------------||------------||------------||---------\n#                                     Kernel group ||   launches || device (ms) ||    share\n"
+                    "# -------------------------------------------------||------------||------------||---------\n");
+        for (int g = 0; g < DVBS2HIP_K_COUNT; g++) if (n[g]) std::printf("# %48s || %10lld || %10.2f || %6.1f %%\n", names[g], n[g], ms[g], 100.0 * ms[g] / (all > 0 ? all : 1));
+    }
     for (auto &k : cl) { dvbs2hip_free(k.h, k.d_pl); dvbs2hip_free(k.h, k.d_sent); dvbs2hip_free(k.h, k.d_got); dvbs2hip_free(k.h, k.d_sig); dvbs2hip_destroy(k.h); }
     return 0;
 }

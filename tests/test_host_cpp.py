@@ -86,6 +86,30 @@ def test_cpp_tx_rx_bb_reproduces_a_reference_row(clones):
 
 
 @pytest.mark.gpu
+def test_sim_stats_tables_of_both_simulators():
+    """--sim-stats (TX_RX_BB/main.cpp:110,170-178: per-task statistics at the end of the simulation): both simulators print the device time per kernel group from the
+    library's hipEvent timers, summed over their clones; the LDPC decoder is the largest group, one launch per batch."""
+    import io
+    from dvbs2_amd import sim
+    build()
+    argv = ["--mod-cod", "QPSK-S_8/9", "-m", "3.9", "-M", "3.91", "--dec-implem", "NMS", "--dec-ite", "10", "-F", "1024", "--clones", "2", "-e", "1000000", "--max-frames", "8192", "--sim-stats"]
+    r = subprocess.run([os.path.join(ROOT, "host", "dvbs2_tx_rx_bb")] + argv, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = io.StringIO()
+    sim.run(sim.build_parser().parse_args(argv), out=out)
+    for text in (r.stdout, out.getvalue()):
+        tab = {}
+        for l in text.splitlines():
+            if l.startswith("#") and "||" in l and "%" in l:
+                f = [x.strip() for x in l[1:].split("||")]
+                tab[f[0]] = (int(f[1]), float(f[2]), float(f[3].rstrip(" %")))
+        assert set(tab) >= {"LDPC decoder", "BCH decoder"}, text
+        fra = int([x.strip() for x in [l for l in text.splitlines() if l.strip() and not l.startswith("#")][0].replace("||", "|").split("|")][2])
+        # (with clones the timers' intervals overlap the other clones' kernels: shares are of the summed intervals, not of the wall clock)
+        assert tab["LDPC decoder"][0] == fra // 1024 and tab["LDPC decoder"][2] == max(v[2] for v in tab.values()) and abs(sum(v[2] for v in tab.values()) - 100.0) < 0.5, tab
+
+
+@pytest.mark.gpu
 def test_cpp_tx_rx_bb_the_references_decoder_as_recalled_and_the_default_lose_the_same_frames():
     """(round 6) `--dec-implem SPA_TANH --dec-sched NATURAL` is the reference's decoder as recalled (AFF3CT's tanh-product rule, the rows of H in order); the default `SPA`
     in the same sweep order loses the same frames on the same seeds (within 1 %: the cap is what matters, results/r06/spa_rules.md), both inside the band of the reference's row;
