@@ -67,3 +67,20 @@ def test_ch_adds_awgn_of_the_requested_variance(tmp_path):
     n = (y - x).astype(np.float64)
     assert abs(n.mean()) < 5e-3 and abs(n.std() - sigma) < 5e-3 * sigma + 2e-3
     assert not np.array_equal(n[0], n[2])                      # a fresh noise block per sequence iteration
+
+
+def test_the_reference_readme_command_lines_parse():
+    """README.md:156,162,168 of the reference (the file workflow) and :203,210 (the transport-stream workflow, radio flags left out: there is no USRP here), word for word behind the
+    program names: the work-alikes take them."""
+    from dvbs2_amd import ch, rx, tx
+    a = tx.build_parser().parse_args("--sim-stats --rad-type USER_BIN --rad-tx-file-path out_tx.bin -F 8 --src-type USER --src-path ../conf/src/K_14232.src --mod-cod QPSK-S_8/9 --tx-time-limit 10000".split())
+    assert a.sim_stats and a.tx_time_limit == 10000 and a.n_frames_batch == 8
+    b = ch.build_parser().parse_args("--sim-stats --rad-type USER_BIN --rad-rx-file-path out_tx.bin --rad-tx-file-path out_tx_noisy.bin --rad-rx-no-loop -F 8 --mod-cod QPSK-S_8/9 -m 4.0".split())
+    assert b.ebn0 == 4.0 and b.rad_rx_no_loop
+    c = rx.build_parser().parse_args(("--sim-stats --src-type USER --src-path ../conf/src/K_14232.src --rad-type USER_BIN --rad-rx-file-path out_tx_noisy.bin -F 8 --mod-cod QPSK-S_8/9 "
+                                      "--dec-implem NMS --dec-ite 10 --dec-simd INTER --snk-path /dev/null --rad-rx-no-loop --no-wl-phases").split())
+    assert c.dec_implem == "NMS" and c.dec_ite == 10 and c.snk_path == "/dev/null"
+    d = tx.build_parser().parse_args("--sim-stats -F 8 --src-type USER_BIN --src-path /path/to/input/ts/video.ts --mod-cod QPSK-S_8/9 --rad-tx-file-path out_tx.bin".split())
+    assert d.src_type == "USER_BIN"
+    e = rx.build_parser().parse_args("--sim-stats -F 16 --mod-cod QPSK-S_8/9 --dec-implem NMS --dec-ite 10 --dec-simd INTER --snk-path output_stream_fifo.ts --rad-rx-file-path out_tx_noisy.bin".split())
+    assert e.snk_path == "output_stream_fifo.ts"
