@@ -44,6 +44,10 @@ def build_parser():
                     help="TX shaping filter -> AWGN at the sample rate -> matched filter -> perfect-timing extraction "
                          "(the filtered loop of src/mains/TX_RX/main.cpp with --perfect-sync); the last frame of every batch "
                          "is cut by the filters' delay and not counted")
+    ap.add_argument("--perfect-sync", action="store_true", help="dvbs2_tx_rx --perfect-sync (DVBS2.cpp:97, TX_RX/main.cpp:440): the same loop as --filtered")
+    ap.add_argument("--chn-max-freq-shift", type=float, default=0.0, help="dvbs2_tx_rx's channel frequency shift: with --perfect-sync the genie removes it, so it is accepted and has no effect; "
+                                                                          "without, the reference's sample-serial synchronizers would have to (out of scope, SURVEY.md 8e): refused")
+    ap.add_argument("--chn-max-delay", type=float, default=0.0, help="dvbs2_tx_rx's channel delay in samples: as --chn-max-freq-shift")
     ap.add_argument("--json", default=None, help="also write the rows as JSON")
     ap.add_argument("--sim-stats", action="store_true", help="per-kernel-group device time at the end (the reference's --sim-stats, TX_RX_BB/main.cpp:110,170-178); the timers' events cost a few percent")
     return ap
@@ -66,6 +70,9 @@ def print_stats(handles, out=sys.stdout):
 
 
 def run(args, out=sys.stdout):
+    args.filtered = args.filtered or args.perfect_sync
+    if (args.chn_max_freq_shift or args.chn_max_delay) and not args.filtered:
+        raise SystemExit("a channel delay / frequency shift needs the reference's timing and coarse-frequency loops (sample-serial: out of scope) or --perfect-sync")
     import torch
     import torch.distributed as dist
     from . import params as P
