@@ -44,6 +44,12 @@ def build_parser():
                     help="TX shaping filter -> AWGN at the sample rate -> matched filter -> perfect-timing extraction "
                          "(the filtered loop of src/mains/TX_RX/main.cpp with --perfect-sync); the last frame of every batch "
                          "is cut by the filters' delay and not counted")
+    ap.add_argument("--src-type", default="RAND", choices=["RAND", "USER", "USER_BIN", "AZCW"],
+                    help="payload source (DVBS2.cpp:66,359-376): RAND = the TX mirror's own generator on the device; USER = a pattern file (conf/src/*.src), USER_BIN = any file, eight bits per byte, "
+                         "AZCW = all-zero payloads: generated on the host and handed to the TX mirror's `info_in` socket")
+    ap.add_argument("--src-path", default="")
+    ap.add_argument("--src-no-loop", action="store_true", help="USER_BIN: stop a noise point when the file has been sent once")
+    ap.add_argument("--ter-freq", type=int, default=500, help="accepted and ignored (a row is printed when its noise point is done)")
     ap.add_argument("--perfect-sync", action="store_true", help="dvbs2_tx_rx --perfect-sync (DVBS2.cpp:97, TX_RX/main.cpp:440): the same loop as --filtered")
     ap.add_argument("--chn-max-freq-shift", type=float, default=0.0, help="dvbs2_tx_rx's channel frequency shift: with --perfect-sync the genie removes it, so it is accepted and has no effect; "
                                                                           "without, the reference's sample-serial synchronizers would have to (out of scope, SURVEY.md 8e): refused")
@@ -78,6 +84,7 @@ def run(args, out=sys.stdout):
     from . import params as P
     from .parallel import reduce_counters, reduce_max
     from .receiver import Dvbs2Hip
+    from .srcfile import SourceDone
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -96,6 +103,14 @@ def run(args, out=sys.stdout):
     if not 1 <= args.clones <= 8:
         raise SystemExit("--clones has to be 1 .. 8")
     osf, delay = 2, 80                       # Shaping_filter.hpp:24-28: osf 2, two group delays of 20 symbols
+    if args.src_type in ("USER", "USER_BIN") and not args.src_path:
+        raise SystemExit("--src-type %s needs --src-path" % args.src_type)
+
+    def make_source():
+        from .srcfile import SourceAZCW, SourceUser, SourceUserBinary
+        return (SourceUser(args.src_path, mc.K_bch) if args.src_type == "USER" else SourceUserBinary(args.src_path, mc.K_bch, auto_reset=not args.src_no_loop) if args.src_type == "USER_BIN"
+                else SourceAZCW(mc.K_bch) if args.src_type == "AZCW" else None)
+    src_box = [make_source()]                 # one source per process: its frames go to the clones in the order the batches are issued; it starts over at every noise point
 
     class Clone:
         def __init__(self):
@@ -114,14 +129,19 @@ def run(args, out=sys.stdout):
 
         def issue(self, seed):
             rx = self.rx
+            info = None
+            if src_box[0] is not None:
+                self.info = torch.from_numpy(src_box[0].generate(F)).to(dev)          # (kept until the next batch of this clone: the copy is asynchronous to the handle's stream)
+                torch.cuda.current_stream().synchronize()
+                info = self.info.data_ptr()
             if args.filtered:
-                rx.tx_bb_dev(None, seed, None, self.sent.data_ptr(), self.pl.data_ptr(), F)
+                rx.tx_bb_dev(info, seed, None, self.sent.data_ptr(), self.pl.data_ptr(), F)
                 rx.shape_filter_dev(self.pl.data_ptr(), self.up.data_ptr(), rx.pl_frame, F)
                 rx.add_noise_dev(self.sig.data_ptr(), self.up.data_ptr(), self.up2.data_ptr(), seed, 2 * rx.pl_frame * osf, F)
                 rx.filter_dev(self.up2.data_ptr(), self.up.data_ptr(), rx.pl_frame * osf, F)
                 rx.extract_dev(self.up.data_ptr(), self.pl.data_ptr(), rx.pl_frame, osf, delay, F)
             else:
-                rx.tx_bb_dev(None, seed, self.sig.data_ptr(), self.sent.data_ptr(), self.pl.data_ptr(), F)
+                rx.tx_bb_dev(info, seed, self.sig.data_ptr(), self.sent.data_ptr(), self.pl.data_ptr(), F)
             rx.rx_bb_dev(self.pl.data_ptr(), self.sig.data_ptr() if args.est_type == "PERFECT" else None, self.got.data_ptr(), None, None, F)
             rx.check_errors_dev(self.sent.data_ptr(), self.got.data_ptr(), F - 1 if args.filtered else F)
             self.busy = True
@@ -152,6 +172,7 @@ def run(args, out=sys.stdout):
     while ebn0 < args.sim_noise_max - 1e-9:
         esn0 = P.ebn0_to_esn0(ebn0, mc.code_rate, mc.bps)          # main.cpp:142-146
         sigma = P.esn0_to_sigma(esn0)
+        src_box[0] = make_source()
         for c in clones:
             c.sig.fill_(sigma)
             c.rx.monitor_reset()
@@ -173,7 +194,10 @@ def run(args, out=sys.stdout):
                 tot = collect(c)
             if tot[2] >= args.max_fe or tot[0] >= args.max_frames:
                 break
-            c.issue((args.seed << 40) + (batch_id << 8) + rank)
+            try:
+                c.issue((args.seed << 40) + (batch_id << 8) + rank)
+            except SourceDone:                                       # --src-type USER_BIN --src-no-loop: the file has been sent
+                break
             batch_id += 1
         for c in clones:                                             # the batches still in flight count (the reference's threads finish theirs)
             if c.busy:

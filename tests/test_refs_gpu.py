@@ -106,6 +106,29 @@ def test_gpu_sim_with_clones_counts_what_one_clone_counts(clones):
     assert (same["fra"], same["be"], same["fe"]) == (many["fra"], many["be"], many["fe"])      # the same batches, seed for seed
 
 
+def test_gpu_sim_payload_sources(tmp_path):
+    """--src-type of dvbs2_tx_rx_bb (DVBS2.cpp:66,359-376): AZCW, the pattern file and a binary file go through the TX mirror's `info_in` socket; the code is linear and the channel
+    symmetric, so at one Eb/N0 every source loses frames at the same rate as the device's own random payloads (here: all four inside 4 sigma of each other at ~5 % FER); a binary file
+    sent once (--src-no-loop) ends its noise point by itself."""
+    import math
+    import numpy as np
+    from dvbs2_amd import sim
+    from dvbs2_amd.srcfile import save_src
+    bits = np.unpackbits(np.load(os.path.join(GOLD, "src_K_14232.npy")))[:14232].astype(np.int32)
+    f_src, f_bin = str(tmp_path / "K_14232.src"), str(tmp_path / "any.bin")
+    save_src(f_src, bits)
+    np.random.default_rng(4).integers(0, 256, 200 * 1779 + 77, dtype=np.uint8).tofile(f_bin)
+    def run(*extra, frames=16384):
+        argv = ["--mod-cod", "QPSK-S_8/9", "-m", "3.70", "-M", "3.71", "--dec-implem", "SPA", "--dec-ite", "50", "-F", "1024", "-e", "100000000", "--max-frames", str(frames), "--clones", "1"]
+        return sim.run(sim.build_parser().parse_args(argv + list(extra)), out=io.StringIO())[0]
+    rows = [run(), run("--src-type", "AZCW"), run("--src-type", "USER", "--src-path", f_src), run("--src-type", "USER_BIN", "--src-path", f_bin)]
+    assert all(r["fra"] == 16384 and r["fe"] > 500 for r in rows), rows
+    for r in rows[1:]:
+        assert abs(math.log(r["fer"] / rows[0]["fer"])) < 4.0 * math.sqrt(1.0 / r["fe"] + 1.0 / rows[0]["fe"]), rows
+    once = run("--src-type", "USER_BIN", "--src-path", f_bin, "--src-no-loop", frames=10 ** 9)
+    assert once["fra"] == 1024 and once["fe"] > 10              # 200.04 frames of payload: one batch of 1024 (the rest of it zero padding), then the source is done
+
+
 def test_filtered_loop_matches_the_baseband_loop_and_stays_below_the_full_chain_traces():
     """The reference's second set of traces, refs/TX_RX/*.txt, is its FULL chain: shaping filter, channel, matched filter and its sample-serial synchronizers.  With genie timing
     (`dvbs2_tx_rx --perfect-sync`, TX_RX/main.cpp:440; here `sim --filtered`) what is left of that loop is rows N2 + a5 around the baseband chain, and since both filters have
