@@ -1494,6 +1494,23 @@ int dvbs2hip_estimate(dvbs2hip_t *h, const float *X, float *SIG, float *EB, floa
     return 0;
 }
 
+// ------------------------------------------------------------------ Multiplier_AGC_cc_naive::imultiply (the two gain stages of the reference's RX graph)
+int dvbs2hip_agc_imultiply_dev(dvbs2hip_t *h, const float *X, float *Z, int32_t n_cplx, float output_energy, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X || !Z) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    if (n_cplx < 1) return fail(h, DVBS2HIP_EINVAL, "'n_cplx' has to be greater than 0");
+    if (!(output_energy > 0.f)) return fail(h, DVBS2HIP_EINVAL, "'output_energy' has to be greater than 0");
+    Timer tm(h, DVBS2HIP_K_MISC);
+    HIPCHK(h, agc_launch(X, Z, n_cplx, output_energy, F, h->stream));
+    return 0;
+}
+int dvbs2hip_agc_imultiply(dvbs2hip_t *h, const float *X, float *Z, int32_t n_cplx, float output_energy, int32_t F)
+{
+    const size_t n = (size_t)2 * (n_cplx > 0 ? n_cplx : 0);
+    return host_wrap<true>(h, X, n, Z, n, F, [&](const float *a, float *b, int nf) { return dvbs2hip_agc_imultiply_dev(h, a, b, n_cplx, output_energy, nf); });
+}
+
 // ------------------------------------------------------------------ a7
 int dvbs2hip_pl_descramble_dev(dvbs2hip_t *h, const float *a, float *b, int32_t F)
 {

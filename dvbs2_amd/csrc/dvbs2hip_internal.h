@@ -242,6 +242,7 @@ hipError_t deinterleave_launch(const float *itl, float *nat, int N, int cols, in
 hipError_t estimate_launch(const float *x, float *sig, float *ebn0, float *esn0, int n_sym, float code_rate,
                            int bps, int F, hipStream_t s);
 hipError_t pl_descramble_launch(const float *in, float *out, const uint8_t *seq, int pl_frame, int F, hipStream_t s);
+hipError_t agc_launch(const float *X, float *Z, int n_cplx, float output_energy, int F, hipStream_t s);      // k_agc.hip
 hipError_t remove_plh_launch(const float *in, float *out, int n_sym, int pl_frame, int F, hipStream_t s);
 hipError_t bb_descramble_launch(const int32_t *in, int32_t *out, const uint32_t *prbs, int K, int F, hipStream_t s);
 hipError_t monitor_launch(const int32_t *U, const int32_t *V, unsigned long long *ctr, int K, int F, hipStream_t s);

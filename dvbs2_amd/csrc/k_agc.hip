@@ -1,0 +1,51 @@
+// Multiplier_AGC_cc_naive::_imultiply (src/common/Module/Multiplier/Sequence/Multiplier_AGC_cc_naive.cpp:22-46): every frame is brought to a given energy --
+//     std = sqrt(N sum|x|^2 - (sum re)^2 - (sum im)^2) / N / sqrt(output_energy),   z = x / std
+// (the frame's standard deviation about its mean).  The reference's RX graph runs it twice: `front_agc` on the received samples (2 pl_frame osf values per frame,
+// energy 1 / osf: RX/main_sched.cpp:74,197; DVBS2.cpp:660-664) and `mult_agc` on the symbols behind the timing synchronizer (energy 1: main_sched.cpp:75,205; DVBS2.cpp:653-657).
+// A block-wise task: one workgroup per frame, the frame read twice (sums, then scale: the second read comes out of L2), 8 + 8 bytes per complex sample at the boundary.
+// The three sums are taken in double precision over a fixed tree, so a frame's gain does not depend on the batch or the launch; the reference adds its floats in order,
+// which rounds differently: the parity bar is relative (tests/test_front_gpu.py: 2e-6 against the sums in double, 1e-4 against the oracle's float order).
+#include "dvbs2hip_internal.h"
+
+namespace dvbs2 {
+
+constexpr int AGC_THREADS = 256;
+
+__global__ void __launch_bounds__(AGC_THREADS)
+agc_kernel(const float2 *__restrict__ x, float2 *__restrict__ z, int n_cplx, float output_energy)
+{
+    const float2 *xf = x + (size_t)blockIdx.x * n_cplx;
+    float2 *zf = z + (size_t)blockIdx.x * n_cplx;
+    double s2 = 0.0, sr = 0.0, si = 0.0;
+    for (int i = threadIdx.x; i < n_cplx; i += AGC_THREADS) {
+        const float2 v = xf[i];
+        s2 += (double)v.x * v.x + (double)v.y * v.y;
+        sr += v.x;
+        si += v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s2 += __shfl_xor(s2, o); sr += __shfl_xor(sr, o); si += __shfl_xor(si, o); }
+    __shared__ double part[3][AGC_THREADS / 64];
+    __shared__ float s_std;
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s2; part[1][threadIdx.x >> 6] = sr; part[2][threadIdx.x >> 6] = si; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double a = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]), b = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]), c = (part[2][0] + part[2][1]) + (part[2][2] + part[2][3]);
+        // (an all-equal frame gives 0 -> z = x / 0 = +-inf or NaN, as in the reference)
+        s_std = (float)(sqrt(fmax(a * (double)n_cplx - b * b - c * c, 0.0)) / (double)n_cplx) / sqrtf(output_energy);
+    }
+    __syncthreads();
+    const float sd = s_std;
+    for (int i = threadIdx.x; i < n_cplx; i += AGC_THREADS) {
+        const float2 v = xf[i];
+        zf[i] = make_float2(v.x / sd, v.y / sd);
+    }
+}
+
+hipError_t agc_launch(const float *X, float *Z, int n_cplx, float output_energy, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(agc_kernel, dim3(F), dim3(AGC_THREADS), 0, s, reinterpret_cast<const float2 *>(X), reinterpret_cast<float2 *>(Z), n_cplx, output_energy);
+    return hipGetLastError();
+}
+
+}  // namespace dvbs2

@@ -104,6 +104,8 @@ ABI = {
     "dvbs2hip_filter2_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i]),
     "dvbs2hip_estimate": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_estimate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i]),
+    "dvbs2hip_agc_imultiply": (C.c_int, [_vp, _vp, _vp, _i, C.c_float, _i]),
+    "dvbs2hip_agc_imultiply_dev": (C.c_int, [_vp, _vp, _vp, _i, C.c_float, _i]),
     "dvbs2hip_pl_descramble": (C.c_int, [_vp, _vp, _vp, _i]),
     "dvbs2hip_pl_descramble_dev": (C.c_int, [_vp, _vp, _vp, _i]),
     "dvbs2hip_remove_plh": (C.c_int, [_vp, _vp, _vp, _i]),

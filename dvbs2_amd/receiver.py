@@ -202,6 +202,18 @@ class Dvbs2Hip:
         return sig, eb, es
 
     # ------------------------------------------------------------------ a7
+    def agc(self, X_N, n_frames=1, output_energy=1.0):
+        """Multiplier_AGC_cc_naive::imultiply: every frame over its standard deviation (x sqrt(output_energy)); frames of any length"""
+        X = np.ascontiguousarray(X_N, dtype=np.float32).ravel()
+        if X.size % (2 * n_frames):
+            raise ValueError("the socket does not hold %d frames of complex samples" % n_frames)
+        Z = np.empty_like(X)
+        self._chk(self.L.dvbs2hip_agc_imultiply(self.h, _ptr(X), _ptr(Z), X.size // (2 * n_frames), float(output_energy), n_frames))
+        return Z
+
+    def agc_dev(self, X, Z, n_cplx, output_energy, n_frames):
+        self._chk(self.L.dvbs2hip_agc_imultiply_dev(self.h, _ptr(X), _ptr(Z), n_cplx, float(output_energy), n_frames))
+
     def pl_descramble(self, Y_N1):
         X, F = self._frames(Y_N1, 2 * self.pl_frame, np.float32)
         out = np.empty_like(X)

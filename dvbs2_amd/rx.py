@@ -1,6 +1,6 @@
-"""`dvbs2_rx` work-alike WITHOUT the sample-serial loops (timing recovery, coarse frequency, AGC: out of scope, SURVEY.md
-section 8): raw IQ file -> matched filter (a5) -> extraction at a known symbol phase -> frame synchronizer (N4) -> pilot-aided
-phase synchronizer (N4, optional) -> fused RX chain (a7 .. a8) -> monitor against the source pattern -> sink.  It serves
+"""`dvbs2_rx` work-alike WITHOUT the sample-serial loops (timing recovery, coarse frequency: out of scope, SURVEY.md
+section 8): raw IQ file -> front gain stage (Multiplier_AGC, RX/main_sched.cpp:197) -> matched filter (a5) -> extraction at a known symbol phase -> gain stage
+(main_sched.cpp:205) -> frame synchronizer (N4) -> pilot-aided phase synchronizer (N4, optional) -> fused RX chain (a7 .. a8) -> monitor against the source pattern -> sink.  It serves
 files made by `dvbs2_amd.tx` / `dvbs2_amd.ch` (or by the reference's dvbs2_tx / dvbs2_ch without timing or frequency
 offsets): README.md:151-169 of the reference.
 
@@ -38,6 +38,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--snk-path", default="", help="decoded payload of every frame, eight bits per byte (the reference's Sink_user_binary: a file sent with dvbs2_tx --src-type USER_BIN comes out as it went in)")
     ap.add_argument("--timing-offset", type=int, default=-1, help="sample index of the first symbol after the matched filter (default: two group delays)")
     ap.add_argument("--sync-fine", action="store_true", help="run the pilot-aided phase synchronizer before the chain")
+    ap.add_argument("--no-agc", action="store_true", help="leave out the two gain stages of the reference's graph (front_agc on the samples, mult_agc on the symbols)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--sim-stats", action="store_true", help="per-kernel-group device time at the end (the reference's --sim-stats)")
     return ap
@@ -66,7 +67,10 @@ def run(args, out=sys.stdout) -> dict:
                 x = rcv.receive()
             except ProcessingAborted:
                 break
-            mf = np.concatenate([tail, rx.filter(x.astype(np.float32, copy=False), n_frames=F).reshape(-1, 2)])
+            x = x.astype(np.float32, copy=False)
+            if not args.no_agc:
+                x = rx.agc(x, n_frames=F, output_energy=1.0 / osf)                  # front_agc: DVBS2.cpp:660-664
+            mf = np.concatenate([tail, rx.filter(x, n_frames=F).reshape(-1, 2)])
             mf, skip = mf[skip:], 0                                                # perfect timing: every osf-th sample from `off`
             n_sym = (mf.shape[0] // osf // n) * n                                  # whole frames of symbols
             if n_sym == 0:
@@ -76,6 +80,8 @@ def run(args, out=sys.stdout) -> dict:
             for b0 in range(0, n_sym // n, F):
                 blk = np.ascontiguousarray(sym[b0 * n:(b0 + F) * n])
                 Fb = blk.shape[0] // n
+                if not args.no_agc:
+                    blk = rx.agc(blk, n_frames=Fb, output_energy=1.0)                   # mult_agc: DVBS2.cpp:653-657
                 delay, flags, tri, aligned = rx.sync_frame_synchronize(blk.reshape(Fb, 2 * n), with_flags=True)
                 if args.sync_fine:
                     # the reference's task order (src/mains/RX/main.cpp): PL descramble -> fine synchronizer -> remove PLH ->

@@ -128,6 +128,8 @@ static int run_matched_filter_graph(const std::string &modcod, int F, int n_ite,
     const int N_pl = 2 * ctx->sz.pl_frame_sym;
     std::vector<float> rx_samples((size_t)F * N_pl * osf);                       // what Radio::receive hands over
     // modules: unique_ptr + the reference's variable names, so that the binding lines below are the reference's own
+    std::unique_ptr<Multiplier_AGC_hip>          front_agc    (new Multiplier_AGC_hip(ctx, N_pl * osf, 1.f / (float)osf));                // DVBS2.cpp:660-664 (build_channel_agc)
+    std::unique_ptr<Multiplier_AGC_hip>          mult_agc     (new Multiplier_AGC_hip(ctx, N_pl, 1.f));                                  // DVBS2.cpp:653-657 (build_agc_shift)
     std::unique_ptr<Sync_coarse_identity>        sync_coarse_f(new Sync_coarse_identity(N_pl * osf, F));
     std::unique_ptr<Filter_FIR_hip>              matched_flt  (new Filter_FIR_hip(ctx, N_pl * osf));
     std::unique_ptr<Sync_timing_perfect>         sync_timing  (new Sync_timing_perfect(N_pl * osf, osf, F));
@@ -149,13 +151,15 @@ static int run_matched_filter_graph(const std::string &modcod, int F, int n_ite,
     spu::module::Probe_value<float> prb_bfer_ber(1, "BER", F);
     spu::module::Probe_value<float> prb_bfer_fer(1, "FER", F);
 
-    (*sync_coarse_f)[sfc::sck::synchronize::X_N1] = rx_samples;                 // stand-in for front_agc <- radio (main_sched.cpp:197-198)
+    (*front_agc    )[             mlt::sck::imultiply    ::X_N     ] = rx_samples;                                                                 // main_sched.cpp:197 (producer = the radio's socket)
+    (*sync_coarse_f)[             sfc::sck::synchronize  ::X_N1    ] = (*front_agc    )[             mlt::sck::imultiply    ::Z_N     ];   // main_sched.cpp:198
     (*matched_flt  )[             flt::sck::filter1      ::X_N1    ] = (*sync_coarse_f)[             sfc::sck::synchronize  ::Y_N2    ];   // main_sched.cpp:199
     (*matched_flt  )[             flt::sck::filter2      ::X_N1    ] = (*sync_coarse_f)[             sfc::sck::synchronize  ::Y_N2    ];   // main_sched.cpp:200
     (*matched_flt  )[             flt::sck::filter2      ::Y_N2h   ] = (*matched_flt  )[             flt::sck::filter1      ::Y_N2    ];   // main_sched.cpp:201
-    sync_timing->in() = (*matched_flt  )[             flt::sck::filter2      ::Y_N2    ];                                                // stand-in for :202-205 (Gardner + AGC)
-    (*sync_frame   )[             sfm::sck::synchronize1 ::X_N1    ] = sync_timing->out();                                              // :206, producer = the stand-in
-    (*sync_frame   )[             sfm::sck::synchronize2 ::X_N1    ] = sync_timing->out();                                              // :207
+    sync_timing->in() = (*matched_flt  )[             flt::sck::filter2      ::Y_N2    ];                                                // stand-in for :202-204 (Gardner)
+    (*mult_agc     )[             mlt::sck::imultiply    ::X_N     ] = sync_timing->out();                                              // main_sched.cpp:205, producer = the stand-in
+    (*sync_frame   )[             sfm::sck::synchronize1 ::X_N1    ] = (*mult_agc     )[             mlt::sck::imultiply    ::Z_N     ];   // main_sched.cpp:206
+    (*sync_frame   )[             sfm::sck::synchronize2 ::X_N1    ] = (*mult_agc     )[             mlt::sck::imultiply    ::Z_N     ];   // main_sched.cpp:207
     (*sync_frame   )[             sfm::sck::synchronize2 ::cor_SOF ] = (*sync_frame   )[             sfm::sck::synchronize1 ::cor_SOF ];   // main_sched.cpp:208
     (*sync_frame   )[             sfm::sck::synchronize2 ::cor_PLSC] = (*sync_frame   )[             sfm::sck::synchronize1 ::cor_PLSC];   // main_sched.cpp:209
     (*pl_scrambler )[             scr::sck::descramble   ::Y_N1    ] = (*sync_frame   )[             sfm::sck::synchronize2 ::Y_N2    ];   // main_sched.cpp:210
@@ -176,8 +180,8 @@ static int run_matched_filter_graph(const std::string &modcod, int F, int n_ite,
     prb_bfer_ber    [spu::module::prb::sck::probe        ::in      ] = (*monitor      )[             mnt::sck::check_errors2::BER     ];   // main_sched.cpp:246
     prb_bfer_fer    [spu::module::prb::sck::probe        ::in      ] = (*monitor      )[             mnt::sck::check_errors2::FER     ];   // main_sched.cpp:247
 
-    spu::runtime::Sequence seq({&(*source)[spu::module::src::tsk::generate], &(*sync_coarse_f)(), &(*matched_flt)[flt::tsk::filter1], &(*matched_flt)[flt::tsk::filter2],
-                                &(*sync_timing)(), &(*sync_frame)[sfm::tsk::synchronize1], &(*sync_frame)[sfm::tsk::synchronize2], &(*pl_scrambler)(),
+    spu::runtime::Sequence seq({&(*source)[spu::module::src::tsk::generate], &(*front_agc)(), &(*sync_coarse_f)(), &(*matched_flt)[flt::tsk::filter1], &(*matched_flt)[flt::tsk::filter2],
+                                &(*sync_timing)(), &(*mult_agc)(), &(*sync_frame)[sfm::tsk::synchronize1], &(*sync_frame)[sfm::tsk::synchronize2], &(*pl_scrambler)(),
                                 &(*sync_fine_lr)(), &(*sync_fine_pf)(), &(*framer)(), &(*estimator)(), &(*modem)(), &(*itl_rx)(), &(*LDPC_decoder)(),
                                 &(*BCH_decoder)(), &(*bb_scrambler)(), &(*monitor)[mnt::tsk::check_errors2], &prb_bfer_be[spu::module::prb::tsk::probe],
                                 &prb_bfer_fe[spu::module::prb::tsk::probe], &prb_bfer_ber[spu::module::prb::tsk::probe], &prb_bfer_fer[spu::module::prb::tsk::probe]});
@@ -189,7 +193,12 @@ static int run_matched_filter_graph(const std::string &modcod, int F, int n_ite,
     size_t batches = 0;
     while (in.read(reinterpret_cast<char *>(rx_samples.data()), rx_samples.size() * sizeof(float))) {
         seq.exec_step();
-        if ((int)batches < mon_skip) monitor->reset();      // the synchronizers are still locking: keep these batches out of the statistics
+        if ((int)batches < mon_skip) monitor->reset();       // the synchronizers are still locking: keep these batches out of the statistics (the reference's waiting and learning phases)
+        // The fine frequency estimate of ONE frame is noisy (sigma ~2.5e-4 cycles per symbol at 16 dB against the +-3.4e-4 the pilot-aided stage can take back): it lives on its memory of
+        // alpha = 0.999.  In the reference the fine synchronizers do not run before the frame synchronizer has locked -- its learning phases 1 and 2 end at sync_frame
+        // (main_sched.cpp:454,535) -- and then settle for a learning phase 3 (:597-630) before anything is counted.  Here: the first half of --mon-skip is phases 1 and 2 (what the
+        // estimate saw of the unaligned frames is dropped), the second half is phase 3.
+        if ((int)batches < (mon_skip + 1) / 2) sync_fine_lr->reset();
         if (out.is_open())
             out.write(reinterpret_cast<const char *>((*bb_scrambler)[scr::sck::descramble::Y_N2].get_dataptr<int>()), (size_t)F * ctx->sz.K_bch * sizeof(int));
         batches++;

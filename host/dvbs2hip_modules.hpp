@@ -78,6 +78,8 @@ namespace flt { enum class tsk : size_t { filter, filter1, filter2, SIZE };
 namespace est { namespace sck { enum class estimate : size_t { X_N, SIG, Eb_N0, Es_N0, status }; } }
 namespace scr { namespace sck { enum class descramble : size_t { Y_N1, Y_N2, status }; } }
 namespace frm { namespace sck { enum class remove_plh : size_t { Y_N1, Y_N2, status }; } }
+// Multiplier.hpp:16-26 (tasks imultiply, multiply; the gain stage has the first)
+namespace mlt { enum class tsk : size_t { imultiply, multiply, SIZE }; namespace sck { enum class imultiply : size_t { X_N, Z_N, status }; } }
 // aff3ct Monitor_BFER (absent submodule): tasks check_errors and check_errors2, the latter bound by the RX mains (main_sched.cpp:222-223,244-247)
 namespace mnt { enum class tsk : size_t { check_errors, check_errors2, SIZE };
                 namespace sck { enum class check_errors : size_t { U, V, status };
@@ -277,6 +279,27 @@ public:
         });
     }
     void descramble(const float *Y_N1, float *Y_N2) { DVBS2HIP_CHK(ctx, dvbs2hip_pl_descramble(ctx->h, Y_N1, Y_N2, F())); }
+};
+
+// replaces Multiplier_AGC_cc_naive<R> (Multiplier_AGC_cc_naive.cpp:22-46; task "imultiply", sockets X_N / Z_N: Multiplier.hxx:49-60): N values per frame, as the reference's
+// constructor takes them -- 2 * pl_frame_size for `mult_agc` (DVBS2.cpp:653-657), 2 * pl_frame_size * osf with energy 1 / osf for `front_agc` (DVBS2.cpp:660-664)
+class Multiplier_AGC_hip : public Module_hip {
+public:
+    Multiplier_AGC_hip(std::shared_ptr<Context> c, int N, float output_energy = 1.f) : Module_hip(std::move(c), "Multiplier_AGC_hip"), N_(N), energy_(output_energy)
+    {
+        if (N <= 0 || N % 2) throw spu::tools::invalid_argument(__FILE__, __LINE__, __func__, "'N' has to be a positive even number of floats");
+        auto &t = create_task("imultiply");
+        auto s1 = create_socket_in<float>(t, "X_N", (size_t)N);
+        auto s2 = create_socket_out<float>(t, "Z_N", (size_t)N);
+        create_codelet(t, [s1, s2](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Multiplier_AGC_hip &>(m).imultiply(tk[s1].template get_dataptr<const float>(), tk[s2].template get_dataptr<float>());
+            return 0;
+        });
+    }
+    void imultiply(const float *X_N, float *Z_N) { DVBS2HIP_CHK(ctx, dvbs2hip_agc_imultiply(ctx->h, X_N, Z_N, N_ / 2, energy_, F())); }
+private:
+    int N_;
+    float energy_;
 };
 
 // replaces Framer<B>::remove_plh (Framer.hxx:330-343)

@@ -235,6 +235,16 @@ int dvbs2hip_set_filter_kernel(dvbs2hip_t *h, int32_t kernel);
 int dvbs2hip_estimate(dvbs2hip_t *h, const float *X_N, float *SIG, float *Eb_N0, float *Es_N0, int32_t n_frames);
 int dvbs2hip_estimate_dev(dvbs2hip_t *h, const float *X_N, float *SIG, float *Eb_N0, float *Es_N0, int32_t n_frames);
 
+/* ------------------------------------------------------------------ the gain stages of the RX graph
+ * replaces: Multiplier_AGC_cc_naive::imultiply -> _imultiply
+ * -- src/common/Module/Multiplier/Sequence/Multiplier_AGC_cc_naive.cpp:22-46 (task / sockets Multiplier.hxx:49-60): every frame is divided by its standard deviation
+ * about its mean over sqrt(output_energy).  The reference builds two: `front_agc` on the received samples (n_cplx = pl_frame * osf, output_energy = 1 / osf: DVBS2.cpp:660-664,
+ * bound RX/main_sched.cpp:197-198) and `mult_agc` on the symbols behind the timing synchronizer, in front of the frame synchronizer (n_cplx = pl_frame, output_energy = 1:
+ * DVBS2.cpp:653-657, bound RX/main_sched.cpp:205-207).  A frame of equal values divides by zero as it does there.
+ *   X_N: float[n_frames * 2*n_cplx]  ->  Z_N: same size                                                   */
+int dvbs2hip_agc_imultiply(dvbs2hip_t *h, const float *X_N, float *Z_N, int32_t n_cplx, float output_energy, int32_t n_frames);
+int dvbs2hip_agc_imultiply_dev(dvbs2hip_t *h, const float *X_N, float *Z_N, int32_t n_cplx, float output_energy, int32_t n_frames);
+
 /* ------------------------------------------------------------------ a7  PL descramble, header/pilot removal
  * replaces: Scrambler_PL<D>::descramble -> __scramble(scr_flag = false)
  * -- src/common/Module/Scrambler/Scrambler_PL/Scrambler_PL.hxx:61-78 (start_ix = 90)

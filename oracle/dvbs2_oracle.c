@@ -935,6 +935,19 @@ void orc_estimate(const float *x, int n_sym, float code_rate, int bps, float *ou
     out3[0] = sigma; out3[1] = ebn0; out3[2] = esn0;
 }
 
+void orc_agc(const float *x, int n_cplx, float output_energy, float *z)
+{
+    float sum_abs_2 = 0.0f, sum_re = 0.0f, sum_im = 0.0f;
+    for (int i = 0; i < n_cplx; i++) {
+        sum_abs_2 += x[2 * i] * x[2 * i] + x[2 * i + 1] * x[2 * i + 1];
+        sum_re += x[2 * i];
+        sum_im += x[2 * i + 1];
+    }
+    float std_xn = sqrtf(sum_abs_2 * (float)n_cplx - sum_re * sum_re - sum_im * sum_im) / (float)n_cplx;
+    std_xn /= sqrtf(output_energy);
+    for (int i = 0; i < n_cplx; i++) { z[2 * i] = x[2 * i] / std_xn; z[2 * i + 1] = x[2 * i + 1] / std_xn; }
+}
+
 void orc_rrc_taps(float rolloff, int osf, int grp, float *taps)
 {
     const float PI = (float)3.1415926535897932384626433832795;

@@ -102,6 +102,8 @@ void orc_framer_remove_plh(const float *plframe, int n_xfec_sym, float *xfec);
 int  orc_pl_frame_size(int n_xfec_sym);
 /* Estimator_DVBS2.hxx:31-58; out[0]=sigma out[1]=ebn0 out[2]=esn0 */
 void orc_estimate(const float *xfec, int n_sym, float code_rate, int bps, float *out3);
+/* Multiplier_AGC_cc_naive.cpp:22-46: one frame of n_cplx complex samples over its standard deviation about its mean, to `output_energy` (float sums in order, as there) */
+void orc_agc(const float *x, int n_cplx, float output_energy, float *z);
 /* Filter_RRC_ccr_naive.cpp:13-48 */
 void orc_rrc_taps(float rolloff, int osf, int grp_delay, float *taps);
 /* Filter_FIR_ccr.cpp:68-142 + .hpp:39-52: streaming FIR, hist = last (T-1) complex samples

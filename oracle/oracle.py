@@ -160,6 +160,7 @@ def lib():
         L.orc_framer_remove_plh.argtypes = [vp, ci, vp]
         L.orc_pl_frame_size.argtypes = [ci]
         L.orc_estimate.argtypes = [vp, ci, cf, ci, vp]
+        L.orc_agc.argtypes = [vp, ci, cf, vp]
         L.orc_rrc_taps.argtypes = [cf, ci, ci, vp]
         L.orc_fir.argtypes = [vp, ci, vp, vp, vp, ci]
         L.orc_upfir.argtypes = [vp, ci, ci, vp, vp, vp, ci]
@@ -398,6 +399,14 @@ def estimate(xfec, code_rate, bps):
     out = np.empty(3, dtype=np.float32)
     lib().orc_estimate(_p(xfec), xfec.size // 2, float(code_rate), bps, _p(out))
     return out   # sigma, ebn0, esn0
+
+
+def agc(x, output_energy=1.0):
+    """Multiplier_AGC_cc_naive::_imultiply on ONE frame of interleaved complex samples"""
+    x = _f32(x).ravel()
+    z = np.empty_like(x)
+    lib().orc_agc(_p(x), x.size // 2, float(output_energy), _p(z))
+    return z
 
 
 def rrc_taps(rolloff=0.2, osf=2, grp_delay=20):

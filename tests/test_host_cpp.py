@@ -139,7 +139,7 @@ def test_host_dvbs2_rx_graph_with_filter1_filter2_and_check_errors2(O, P, tmp_pa
     BE / FE / BER / FER sockets into probes) against the HIP modules: a shaped stream that starts mid-frame is filtered,
     aligned, corrected and decoded; the monitor (source delayed by the frame synchronizer's one frame) counts no error."""
     exe = build()
-    n_fr, off = 6 * F if F > 1 else 10, 1777
+    n_fr, off = 8 * F if F > 1 else 16, 1777
     info, pl, _, _ = make_pl_frames(O, modcod, n_fr, 14.0, seed=63)
     n = pl.shape[1] // 2
     stream = np.concatenate([np.zeros(2 * off, np.float32), pl.reshape(-1)])[:n_fr * 2 * n]
@@ -148,7 +148,7 @@ def test_host_dvbs2_rx_graph_with_filter1_filter2_and_check_errors2(O, P, tmp_pa
     pin, psrc, pout = (str(tmp_path / x) for x in ("rx.f32", "src.i32", "out.i32"))
     shaped.astype(np.float32).tofile(pin)
     info.astype(np.int32).tofile(psrc)
-    skip = 4 if F == 1 else 2
+    skip = 10 if F == 1 else 4          # batches of lock-in: half of them the frame synchronizer's, half the fine frequency estimate's settling (host/dvbs2_rx_bb.cpp, "learning phases")
     r = subprocess.run([exe, "--matched-filter", "--mod-cod", modcod, "-F", str(F), "--dec-implem", "NMS", "--dec-ite", "10", "--in", pin, "--src", psrc,
                         "--src-delay", "1", "--mon-skip", str(skip), "--out", pout], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr

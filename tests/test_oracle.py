@@ -278,3 +278,16 @@ def test_spa_tanh_check_node(O):
     assert 4 < len(steps) < 40 and max(np.diff(steps)) > 0.3          # a staircase: 2^-24 steps of the quotient
     z = O.chk_update(np.float32([0.0, 3.0, -2.0]), O.SPA_TANH)
     assert abs(abs(z[0]) - 16.6355) < 1e-3 and z[1] == 0.0 and z[2] == 0.0
+
+
+def test_agc_brings_every_frame_to_the_requested_energy(O):
+    """orc_agc = Multiplier_AGC_cc_naive::_imultiply (Multiplier_AGC_cc_naive.cpp:22-46): the output's variance about its mean is `output_energy`, the mean is scaled with the rest,
+    and scaling the input leaves the output where it was."""
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal(2 * 4212) * 3.3 + 0.4).astype(np.float32)
+    for e in (1.0, 0.5):
+        z = O.agc(x, e)
+        c = z[0::2].astype(np.float64) + 1j * z[1::2]
+        assert abs(np.mean(np.abs(c - c.mean()) ** 2) - e) < 1e-4 * e
+        assert np.max(np.abs(O.agc(x * np.float32(8.0), e) - z)) < 1e-5 * np.max(np.abs(z))
+    assert np.allclose(O.agc(x, 1.0) * np.float32(np.sqrt(0.5)), O.agc(x, 0.5), rtol=1e-6, atol=0)
