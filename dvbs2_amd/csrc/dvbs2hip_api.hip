@@ -119,6 +119,8 @@ struct dvbs2hip_handle {
     unsigned long long *h_red = nullptr;      // pinned: the reduced counters' way back (a copy into pageable memory would wait for the stream itself -- and for a dead peer for ever)
     int red_rank = 0, red_world = 1;
     // timing
+    float nco_nu = 0.f, nco_omega = 0.f;                   // Synchronizer_freq_coarse in the transmission phase: Multiplier_sine_ccc_naive's nu / omega and its sample counter n
+    uint32_t nco_n = 0;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[DVBS2HIP_K_COUNT];
     std::string err;
@@ -1509,6 +1511,44 @@ int dvbs2hip_agc_imultiply(dvbs2hip_t *h, const float *X, float *Z, int32_t n_cp
 {
     const size_t n = (size_t)2 * (n_cplx > 0 ? n_cplx : 0);
     return host_wrap<true>(h, X, n, Z, n, F, [&](const float *a, float *b, int nf) { return dvbs2hip_agc_imultiply_dev(h, a, b, n_cplx, output_energy, nf); });
+}
+
+// ------------------------------------------------------------------ Synchronizer_freq_coarse::synchronize in the transmission phase (the frequency shift; the loop that finds it is sample-serial)
+int dvbs2hip_sync_coarse_set_freq(dvbs2hip_t *h, float estimated_freq)
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    if (!(estimated_freq == estimated_freq) || fabsf(estimated_freq) > 0.5f) return fail(h, DVBS2HIP_EINVAL, "'estimated_freq' has to be a normalized frequency in [-0.5, 0.5]");
+    const float nu = -estimated_freq;                                  // Synchronizer_freq_coarse_DVBS2_aib.cpp:82: mult.set_nu(-estimated_freq)
+    const float new_nu = floorf(nu * 1e6f) / 1e6f;                     // Multiplier_sine_ccc_naive::set_nu, .cpp:44-51
+    h->nco_nu = new_nu;
+    h->nco_omega = (float)(2 * 3.1415926535897932384626433832795 * new_nu);
+    return 0;
+}
+int dvbs2hip_sync_coarse_reset(dvbs2hip_t *h)                          // Synchronizer_freq_coarse_DVBS2_aib::_reset, .cpp:123-135
+{
+    if (!h) return DVBS2HIP_EINVAL;
+    h->nco_n = 0; h->nco_nu = 0.f; h->nco_omega = 0.f;
+    return 0;
+}
+int dvbs2hip_sync_coarse_synchronize_dev(dvbs2hip_t *h, const float *X, float *FRQ, float *PHS, float *Y, int32_t n_cplx, int32_t F)
+{
+    int r = check_frames(h, F); if (r) return r;
+    if (!X || !Y) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
+    if (n_cplx < 1) return fail(h, DVBS2HIP_EINVAL, "'n_cplx' has to be greater than 0");
+    Timer tm(h, DVBS2HIP_K_MISC);
+    const long long total = (long long)n_cplx * F;
+    HIPCHK(h, nco_launch(X, Y, h->nco_omega, h->nco_n, total, FRQ, PHS, -h->nco_nu, F, h->stream));
+    h->nco_n = (uint32_t)(((unsigned long long)h->nco_n + (unsigned long long)total) % 1000000ull);
+    return 0;
+}
+int dvbs2hip_sync_coarse_synchronize(dvbs2hip_t *h, const float *X, float *FRQ, float *PHS, float *Y, int32_t n_cplx, int32_t F)
+{
+    const size_t n = (size_t)2 * (n_cplx > 0 ? n_cplx : 0);
+    // (one stream in order: the chunks of pinned sockets advance the sample counter as they come)
+    int r = host_wrap<true>(h, X, n, Y, n, F, [&](const float *a, float *b, int nf) { return dvbs2hip_sync_coarse_synchronize_dev(h, a, nullptr, nullptr, b, n_cplx, nf); });
+    if (r) return r;
+    for (int f = 0; f < F; f++) { if (FRQ) FRQ[f] = -h->nco_nu; if (PHS) PHS[f] = 0.f; }
+    return 0;
 }
 
 // ------------------------------------------------------------------ a7

@@ -243,6 +243,7 @@ hipError_t estimate_launch(const float *x, float *sig, float *ebn0, float *esn0,
                            int bps, int F, hipStream_t s);
 hipError_t pl_descramble_launch(const float *in, float *out, const uint8_t *seq, int pl_frame, int F, hipStream_t s);
 hipError_t agc_launch(const float *X, float *Z, int n_cplx, float output_energy, int F, hipStream_t s);      // k_agc.hip
+hipError_t nco_launch(const float *X, float *Z, float omega, uint32_t n0, long long total, float *FRQ, float *PHS, float frq, int F, hipStream_t s);    // k_agc.hip
 hipError_t remove_plh_launch(const float *in, float *out, int n_sym, int pl_frame, int F, hipStream_t s);
 hipError_t bb_descramble_launch(const int32_t *in, int32_t *out, const uint32_t *prbs, int K, int F, hipStream_t s);
 hipError_t monitor_launch(const int32_t *U, const int32_t *V, unsigned long long *ctr, int K, int F, hipStream_t s);

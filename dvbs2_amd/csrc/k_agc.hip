@@ -1,3 +1,5 @@
+// The two element-wise stages at the front of the reference's RX graph that are block-wise tasks: the gain stage and the frequency shift of the coarse synchronizer.
+//
 // Multiplier_AGC_cc_naive::_imultiply (src/common/Module/Multiplier/Sequence/Multiplier_AGC_cc_naive.cpp:22-46): every frame is brought to a given energy --
 //     std = sqrt(N sum|x|^2 - (sum re)^2 - (sum im)^2) / N / sqrt(output_energy),   z = x / std
 // (the frame's standard deviation about its mean).  The reference's RX graph runs it twice: `front_agc` on the received samples (2 pl_frame osf values per frame,
@@ -45,6 +47,30 @@ agc_kernel(const float2 *__restrict__ x, float2 *__restrict__ z, int n_cplx, flo
 hipError_t agc_launch(const float *X, float *Z, int n_cplx, float output_energy, int F, hipStream_t s)
 {
     hipLaunchKernelGGL(agc_kernel, dim3(F), dim3(AGC_THREADS), 0, s, reinterpret_cast<const float2 *>(X), reinterpret_cast<float2 *>(Z), n_cplx, output_energy);
+    return hipGetLastError();
+}
+
+// Synchronizer_freq_coarse_DVBS2_aib::_synchronize in the transmission phase = Multiplier_sine_ccc_naive::imultiply with the frequency the loop has settled on
+// (Synchronizer_freq_coarse_DVBS2_aib.cpp:43-50; Multiplier_sine_ccc_naive.cpp:69-77: phase = omega n in the module's float type, z = x (cos phase + j sin phase), n counts
+// the samples of the stream and starts over after 999999 -- nu is kept to six decimals, set_nu :44-51, so that omega 1e6 is a whole number of turns).  A block-wise task: the
+// phase of sample i is a closed form of the stream position, nothing is carried from sample to sample.
+__global__ void __launch_bounds__(256)
+nco_kernel(const float2 *__restrict__ x, float2 *__restrict__ z, float omega, uint32_t n0, long long total, float *FRQ, float *PHS, float frq, int F)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < F) { if (FRQ) FRQ[i] = frq; if (PHS) PHS[i] = 0.f; }      // the module's estimated_freq / estimated_phase per frame (Synchronizer_freq_coarse.hxx:40-47): constant while its loop does not run
+    if (i >= total) return;
+    const float n = (float)(uint32_t)(((unsigned long long)n0 + (unsigned long long)i) % 1000000ull);
+    const float phase = omega * n;
+    float sn, cs;
+    sincosf(phase, &sn, &cs);
+    const float2 v = x[i];
+    z[i] = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
+}
+
+hipError_t nco_launch(const float *X, float *Z, float omega, uint32_t n0, long long total, float *FRQ, float *PHS, float frq, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(nco_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float2 *>(X), reinterpret_cast<float2 *>(Z), omega, n0, total, FRQ, PHS, frq, F);
     return hipGetLastError();
 }
 

@@ -106,6 +106,10 @@ ABI = {
     "dvbs2hip_estimate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i]),
     "dvbs2hip_agc_imultiply": (C.c_int, [_vp, _vp, _vp, _i, C.c_float, _i]),
     "dvbs2hip_agc_imultiply_dev": (C.c_int, [_vp, _vp, _vp, _i, C.c_float, _i]),
+    "dvbs2hip_sync_coarse_set_freq": (C.c_int, [_vp, C.c_float]),
+    "dvbs2hip_sync_coarse_reset": (C.c_int, [_vp]),
+    "dvbs2hip_sync_coarse_synchronize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i]),
+    "dvbs2hip_sync_coarse_synchronize_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i]),
     "dvbs2hip_pl_descramble": (C.c_int, [_vp, _vp, _vp, _i]),
     "dvbs2hip_pl_descramble_dev": (C.c_int, [_vp, _vp, _vp, _i]),
     "dvbs2hip_remove_plh": (C.c_int, [_vp, _vp, _vp, _i]),

@@ -214,6 +214,21 @@ class Dvbs2Hip:
     def agc_dev(self, X, Z, n_cplx, output_energy, n_frames):
         self._chk(self.L.dvbs2hip_agc_imultiply_dev(self.h, _ptr(X), _ptr(Z), n_cplx, float(output_energy), n_frames))
 
+    def sync_coarse_set_freq(self, estimated_freq):
+        self._chk(self.L.dvbs2hip_sync_coarse_set_freq(self.h, float(estimated_freq)))
+
+    def sync_coarse_reset(self):
+        self._chk(self.L.dvbs2hip_sync_coarse_reset(self.h))
+
+    def sync_coarse_synchronize(self, X_N1, n_frames=1):
+        """the coarse frequency synchronizer's task in the transmission phase: the stream times exp(-j 2 pi estimated_freq n) -> (FRQ[F], PHS[F], Y_N2)"""
+        X = np.ascontiguousarray(X_N1, dtype=np.float32).ravel()
+        if X.size % (2 * n_frames):
+            raise ValueError("the socket does not hold %d frames of complex samples" % n_frames)
+        FRQ, PHS, Y = np.empty(n_frames, np.float32), np.empty(n_frames, np.float32), np.empty_like(X)
+        self._chk(self.L.dvbs2hip_sync_coarse_synchronize(self.h, _ptr(X), _ptr(FRQ), _ptr(PHS), _ptr(Y), X.size // (2 * n_frames), n_frames))
+        return FRQ, PHS, Y
+
     def pl_descramble(self, Y_N1):
         X, F = self._frames(Y_N1, 2 * self.pl_frame, np.float32)
         out = np.empty_like(X)

@@ -1,5 +1,5 @@
 """`dvbs2_rx` work-alike WITHOUT the sample-serial loops (timing recovery, coarse frequency: out of scope, SURVEY.md
-section 8): raw IQ file -> front gain stage (Multiplier_AGC, RX/main_sched.cpp:197) -> matched filter (a5) -> extraction at a known symbol phase -> gain stage
+section 8): raw IQ file -> front gain stage (Multiplier_AGC, RX/main_sched.cpp:197) -> coarse frequency shift (--coarse-freq; :198) -> matched filter (a5) -> extraction at a known symbol phase -> gain stage
 (main_sched.cpp:205) -> frame synchronizer (N4) -> pilot-aided phase synchronizer (N4, optional) -> fused RX chain (a7 .. a8) -> monitor against the source pattern -> sink.  It serves
 files made by `dvbs2_amd.tx` / `dvbs2_amd.ch` (or by the reference's dvbs2_tx / dvbs2_ch without timing or frequency
 offsets): README.md:151-169 of the reference.
@@ -38,6 +38,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--snk-path", default="", help="decoded payload of every frame, eight bits per byte (the reference's Sink_user_binary: a file sent with dvbs2_tx --src-type USER_BIN comes out as it went in)")
     ap.add_argument("--timing-offset", type=int, default=-1, help="sample index of the first symbol after the matched filter (default: two group delays)")
     ap.add_argument("--sync-fine", action="store_true", help="run the pilot-aided phase synchronizer before the chain")
+    ap.add_argument("--coarse-freq", type=float, default=0.0, help="carrier offset of the received samples in cycles per sample: the coarse frequency synchronizer's task of the transmission "
+                                                                   "phase (the frequency shift) with this as its loop's frozen estimate; the loop itself is sample-serial and out of scope")
     ap.add_argument("--no-agc", action="store_true", help="leave out the two gain stages of the reference's graph (front_agc on the samples, mult_agc on the symbols)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--sim-stats", action="store_true", help="per-kernel-group device time at the end (the reference's --sim-stats)")
@@ -54,6 +56,8 @@ def run(args, out=sys.stdout) -> dict:
     rx = Dvbs2Hip(mc.name, max_frames=F, n_ite=args.dec_ite, alpha=args.dec_alpha, early_stop=True, implem=args.dec_implem, device=args.device)
     if args.sim_stats:
         rx.timing_enable(True)
+    if args.coarse_freq:
+        rx.sync_coarse_set_freq(args.coarse_freq)
     rcv = RadioUserBinary(n * osf, input_filename=args.rad_rx_file_path, auto_reset=not args.rad_rx_no_loop, n_frames=F)
     snk = SinkUserBinary(args.snk_path, mc.K_bch) if args.snk_path else None
     off = args.timing_offset if args.timing_offset >= 0 else 2 * 20 * osf          # two group delays of grp_delay * osf samples
@@ -70,6 +74,8 @@ def run(args, out=sys.stdout) -> dict:
             x = x.astype(np.float32, copy=False)
             if not args.no_agc:
                 x = rx.agc(x, n_frames=F, output_energy=1.0 / osf)                  # front_agc: DVBS2.cpp:660-664
+            if args.coarse_freq:
+                _, _, x = rx.sync_coarse_synchronize(x, n_frames=F)                  # sync_coarse_f: RX/main_sched.cpp:198-200
             mf = np.concatenate([tail, rx.filter(x, n_frames=F).reshape(-1, 2)])
             mf, skip = mf[skip:], 0                                                # perfect timing: every osf-th sample from `off`
             n_sym = (mf.shape[0] // osf // n) * n                                  # whole frames of symbols

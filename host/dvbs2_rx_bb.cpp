@@ -77,26 +77,6 @@ public:
 };
 }}  // namespace spu::module
 namespace aff3ct { namespace module {
-namespace sfc { namespace sck { enum class synchronize : size_t { X_N1, FRQ, Y_N2, status }; } }
-namespace stm { namespace sck { enum class synchronize : size_t { X_N1, MU, Y_N1, B_N1, status }; enum class extract : size_t { B_N1, Y_N1, UFW, Y_N2, status }; } }
-class Sync_coarse_identity : public spu::module::Module {       // stand-in for Synchronizer_freq_coarse (PLL, out of scope): no frequency offset
-public:
-    Sync_coarse_identity(int N, int n_frames_)
-    {
-        n_frames = (size_t)n_frames_;
-        auto &t = create_task("synchronize");
-        auto sx = create_socket_in<float>(t, "X_N1", N);
-        auto sf = create_socket_out<float>(t, "FRQ", 1);
-        auto sy = create_socket_out<float>(t, "Y_N2", N);
-        create_codelet(t, [sx, sf, sy](spu::module::Module &, spu::runtime::Task &tk, size_t) -> int {
-            std::memcpy(tk[sy].get_dataptr(), tk[sx].get_dataptr(), tk[sy].get_databytes());
-            std::memset(tk[sf].get_dataptr(), 0, tk[sf].get_databytes());
-            return 0;
-        });
-    }
-    spu::runtime::Socket &operator[](sfc::sck::synchronize s) { return (*tasks[0])[(size_t)s]; }
-    spu::runtime::Task &operator()() { return *tasks[0]; }
-};
 class Sync_timing_perfect : public spu::module::Module {        // stand-in for Synchronizer_timing (Gardner, out of scope): even phase of osf = 2
 public:
     Sync_timing_perfect(int N_in, int osf, int n_frames_)
@@ -120,7 +100,7 @@ public:
 }}  // namespace aff3ct::module
 
 static int run_matched_filter_graph(const std::string &modcod, int F, int n_ite, float alpha, const std::string &implem, const std::string &in_path,
-                                    const std::string &out_path, const std::string &src_path, int src_delay, int mon_skip)
+                                    const std::string &out_path, const std::string &src_path, int src_delay, int mon_skip, float coarse_freq)
 {
     using namespace module;
     const int osf = 2;
@@ -130,7 +110,8 @@ static int run_matched_filter_graph(const std::string &modcod, int F, int n_ite,
     // modules: unique_ptr + the reference's variable names, so that the binding lines below are the reference's own
     std::unique_ptr<Multiplier_AGC_hip>          front_agc    (new Multiplier_AGC_hip(ctx, N_pl * osf, 1.f / (float)osf));                // DVBS2.cpp:660-664 (build_channel_agc)
     std::unique_ptr<Multiplier_AGC_hip>          mult_agc     (new Multiplier_AGC_hip(ctx, N_pl, 1.f));                                  // DVBS2.cpp:653-657 (build_agc_shift)
-    std::unique_ptr<Sync_coarse_identity>        sync_coarse_f(new Sync_coarse_identity(N_pl * osf, F));
+    std::unique_ptr<Synchronizer_freq_coarse_hip<>> sync_coarse_f(new Synchronizer_freq_coarse_hip<>(ctx, N_pl * osf));                  // the frequency shift of the transmission phase
+    sync_coarse_f->set_curr_freq(coarse_freq);                                                                                          // (what the reference's loop would have settled on: --coarse-freq)
     std::unique_ptr<Filter_FIR_hip>              matched_flt  (new Filter_FIR_hip(ctx, N_pl * osf));
     std::unique_ptr<Sync_timing_perfect>         sync_timing  (new Sync_timing_perfect(N_pl * osf, osf, F));
     std::unique_ptr<Synchronizer_frame_hip<>>    sync_frame   (new Synchronizer_frame_hip<>(ctx));
@@ -216,6 +197,7 @@ int main(int argc, char **argv)
 {
     std::string modcod = "QPSK-S_8/9", in_path, out_path, src_path, implem = "SPA";     // DVBS2.cpp:135-138: SPA, 50 iterations
     int F = 1, n_ite = 50, src_delay = 0, mon_skip = 0;
+    float coarse_freq = 0.f;
     float alpha = 1.0f;
     bool frame_sync = false, matched = false;
     for (int i = 1; i < argc; i++) {
@@ -231,12 +213,13 @@ int main(int argc, char **argv)
         else if (a == "--src") src_path = next();
         else if (a == "--src-delay") src_delay = std::stoi(next());
         else if (a == "--mon-skip") mon_skip = std::stoi(next());
+        else if (a == "--coarse-freq") coarse_freq = std::stof(next());      // normalized frequency offset of the received samples (cycles per sample): the coarse synchronizer's frozen estimate
         else if (a == "--frame-sync") frame_sync = true;
         else if (a == "--matched-filter") matched = true;
         else { std::cerr << "unknown argument " << a << "\n"; return 2; }
     }
     try {
-        if (matched) return run_matched_filter_graph(modcod, F, n_ite, alpha, implem, in_path, out_path, src_path, src_delay, mon_skip);
+        if (matched) return run_matched_filter_graph(modcod, F, n_ite, alpha, implem, in_path, out_path, src_path, src_delay, mon_skip, coarse_freq);
         auto ctx = std::make_shared<module::Context>(modcod, F, n_ite, alpha, true, 0, implem);
         ctx->pin_sockets = true;            // the sockets below live until the modules go: pin them for overlapped PCIe copies
         module::Scrambler_PL_hip pl_scrambler(ctx);

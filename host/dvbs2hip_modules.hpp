@@ -78,6 +78,8 @@ namespace flt { enum class tsk : size_t { filter, filter1, filter2, SIZE };
 namespace est { namespace sck { enum class estimate : size_t { X_N, SIG, Eb_N0, Es_N0, status }; } }
 namespace scr { namespace sck { enum class descramble : size_t { Y_N1, Y_N2, status }; } }
 namespace frm { namespace sck { enum class remove_plh : size_t { Y_N1, Y_N2, status }; } }
+// Synchronizer_freq_coarse.hpp:14-19
+namespace sfc { enum class tsk : size_t { synchronize, SIZE }; namespace sck { enum class synchronize : size_t { X_N1, FRQ, PHS, Y_N2, status }; } }
 // Multiplier.hpp:16-26 (tasks imultiply, multiply; the gain stage has the first)
 namespace mlt { enum class tsk : size_t { imultiply, multiply, SIZE }; namespace sck { enum class imultiply : size_t { X_N, Z_N, status }; } }
 // aff3ct Monitor_BFER (absent submodule): tasks check_errors and check_errors2, the latter bound by the RX mains (main_sched.cpp:222-223,244-247)
@@ -300,6 +302,33 @@ public:
 private:
     int N_;
     float energy_;
+};
+
+// replaces Synchronizer_freq_coarse<R> in the transmission phase: its task `synchronize` is the frequency shift alone (Synchronizer_freq_coarse_DVBS2_aib.cpp:43-50 ->
+// Multiplier_sine_ccc_naive::imultiply; sockets Synchronizer_freq_coarse.hxx:35-39).  The PLL that finds the frequency (update_phase, one step per pilot symbol fed back from the
+// timing synchronizer in the learning phases) is sample-serial and stays on the CPU: set_curr_freq() takes its result.  N values per frame (2 * pl_frame_size * osf: DVBS2.cpp build_synchronizer_freq_coarse)
+template <typename R = float>
+class Synchronizer_freq_coarse_hip : public Module_hip {
+public:
+    Synchronizer_freq_coarse_hip(std::shared_ptr<Context> c, int N) : Module_hip(std::move(c), "Synchronizer_freq_coarse_hip"), N_(N)
+    {
+        if (N <= 0 || N % 2) throw spu::tools::invalid_argument(__FILE__, __LINE__, __func__, "'N' has to be a positive even number of floats");
+        auto &t = create_task("synchronize");
+        auto sX = create_socket_in<R>(t, "X_N1", (size_t)N);
+        auto sF = create_socket_out<R>(t, "FRQ", 1);
+        auto sP = create_socket_out<R>(t, "PHS", 1);
+        auto sY = create_socket_out<R>(t, "Y_N2", (size_t)N);
+        create_codelet(t, [sX, sF, sP, sY](spu::module::Module &m, spu::runtime::Task &tk, size_t) -> int {
+            static_cast<Synchronizer_freq_coarse_hip &>(m).synchronize(tk[sX].template get_dataptr<const R>(), tk[sF].template get_dataptr<R>(), tk[sP].template get_dataptr<R>(),
+                                                                       tk[sY].template get_dataptr<R>());
+            return 0;
+        });
+    }
+    void synchronize(const R *X_N1, R *FRQ, R *PHS, R *Y_N2) { DVBS2HIP_CHK(ctx, dvbs2hip_sync_coarse_synchronize(ctx->h, X_N1, FRQ, PHS, Y_N2, N_ / 2, F())); }
+    void set_curr_freq(R estimated_freq) { DVBS2HIP_CHK(ctx, dvbs2hip_sync_coarse_set_freq(ctx->h, (float)estimated_freq)); }
+    void reset() { DVBS2HIP_CHK(ctx, dvbs2hip_sync_coarse_reset(ctx->h)); }
+private:
+    int N_;
 };
 
 // replaces Framer<B>::remove_plh (Framer.hxx:330-343)

@@ -245,6 +245,18 @@ int dvbs2hip_estimate_dev(dvbs2hip_t *h, const float *X_N, float *SIG, float *Eb
 int dvbs2hip_agc_imultiply(dvbs2hip_t *h, const float *X_N, float *Z_N, int32_t n_cplx, float output_energy, int32_t n_frames);
 int dvbs2hip_agc_imultiply_dev(dvbs2hip_t *h, const float *X_N, float *Z_N, int32_t n_cplx, float output_energy, int32_t n_frames);
 
+/* The coarse frequency synchronizer's task in the TRANSMISSION phase: the frequency shift alone
+ * replaces: Synchronizer_freq_coarse::synchronize -> Synchronizer_freq_coarse_DVBS2_aib::_synchronize = Multiplier_sine_ccc_naive::imultiply
+ * -- src/common/Module/Synchronizer/Synchronizer_freq/Synchronizer_freq_coarse/Synchronizer_freq_coarse_DVBS2_aib.cpp:43-50, Multiplier/Sine/Multiplier_sine_ccc_naive.cpp:69-77
+ * (sockets X_N1 / FRQ / PHS / Y_N2: Synchronizer_freq_coarse.hxx:35-39; bound RX/main_sched.cpp:198-200).  z_n = x_n exp(j omega n), n the position in the stream (it starts
+ * over after 999999; the frequency is kept to six decimals so that this is seamless).  The LOOP that finds the frequency (update_phase, :53-95, one step per pilot symbol fed back
+ * from the timing synchronizer) is sample-serial and out of scope: _set_freq takes what it, or anything else, has estimated.  FRQ / PHS per frame: that frequency and 0.
+ *   X_N1: float[n_frames * 2*n_cplx] -> Y_N2: same size (frames = consecutive stretches of ONE stream)             */
+int dvbs2hip_sync_coarse_set_freq(dvbs2hip_t *h, float estimated_freq);
+int dvbs2hip_sync_coarse_reset(dvbs2hip_t *h);
+int dvbs2hip_sync_coarse_synchronize(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t n_cplx, int32_t n_frames);
+int dvbs2hip_sync_coarse_synchronize_dev(dvbs2hip_t *h, const float *X_N1, float *FRQ, float *PHS, float *Y_N2, int32_t n_cplx, int32_t n_frames);
+
 /* ------------------------------------------------------------------ a7  PL descramble, header/pilot removal
  * replaces: Scrambler_PL<D>::descramble -> __scramble(scr_flag = false)
  * -- src/common/Module/Scrambler/Scrambler_PL/Scrambler_PL.hxx:61-78 (start_ix = 90)

@@ -948,6 +948,18 @@ void orc_agc(const float *x, int n_cplx, float output_energy, float *z)
     for (int i = 0; i < n_cplx; i++) { z[2 * i] = x[2 * i] / std_xn; z[2 * i + 1] = x[2 * i + 1] / std_xn; }
 }
 
+void orc_nco(const float *x, int n_cplx, float nu, float *n, float *z)
+{
+    const float new_nu = floorf(nu * 1e6f) / 1e6f;
+    const float omega = (float)(2 * 3.1415926535897932384626433832795 * new_nu);
+    for (int i = 0; i < n_cplx; i++) {
+        const float phase = omega * *n, c = cosf(phase), s = sinf(phase);
+        z[2 * i] = x[2 * i] * c - x[2 * i + 1] * s;
+        z[2 * i + 1] = x[2 * i] * s + x[2 * i + 1] * c;
+        *n = (*n >= 999999.f) ? 0.f : *n + 1.f;
+    }
+}
+
 void orc_rrc_taps(float rolloff, int osf, int grp, float *taps)
 {
     const float PI = (float)3.1415926535897932384626433832795;

@@ -104,6 +104,8 @@ int  orc_pl_frame_size(int n_xfec_sym);
 void orc_estimate(const float *xfec, int n_sym, float code_rate, int bps, float *out3);
 /* Multiplier_AGC_cc_naive.cpp:22-46: one frame of n_cplx complex samples over its standard deviation about its mean, to `output_energy` (float sums in order, as there) */
 void orc_agc(const float *x, int n_cplx, float output_energy, float *z);
+/* Multiplier_sine_ccc_naive.cpp:44-51,69-77 (set_nu, step): n_cplx samples of the stream from position *n on (updated), float throughout as in the module's <float> form */
+void orc_nco(const float *x, int n_cplx, float nu, float *n, float *z);
 /* Filter_RRC_ccr_naive.cpp:13-48 */
 void orc_rrc_taps(float rolloff, int osf, int grp_delay, float *taps);
 /* Filter_FIR_ccr.cpp:68-142 + .hpp:39-52: streaming FIR, hist = last (T-1) complex samples

@@ -161,6 +161,7 @@ def lib():
         L.orc_pl_frame_size.argtypes = [ci]
         L.orc_estimate.argtypes = [vp, ci, cf, ci, vp]
         L.orc_agc.argtypes = [vp, ci, cf, vp]
+        L.orc_nco.argtypes = [vp, ci, cf, vp, vp]
         L.orc_rrc_taps.argtypes = [cf, ci, ci, vp]
         L.orc_fir.argtypes = [vp, ci, vp, vp, vp, ci]
         L.orc_upfir.argtypes = [vp, ci, ci, vp, vp, vp, ci]
@@ -407,6 +408,15 @@ def agc(x, output_energy=1.0):
     z = np.empty_like(x)
     lib().orc_agc(_p(x), x.size // 2, float(output_energy), _p(z))
     return z
+
+
+def nco(x, nu, n0=0.0):
+    """Multiplier_sine_ccc_naive::imultiply on a stretch of the stream that starts at position n0 -> (z, position behind it)"""
+    x = _f32(x).ravel()
+    z = np.empty_like(x)
+    n = np.array([n0], dtype=np.float32)
+    lib().orc_nco(_p(x), x.size // 2, float(nu), _p(n), _p(z))
+    return z, float(n[0])
 
 
 def rrc_taps(rolloff=0.2, osf=2, grp_delay=20):

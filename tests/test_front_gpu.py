@@ -192,3 +192,35 @@ def test_agc_matches_oracle(O, Rx, n_cplx, energy, F):
     with pytest.raises(Exception):
         rx.agc(x, n_frames=F, output_energy=0.0)
     rx.close()
+
+
+def test_coarse_frequency_shift_matches_oracle_across_calls_and_the_counter_wrap(O, Rx):
+    """Synchronizer_freq_coarse::synchronize in the transmission phase = Multiplier_sine_ccc_naive::imultiply (Synchronizer_freq_coarse_DVBS2_aib.cpp:43-50): the stream times
+    exp(j omega n) with omega = 2 pi floor(-f 1e6) / 1e6 in float and n the stream position, which starts over after 999999.  Against the oracle's sample-by-sample restatement
+    (same float phase, libm's cosf / sinf): 2e-6 of the largest sample; the position carries from call to call and across the wrap; FRQ / PHS report the frequency and 0."""
+    rng = np.random.default_rng(5)
+    n_cplx, F = 33480, 8                                                    # QPSK-S at osf 2: 267840 samples per call, the fourth call crosses n = 1e6
+    f_est = 0.0123456789
+    rx = Rx("QPSK-S_8/9", max_frames=F)
+    rx.sync_coarse_set_freq(f_est)
+    pos = 0.0
+    for call in range(5):
+        x = rng.standard_normal(2 * n_cplx * F).astype(np.float32)
+        FRQ, PHS, y = rx.sync_coarse_synchronize(x, n_frames=F)
+        yo, pos = O.nco(x, -f_est, pos)
+        assert np.max(np.abs(y - yo)) <= 2e-6 * np.max(np.abs(x)), call
+        assert np.all(FRQ == np.float32(-np.floor(np.float32(-f_est) * np.float32(1e6)) / np.float32(1e6))) and not PHS.any()
+    assert pos == (5 * n_cplx * F) % 1000000
+    # a shifted stream comes back: the channel's shift by +f, then the synchronizer set to f
+    rx.sync_coarse_reset()
+    x = rng.standard_normal(2 * n_cplx * F).astype(np.float32)
+    f = 0.001234
+    t = np.arange(n_cplx * F, dtype=np.float64)
+    c = (x[0::2] + 1j * x[1::2]) * np.exp(2j * np.pi * f * t)
+    sh = np.empty_like(x); sh[0::2] = c.real; sh[1::2] = c.imag
+    rx.sync_coarse_set_freq(f)
+    _, _, back = rx.sync_coarse_synchronize(sh, n_frames=F)
+    assert np.max(np.abs(back - x)) < 2e-3 * np.max(np.abs(x))              # (float phase omega n at n ~ 2.7e5: 1e-4 rad)
+    with pytest.raises(Exception):
+        rx.sync_coarse_set_freq(0.7)
+    rx.close()

@@ -132,8 +132,8 @@ def test_cpp_tx_rx_bb_the_references_decoder_as_recalled_and_the_default_lose_th
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("modcod,F", [("QPSK-S_8/9", 1), ("QPSK-S_8/9", 4), ("16APSK-S_8/9", 2)])
-def test_host_dvbs2_rx_graph_with_filter1_filter2_and_check_errors2(O, P, tmp_path, modcod, F):
+@pytest.mark.parametrize("modcod,F,cfo", [("QPSK-S_8/9", 1, 0.0), ("QPSK-S_8/9", 4, 0.0), ("16APSK-S_8/9", 2, 0.0), ("QPSK-S_8/9", 4, 0.012345)])
+def test_host_dvbs2_rx_graph_with_filter1_filter2_and_check_errors2(O, P, tmp_path, modcod, F, cfo):
     """The dvbs2_rx graph from the matched filter to the monitor, bound with the reference's own lines
     (src/mains/RX/main_sched.cpp:199-201 filter1 / filter2 / Y_N2h, :206-222 frame sync .. monitor check_errors2, :244-247 the
     BE / FE / BER / FER sockets into probes) against the HIP modules: a shaped stream that starts mid-frame is filtered,
@@ -145,12 +145,15 @@ def test_host_dvbs2_rx_graph_with_filter1_filter2_and_check_errors2(O, P, tmp_pa
     stream = np.concatenate([np.zeros(2 * off, np.float32), pl.reshape(-1)])[:n_fr * 2 * n]
     taps = P.rrc_taps(0.2, 2, 20)
     shaped = O.upfir(taps, 2, np.zeros(2 * 80, np.float32), stream)              # TX shaping filter, 2 samples per symbol
+    if cfo:       # a carrier offset of `cfo` cycles per sample, which the coarse synchronizer of the transmission phase (its loop's estimate frozen: --coarse-freq) takes out again
+        c = (shaped[0::2] + 1j * shaped[1::2]) * np.exp(2j * np.pi * cfo * np.arange(shaped.size // 2, dtype=np.float64))
+        shaped = np.empty_like(shaped); shaped[0::2] = c.real; shaped[1::2] = c.imag
     pin, psrc, pout = (str(tmp_path / x) for x in ("rx.f32", "src.i32", "out.i32"))
     shaped.astype(np.float32).tofile(pin)
     info.astype(np.int32).tofile(psrc)
     skip = 10 if F == 1 else 4          # batches of lock-in: half of them the frame synchronizer's, half the fine frequency estimate's settling (host/dvbs2_rx_bb.cpp, "learning phases")
     r = subprocess.run([exe, "--matched-filter", "--mod-cod", modcod, "-F", str(F), "--dec-implem", "NMS", "--dec-ite", "10", "--in", pin, "--src", psrc,
-                        "--src-delay", "1", "--mon-skip", str(skip), "--out", pout], capture_output=True, text=True)
+                        "--src-delay", "1", "--mon-skip", str(skip), "--out", pout, "--coarse-freq", repr(cfo)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     fra = n_fr - skip * F
     assert "FRA %d BE 0 FE 0" % fra in r.stdout, r.stdout
