@@ -25,6 +25,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <iterator>
 #include <string>
 #include <vector>
 #include "../include/dvbs2hip.h"
@@ -38,8 +40,9 @@ int main(int argc, char **argv)
     double ebn0_min = 3.2, ebn0_max = 6.0, step = 0.1;     // DVBS2.cpp:121-123
     int F = 512, n_ite = 50, max_fe = 100, n_clones = 3;   // DVBS2.cpp:135-142 (implem SPA, 50 ite, 100 frame errors)
     long long max_frames = 10000000;
-    int reduce_timeout_ms = 120000;
-    bool sim_stats = false;      // rendezvous and every later reduction: a rank whose peers do not arrive leaves with exit code 4
+    int reduce_timeout_ms = 120000;      // rendezvous and every later reduction: a rank whose peers do not arrive leaves with exit code 4
+    bool sim_stats = false, src_no_loop = false;
+    std::string src_type = "RAND", src_path;      // DVBS2.cpp:66,359-376: RAND = the TX mirror's own generator on the device; USER / USER_BIN / AZCW: payloads made here, handed to its `info_in` socket
     float alpha = 1.0f;
     auto env_int = [](const char *n, int d) { const char *v = std::getenv(n); return v && *v ? std::atoi(v) : d; };
     int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0), local_rank = env_int("LOCAL_RANK", -1);
@@ -65,6 +68,10 @@ int main(int argc, char **argv)
         else if (a == "--local-rank") local_rank = std::atoi(next());
         else if (a == "--rendezvous") rendezvous = next();
         else if (a == "--reduce-timeout-ms") reduce_timeout_ms = std::atoi(next());
+        else if (a == "--src-type") src_type = next();
+        else if (a == "--src-path") src_path = next();
+        else if (a == "--src-no-loop") src_no_loop = true;
+        else if (a == "--ter-freq") (void)next();                               // accepted and ignored: a row is printed when its noise point is done
         else if (a == "--sim-stats") sim_stats = true;                         // TX_RX_BB/main.cpp:110,170-178: per-task statistics at the end
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -78,7 +85,9 @@ int main(int argc, char **argv)
     cfg.ldpc_implem = implem == "SPA" ? DVBS2HIP_IMPLEM_SPA : implem == "SPA_TANH" ? DVBS2HIP_IMPLEM_SPA_TANH : implem == "SPA_EXACT" ? DVBS2HIP_IMPLEM_SPA_EXACT : implem == "MS" ? DVBS2HIP_IMPLEM_MS : DVBS2HIP_IMPLEM_NMS;
     if (implem != "SPA" && implem != "SPA_TANH" && implem != "SPA_EXACT" && implem != "MS" && implem != "NMS") { std::fprintf(stderr, "--dec-implem has to be SPA, SPA_TANH, SPA_EXACT, MS or NMS\n"); return 2; }
     if (n_clones < 1 || n_clones > 8) { std::fprintf(stderr, "--clones has to be 1 .. 8\n"); return 2; }
-    struct Clone { dvbs2hip_t *h = nullptr; void *d_pl = nullptr, *d_sent = nullptr, *d_got = nullptr, *d_sig = nullptr; uint64_t c[3] = {0, 0, 0}; bool busy = false; };
+    struct Clone { dvbs2hip_t *h = nullptr; void *d_pl = nullptr, *d_sent = nullptr, *d_got = nullptr, *d_sig = nullptr, *d_info = nullptr; uint64_t c[3] = {0, 0, 0}; bool busy = false; };
+    if (src_type != "RAND" && src_type != "USER" && src_type != "USER_BIN" && src_type != "AZCW") { std::fprintf(stderr, "--src-type has to be RAND, USER, USER_BIN or AZCW\n"); return 2; }
+    if ((src_type == "USER" || src_type == "USER_BIN") && src_path.empty()) { std::fprintf(stderr, "--src-type %s needs --src-path\n", src_type.c_str()); return 2; }
     std::vector<Clone> cl((size_t)n_clones);
     dvbs2hip_sizes sz;
     const bool reduce = world > 1 || std::getenv("DVBS2HIP_FORCE_RCCL");
@@ -95,7 +104,43 @@ int main(int argc, char **argv)
         CHK(dvbs2hip_malloc(h, &cl[k].d_sent, (size_t)F * sz.K_bch * sizeof(int32_t)));
         CHK(dvbs2hip_malloc(h, &cl[k].d_got, (size_t)F * sz.K_bch * sizeof(int32_t)));
         CHK(dvbs2hip_malloc(h, &cl[k].d_sig, (size_t)F * sizeof(float)));
+        if (src_type != "RAND") CHK(dvbs2hip_malloc(h, &cl[k].d_info, (size_t)F * sz.K_bch * sizeof(int32_t)));
     }
+    // the payload sources of the reference that are files or constants (the modules themselves are StreamPU's): Source_user = text, `n_frames`, `K`, then the bits, cycled through;
+    // Source_user_binary = any file, eight payload bits per byte, least significant first, started over at its end (--src-no-loop: last frame zero-padded, then done); Source_AZCW = zeros
+    std::vector<int32_t> pattern;      // USER: [n_pat][K_bch]
+    std::vector<unsigned char> blob;   // USER_BIN
+    size_t n_pat = 0, src_pos = 0;
+    bool src_done = false;
+    if (src_type == "USER") {
+        std::ifstream f(src_path);
+        long long np = 0, k = 0;
+        if (!(f >> np >> k) || np < 1 || k != sz.K_bch) { std::fprintf(stderr, "'%s' is not a source pattern file of %d-bit frames\n", src_path.c_str(), (int)sz.K_bch); return 2; }
+        pattern.resize((size_t)np * sz.K_bch);
+        for (auto &b : pattern) { int v; if (!(f >> v) || (v != 0 && v != 1)) { std::fprintf(stderr, "'%s' is truncated or holds something else than bits\n", src_path.c_str()); return 2; } b = v; }
+        n_pat = (size_t)np;
+    } else if (src_type == "USER_BIN") {
+        std::ifstream f(src_path, std::ios::binary);
+        blob.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        if (blob.empty() || sz.K_bch % 8) { std::fprintf(stderr, "'%s' is empty or unreadable\n", src_path.c_str()); return 2; }
+    }
+    std::vector<int32_t> h_info(src_type == "RAND" ? 0 : (size_t)F * sz.K_bch, 0);
+    auto generate = [&]() -> bool {      // the next F frames into h_info; false: the source is done
+        if (src_type == "USER") {
+            for (int f = 0; f < F; f++) { std::memcpy(&h_info[(size_t)f * sz.K_bch], &pattern[(src_pos % n_pat) * sz.K_bch], (size_t)sz.K_bch * sizeof(int32_t)); src_pos++; }
+        } else if (src_type == "USER_BIN") {
+            if (src_done) return false;
+            const size_t nb = (size_t)F * sz.K_bch / 8;
+            for (size_t i = 0; i < nb; i++) {
+                unsigned char byte = 0;
+                if (!src_no_loop) { byte = blob[src_pos % blob.size()]; src_pos++; }
+                else if (src_pos < blob.size()) byte = blob[src_pos++];
+                for (int b = 0; b < 8; b++) h_info[i * 8 + b] = (byte >> b) & 1;
+            }
+            if (src_no_loop && src_pos >= blob.size()) src_done = true;
+        }
+        return true;                     // (AZCW: h_info stays zero)
+    };
     const bool chief = rank == 0;
 
     if (chief) std::printf("# * DVB-S2 (HIP) ------------------------------------\n#    ** Modulation and coding = %s\n#    ** LDPC implem           = %s\n"
@@ -111,6 +156,7 @@ int main(int argc, char **argv)
         const float sigma = (float)std::sqrt(1.0 / (2.0 * std::pow(10.0, esn0 / 10.0)));
         std::vector<float> sig(F, sigma);
         for (auto &k : cl) { h = k.h; CHK(dvbs2hip_memcpy_h2d(h, k.d_sig, sig.data(), sig.size() * sizeof(float))); CHK(dvbs2hip_monitor_reset(h)); k.c[0] = k.c[1] = k.c[2] = 0; k.busy = false; }
+        src_pos = 0; src_done = false;                                          // the source starts over at every noise point
         uint64_t c[3] = {0, 0, 0};
         // a clone's counters run on the device from the reset above; the sum over the clones of what each one last reported is what the stopping rule sees
         auto collect = [&](Clone &k) -> int {
@@ -126,7 +172,11 @@ int main(int argc, char **argv)
             if (k.busy) { const int rc = collect(k); if (rc) return rc; }
             if (c[2] >= (uint64_t)max_fe || (long long)c[0] >= max_frames) break;     // Monitor_BFER: stop at max_fe (DVBS2.cpp:136)
             h = k.h;
-            CHK(dvbs2hip_tx_bb_dev(h, nullptr, (batch++ << 8), (const float *)k.d_sig, (int32_t *)k.d_sent, (float *)k.d_pl, F));
+            if (src_type != "RAND") {
+                if (!generate()) break;                                         // --src-type USER_BIN --src-no-loop: the file has been sent
+                CHK(dvbs2hip_memcpy_h2d(h, k.d_info, h_info.data(), h_info.size() * sizeof(int32_t)));      // (returns when the copy is done: h_info is free for the next clone)
+            }
+            CHK(dvbs2hip_tx_bb_dev(h, (const int32_t *)k.d_info, (batch++ << 8), (const float *)k.d_sig, (int32_t *)k.d_sent, (float *)k.d_pl, F));
             CHK(dvbs2hip_rx_bb_dev(h, (const float *)k.d_pl, est == "PERFECT" ? (const float *)k.d_sig : nullptr, (int32_t *)k.d_got, nullptr, nullptr, F));
             CHK(dvbs2hip_monitor_check_errors_dev(h, (const int32_t *)k.d_sent, (const int32_t *)k.d_got, F));
             k.busy = true;
@@ -149,6 +199,6 @@ int main(int argc, char **argv)
                     "# -------------------------------------------------||------------||------------||---------\n");
         for (int g = 0; g < DVBS2HIP_K_COUNT; g++) if (n[g]) std::printf("# %48s || %10lld || %10.2f || %6.1f %%\n", names[g], n[g], ms[g], 100.0 * ms[g] / (all > 0 ? all : 1));
     }
-    for (auto &k : cl) { dvbs2hip_free(k.h, k.d_pl); dvbs2hip_free(k.h, k.d_sent); dvbs2hip_free(k.h, k.d_got); dvbs2hip_free(k.h, k.d_sig); dvbs2hip_destroy(k.h); }
+    for (auto &k : cl) { if (k.d_info) dvbs2hip_free(k.h, k.d_info); dvbs2hip_free(k.h, k.d_pl); dvbs2hip_free(k.h, k.d_sent); dvbs2hip_free(k.h, k.d_got); dvbs2hip_free(k.h, k.d_sig); dvbs2hip_destroy(k.h); }
     return 0;
 }

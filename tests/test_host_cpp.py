@@ -86,6 +86,34 @@ def test_cpp_tx_rx_bb_reproduces_a_reference_row(clones):
 
 
 @pytest.mark.gpu
+def test_cpp_tx_rx_bb_payload_sources(tmp_path):
+    """--src-type of the reference's simulator (DVBS2.cpp:66,359-376) in the C++ work-alike: the pattern file, a binary file and all-zero payloads go through the TX mirror's
+    `info_in` socket and lose frames at the rate of the device's own random payloads (linear code, symmetric channel: within 4 sigma at ~5 % FER); a binary file sent once ends its
+    noise point by itself."""
+    import math
+    from dvbs2_amd.srcfile import save_src
+    build()
+    exe = os.path.join(ROOT, "host", "dvbs2_tx_rx_bb")
+    bits = np.unpackbits(np.load(os.path.join(ROOT, "tests", "golden", "src_K_14232.npy")))[:14232].astype(np.int32)
+    f_src, f_bin = str(tmp_path / "K_14232.src"), str(tmp_path / "any.bin")
+    save_src(f_src, bits)
+    np.random.default_rng(4).integers(0, 256, 200 * 1779 + 77, dtype=np.uint8).tofile(f_bin)
+    def run(*extra, frames=16384):
+        r = subprocess.run([exe, "--mod-cod", "QPSK-S_8/9", "-m", "3.70", "-M", "3.71", "--dec-implem", "SPA", "--dec-ite", "50", "-F", "1024", "-e", "100000000", "--max-frames", str(frames),
+                            "--clones", "1"] + list(extra), capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        f = [x.strip() for x in [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("#")][0].replace("||", "|").split("|")]
+        return int(f[2]), int(f[4])
+    rows = [run(), run("--src-type", "AZCW"), run("--src-type", "USER", "--src-path", f_src), run("--src-type", "USER_BIN", "--src-path", f_bin)]
+    assert all(fra == 16384 and fe > 500 for fra, fe in rows), rows
+    for fra, fe in rows[1:]:
+        assert abs(math.log(fe / rows[0][1])) < 4.0 * math.sqrt(1.0 / fe + 1.0 / rows[0][1]), rows
+    assert run("--src-type", "USER_BIN", "--src-path", f_bin, "--src-no-loop", frames=10 ** 9)[0] == 1024
+    r = subprocess.run([exe, "--src-type", "USER"], capture_output=True, text=True)
+    assert r.returncode == 2 and "--src-path" in r.stderr
+
+
+@pytest.mark.gpu
 def test_sim_stats_tables_of_both_simulators():
     """--sim-stats (TX_RX_BB/main.cpp:110,170-178: per-task statistics at the end of the simulation): both simulators print the device time per kernel group from the
     library's hipEvent timers, summed over their clones; the LDPC decoder is the largest group, one launch per batch."""
