@@ -164,7 +164,7 @@ def test_qpsk_general_demapper_equals_the_linear_form(O, Rx, modcod, monkeypatch
     assert np.all(np.abs(res[True] - res[False]) <= 1e-4 * np.maximum(1.0, np.abs(res[False])))
 
 
-@pytest.mark.parametrize("n_cplx,energy,F", [(8370, 1.0, 5), (2 * 8370, 0.5, 3), (3402, 1.0, 64), (33282, 1.0, 2), (7, 2.0, 4)])
+@pytest.mark.parametrize("n_cplx,energy,F", [(8370, 1.0, 5), (2 * 8370, 0.5, 3), (3402, 1.0, 64), (33282, 1.0, 2), (7, 2.0, 4), (18000, 1.0, 2), (20480, 1.0, 2), (20481, 1.0, 2)])
 def test_agc_matches_oracle(O, Rx, n_cplx, energy, F):
     """Multiplier_AGC_cc_naive::imultiply (the reference's `front_agc` on 2 pl_frame osf values at energy 1 / osf, `mult_agc` on 2 pl_frame values at energy 1; RX/main_sched.cpp:197,205):
     every frame over its own standard deviation.  The reference adds its floats in order, the kernel sums in double over a fixed tree: the gain agrees with the oracle's float
