@@ -116,7 +116,7 @@ def test_in_scope_synchronizers_in_the_loop_at_the_operating_point():
     from dvbs2_amd.receiver import Dvbs2Hip
     from dvbs2_amd import params as P
     mc = P.get_modcod("QPSK-S_8/9")
-    a = types.SimpleNamespace(F=256, off=1234, phase=0.7, freq=1e-4, seed=3, fe=250, max_frames=20000, skip=32, est_perfect=False)
+    a = types.SimpleNamespace(F=256, off=1234, phase=0.7, freq=1e-4, seed=3, fe=250, max_frames=20000, skip=32, est_perfect=False, agc=False)
     fr = S.run_point(Dvbs2Hip, P, mc, 3.7, "frame", a)
     fi = S.run_point(Dvbs2Hip, P, mc, 3.7, "fine", a)
     assert fr["moved"] == 0 and fi["moved"] == 0 and fr["delay"] == fi["delay"] == 1234 + 40            # the two filters' 40 symbols are part of the frame start it finds

@@ -67,8 +67,10 @@ def build(tag):
             j = json.load(open(fn))
             for r in j["rows"]:
                 x = interp_db(gen, r["fer"])
-                out.append("| %.1f | %s | %s | %.3g (%d / %d) | %.3g | %s | %s | %d times |" % (r["ebn0"], r["variant"], "--" if r["variant"] == "frame" else "%g" % j["args"]["freq"], r["fer"], r["fe"], r["counted"],
+                out.append("| %.1f | %s | %s | %.3g (%d / %d) | %.3g | %s | %s | %d times |" % (r["ebn0"], r["variant"] + (" + gain stages" if j["args"].get("agc") else ""), "--" if r["variant"] == "frame" else "%g" % j["args"]["freq"], r["fer"], r["fe"], r["counted"],
                            gmap[round(r["ebn0"], 2)]["fer"], "%.3f dB" % x if x else "--", "%.3f dB" % (r["ebn0"] - x) if x else "--", r["moved"]))
+        out += ["", "(`+ gain stages`: the reference's `front_agc` and `mult_agc` in the loop as well, `--agc`: they bring signal PLUS noise to unit energy, so the constellation the demapper assumes is "
+                "1 / sqrt(1 + N0 / Es) too large -- immaterial for QPSK, 1.4 x the frame errors = 0.015 dB on 16APSK at 12.9 dB, last table.)"]
         out += ["", "The frame synchronizer costs nothing (it holds its alignment through every run, and the FER is the genie loop's to within the counting error).  "
                 "The fine synchronizers cost 0.05-0.06 dB whatever the frequency offset up to 5e-4 cycles per symbol (Luise-Reggiannini removes it): that is the noise of a phase estimate from 36 pilot symbols -- "
                 "variance 1 / (2 . 36 . Es/N0) = 0.0033 rad^2 at 6.25 dB, i.e. crosstalk 25 dB below the signal, 0.06 dB on top of the channel's noise.  These kernels match "
@@ -84,7 +86,7 @@ def build(tag):
             b = json.load(open(fn[:-5] + "_bb.json"))["rows"][0]
             r = {x["variant"]: x for x in j["rows"]}
             fr, fi = r["frame"], r["fine"]
-            out.append("| %s | %.1f (%.2f) | %.3g (%d / %d) | %.3g (%d / %d), %.2f +- %.2f | %.3g (%d / %d), %.1f x |" % (j["args"]["mod_cod"], fr["ebn0"], b["esn0"], b["fer"], b["fe"], b["fra"],
+            out.append("| %s | %.1f (%.2f) | %.3g (%d / %d) | %.3g (%d / %d), %.2f +- %.2f | %.3g (%d / %d), %.1f x |" % (j["args"]["mod_cod"] + (" + gain stages" if j["args"].get("agc") else ""), fr["ebn0"], b["esn0"], b["fer"], b["fe"], b["fra"],
                        fr["fer"], fr["fe"], fr["counted"], fr["fer"] / b["fer"], fr["fer"] / b["fer"] * math.sqrt(1.0 / fr["fe"] + 1.0 / b["fe"]), fi["fer"], fi["fe"], fi["counted"], fi["fer"] / b["fer"]))
         out += ["", "Again the frame synchronizer is free.  Read against the slopes of the reference's own baseband traces (`refs/TX_RX_BB/*.txt`: 7-15 x in FER per 0.1 dB at these points) the fine "
                 "synchronizers cost 0.09 dB on QPSK 3/5, 0.10 / 0.09 dB on 8PSK 3/5 / 8/9 and 0.13 dB on 16APSK 8/9 -- more than QPSK 8/9's 0.06 dB, as it must be: the estimate's variance "

@@ -36,8 +36,13 @@ def run_point(Rx, P, mc, ebn0, variant, a):
             s = s * np.exp(1j * (a.phase + 2.0 * np.pi * a.freq * t))
         x = np.empty((F * n, 2), np.float32); x[:, 0] = s.real; x[:, 1] = s.imag
         up = rx.shape_filter(x, n_frames=F, osf=2)
-        mf = rx.filter(rx.add_noise(sigma, up, seed=(a.seed << 20) + k, n_frames=F), n_frames=F).reshape(-1, 2)
+        noisy = rx.add_noise(sigma, up, seed=(a.seed << 20) + k, n_frames=F)
+        if a.agc:
+            noisy = rx.agc(noisy, n_frames=F, output_energy=0.5)                        # front_agc (RX/main_sched.cpp:197; DVBS2.cpp:660-664)
+        mf = rx.filter(noisy, n_frames=F).reshape(-1, 2)
         sym = np.ascontiguousarray(mf[0::2]).reshape(F, 2 * n)                         # the two filters delay the stream by 40 symbols: part of the unknown frame start
+        if a.agc:
+            sym = rx.agc(sym, n_frames=F, output_energy=1.0).reshape(F, 2 * n)          # mult_agc (main_sched.cpp:205; DVBS2.cpp:653-657)
         delay, flags, tri, aligned = rx.sync_frame_synchronize(sym, with_flags=True)
         if variant == "frame":
             bits, _, _ = rx.rx_bb(aligned, sigma=sigma if a.est_perfect else None)
@@ -79,6 +84,7 @@ def main():
     ap.add_argument("--freq", type=float, default=2e-5)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--est-perfect", action="store_true", help="the channel's sigma instead of the M2M4 estimate (the reference's 16APSK trace: --est-type PERFECT)")
+    ap.add_argument("--agc", action="store_true", help="the reference's two gain stages in the loop (front_agc on the samples, mult_agc on the symbols)")
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
     from dvbs2_amd.receiver import Dvbs2Hip
