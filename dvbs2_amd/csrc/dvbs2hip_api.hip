@@ -1535,6 +1535,7 @@ int dvbs2hip_sync_coarse_synchronize_dev(dvbs2hip_t *h, const float *X, float *F
     int r = check_frames(h, F); if (r) return r;
     if (!X || !Y) return fail(h, DVBS2HIP_EINVAL, "null socket pointer");
     if (n_cplx < 1) return fail(h, DVBS2HIP_EINVAL, "'n_cplx' has to be greater than 0");
+    if (h->capturing) return fail(h, DVBS2HIP_EUNSUPPORTED, "the stream position is a launch argument: this task cannot be recorded into a graph");
     Timer tm(h, DVBS2HIP_K_MISC);
     const long long total = (long long)n_cplx * F;
     HIPCHK(h, nco_launch(X, Y, h->nco_omega, h->nco_n, total, FRQ, PHS, -h->nco_nu, F, h->stream));

@@ -142,7 +142,8 @@ void *dvbs2hip_get_stream(dvbs2hip_t *h);      /* hipStream_t */
 int dvbs2hip_synchronize(dvbs2hip_t *h);
 /* A sequence of _dev calls as ONE submission (hipGraph; BASELINE configs[4], small-frame latency: at -F 1 the sequence filter -> extract -> rx_bb is six launches and a fill
  * around one workgroup's ten iterations).  Between _begin and _end the _dev calls of this handle are RECORDED, not run (same pointers, same n_frames on every replay; no host-
- * socket form, no dvbs2hip_synchronize in between; _begin returns DVBS2HIP_EINVAL while dvbs2hip_timing_enable is on; run the sequence once before recording it: first calls allocate).  The reference's counterpart is the task
+ * socket form, no dvbs2hip_synchronize in between; _begin returns DVBS2HIP_EINVAL while dvbs2hip_timing_enable is on; run the sequence once before recording it: first calls allocate).  Tasks that keep a memory from call to call (filter, shape_filter, the synchronizers) are recorded with the memory buffers of that moment: every replay starts from the state the stream had when the
+ * sequence was recorded, which is what a latency measurement on one frame wants and NOT a way to run a stream; dvbs2hip_sync_coarse_synchronize_dev, whose stream position is a launch argument, refuses to be recorded.  The reference's counterpart is the task
  * sequence itself (RX/main_sched.cpp:199-223: a spu::runtime::Sequence runs its bound tasks back to back). */
 int dvbs2hip_graph_begin(dvbs2hip_t *h);
 int dvbs2hip_graph_end(dvbs2hip_t *h, int32_t *graph);
