@@ -58,9 +58,10 @@ class SourceUserBinary:
     def __init__(self, path: str, K: int, auto_reset: bool = True):
         if K % 8:
             raise ValueError("K = %d is not a whole number of bytes" % K)
-        self.data = np.fromfile(path, dtype=np.uint8)
-        if self.data.size == 0:
+        import os
+        if os.path.getsize(path) == 0:
             raise ValueError("'%s' is empty" % path)
+        self.data = np.memmap(path, dtype=np.uint8, mode="r")          # (a transport stream of gigabytes stays on disk)
         self.K, self.pos, self.auto_reset, self.done = K, 0, auto_reset, False
 
     def generate(self, F: int) -> np.ndarray:
@@ -69,7 +70,7 @@ class SourceUserBinary:
         nb = F * self.K // 8
         if self.auto_reset:
             idx = (self.pos + np.arange(nb)) % self.data.size
-            chunk = self.data[idx]
+            chunk = np.asarray(self.data[idx])
             self.pos = int((self.pos + nb) % self.data.size)
         else:
             chunk = np.zeros(nb, np.uint8)
