@@ -105,6 +105,7 @@ class SinkUserBinary:
     def send(self, bits) -> None:
         b = np.ascontiguousarray(bits).reshape(-1, self.K)
         self.f.write(np.packbits((b != 0).astype(np.uint8), axis=1, bitorder="little").tobytes())
+        self.f.flush()                                               # (the sink may be a FIFO with a player behind it: README.md:206-217 of the reference)
 
     def close(self) -> None:
         self.f.close()
